@@ -1,0 +1,107 @@
+"""ctypes binding of ``libag_hip.so`` (the C ABI declared in ``include/ag_raster.h``).
+
+There is NO fallback: if the shared library is missing or a symbol cannot be resolved this module raises, and every
+operator that needs it raises with it.  ``torch`` is imported first on purpose: the library links against
+``libamdhip64.so.7`` and must bind to the HIP runtime instance torch already loaded, so that torch's streams and
+device pointers are valid inside our launches.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import torch  # noqa: F401  (loads the HIP runtime the library must share)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libag_hip.so")
+
+c_i32 = ctypes.c_int32
+c_f = ctypes.c_float
+c_vp = ctypes.c_void_p
+c_sz = ctypes.c_size_t
+
+
+class AgRasterForwardArgs(ctypes.Structure):
+    _fields_ = [
+        ("P", c_i32), ("W", c_i32), ("H", c_i32),
+        ("sh_degree", c_i32), ("sh_coeffs", c_i32), ("prefiltered", c_i32),
+        ("tan_fovx", c_f), ("tan_fovy", c_f), ("scale_modifier", c_f),
+        ("bg", c_vp), ("means3D", c_vp), ("colors_precomp", c_vp), ("shs", c_vp), ("opacities", c_vp),
+        ("scales", c_vp), ("rotations", c_vp), ("cov3D_precomp", c_vp),
+        ("viewmatrix", c_vp), ("projmatrix", c_vp), ("campos", c_vp),
+        ("out_color", c_vp), ("out_depth", c_vp), ("out_alpha", c_vp), ("radii", c_vp),
+        ("geom_buffer", c_vp), ("geom_bytes", c_sz),
+        ("image_buffer", c_vp), ("image_bytes", c_sz),
+        ("binning_buffer", c_vp), ("binning_bytes", c_sz),
+    ]
+
+
+class AgRasterBackwardArgs(ctypes.Structure):
+    _fields_ = [
+        ("P", c_i32), ("W", c_i32), ("H", c_i32),
+        ("sh_degree", c_i32), ("sh_coeffs", c_i32), ("num_rendered", c_i32),
+        ("tan_fovx", c_f), ("tan_fovy", c_f), ("scale_modifier", c_f),
+        ("bg", c_vp), ("means3D", c_vp), ("radii", c_vp), ("colors_precomp", c_vp), ("shs", c_vp),
+        ("scales", c_vp), ("rotations", c_vp), ("cov3D_precomp", c_vp),
+        ("viewmatrix", c_vp), ("projmatrix", c_vp), ("campos", c_vp), ("alphas", c_vp),
+        ("dL_dout_color", c_vp), ("dL_dout_depth", c_vp), ("dL_dout_alpha", c_vp),
+        ("geom_buffer", c_vp), ("image_buffer", c_vp), ("binning_buffer", c_vp),
+        ("dL_dmeans2D", c_vp), ("dL_dcolors", c_vp), ("dL_dopacity", c_vp), ("dL_dmeans3D", c_vp),
+        ("dL_dcov3D", c_vp), ("dL_dsh", c_vp), ("dL_dscales", c_vp), ("dL_drotations", c_vp),
+        ("accum_buffer", c_vp), ("accum_bytes", c_sz),
+    ]
+
+
+class AgRasterScratchLayout(ctypes.Structure):
+    _fields_ = [(n, c_sz) for n in (
+        "geom_rec_off", "geom_rec_stride", "geom_cov3d_off", "geom_tiles_touched_off",
+        "img_ranges_off", "img_n_contrib_off", "img_tile_count_off", "img_num_rendered_off",
+        "bin_point_list_off", "bin_keys_off")]
+
+
+# every symbol include/ag_raster.h declares: (name, restype, argtypes)
+SYMBOLS = [
+    ("ag_abi_version", ctypes.c_int, []),
+    ("ag_last_error", ctypes.c_char_p, []),
+    ("ag_raster_geom_bytes", c_sz, [c_i32]),
+    ("ag_raster_image_bytes", c_sz, [c_i32, c_i32]),
+    ("ag_raster_binning_bytes", c_sz, [c_i32]),
+    ("ag_raster_accum_bytes", c_sz, [c_i32]),
+    ("ag_raster_describe_scratch", ctypes.c_int, [c_i32, c_i32, c_i32, c_i32, ctypes.POINTER(AgRasterScratchLayout)]),
+    ("ag_raster_forward_plan", ctypes.c_int, [ctypes.POINTER(AgRasterForwardArgs), c_vp, ctypes.POINTER(c_i32)]),
+    ("ag_raster_forward_render", ctypes.c_int, [ctypes.POINTER(AgRasterForwardArgs), c_i32, c_vp]),
+    ("ag_raster_backward", ctypes.c_int, [ctypes.POINTER(AgRasterBackwardArgs), c_vp]),
+    ("ag_raster_mark_visible", ctypes.c_int, [c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    ("ag_debug_wave_reduce16", ctypes.c_int, [c_vp, c_vp, c_vp]),
+]
+
+_lib = None
+
+
+class AgNativeError(RuntimeError):
+    pass
+
+
+def lib() -> ctypes.CDLL:
+    """Load (once) and return the library; raise loudly when it is not there."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise AgNativeError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(animatablegaussians_amd/csrc/build.sh).  There is no CPU or PyTorch fallback for this path.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, res, args in SYMBOLS:
+            fn = getattr(L, name)   # AttributeError if the export is missing
+            fn.restype = res
+            fn.argtypes = args
+        if L.ag_abi_version() != 1:
+            raise AgNativeError(f"libag_hip.so ABI version {L.ag_abi_version()} != 1")
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().ag_last_error().decode("utf-8", "replace")
+        raise AgNativeError(f"{what} failed (code {rc}): {msg}")

@@ -1,0 +1,167 @@
+// C-ABI entry points of libag_hip.so (declared in include/ag_raster.h): argument validation, scratch sizing,
+// stage orchestration.  Host code only; the kernels live in the other translation units.
+#include <cstdarg>
+#include <cstdio>
+#include <mutex>
+
+#include "ag_common.h"
+
+namespace ag {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int check_hip(hipError_t e, const char* what)
+{
+    if (e == hipSuccess) return AG_OK;
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return AG_ERR_HIP;
+}
+
+// One pinned word per thread for the num_rendered read-back (the reference's blocking cudaMemcpy,
+// rasterizer_impl.cu:282).
+static int32_t* pinned_word()
+{
+    static thread_local int32_t* w = nullptr;
+    if (!w) {
+        if (hipHostMalloc(reinterpret_cast<void**>(&w), 64, hipHostMallocDefault) != hipSuccess) w = nullptr;
+    }
+    return w;
+}
+
+static int validate_forward(const AgRasterForwardArgs* a, bool need_bin, int R)
+{
+    if (!a) { set_error("null args"); return AG_ERR_INVALID_ARGUMENT; }
+    if (a->P < 0 || a->W <= 0 || a->H <= 0) { set_error("bad sizes P=%d W=%d H=%d", a->P, a->W, a->H); return AG_ERR_INVALID_ARGUMENT; }
+    if (a->P == 0) return AG_OK;
+    if (!a->means3D || !a->opacities || !a->bg || !a->viewmatrix || !a->projmatrix) {
+        set_error("means3D/opacities/bg/viewmatrix/projmatrix must be non-null");
+        return AG_ERR_INVALID_ARGUMENT;
+    }
+    if (!a->colors_precomp) {
+        set_error("spherical-harmonics colours are not implemented yet: pass colors_precomp");
+        return AG_ERR_UNSUPPORTED;
+    }
+    const bool sr = a->scales && a->rotations;
+    if (!sr && !a->cov3D_precomp) { set_error("need scales+rotations or cov3D_precomp"); return AG_ERR_INVALID_ARGUMENT; }
+    if (!a->out_color || !a->out_depth || !a->out_alpha || !a->radii) { set_error("null output"); return AG_ERR_INVALID_ARGUMENT; }
+    if (!a->geom_buffer || a->geom_bytes < ag_raster_geom_bytes(a->P)) { set_error("geom_buffer too small"); return AG_ERR_SCRATCH_TOO_SMALL; }
+    if (!a->image_buffer || a->image_bytes < ag_raster_image_bytes(a->W, a->H)) { set_error("image_buffer too small"); return AG_ERR_SCRATCH_TOO_SMALL; }
+    if (need_bin && R > 0 && (!a->binning_buffer || a->binning_bytes < ag_raster_binning_bytes(R))) {
+        set_error("binning_buffer too small for %d instances", R);
+        return AG_ERR_SCRATCH_TOO_SMALL;
+    }
+    return AG_OK;
+}
+
+}  // namespace ag
+
+using namespace ag;
+
+extern "C" {
+
+int ag_abi_version(void) { return AG_ABI_VERSION; }
+const char* ag_last_error(void) { return g_err; }
+
+size_t ag_raster_geom_bytes(int32_t P) { return GeomLayout((size_t)(P > 0 ? P : 0)).total; }
+size_t ag_raster_image_bytes(int32_t W, int32_t H) { return ImageLayout((size_t)W, (size_t)H).total; }
+size_t ag_raster_binning_bytes(int32_t R) { return BinLayout((size_t)(R > 0 ? R : 0)).total; }
+size_t ag_raster_accum_bytes(int32_t P) { return (size_t)(P > 0 ? P : 0) * kAccumFloats * sizeof(float) + 512; }
+
+int ag_raster_describe_scratch(int32_t P, int32_t W, int32_t H, int32_t R, AgRasterScratchLayout* o)
+{
+    if (!o) return AG_ERR_INVALID_ARGUMENT;
+    GeomLayout gl((size_t)P);
+    ImageLayout il((size_t)W, (size_t)H);
+    BinLayout bl((size_t)(R > 0 ? R : 0));
+    o->geom_rec_off = gl.rec; o->geom_rec_stride = sizeof(GaussRec);
+    o->geom_cov3d_off = gl.cov3d; o->geom_tiles_touched_off = gl.tiles_touched;
+    o->img_ranges_off = il.ranges; o->img_n_contrib_off = il.n_contrib; o->img_tile_count_off = il.tile_count;
+    o->img_num_rendered_off = il.num_rendered;
+    o->bin_point_list_off = bl.point_list; o->bin_keys_off = bl.keys;
+    return AG_OK;
+}
+
+int ag_raster_forward_plan(const AgRasterForwardArgs* a, void* stream, int32_t* num_rendered_host)
+{
+    if (!num_rendered_host) { set_error("null num_rendered_host"); return AG_ERR_INVALID_ARGUMENT; }
+    *num_rendered_host = 0;
+    int rc = validate_forward(a, false, 0);
+    if (rc) return rc;
+    if (a->P == 0) return AG_OK;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if ((rc = launch_preprocess(*a, s))) return rc;
+    if ((rc = launch_tile_scan(*a, s))) return rc;
+    int32_t* w = pinned_word();
+    if (!w) { set_error("hipHostMalloc failed"); return AG_ERR_HIP; }
+    ImageLayout il((size_t)a->W, (size_t)a->H);
+    const char* ib = aligned_base(a->image_buffer);
+    if ((rc = check_hip(hipMemcpyAsync(w, ib + il.num_rendered, sizeof(int32_t), hipMemcpyDeviceToHost, s), "read num_rendered"))) return rc;
+    if ((rc = check_hip(hipStreamSynchronize(s), "sync after plan"))) return rc;
+    *num_rendered_host = *w;
+    return AG_OK;
+}
+
+int ag_raster_forward_render(const AgRasterForwardArgs* a, int32_t R, void* stream)
+{
+    int rc = validate_forward(a, true, R);
+    if (rc) return rc;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (a->P == 0) {
+        // rasterize_points.cu:68-83: the native call is skipped; colour/depth/alpha stay all-zero (not bg)
+        const size_t HW = (size_t)a->W * a->H;
+        if ((rc = check_hip(hipMemsetAsync(a->out_color, 0, 3 * HW * sizeof(float), s), "memset"))) return rc;
+        if ((rc = check_hip(hipMemsetAsync(a->out_depth, 0, HW * sizeof(float), s), "memset"))) return rc;
+        return check_hip(hipMemsetAsync(a->out_alpha, 0, HW * sizeof(float), s), "memset");
+    }
+    if ((rc = launch_bin_sort(*a, R, s))) return rc;
+    return launch_blend_forward(*a, R, s);
+}
+
+int ag_raster_backward(const AgRasterBackwardArgs* a, void* stream)
+{
+    if (!a) { set_error("null args"); return AG_ERR_INVALID_ARGUMENT; }
+    if (a->P < 0 || a->W <= 0 || a->H <= 0 || a->num_rendered < 0) { set_error("bad sizes"); return AG_ERR_INVALID_ARGUMENT; }
+    if (a->P == 0) return AG_OK;   // all outputs are empty
+    if (!a->colors_precomp) { set_error("spherical-harmonics colours are not implemented yet"); return AG_ERR_UNSUPPORTED; }
+    if (!a->means3D || !a->radii || !a->bg || !a->viewmatrix || !a->projmatrix || !a->alphas || !a->dL_dout_color ||
+        !a->dL_dout_depth || !a->dL_dout_alpha || !a->geom_buffer || !a->image_buffer) {
+        set_error("null input to backward");
+        return AG_ERR_INVALID_ARGUMENT;
+    }
+    if (a->num_rendered > 0 && !a->binning_buffer) { set_error("null binning_buffer"); return AG_ERR_INVALID_ARGUMENT; }
+    if (!(a->scales && a->rotations) && !a->cov3D_precomp) { set_error("need scales+rotations or cov3D_precomp"); return AG_ERR_INVALID_ARGUMENT; }
+    if (!a->dL_dmeans2D || !a->dL_dcolors || !a->dL_dopacity || !a->dL_dmeans3D || !a->dL_dcov3D || !a->dL_dscales ||
+        !a->dL_drotations) {
+        set_error("null gradient output");
+        return AG_ERR_INVALID_ARGUMENT;
+    }
+    if (!a->accum_buffer || a->accum_bytes < ag_raster_accum_bytes(a->P)) { set_error("accum_buffer too small"); return AG_ERR_SCRATCH_TOO_SMALL; }
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    int rc;
+    if ((rc = launch_blend_backward(*a, s))) return rc;
+    return launch_preprocess_backward(*a, s);
+}
+
+int ag_debug_wave_reduce16(const float* in, float* out, void* stream)
+{
+    return launch_debug_wave_reduce16(in, out, reinterpret_cast<hipStream_t>(stream));
+}
+
+int ag_raster_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                           uint8_t* present, void* stream)
+{
+    (void)projmatrix;
+    if (P < 0 || (P > 0 && (!means3D || !viewmatrix || !present))) { set_error("bad mark_visible args"); return AG_ERR_INVALID_ARGUMENT; }
+    if (P == 0) return AG_OK;
+    return launch_mark_visible(P, means3D, viewmatrix, present, reinterpret_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

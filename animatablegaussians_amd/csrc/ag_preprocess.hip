@@ -1,0 +1,235 @@
+// Forward per-Gaussian preprocess + per-tile instance counting (gfx950).
+//
+// Replaces preprocessCUDA<3> (reference cuda_rasterizer/forward.cu:155-256) and produces, instead of the
+// reference's Gaussian-major `tiles_touched` prefix sum, per-TILE instance counts (one global atomic per
+// (Gaussian, tile) instance).  The tile-major counts make the later binning a counting sort by tile, so no
+// device-wide 64-bit radix sort is needed (see ag_binning.hip).
+//
+// THIS TRANSLATION UNIT IS COMPILED WITH -ffp-contract=off: the fp32 expression order below is the contract that
+// makes radii / tile rects / depth keys bit-identical to the CPU oracle (oracle/raster_oracle.c), which in turn
+// restates the reference's expression order (GLM column-major mat3 products, left-to-right sums).
+// HBM-bound streaming kernel: 44 B in, 48 B record + 24 B cov3D + 8 B out per Gaussian.
+#include "ag_common.h"
+
+namespace ag {
+
+struct M3 { float m[3][3]; };  // m[col][row], GLM convention
+
+__device__ __forceinline__ M3 m3_cols(float a, float b, float c, float d, float e, float f, float g, float h, float i)
+{
+    M3 r;
+    r.m[0][0] = a; r.m[0][1] = b; r.m[0][2] = c;
+    r.m[1][0] = d; r.m[1][1] = e; r.m[1][2] = f;
+    r.m[2][0] = g; r.m[2][1] = h; r.m[2][2] = i;
+    return r;
+}
+
+__device__ __forceinline__ M3 m3_mul(const M3& a, const M3& b)
+{
+    M3 r;
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int q = 0; q < 3; q++)
+            r.m[c][q] = a.m[0][q] * b.m[c][0] + a.m[1][q] * b.m[c][1] + a.m[2][q] * b.m[c][2];
+    return r;
+}
+
+__device__ __forceinline__ M3 m3_t(const M3& a)
+{
+    M3 r;
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int q = 0; q < 3; q++) r.m[c][q] = a.m[q][c];
+    return r;
+}
+
+__device__ __forceinline__ float ndc2pix(float v, int S)
+{
+    return (float)((((double)v + 1.0) * (double)S - 1.0) * 0.5);
+}
+
+__device__ __forceinline__ void get_rect(float px, float py, int max_radius, int gx, int gy,
+                                         uint32_t& x0o, uint32_t& y0o, uint32_t& x1o, uint32_t& y1o)
+{
+    const float r = (float)max_radius;
+    int x0 = (int)((px - r) / (float)kTileX);
+    int y0 = (int)((py - r) / (float)kTileY);
+    int x1 = (int)((px + r + (float)kTileX - 1.0f) / (float)kTileX);
+    int y1 = (int)((py + r + (float)kTileY - 1.0f) / (float)kTileY);
+    x0 = max(0, x0); y0 = max(0, y0); x1 = max(0, x1); y1 = max(0, y1);
+    x0o = (uint32_t)min(gx, x0); y0o = (uint32_t)min(gy, y0);
+    x1o = (uint32_t)min(gx, x1); y1o = (uint32_t)min(gy, y1);
+}
+
+struct PreParams {
+    int P, W, H, gx, gy;
+    float tan_fovx, tan_fovy, focal_x, focal_y, scale_modifier;
+    const float* __restrict__ means3D;
+    const float* __restrict__ scales;
+    const float* __restrict__ rotations;
+    const float* __restrict__ opacities;
+    const float* __restrict__ colors;
+    const float* __restrict__ cov3D_precomp;
+    const float* __restrict__ view;
+    const float* __restrict__ proj;
+    int* __restrict__ radii;
+    GaussRec* __restrict__ rec;
+    float* __restrict__ cov3Ds;
+    uint32_t* __restrict__ tiles_touched;
+    uint32_t* __restrict__ tile_count;
+};
+
+__global__ void __launch_bounds__(256) preprocess_kernel(PreParams p)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= p.P) return;
+
+    // wave-uniform camera: scalar loads
+    float V[16], Pm[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) { V[i] = p.view[i]; Pm[i] = p.proj[i]; }
+
+    int my_radii = 0;
+    uint32_t touched = 0;
+    const float ox = p.means3D[3 * idx + 0], oy = p.means3D[3 * idx + 1], oz = p.means3D[3 * idx + 2];
+
+    // near-plane cull only (auxiliary.h:154)
+    const float vz = V[2] * ox + V[6] * oy + V[10] * oz + V[14];
+    if (vz > 0.2f) {
+        const float hx = Pm[0] * ox + Pm[4] * oy + Pm[8] * oz + Pm[12];
+        const float hy = Pm[1] * ox + Pm[5] * oy + Pm[9] * oz + Pm[13];
+        const float hw = Pm[3] * ox + Pm[7] * oy + Pm[11] * oz + Pm[15];
+        const float p_w = 1.0f / (hw + 0.0000001f);
+        const float projx = hx * p_w, projy = hy * p_w;
+
+        float c3[6];
+        if (p.cov3D_precomp) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) c3[k] = p.cov3D_precomp[6 * idx + k];
+        } else {
+            // computeCov3D, forward.cu:116-152 — quaternion used un-normalised
+            const float mod = p.scale_modifier;
+            M3 S = m3_cols(1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f);
+            S.m[0][0] = mod * p.scales[3 * idx + 0];
+            S.m[1][1] = mod * p.scales[3 * idx + 1];
+            S.m[2][2] = mod * p.scales[3 * idx + 2];
+            const float r = p.rotations[4 * idx + 0], x = p.rotations[4 * idx + 1];
+            const float y = p.rotations[4 * idx + 2], z = p.rotations[4 * idx + 3];
+            const M3 R = m3_cols(
+                1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y),
+                2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x),
+                2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y));
+            const M3 M = m3_mul(S, R);
+            const M3 Sigma = m3_mul(m3_t(M), M);
+            c3[0] = Sigma.m[0][0]; c3[1] = Sigma.m[0][1]; c3[2] = Sigma.m[0][2];
+            c3[3] = Sigma.m[1][1]; c3[4] = Sigma.m[1][2]; c3[5] = Sigma.m[2][2];
+        }
+#pragma unroll
+        for (int k = 0; k < 6; k++) p.cov3Ds[6 * idx + k] = c3[k];
+
+        // computeCov2D, forward.cu:74-113
+        float tx = V[0] * ox + V[4] * oy + V[8] * oz + V[12];
+        float ty = V[1] * ox + V[5] * oy + V[9] * oz + V[13];
+        const float tz = vz;
+        const float limx = 1.3f * p.tan_fovx, limy = 1.3f * p.tan_fovy;
+        const float txtz = tx / tz, tytz = ty / tz;
+        tx = fminf(limx, fmaxf(-limx, txtz)) * tz;
+        ty = fminf(limy, fmaxf(-limy, tytz)) * tz;
+        const M3 J = m3_cols(
+            p.focal_x / tz, 0.0f, -(p.focal_x * tx) / (tz * tz),
+            0.0f, p.focal_y / tz, -(p.focal_y * ty) / (tz * tz),
+            0.f, 0.f, 0.f);
+        const M3 Wm = m3_cols(V[0], V[4], V[8], V[1], V[5], V[9], V[2], V[6], V[10]);
+        const M3 T = m3_mul(Wm, J);
+        const M3 Vrk = m3_cols(c3[0], c3[1], c3[2], c3[1], c3[3], c3[4], c3[2], c3[4], c3[5]);
+        const M3 cov = m3_mul(m3_mul(m3_t(T), m3_t(Vrk)), T);
+        const float cxx = cov.m[0][0] + 0.3f, cxy = cov.m[0][1], cyy = cov.m[1][1] + 0.3f;
+
+        const float det = (cxx * cyy - cxy * cxy);
+        if (det != 0.0f) {
+            const float det_inv = 1.f / det;
+            const float ca = cyy * det_inv, cb = -cxy * det_inv, cc = cxx * det_inv;
+            const float mid = 0.5f * (cxx + cyy);
+            const float lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
+            const float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
+            const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
+            const float px = ndc2pix(projx, p.W), py = ndc2pix(projy, p.H);
+            uint32_t x0, y0, x1, y1;
+            get_rect(px, py, (int)my_radius, p.gx, p.gy, x0, y0, x1, y1);
+            const uint32_t n = (x1 - x0) * (y1 - y0);
+            if (n != 0) {
+                my_radii = (int)my_radius;
+                touched = n;
+                const float op = p.opacities[idx];
+                GaussRec g;
+                g.x = px; g.y = py; g.ca = ca; g.cb = cb; g.cc = cc; g.op = op;
+                g.r = p.colors[3 * idx + 0]; g.g = p.colors[3 * idx + 1]; g.b = p.colors[3 * idx + 2];
+                g.depth = vz;
+                // Wave-level cull radius for the blend kernels.  power <= -0.5*d^2/lambda_max(cov2D) and
+                // alpha = op*exp(power) < 1/255  <=>  power < -ln(255*op); lambda1 >= lambda_max (0.1 floor above).
+                // 1 % + 0.01 slack in log space dwarfs every fp32 rounding of conic/power; huge or degenerate
+                // splats are never culled.
+                float r2 = 3.0e38f;
+                if (lambda1 < 1.0e4f && lambda1 > 0.f && op >= 0.f) {
+                    const float lg = __logf(255.0f * op) + 0.01f;   // -inf for op == 0
+                    r2 = (lg > 0.f) ? 2.0f * lambda1 * lg * 1.01f : -1.0f;
+                }
+                g.r2cut = r2;
+                g.pad = 0.f;
+                p.rec[idx] = g;
+                for (uint32_t y = y0; y < y1; y++)
+                    for (uint32_t x = x0; x < x1; x++) atomicAdd(&p.tile_count[y * (uint32_t)p.gx + x], 1u);
+            }
+        }
+    }
+    p.radii[idx] = my_radii;
+    p.tiles_touched[idx] = touched;
+}
+
+int launch_preprocess(const AgRasterForwardArgs& a, hipStream_t s)
+{
+    PreParams p;
+    p.P = a.P; p.W = a.W; p.H = a.H;
+    p.gx = (a.W + kTileX - 1) / kTileX;
+    p.gy = (a.H + kTileY - 1) / kTileY;
+    p.tan_fovx = a.tan_fovx; p.tan_fovy = a.tan_fovy;
+    p.focal_y = a.H / (2.0f * a.tan_fovy);   // rasterizer_impl.cu:223-224
+    p.focal_x = a.W / (2.0f * a.tan_fovx);
+    p.scale_modifier = a.scale_modifier;
+    p.means3D = a.means3D; p.scales = a.scales; p.rotations = a.rotations; p.opacities = a.opacities;
+    p.colors = a.colors_precomp; p.cov3D_precomp = a.cov3D_precomp;
+    p.view = a.viewmatrix; p.proj = a.projmatrix;
+    p.radii = a.radii;
+    char* gb = aligned_base(a.geom_buffer);
+    char* ib = aligned_base(a.image_buffer);
+    GeomLayout gl((size_t)a.P);
+    ImageLayout il((size_t)a.W, (size_t)a.H);
+    p.rec = reinterpret_cast<GaussRec*>(gb + gl.rec);
+    p.cov3Ds = reinterpret_cast<float*>(gb + gl.cov3d);
+    p.tiles_touched = reinterpret_cast<uint32_t*>(gb + gl.tiles_touched);
+    p.tile_count = reinterpret_cast<uint32_t*>(ib + il.tile_count);
+    const size_t T = (size_t)p.gx * p.gy;
+    if (check_hip(hipMemsetAsync(p.tile_count, 0, T * sizeof(uint32_t), s), "memset tile_count")) return AG_ERR_HIP;
+    hipLaunchKernelGGL(preprocess_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, p);
+    return check_hip(hipGetLastError(), "preprocess_kernel");
+}
+
+__global__ void __launch_bounds__(256) mark_visible_kernel(int P, const float* __restrict__ means3D,
+                                                          const float* __restrict__ view, uint8_t* __restrict__ present)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= P) return;
+    const float ox = means3D[3 * idx + 0], oy = means3D[3 * idx + 1], oz = means3D[3 * idx + 2];
+    const float vz = view[2] * ox + view[6] * oy + view[10] * oz + view[14];
+    present[idx] = (vz <= 0.2f) ? 0 : 1;
+}
+
+int launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t s)
+{
+    hipLaunchKernelGGL(mark_visible_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, means3D, view, present);
+    return check_hip(hipGetLastError(), "mark_visible_kernel");
+}
+
+}  // namespace ag

@@ -1,0 +1,29 @@
+#!/bin/bash
+# Builds libag_hip.so for gfx950 (cross-compiles without a GPU).  Output: animatablegaussians_amd/lib/libag_hip.so
+set -euo pipefail
+HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+OUT="$HERE/../lib"
+OBJ="$HERE/../lib/obj"
+mkdir -p "$OUT" "$OBJ"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+COMMON="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
+# fp32 op order is a parity contract in the preprocess kernels: no FMA contraction there.
+EXACT="-ffp-contract=off"
+FAST="-ffp-contract=fast"
+compile() { # src flags
+  local src="$1"; shift
+  local obj="$OBJ/$(basename "${src%.hip}").o"
+  if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ "$HERE/ag_common.h" -nt "$obj" ] || [ "$HERE/../../include/ag_raster.h" -nt "$obj" ]; then
+    echo "hipcc $(basename "$src") $*"
+    "$HIPCC" $COMMON "$@" -c "$src" -o "$obj"
+  fi
+}
+compile "$HERE/ag_abi.hip" $FAST &
+compile "$HERE/ag_preprocess.hip" $EXACT &
+compile "$HERE/ag_binning.hip" $EXACT &
+compile "$HERE/ag_blend_forward.hip" $FAST &
+compile "$HERE/ag_blend_backward.hip" $FAST &
+compile "$HERE/ag_preprocess_backward.hip" $FAST &
+wait
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT/libag_hip.so" "$OBJ"/*.o
+echo "built $OUT/libag_hip.so"

@@ -1,0 +1,272 @@
+"""Python operator surface of the depth+alpha Gaussian rasterizer, backed by ``libag_hip.so``.
+
+Same names, argument order, return tuples and error behaviour as the reference package
+``diff_gaussian_rasterization_depth_alpha`` (``.../diff_gaussian_rasterization_depth_alpha/__init__.py:21-223``) and its
+pybind module ``_C`` (``ext.cpp:15-19``, ``rasterize_points.cu:35-229``), so ``gaussians/gaussian_renderer.py`` can
+import it unchanged:
+
+* ``GaussianRasterizationSettings`` (NamedTuple, ``__init__.py:160-172``)
+* ``GaussianRasterizer(raster_settings)(means3D, means2D, opacities, shs, colors_precomp, scales, rotations,
+  cov3D_precomp) -> (color[3,H,W], radii[P] int32, depth[1,H,W], alpha[1,H,W])`` and ``.markVisible``
+* ``_C.rasterize_gaussians`` / ``_C.rasterize_gaussians_backward`` / ``_C.mark_visible`` equivalents:
+  :func:`native_rasterize_gaussians`, :func:`native_rasterize_gaussians_backward`, :func:`native_mark_visible`.
+
+Host code is plumbing only (allocation, pointer passing, autograd bookkeeping); all arithmetic happens in the HIP
+kernels.  There is no CPU or eager-PyTorch fallback: non-GPU tensors raise.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import NamedTuple, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+NUM_CHANNELS = 3  # cuda_rasterizer/config.h:15
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    """Device pointer of a tensor, or NULL for None / empty (the reference's 'not provided' torch.Tensor([]))."""
+    if t is None or t.numel() == 0:
+        return None
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
+    if t.numel() == 0:
+        return t
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must live on the GPU (there is no CPU rasterizer in this package)")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name} must be float32, got {t.dtype}")
+    return t.contiguous()
+
+
+def _stream_ptr(device) -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def native_rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+                               viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree,
+                               campos, prefiltered, debug):
+    """``_C.rasterize_gaussians`` (``rasterize_points.cu:35-119``).
+
+    Returns ``(num_rendered, color, depth, alpha, radii, geomBuffer, binningBuffer, imgBuffer)``.
+    """
+    if means3D.dim() != 2 or means3D.size(1) != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")
+    L = _lib.lib()
+    P, H, W = int(means3D.size(0)), int(image_height), int(image_width)
+    dev = means3D.device
+    f_opts = dict(dtype=torch.float32, device=dev)
+    radii = torch.empty((P,), dtype=torch.int32, device=dev)
+    byte = dict(dtype=torch.uint8, device=dev)
+    if P == 0:
+        # the reference skips the native call and returns its zero-filled outputs and empty buffers
+        z = lambda c: torch.zeros((c, H, W), **f_opts)  # noqa: E731
+        e = lambda: torch.empty((0,), **byte)           # noqa: E731
+        return 0, z(NUM_CHANNELS), z(1), z(1), radii, e(), e(), e()
+
+    out_color = torch.empty((NUM_CHANNELS, H, W), **f_opts)
+    out_depth = torch.empty((1, H, W), **f_opts)
+    out_alpha = torch.empty((1, H, W), **f_opts)
+    means3D = _f32c(means3D, "means3D")
+    colors = _f32c(colors, "colors_precomp")
+    opacity = _f32c(opacity, "opacities")
+    scales = _f32c(scales, "scales")
+    rotations = _f32c(rotations, "rotations")
+    cov3D_precomp = _f32c(cov3D_precomp, "cov3D_precomp")
+    sh = _f32c(sh, "shs")
+    background = _f32c(background, "bg")
+    viewmatrix = _f32c(viewmatrix, "viewmatrix")
+    projmatrix = _f32c(projmatrix, "projmatrix")
+    campos = _f32c(campos, "campos")
+
+    geom = torch.empty((L.ag_raster_geom_bytes(P),), **byte)
+    img = torch.empty((L.ag_raster_image_bytes(W, H),), **byte)
+
+    a = _lib.AgRasterForwardArgs()
+    a.P, a.W, a.H = P, W, H
+    a.sh_degree = int(degree)
+    a.sh_coeffs = int(sh.size(1)) if sh.numel() else 0
+    a.prefiltered = int(bool(prefiltered))
+    a.tan_fovx, a.tan_fovy, a.scale_modifier = float(tan_fovx), float(tan_fovy), float(scale_modifier)
+    a.bg = _ptr(background); a.means3D = _ptr(means3D); a.colors_precomp = _ptr(colors); a.shs = _ptr(sh)
+    a.opacities = _ptr(opacity); a.scales = _ptr(scales); a.rotations = _ptr(rotations)
+    a.cov3D_precomp = _ptr(cov3D_precomp)
+    a.viewmatrix = _ptr(viewmatrix); a.projmatrix = _ptr(projmatrix); a.campos = _ptr(campos)
+    a.out_color = _ptr(out_color); a.out_depth = _ptr(out_depth); a.out_alpha = _ptr(out_alpha); a.radii = _ptr(radii)
+    a.geom_buffer = _ptr(geom); a.geom_bytes = geom.numel()
+    a.image_buffer = _ptr(img); a.image_bytes = img.numel()
+    a.binning_buffer = None; a.binning_bytes = 0
+
+    with torch.cuda.device(dev):
+        stream = _stream_ptr(dev)
+        R = ctypes.c_int32(0)
+        _lib.check(L.ag_raster_forward_plan(ctypes.byref(a), stream, ctypes.byref(R)), "ag_raster_forward_plan")
+        num_rendered = int(R.value)
+        binning = torch.empty((L.ag_raster_binning_bytes(num_rendered),), **byte)
+        a.binning_buffer = _ptr(binning); a.binning_bytes = binning.numel()
+        _lib.check(L.ag_raster_forward_render(ctypes.byref(a), num_rendered, stream), "ag_raster_forward_render")
+        if debug:
+            torch.cuda.synchronize(dev)
+    return num_rendered, out_color, out_depth, out_alpha, radii, geom, binning, img
+
+
+def native_rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier,
+                                        cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color,
+                                        dL_dout_depth, dL_dout_alpha, sh, degree, campos, geomBuffer, R,
+                                        binningBuffer, imageBuffer, alphas, debug, *, _accum_buffer=None):
+    """``_C.rasterize_gaussians_backward`` (``rasterize_points.cu:121-208``).
+
+    Returns ``(dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)``.
+    ``_accum_buffer`` (tests only) lets the caller own the per-Gaussian accumulator scratch so the internal
+    ``dL_dconic`` / ``dL_ddepths`` sums can be inspected.
+    """
+    L = _lib.lib()
+    P = int(means3D.size(0))
+    H, W = int(dL_dout_color.size(1)), int(dL_dout_color.size(2))
+    M = int(sh.size(1)) if sh.numel() else 0
+    dev = means3D.device
+    f = dict(dtype=torch.float32, device=dev)
+    dL_dmeans3D = torch.empty((P, 3), **f)
+    dL_dmeans2D = torch.empty((P, 3), **f)
+    dL_dcolors = torch.empty((P, NUM_CHANNELS), **f)
+    dL_dopacity = torch.empty((P, 1), **f)
+    dL_dcov3D = torch.empty((P, 6), **f)
+    dL_dsh = torch.zeros((P, M, 3), **f)
+    dL_dscales = torch.empty((P, 3), **f)
+    dL_drotations = torch.empty((P, 4), **f)
+    if P == 0:
+        return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations
+
+    accum = _accum_buffer if _accum_buffer is not None else torch.empty((L.ag_raster_accum_bytes(P),), dtype=torch.uint8, device=dev)
+    keep = [_f32c(t, n) for t, n in ((background, "bg"), (means3D, "means3D"), (colors, "colors_precomp"),
+                                     (scales, "scales"), (rotations, "rotations"), (cov3D_precomp, "cov3D_precomp"),
+                                     (viewmatrix, "viewmatrix"), (projmatrix, "projmatrix"), (campos, "campos"),
+                                     (alphas, "alphas"), (dL_dout_color, "dL_dout_color"),
+                                     (dL_dout_depth, "dL_dout_depth"), (dL_dout_alpha, "dL_dout_alpha"), (sh, "shs"))]
+    (background, means3D, colors, scales, rotations, cov3D_precomp, viewmatrix, projmatrix, campos, alphas,
+     dL_dout_color, dL_dout_depth, dL_dout_alpha, sh) = keep
+    radii = radii.contiguous()
+
+    b = _lib.AgRasterBackwardArgs()
+    b.P, b.W, b.H = P, W, H
+    b.sh_degree, b.sh_coeffs, b.num_rendered = int(degree), M, int(R)
+    b.tan_fovx, b.tan_fovy, b.scale_modifier = float(tan_fovx), float(tan_fovy), float(scale_modifier)
+    b.bg = _ptr(background); b.means3D = _ptr(means3D); b.radii = _ptr(radii); b.colors_precomp = _ptr(colors)
+    b.shs = _ptr(sh); b.scales = _ptr(scales); b.rotations = _ptr(rotations); b.cov3D_precomp = _ptr(cov3D_precomp)
+    b.viewmatrix = _ptr(viewmatrix); b.projmatrix = _ptr(projmatrix); b.campos = _ptr(campos); b.alphas = _ptr(alphas)
+    b.dL_dout_color = _ptr(dL_dout_color); b.dL_dout_depth = _ptr(dL_dout_depth); b.dL_dout_alpha = _ptr(dL_dout_alpha)
+    b.geom_buffer = _ptr(geomBuffer); b.image_buffer = _ptr(imageBuffer); b.binning_buffer = _ptr(binningBuffer)
+    b.dL_dmeans2D = _ptr(dL_dmeans2D); b.dL_dcolors = _ptr(dL_dcolors); b.dL_dopacity = _ptr(dL_dopacity)
+    b.dL_dmeans3D = _ptr(dL_dmeans3D); b.dL_dcov3D = _ptr(dL_dcov3D); b.dL_dsh = _ptr(dL_dsh)
+    b.dL_dscales = _ptr(dL_dscales); b.dL_drotations = _ptr(dL_drotations)
+    b.accum_buffer = _ptr(accum); b.accum_bytes = accum.numel()
+    with torch.cuda.device(dev):
+        _lib.check(L.ag_raster_backward(ctypes.byref(b), _stream_ptr(dev)), "ag_raster_backward")
+        if debug:
+            torch.cuda.synchronize(dev)
+    return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations
+
+
+def native_mark_visible(means3D, viewmatrix, projmatrix):
+    """``_C.mark_visible`` (``rasterize_points.cu:210-229``)."""
+    L = _lib.lib()
+    P = int(means3D.size(0))
+    present = torch.zeros((P,), dtype=torch.bool, device=means3D.device)
+    if P:
+        means3D = _f32c(means3D, "means3D")
+        viewmatrix = _f32c(viewmatrix, "viewmatrix")
+        projmatrix = _f32c(projmatrix, "projmatrix")
+        with torch.cuda.device(means3D.device):
+            _lib.check(L.ag_raster_mark_visible(P, _ptr(means3D), _ptr(viewmatrix), _ptr(projmatrix), _ptr(present),
+                                                _stream_ptr(means3D.device)), "ag_raster_mark_visible")
+    return present
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    """Autograd node with the reference's input order (``__init__.py:44-158``)."""
+
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+        rs = raster_settings
+        num_rendered, color, depth, alpha, radii, geom, binning, img = native_rasterize_gaussians(
+            rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
+            rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh, rs.sh_degree,
+            rs.campos, rs.prefiltered, rs.debug)
+        ctx.raster_settings = rs
+        ctx.num_rendered = num_rendered
+        ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning,
+                              img, alpha)
+        ctx.mark_non_differentiable(radii)
+        return color, radii, depth, alpha
+
+    @staticmethod
+    def backward(ctx, grad_color, grad_radii, grad_depth, grad_alpha):
+        rs = ctx.raster_settings
+        colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img, alpha = ctx.saved_tensors
+        (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
+         grad_rotations) = native_rasterize_gaussians_backward(
+            rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
+            rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_color, grad_depth, grad_alpha, sh, rs.sh_degree, rs.campos,
+            geom, ctx.num_rendered, binning, img, alpha, rs.debug)
+        # gradients of inputs that were "not provided" (empty tensors) are dropped, as autograd would ignore them
+        return (grad_means3D, grad_means2D,
+                grad_sh if sh.numel() else None,
+                grad_colors_precomp if colors_precomp.numel() else None,
+                grad_opacities,
+                grad_scales if scales.numel() else None,
+                grad_rotations if rotations.numel() else None,
+                grad_cov3Ds_precomp if cov3Ds_precomp.numel() else None,
+                None)
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                                     raster_settings)
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings: GaussianRasterizationSettings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        with torch.no_grad():
+            rs = self.raster_settings
+            return native_mark_visible(positions, rs.viewmatrix, rs.projmatrix)
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        # same argument contract and messages as the reference (__init__.py:194-198)
+        if (shs is None) == (colors_precomp is None):
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+        has_sr = scales is not None or rotations is not None
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or (has_sr and cov3D_precomp is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+        empty = torch.Tensor([])
+        shs = empty if shs is None else shs
+        colors_precomp = empty if colors_precomp is None else colors_precomp
+        scales = empty if scales is None else scales
+        rotations = empty if rotations is None else rotations
+        cov3D_precomp = empty if cov3D_precomp is None else cov3D_precomp
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                                   self.raster_settings)

@@ -1,0 +1,117 @@
+"""Seeded synthetic inputs for the render hot path (no dataset or checkpoint can be fetched here).
+
+Two scene families, both from ``numpy.random.RandomState(31359)`` (the reference's seed,
+``main_avatar.py:817``; numpy's legacy generator is bit-stable across versions and machines):
+
+* ``random_gaussians``  - BASELINE.json configs[0]: P random Gaussians in a body-sized box, one 512x512 front
+  camera (f = 550, c = 256: the dataset default, ``dataset/dataset_mv_rgb.py:216-218``).
+* ``avatar_map_gaussians`` - configs[1]/[4]: Gaussians laid out like the reference's canonical front|back position
+  map (``gen_data/gen_pos_maps.py:42,61,112-113``): one Gaussian per set pixel of a (S x 2S) silhouette mask,
+  S = 1024 -> ~234 k Gaussians on a 2 mm grid; free-view cameras at f = 1100, 1024x1024, subject 2.5 m away
+  (``main_avatar.py:601-615``).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List
+
+import numpy as np
+
+from . import camera as cam
+
+f32 = np.float32
+SEED = 31359
+
+
+def _sigmoid(x):
+    return 1.0 / (1.0 + np.exp(-x))
+
+
+def random_gaussians(P: int = 10000, seed: int = SEED, img: int = 512, focal: float = 550.0) -> Dict[str, object]:
+    rs = np.random.RandomState(seed)
+    means3D = np.stack([rs.uniform(-0.5, 0.5, P), rs.uniform(-0.9, 0.9, P), rs.uniform(-0.2, 0.2, P)], 1).astype(f32)
+    scales = np.exp(rs.normal(math.log(0.01), 0.3, (P, 3))).astype(f32)
+    q = rs.normal(0, 1, (P, 4))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    q *= rs.uniform(0.8, 1.2, (P, 1))          # deliberately NOT unit: the rasterizer uses raw quaternions
+    rotations = q.astype(f32)
+    opacities = _sigmoid(rs.normal(0, 1.5, (P, 1))).astype(f32)
+    colors = rs.uniform(0, 1, (P, 3)).astype(f32)
+    bg = rs.uniform(0, 1, 3).astype(f32)
+    extr = cam.calc_front_mv(np.zeros(3, f32), tar_pos=(0.0, 0.0, 2.5))
+    intr = np.array([[focal, 0, img / 2], [0, focal, img / 2], [0, 0, 1]], f32)
+    scene = {
+        "means3D": means3D, "scales": scales, "rotations": rotations, "opacities": opacities, "colors": colors,
+        "bg": bg, "extr": extr, "intr": intr, "img_w": img, "img_h": img,
+    }
+    scene.update(upstream_grads(img, img, seed + 1))
+    return scene
+
+
+def upstream_grads(W: int, H: int, seed: int) -> Dict[str, np.ndarray]:
+    rs = np.random.RandomState(seed)
+    return {
+        "dL_dcolor": rs.normal(0, 1, (3, H, W)).astype(f32),
+        "dL_ddepth": rs.normal(0, 1, (1, H, W)).astype(f32),
+        "dL_dalpha": rs.normal(0, 1, (1, H, W)).astype(f32),
+    }
+
+
+def body_mask(S: int = 1024) -> np.ndarray:
+    """(S, S) bool silhouette: union of ellipses (head, torso, two arms in A-pose, two legs)."""
+    v, u = np.mgrid[0:S, 0:S].astype(np.float64)
+    x = (u + 0.5) / S * 2.0 - 1.0       # [-1, 1] across the map
+    y = (v + 0.5) / S * 2.0 - 1.0       # top (-1) -> bottom (+1)
+
+    def ell(cx, cy, rx, ry, ang=0.0):
+        c, s = math.cos(ang), math.sin(ang)
+        xr = (x - cx) * c + (y - cy) * s
+        yr = -(x - cx) * s + (y - cy) * c
+        return (xr / rx) ** 2 + (yr / ry) ** 2 <= 1.0
+
+    m = ell(0.0, -0.78, 0.085, 0.11)                     # head
+    m |= ell(0.0, -0.36, 0.17, 0.30)                     # torso
+    m |= ell(-0.33, -0.36, 0.056, 0.30, math.radians(-38))   # arms
+    m |= ell(0.33, -0.36, 0.056, 0.30, math.radians(38))
+    m |= ell(-0.10, 0.42, 0.075, 0.46, math.radians(4))   # legs
+    m |= ell(0.10, 0.42, 0.075, 0.46, math.radians(-4))
+    return m
+
+
+def avatar_map_gaussians(S: int = 1024, seed: int = SEED) -> Dict[str, object]:
+    """Canonical Gaussians on an (S x 2S) front|back map.  Pixel pitch = 2.048 m / S."""
+    rs = np.random.RandomState(seed)
+    m = body_mask(S)
+    mask = np.concatenate([m, m[:, ::-1]], axis=1)            # back half is the mirrored silhouette
+    pitch = 2.048 / S
+    vv, uu = np.nonzero(mask)                                  # row-major == the reference's boolean-mask order
+    front = uu < S
+    ul = np.where(front, uu, 2 * S - 1 - uu).astype(np.float64)
+    x = (ul + 0.5 - S / 2) * pitch
+    y = (S / 2 - (vv + 0.5)) * pitch
+    bump = 0.10 * np.cos(np.clip(x / 0.45, -1, 1) * math.pi / 2)       # thickness profile
+    z = np.where(front, bump, -bump)
+    means3D = np.stack([x, y, z], 1).astype(f32)
+    P = means3D.shape[0]
+    base = math.log(pitch)                                     # ~mean 3-NN distance (create_from_pcd)
+    scales = np.exp(base + rs.normal(0, 0.2, (P, 3))).astype(f32)
+    q = rs.normal(0, 1, (P, 4))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    rotations = q.astype(f32)
+    opacities = _sigmoid(rs.normal(2.0, 1.0, (P, 1))).astype(f32)
+    colors = rs.uniform(0, 1, (P, 3)).astype(f32)
+    bg = np.array([1.0, 1.0, 1.0], f32)
+    return {
+        "mask": mask, "means3D": means3D, "scales": scales, "rotations": rotations,
+        "opacities": opacities, "colors": colors, "bg": bg,
+    }
+
+
+def free_view_cameras(n_views: int = 8, img: int = 1024, focal: float = 1100.0, dist: float = 2.5) -> List[Dict[str, object]]:
+    cams = []
+    for i in range(n_views):
+        rot_Y = i / float(n_views) * 2.0 * math.pi
+        extr = cam.calc_free_mv(np.zeros(3, f32), tar_pos=(0.0, 0.0, dist), rot_Y=rot_Y)
+        intr = np.array([[focal, 0, img / 2], [0, focal, img / 2], [0, 0, 1]], f32)
+        cams.append({"extr": extr, "intr": intr, "img_w": img, "img_h": img})
+    return cams

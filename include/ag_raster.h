@@ -1,0 +1,170 @@
+/*
+ * ag_raster.h — C ABI of the MI355X-native depth+alpha Gaussian rasterizer (libag_hip.so).
+ *
+ * Drop-in boundary for the reference's native rasterizer extension
+ *   gaussians/diff_gaussian_rasterization_depth_alpha/ext.cpp:15-19 (pybind module `_C`)
+ *   .../rasterize_points.h:17-69 / rasterize_points.cu:35-229  (RasterizeGaussiansCUDA,
+ *                                                               RasterizeGaussiansBackwardCUDA, markVisible)
+ *   .../cuda_rasterizer/rasterizer.h:20-90 (CudaRasterizer::Rasterizer::forward/backward/markVisible)
+ *
+ * Plain C: device pointers, sizes, scalars; no torch / pybind types.  All pointers are DEVICE pointers unless
+ * a name ends in `_host`.  Every float array is fp32, contiguous, laid out exactly as the reference's tensors
+ * (means3D [P,3], scales [P,3], rotations [P,4] as (r,x,y,z), opacities [P], colors [P,3], cov3D [P,6],
+ *  viewmatrix/projmatrix: 16 floats, element (i,j) of the TRANSPOSED matrix at 4*i+j, i.e. what
+ *  gaussian_renderer.py:49-51 uploads).  Images are CHW ([3,H,W], [1,H,W]).
+ *
+ * Scratch memory is owned by the caller (torch uint8 tensors in the Python host) and opaque: its layout is
+ * private to the library (ag_raster_describe_scratch exposes it for the parity tests only).  The three buffers
+ * play the roles of the reference's geomBuffer / binningBuffer / imgBuffer (rasterize_points.cu:73-80) and, like
+ * there, must be handed unchanged to the backward call.
+ *
+ * `stream` is a hipStream_t passed as void* (NULL = the null stream).  Functions return 0 on success or a
+ * negative AG_ERR_* code; ag_last_error() describes the most recent failure on the calling thread.
+ */
+#ifndef AG_RASTER_H
+#define AG_RASTER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AG_ABI_VERSION 1
+
+#define AG_OK 0
+#define AG_ERR_INVALID_ARGUMENT (-1)
+#define AG_ERR_SCRATCH_TOO_SMALL (-2)
+#define AG_ERR_HIP (-3)
+#define AG_ERR_UNSUPPORTED (-4)
+
+#define AG_TILE_X 16 /* cuda_rasterizer/config.h:16-17 — baked into the bit-exact tile/sort indices */
+#define AG_TILE_Y 16
+
+typedef struct AgRasterForwardArgs {
+    /* ---- problem ---- */
+    int32_t P;              /* number of Gaussians (means3D.size(0)) */
+    int32_t W, H;           /* image_width, image_height */
+    int32_t sh_degree;      /* active SH degree D (0..3); ignored when colors_precomp != NULL */
+    int32_t sh_coeffs;      /* M = shs.size(1); 0 when shs == NULL */
+    int32_t prefiltered;    /* reference flag; a culled Gaussian with prefiltered != 0 is an error there, ignored here */
+    float tan_fovx, tan_fovy;
+    float scale_modifier;
+    /* ---- inputs ---- */
+    const float* bg;             /* [3] */
+    const float* means3D;        /* [P,3] */
+    const float* colors_precomp; /* [P,3] or NULL */
+    const float* shs;            /* [P,M,3] or NULL */
+    const float* opacities;      /* [P] */
+    const float* scales;         /* [P,3] or NULL (then cov3D_precomp) */
+    const float* rotations;      /* [P,4] or NULL */
+    const float* cov3D_precomp;  /* [P,6] or NULL */
+    const float* viewmatrix;     /* [16] */
+    const float* projmatrix;     /* [16] */
+    const float* campos;         /* [3] */
+    /* ---- outputs (caller-allocated; need NOT be zero-filled) ---- */
+    float* out_color;            /* [3,H,W] */
+    float* out_depth;            /* [1,H,W] */
+    float* out_alpha;            /* [1,H,W] */
+    int32_t* radii;              /* [P] */
+    /* ---- scratch ---- */
+    void* geom_buffer;    size_t geom_bytes;     /* >= ag_raster_geom_bytes(P) */
+    void* image_buffer;   size_t image_bytes;    /* >= ag_raster_image_bytes(W,H) */
+    void* binning_buffer; size_t binning_bytes;  /* >= ag_raster_binning_bytes(num_rendered); only for _render */
+} AgRasterForwardArgs;
+
+typedef struct AgRasterBackwardArgs {
+    int32_t P, W, H;
+    int32_t sh_degree, sh_coeffs;
+    int32_t num_rendered;        /* R returned by the forward */
+    float tan_fovx, tan_fovy;
+    float scale_modifier;
+    const float* bg;
+    const float* means3D;
+    const int32_t* radii;        /* forward output */
+    const float* colors_precomp;
+    const float* shs;
+    const float* scales;
+    const float* rotations;
+    const float* cov3D_precomp;
+    const float* viewmatrix;
+    const float* projmatrix;
+    const float* campos;
+    const float* alphas;         /* forward out_alpha [1,H,W] */
+    const float* dL_dout_color;  /* [3,H,W] */
+    const float* dL_dout_depth;  /* [1,H,W] */
+    const float* dL_dout_alpha;  /* [1,H,W] */
+    const void* geom_buffer;
+    const void* image_buffer;
+    const void* binning_buffer;
+    /* ---- outputs (caller-allocated, need NOT be zero-filled; every element is written) ---- */
+    float* dL_dmeans2D;   /* [P,3] (x,y in NDC-scaled units, z = 0)   rasterize_points.cu:159 */
+    float* dL_dcolors;    /* [P,3] */
+    float* dL_dopacity;   /* [P,1] */
+    float* dL_dmeans3D;   /* [P,3] */
+    float* dL_dcov3D;     /* [P,6] */
+    float* dL_dsh;        /* [P,M,3] or NULL when M == 0 */
+    float* dL_dscales;    /* [P,3] */
+    float* dL_drotations; /* [P,4] */
+    /* ---- scratch: per-Gaussian accumulators of the blend backward (dL_dconic, dL_ddepths, ...) ---- */
+    void* accum_buffer; size_t accum_bytes;      /* >= ag_raster_accum_bytes(P) */
+} AgRasterBackwardArgs;
+
+/* Byte offsets of the private scratch sub-arrays, for the parity tests (tests/ only). */
+typedef struct AgRasterScratchLayout {
+    /* geom_buffer */
+    size_t geom_rec_off;      size_t geom_rec_stride;   /* per-Gaussian record: x,y,conic a,b,c,opacity,r,g,b,depth,r2cut,pad (floats) */
+    size_t geom_cov3d_off;                               /* [P,6] float */
+    size_t geom_tiles_touched_off;                       /* [P] u32 */
+    /* image_buffer */
+    size_t img_ranges_off;                               /* [T,2] u32 */
+    size_t img_n_contrib_off;                            /* [H*W] u32 */
+    size_t img_tile_count_off;                           /* [T] u32 */
+    size_t img_num_rendered_off;                         /* u32 */
+    /* binning_buffer */
+    size_t bin_point_list_off;                           /* [R] u32, sorted */
+    size_t bin_keys_off;                                 /* [R] u64 (depth_bits<<32 | gaussian index), sorted per tile */
+} AgRasterScratchLayout;
+
+int ag_abi_version(void);
+const char* ag_last_error(void);
+
+size_t ag_raster_geom_bytes(int32_t P);
+size_t ag_raster_image_bytes(int32_t W, int32_t H);
+size_t ag_raster_binning_bytes(int32_t num_rendered);
+size_t ag_raster_accum_bytes(int32_t P);
+int ag_raster_describe_scratch(int32_t P, int32_t W, int32_t H, int32_t num_rendered, AgRasterScratchLayout* out);
+
+/*
+ * Forward, stage 1 (replaces forward.cu preprocess + the InclusiveSum + the blocking D2H read of
+ * num_rendered, rasterizer_impl.cu:249-282): per-Gaussian projection/covariance/tile rect, per-tile counts and
+ * their scan.  Blocks until the number of (Gaussian, tile) instances is known and stores it in
+ * *num_rendered_host.  P == 0 is legal (returns 0 instances and touches nothing).
+ */
+int ag_raster_forward_plan(const AgRasterForwardArgs* args, void* stream, int32_t* num_rendered_host);
+
+/*
+ * Forward, stage 2 (replaces duplicateWithKeys + SortPairs + identifyTileRanges + renderCUDA,
+ * rasterizer_impl.cu:284-337): bins instances per tile, depth-sorts every tile list (ties by Gaussian index,
+ * identical to the reference's stable (tile|depth) sort), blends.  Asynchronous on `stream`.
+ */
+int ag_raster_forward_render(const AgRasterForwardArgs* args, int32_t num_rendered, void* stream);
+
+/* Backward (replaces CudaRasterizer::Rasterizer::backward, rasterizer_impl.cu:341-446).  Asynchronous. */
+int ag_raster_backward(const AgRasterBackwardArgs* args, void* stream);
+
+/* mark_visible (rasterize_points.cu:210-229, rasterizer_impl.cu:54-66,141-152): present[i] = view-space z > 0.2 */
+int ag_raster_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                           uint8_t* present, void* stream);
+
+/*
+ * Test hook (tests/ only): runs the wave64 transposed butterfly reduction used by the blend backward on one
+ * wavefront.  in: [64 lanes][16 values] floats, out: [64] floats; out[l] = sum over lanes of in[.][(l >> 2) & 15].
+ */
+int ag_debug_wave_reduce16(const float* in, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AG_RASTER_H */

@@ -1,0 +1,670 @@
+/*
+ * raster_oracle.c — CPU restatement of the reference rasterizer.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+ * The product path (animatablegaussians_amd/) never links, imports or calls it.
+ *
+ * It restates, in plain scalar C, the algorithm of
+ *   gaussians/diff_gaussian_rasterization_depth_alpha/cuda_rasterizer/forward.cu      (preprocess :155-256, blend :261-381)
+ *   .../cuda_rasterizer/backward.cu     (cov2D bwd :144-274, cov3D bwd :278-341, preprocess bwd :346-412, blend bwd :415-601)
+ *   .../cuda_rasterizer/rasterizer_impl.cu (getHigherMsb :35-50, duplicateWithKeys :70-111, identifyTileRanges :116-138,
+ *                                           forward orchestration :197-339)
+ *   .../cuda_rasterizer/auxiliary.h     (ndc2Pix :41-44, getRect :46-56, transformPoint* :58-97, in_frustum :137-164)
+ * with one explicit fp32 evaluation order: every expression is evaluated left-to-right exactly as written in
+ * the reference, with NO fused multiply-add contraction (build with -ffp-contract=off).  GLM's column-major
+ * mat3 product order (third_party/glm/glm/detail/type_mat3x3.inl operator*) is mirrored by m3_mul below.
+ *
+ * Pinning: the reference ships no tests/golden vectors.  This restatement is pinned against the
+ * reference's own .cu sources executed on the CPU through oracle/_ref (see oracle/ref_build.py and
+ * tests/test_oracle_vs_ref.py); the golden fixtures under tests/golden/ were produced by that build.
+ *
+ * Colours-precomputed path only (sh_degree 0, shs = None is the only configuration AnimatableGaussians uses:
+ * gaussians/gaussian_renderer.py:26,63-66,84).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define BLOCK_X 16
+#define BLOCK_Y 16
+#define BLOCK_SIZE (BLOCK_X * BLOCK_Y)
+
+/* ---- tiny column-major 3x3 helper mirroring GLM's evaluation order: m[col][row] ---- */
+typedef struct { float m[3][3]; } mat3;
+
+static mat3 m3_cols(float a, float b, float c, float d, float e, float f, float g, float h, float i)
+{
+    /* glm::mat3(a,b,c, d,e,f, g,h,i): first three scalars form column 0 */
+    mat3 r;
+    r.m[0][0] = a; r.m[0][1] = b; r.m[0][2] = c;
+    r.m[1][0] = d; r.m[1][1] = e; r.m[1][2] = f;
+    r.m[2][0] = g; r.m[2][1] = h; r.m[2][2] = i;
+    return r;
+}
+
+static mat3 m3_mul(mat3 a, mat3 b)
+{
+    /* Result[c][r] = a[0][r]*b[c][0] + a[1][r]*b[c][1] + a[2][r]*b[c][2], summed left to right */
+    mat3 r;
+    for (int c = 0; c < 3; c++)
+        for (int q = 0; q < 3; q++)
+            r.m[c][q] = a.m[0][q] * b.m[c][0] + a.m[1][q] * b.m[c][1] + a.m[2][q] * b.m[c][2];
+    return r;
+}
+
+static mat3 m3_transpose(mat3 a)
+{
+    mat3 r;
+    for (int c = 0; c < 3; c++)
+        for (int q = 0; q < 3; q++)
+            r.m[c][q] = a.m[q][c];
+    return r;
+}
+
+static mat3 m3_scale(float s, mat3 a)
+{
+    mat3 r;
+    for (int c = 0; c < 3; c++)
+        for (int q = 0; q < 3; q++)
+            r.m[c][q] = s * a.m[c][q];   /* glm: scalar * mat -> m[i] * s; multiplication commutes bitwise */
+    return r;
+}
+
+static float fminf_(float a, float b) { return a < b ? a : b; }   /* CUDA min(float,float) for non-NaN inputs */
+static float fmaxf_(float a, float b) { return a > b ? a : b; }
+
+/* auxiliary.h:58-78 */
+static void transform_point_4x3(const float p[3], const float* m, float out[3])
+{
+    out[0] = m[0] * p[0] + m[4] * p[1] + m[8] * p[2] + m[12];
+    out[1] = m[1] * p[0] + m[5] * p[1] + m[9] * p[2] + m[13];
+    out[2] = m[2] * p[0] + m[6] * p[1] + m[10] * p[2] + m[14];
+}
+
+static void transform_point_4x4(const float p[3], const float* m, float out[4])
+{
+    out[0] = m[0] * p[0] + m[4] * p[1] + m[8] * p[2] + m[12];
+    out[1] = m[1] * p[0] + m[5] * p[1] + m[9] * p[2] + m[13];
+    out[2] = m[2] * p[0] + m[6] * p[1] + m[10] * p[2] + m[14];
+    out[3] = m[3] * p[0] + m[7] * p[1] + m[11] * p[2] + m[15];
+}
+
+/* auxiliary.h:41-44: evaluated in double, narrowed on return */
+static float ndc2pix(float v, int S)
+{
+    return (float)((((double)v + 1.0) * (double)S - 1.0) * 0.5);
+}
+
+/* auxiliary.h:46-56.  max_radius is an int parameter (float radius is converted by the caller). */
+static void get_rect(float px, float py, int max_radius, int gx, int gy, uint32_t rmin[2], uint32_t rmax[2])
+{
+    float r = (float)max_radius;
+    int x0 = (int)((px - r) / (float)BLOCK_X);
+    int y0 = (int)((py - r) / (float)BLOCK_Y);
+    int x1 = (int)((px + r + (float)BLOCK_X - (float)1) / (float)BLOCK_X);
+    int y1 = (int)((py + r + (float)BLOCK_Y - (float)1) / (float)BLOCK_Y);
+    if (x0 < 0) x0 = 0;
+    if (y0 < 0) y0 = 0;
+    if (x1 < 0) x1 = 0;
+    if (y1 < 0) y1 = 0;
+    rmin[0] = (uint32_t)(x0 < gx ? x0 : gx);
+    rmin[1] = (uint32_t)(y0 < gy ? y0 : gy);
+    rmax[0] = (uint32_t)(x1 < gx ? x1 : gx);
+    rmax[1] = (uint32_t)(y1 < gy ? y1 : gy);
+}
+
+/* forward.cu:116-152 (quaternion deliberately NOT normalised, :127) */
+static void compute_cov3d(const float scale[3], float mod, const float rot[4], float cov3D[6])
+{
+    mat3 S = m3_cols(1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f);
+    S.m[0][0] = mod * scale[0];
+    S.m[1][1] = mod * scale[1];
+    S.m[2][2] = mod * scale[2];
+    float r = rot[0], x = rot[1], y = rot[2], z = rot[3];
+    mat3 R = m3_cols(
+        1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y),
+        2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x),
+        2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y));
+    mat3 M = m3_mul(S, R);
+    mat3 Sigma = m3_mul(m3_transpose(M), M);
+    cov3D[0] = Sigma.m[0][0];
+    cov3D[1] = Sigma.m[0][1];
+    cov3D[2] = Sigma.m[0][2];
+    cov3D[3] = Sigma.m[1][1];
+    cov3D[4] = Sigma.m[1][2];
+    cov3D[5] = Sigma.m[2][2];
+}
+
+/* forward.cu:74-113 */
+static void compute_cov2d(const float mean[3], float focal_x, float focal_y, float tan_fovx, float tan_fovy,
+                          const float* cov3D, const float* view, float cov[3])
+{
+    float t[3];
+    transform_point_4x3(mean, view, t);
+    const float limx = 1.3f * tan_fovx;
+    const float limy = 1.3f * tan_fovy;
+    const float txtz = t[0] / t[2];
+    const float tytz = t[1] / t[2];
+    t[0] = fminf_(limx, fmaxf_(-limx, txtz)) * t[2];
+    t[1] = fminf_(limy, fmaxf_(-limy, tytz)) * t[2];
+
+    mat3 J = m3_cols(
+        focal_x / t[2], 0.0f, -(focal_x * t[0]) / (t[2] * t[2]),
+        0.0f, focal_y / t[2], -(focal_y * t[1]) / (t[2] * t[2]),
+        0, 0, 0);
+    mat3 Wm = m3_cols(
+        view[0], view[4], view[8],
+        view[1], view[5], view[9],
+        view[2], view[6], view[10]);
+    mat3 T = m3_mul(Wm, J);
+    mat3 Vrk = m3_cols(
+        cov3D[0], cov3D[1], cov3D[2],
+        cov3D[1], cov3D[3], cov3D[4],
+        cov3D[2], cov3D[4], cov3D[5]);
+    mat3 c = m3_mul(m3_mul(m3_transpose(T), m3_transpose(Vrk)), T);
+    c.m[0][0] += 0.3f;
+    c.m[1][1] += 0.3f;
+    cov[0] = c.m[0][0];
+    cov[1] = c.m[0][1];
+    cov[2] = c.m[1][1];
+}
+
+/* rasterizer_impl.cu:35-50 */
+uint32_t ago_get_higher_msb(uint32_t n)
+{
+    uint32_t msb = sizeof(n) * 4;
+    uint32_t step = msb;
+    while (step > 1) {
+        step /= 2;
+        if (n >> msb) msb += step;
+        else msb -= step;
+    }
+    if (n >> msb) msb++;
+    return msb;
+}
+
+/*
+ * Stage 1: per-Gaussian preprocess (forward.cu:155-256) + inclusive scan of tiles_touched
+ * (rasterizer_impl.cu:278).  Returns num_rendered (= point_offsets[P-1]).
+ * Outputs are zero-initialised here the way the wrapper/chunk would leave untouched entries
+ * (radii 0, tiles_touched 0; the other per-Gaussian slots are left 0 for culled Gaussians).
+ */
+int ago_preprocess(int P, int W, int H,
+                   const float* means3D, const float* scales, float scale_modifier, const float* rotations,
+                   const float* opacities, const float* cov3D_precomp,
+                   const float* view, const float* proj, float tan_fovx, float tan_fovy,
+                   int* radii, float* means2D, float* depths, float* cov3Ds, float* conic_opacity,
+                   uint32_t* tiles_touched, uint32_t* point_offsets)
+{
+    const float focal_y = H / (2.0f * tan_fovy);   /* rasterizer_impl.cu:223-224 */
+    const float focal_x = W / (2.0f * tan_fovx);
+    const int gx = (W + BLOCK_X - 1) / BLOCK_X, gy = (H + BLOCK_Y - 1) / BLOCK_Y;
+
+    for (int idx = 0; idx < P; idx++) {
+        radii[idx] = 0;
+        tiles_touched[idx] = 0;
+        means2D[2 * idx] = means2D[2 * idx + 1] = 0.f;
+        depths[idx] = 0.f;
+        for (int k = 0; k < 6; k++) cov3Ds[6 * idx + k] = 0.f;
+        for (int k = 0; k < 4; k++) conic_opacity[4 * idx + k] = 0.f;
+
+        const float* p_orig = means3D + 3 * idx;
+        /* in_frustum, auxiliary.h:137-164: near-plane cull only */
+        float p_view[3];
+        transform_point_4x3(p_orig, view, p_view);
+        if (p_view[2] <= 0.2f) continue;
+
+        float p_hom[4];
+        transform_point_4x4(p_orig, proj, p_hom);
+        float p_w = 1.0f / (p_hom[3] + 0.0000001f);
+        float p_proj[3] = { p_hom[0] * p_w, p_hom[1] * p_w, p_hom[2] * p_w };
+
+        const float* cov3D;
+        if (cov3D_precomp) {
+            cov3D = cov3D_precomp + 6 * idx;
+            /* the reference leaves geomState.cov3D untouched in this case; we mirror the precomputed values */
+            for (int k = 0; k < 6; k++) cov3Ds[6 * idx + k] = cov3D[k];
+        } else {
+            compute_cov3d(scales + 3 * idx, scale_modifier, rotations + 4 * idx, cov3Ds + 6 * idx);
+            cov3D = cov3Ds + 6 * idx;
+        }
+
+        float cov[3];
+        compute_cov2d(p_orig, focal_x, focal_y, tan_fovx, tan_fovy, cov3D, view, cov);
+
+        float det = (cov[0] * cov[2] - cov[1] * cov[1]);
+        if (det == 0.0f) continue;
+        float det_inv = 1.f / det;
+        float conic[3] = { cov[2] * det_inv, -cov[1] * det_inv, cov[0] * det_inv };
+
+        float mid = 0.5f * (cov[0] + cov[2]);
+        float lambda1 = mid + sqrtf(fmaxf_(0.1f, mid * mid - det));
+        float lambda2 = mid - sqrtf(fmaxf_(0.1f, mid * mid - det));
+        float my_radius = ceilf(3.f * sqrtf(fmaxf_(lambda1, lambda2)));
+        float px = ndc2pix(p_proj[0], W), py = ndc2pix(p_proj[1], H);
+        uint32_t rmin[2], rmax[2];
+        get_rect(px, py, (int)my_radius, gx, gy, rmin, rmax);
+        if ((rmax[0] - rmin[0]) * (rmax[1] - rmin[1]) == 0) continue;
+
+        depths[idx] = p_view[2];
+        radii[idx] = (int)my_radius;
+        means2D[2 * idx] = px;
+        means2D[2 * idx + 1] = py;
+        conic_opacity[4 * idx + 0] = conic[0];
+        conic_opacity[4 * idx + 1] = conic[1];
+        conic_opacity[4 * idx + 2] = conic[2];
+        conic_opacity[4 * idx + 3] = opacities[idx];
+        tiles_touched[idx] = (rmax[1] - rmin[1]) * (rmax[0] - rmin[0]);
+    }
+    uint32_t acc = 0;
+    for (int idx = 0; idx < P; idx++) { acc += tiles_touched[idx]; point_offsets[idx] = acc; }
+    return P > 0 ? (int)point_offsets[P - 1] : 0;
+}
+
+/* mark_visible / checkFrustum (rasterizer_impl.cu:54-66) */
+void ago_mark_visible(int P, const float* means3D, const float* view, const float* proj, uint8_t* present)
+{
+    (void)proj;
+    for (int idx = 0; idx < P; idx++) {
+        float p_view[3];
+        transform_point_4x3(means3D + 3 * idx, view, p_view);
+        present[idx] = (p_view[2] <= 0.2f) ? 0 : 1;
+    }
+}
+
+/*
+ * Stage 2: duplicateWithKeys (rasterizer_impl.cu:70-111), stable LSD radix sort over bits [0, 32+bit)
+ * (cub::DeviceRadixSort::SortPairs call site :304-309) and identifyTileRanges (:116-138, after the
+ * memset of ranges :311).  R = num_rendered from stage 1.
+ */
+void ago_bin(int P, int W, int H, int R,
+             const float* means2D, const float* depths, const uint32_t* point_offsets, const int* radii,
+             uint64_t* keys_unsorted, uint32_t* vals_unsorted, uint64_t* keys_sorted, uint32_t* point_list,
+             uint32_t* ranges /* [tiles][2] */)
+{
+    const int gx = (W + BLOCK_X - 1) / BLOCK_X, gy = (H + BLOCK_Y - 1) / BLOCK_Y;
+    for (int idx = 0; idx < P; idx++) {
+        if (radii[idx] > 0) {
+            uint32_t off = (idx == 0) ? 0 : point_offsets[idx - 1];
+            uint32_t rmin[2], rmax[2];
+            get_rect(means2D[2 * idx], means2D[2 * idx + 1], radii[idx], gx, gy, rmin, rmax);
+            uint32_t dbits;
+            memcpy(&dbits, depths + idx, 4);
+            for (uint32_t y = rmin[1]; y < rmax[1]; y++)
+                for (uint32_t x = rmin[0]; x < rmax[0]; x++) {
+                    uint64_t key = (uint64_t)(y * (uint32_t)gx + x);
+                    key <<= 32;
+                    key |= dbits;
+                    keys_unsorted[off] = key;
+                    vals_unsorted[off] = (uint32_t)idx;
+                    off++;
+                }
+        }
+    }
+
+    /* stable LSD radix sort, 8-bit digits, only bits [0, 32+bit) participate */
+    const int end_bit = 32 + (int)ago_get_higher_msb((uint32_t)(gx * gy));
+    uint64_t* ka = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)(R > 0 ? R : 1));
+    uint32_t* va = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)(R > 0 ? R : 1));
+    uint64_t* kb = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)(R > 0 ? R : 1));
+    uint32_t* vb = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)(R > 0 ? R : 1));
+    memcpy(ka, keys_unsorted, sizeof(uint64_t) * (size_t)R);
+    memcpy(va, vals_unsorted, sizeof(uint32_t) * (size_t)R);
+    for (int shift = 0; shift < end_bit; shift += 8) {
+        int nbits = end_bit - shift < 8 ? end_bit - shift : 8;
+        uint32_t mask = (1u << nbits) - 1u;
+        size_t hist[257];
+        memset(hist, 0, sizeof(hist));
+        for (int i = 0; i < R; i++) hist[((ka[i] >> shift) & mask) + 1]++;
+        for (int d = 0; d < 256; d++) hist[d + 1] += hist[d];
+        for (int i = 0; i < R; i++) {
+            size_t dst = hist[(ka[i] >> shift) & mask]++;
+            kb[dst] = ka[i];
+            vb[dst] = va[i];
+        }
+        uint64_t* tk = ka; ka = kb; kb = tk;
+        uint32_t* tv = va; va = vb; vb = tv;
+    }
+    memcpy(keys_sorted, ka, sizeof(uint64_t) * (size_t)R);
+    memcpy(point_list, va, sizeof(uint32_t) * (size_t)R);
+    free(ka); free(va); free(kb); free(vb);
+
+    memset(ranges, 0, sizeof(uint32_t) * 2 * (size_t)(gx * gy));
+    for (int idx = 0; idx < R; idx++) {
+        uint32_t currtile = (uint32_t)(keys_sorted[idx] >> 32);
+        if (idx == 0) ranges[2 * currtile] = 0;
+        else {
+            uint32_t prevtile = (uint32_t)(keys_sorted[idx - 1] >> 32);
+            if (currtile != prevtile) {
+                ranges[2 * prevtile + 1] = (uint32_t)idx;
+                ranges[2 * currtile] = (uint32_t)idx;
+            }
+        }
+        if (idx == R - 1) ranges[2 * currtile + 1] = (uint32_t)R;
+    }
+}
+
+/*
+ * Stage 3: per-tile front-to-back blend (forward.cu:261-381).  One pixel at a time; the block-level
+ * batching/`done` voting of the CUDA kernel does not change any per-pixel result.
+ * `fragile` (may be NULL) is test infrastructure: it flags pixels where a discrete decision of the blend
+ * (power > 0, alpha < 1/255, T*(1-alpha) < 1e-4) sat within rounding distance of its threshold, so a
+ * different-but-valid exp()/rounding could legitimately flip it.
+ */
+void ago_render_forward(int W, int H, const uint32_t* ranges, const uint32_t* point_list,
+                        const float* means2D, const float* colors, const float* depths, const float* conic_opacity,
+                        const float* bg, float* out_color, float* out_depth, float* out_alpha,
+                        uint32_t* n_contrib, uint8_t* fragile)
+{
+    const int gx = (W + BLOCK_X - 1) / BLOCK_X, gy = (H + BLOCK_Y - 1) / BLOCK_Y;
+#pragma omp parallel for collapse(2) schedule(dynamic, 1)
+    for (int ty = 0; ty < gy; ty++)
+        for (int tx = 0; tx < gx; tx++) {
+            const uint32_t r0 = ranges[2 * (ty * gx + tx)], r1 = ranges[2 * (ty * gx + tx) + 1];
+            for (int ly = 0; ly < BLOCK_Y; ly++)
+                for (int lx = 0; lx < BLOCK_X; lx++) {
+                    const int pxi = tx * BLOCK_X + lx, pyi = ty * BLOCK_Y + ly;
+                    if (pxi >= W || pyi >= H) continue;
+                    const int pix_id = W * pyi + pxi;
+                    const float pixfx = (float)pxi, pixfy = (float)pyi;
+                    float T = 1.0f;
+                    uint32_t contributor = 0, last_contributor = 0;
+                    float C[3] = { 0, 0, 0 };
+                    float weight = 0, D = 0;
+                    uint8_t frag = 0;
+                    for (uint32_t k = r0; k < r1; k++) {
+                        contributor++;
+                        const uint32_t id = point_list[k];
+                        const float dx = means2D[2 * id] - pixfx, dy = means2D[2 * id + 1] - pixfy;
+                        const float* co = conic_opacity + 4 * id;
+                        const float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                        if (fabsf(power) < 1e-6f) frag = 1;
+                        if (power > 0.0f) continue;
+                        const float alpha = fminf_(0.99f, co[3] * expf(power));
+                        if (fabsf(alpha * 255.0f - 1.0f) < 1e-4f) frag = 1;
+                        if (alpha < 1.0f / 255.0f) continue;
+                        const float test_T = T * (1 - alpha);
+                        if (fabsf(test_T * 10000.0f - 1.0f) < 1e-3f) frag = 1;
+                        if (test_T < 0.0001f) break;   /* done = true: nothing further can change this pixel */
+                        for (int ch = 0; ch < 3; ch++) C[ch] += colors[3 * id + ch] * alpha * T;
+                        weight += alpha * T;
+                        D += depths[id] * alpha * T;
+                        T = test_T;
+                        last_contributor = contributor;
+                    }
+                    n_contrib[pix_id] = last_contributor;
+                    for (int ch = 0; ch < 3; ch++) out_color[ch * H * W + pix_id] = C[ch] + T * bg[ch];
+                    out_alpha[pix_id] = weight;
+                    out_depth[pix_id] = D;
+                    if (fragile) fragile[pix_id] = frag;
+                }
+        }
+}
+
+/*
+ * Backward blend (backward.cu:415-601).  Every per-(pixel, Gaussian) term is computed in fp32 exactly as the
+ * reference writes it; the per-Gaussian SUMS of those terms (float atomicAdd in the CUDA kernel, in an
+ * unspecified order) are accumulated here in tile-major, pixel-row-major, back-to-front order, either
+ *   f32_accum != 0: in fp32, one rounding per add (one admissible order of the reference's atomics), or
+ *   f32_accum == 0: in fp64 (the order-independent limit every admissible order scatters around).
+ * abs_sum (may be NULL, [P,10] floats in AccumSlot order m2x,m2y,conx,cony,conw,opac,r,g,b,depth) receives
+ * sum |term|: eps_fp32 * abs_sum bounds how far two admissible summation orders can differ.
+ * dL_dmean2D is [P,3] (z untouched), dL_dconic is [P,4] (x,y,.,w used), others as in the reference.
+ */
+#define ACC(dst, term) do { double t_ = (double)(term); \
+        (dst) = f32_accum ? (double)(float)((float)(dst) + (float)t_) : (dst) + t_; } while (0)
+void ago_render_backward(int P, int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* bg,
+                         const float* means2D, const float* conic_opacity, const float* colors, const float* depths,
+                         const float* alphas, const uint32_t* n_contrib,
+                         const float* dL_dpixels, const float* dL_dpixel_depths, const float* dL_dalphas,
+                         float* dL_dmean2D, float* dL_dconic2D, float* dL_dopacity, float* dL_dcolors,
+                         float* dL_ddepths, float* abs_sum, int f32_accum)
+{
+    const int gx = (W + BLOCK_X - 1) / BLOCK_X, gy = (H + BLOCK_Y - 1) / BLOCK_Y;
+    const float ddelx_dx = (float)(0.5 * W);
+    const float ddely_dy = (float)(0.5 * H);
+    double* acc = (double*)calloc((size_t)(P > 0 ? P : 1) * 10, sizeof(double));
+    double* aabs = (double*)calloc((size_t)(P > 0 ? P : 1) * 10, sizeof(double));
+    for (int ty = 0; ty < gy; ty++)
+        for (int tx = 0; tx < gx; tx++) {
+            const uint32_t r0 = ranges[2 * (ty * gx + tx)], r1 = ranges[2 * (ty * gx + tx) + 1];
+            for (int ly = 0; ly < BLOCK_Y; ly++)
+                for (int lx = 0; lx < BLOCK_X; lx++) {
+                    const int pxi = tx * BLOCK_X + lx, pyi = ty * BLOCK_Y + ly;
+                    if (pxi >= W || pyi >= H) continue;
+                    const int pix_id = W * pyi + pxi;
+                    const float pixfx = (float)pxi, pixfy = (float)pyi;
+                    const float T_final = 1 - alphas[pix_id];
+                    float T = T_final;
+                    uint32_t contributor = r1 - r0;
+                    const uint32_t last_contributor = n_contrib[pix_id];
+                    float accum_rec[3] = { 0, 0, 0 };
+                    float dL_dpixel[3];
+                    for (int i = 0; i < 3; i++) dL_dpixel[i] = dL_dpixels[i * H * W + pix_id];
+                    const float dL_dpixel_depth = dL_dpixel_depths[pix_id];
+                    const float dL_dalpha = dL_dalphas[pix_id];
+                    float accum_depth_rec = 0, accum_alpha_rec = 0;
+                    float last_alpha = 0, last_color[3] = { 0, 0, 0 }, last_depth = 0;
+                    for (uint32_t k = r1; k-- > r0;) {
+                        contributor--;
+                        if (contributor >= last_contributor) continue;
+                        const uint32_t id = point_list[k];
+                        const float dx = means2D[2 * id] - pixfx, dy = means2D[2 * id + 1] - pixfy;
+                        const float* co = conic_opacity + 4 * id;
+                        const float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                        if (power > 0.0f) continue;
+                        const float G = expf(power);
+                        const float alpha = fminf_(0.99f, co[3] * G);
+                        if (alpha < 1.0f / 255.0f) continue;
+                        T = T / (1.f - alpha);
+                        const float dchannel_dcolor = alpha * T;
+                        const float dpixel_depth_ddepth = alpha * T;
+                        float dL_dopa = 0.0f;
+                        float term[10];
+                        for (int ch = 0; ch < 3; ch++) {
+                            const float c = colors[3 * id + ch];
+                            accum_rec[ch] = last_alpha * last_color[ch] + (1.f - last_alpha) * accum_rec[ch];
+                            last_color[ch] = c;
+                            const float dL_dchannel = dL_dpixel[ch];
+                            dL_dopa += (c - accum_rec[ch]) * dL_dchannel;
+                            term[6 + ch] = dchannel_dcolor * dL_dchannel;
+                        }
+                        const float c_d = depths[id];
+                        accum_depth_rec = last_alpha * last_depth + (1.f - last_alpha) * accum_depth_rec;
+                        last_depth = c_d;
+                        dL_dopa += (c_d - accum_depth_rec) * dL_dpixel_depth;
+                        term[9] = dpixel_depth_ddepth * dL_dpixel_depth;
+                        accum_alpha_rec = last_alpha + (1.f - last_alpha) * accum_alpha_rec;
+                        dL_dopa += (1 - accum_alpha_rec) * dL_dalpha;
+                        dL_dopa *= T;
+                        last_alpha = alpha;
+                        float bg_dot_dpixel = 0;
+                        for (int i = 0; i < 3; i++) bg_dot_dpixel += bg[i] * dL_dpixel[i];
+                        dL_dopa += (-T_final / (1.f - alpha)) * bg_dot_dpixel;
+                        const float dL_dG = co[3] * dL_dopa;
+                        const float gdx = G * dx;
+                        const float gdy = G * dy;
+                        const float dG_ddelx = -gdx * co[0] - gdy * co[1];
+                        const float dG_ddely = -gdy * co[2] - gdx * co[1];
+                        term[0] = dL_dG * dG_ddelx * ddelx_dx;
+                        term[1] = dL_dG * dG_ddely * ddely_dy;
+                        term[2] = -0.5f * gdx * dx * dL_dG;
+                        term[3] = -0.5f * gdx * dy * dL_dG;
+                        term[4] = -0.5f * gdy * dy * dL_dG;
+                        term[5] = G * dL_dopa;
+                        for (int q = 0; q < 10; q++) {
+                            ACC(acc[10 * (size_t)id + q], term[q]);
+                            aabs[10 * (size_t)id + q] += fabs((double)term[q]);
+                        }
+                    }
+                }
+        }
+    for (int id = 0; id < P; id++) {
+        const double* a = acc + 10 * (size_t)id;
+        dL_dmean2D[3 * id + 0] += (float)a[0];
+        dL_dmean2D[3 * id + 1] += (float)a[1];
+        dL_dconic2D[4 * id + 0] += (float)a[2];
+        dL_dconic2D[4 * id + 1] += (float)a[3];
+        dL_dconic2D[4 * id + 3] += (float)a[4];
+        dL_dopacity[id] += (float)a[5];
+        for (int ch = 0; ch < 3; ch++) dL_dcolors[3 * id + ch] += (float)a[6 + ch];
+        dL_ddepths[id] += (float)a[9];
+        if (abs_sum)
+            for (int q = 0; q < 10; q++) abs_sum[10 * (size_t)id + q] = (float)aabs[10 * (size_t)id + q];
+    }
+    free(acc);
+    free(aabs);
+}
+#undef ACC
+
+/* backward.cu:278-341: dL/dcov3D -> dL/dscale, dL/drot (raw quaternion, no normalisation gradient :340) */
+static void compute_cov3d_backward(const float scale[3], float mod, const float rot[4], const float* dL_dcov3D,
+                                   float dL_dscale[3], float dL_drot[4])
+{
+    float r = rot[0], x = rot[1], y = rot[2], z = rot[3];
+    mat3 R = m3_cols(
+        1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y),
+        2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x),
+        2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y));
+    mat3 S = m3_cols(1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f);
+    float s[3] = { mod * scale[0], mod * scale[1], mod * scale[2] };
+    S.m[0][0] = s[0]; S.m[1][1] = s[1]; S.m[2][2] = s[2];
+    mat3 M = m3_mul(S, R);
+    mat3 dL_dSigma = m3_cols(
+        dL_dcov3D[0], 0.5f * dL_dcov3D[1], 0.5f * dL_dcov3D[2],
+        0.5f * dL_dcov3D[1], dL_dcov3D[3], 0.5f * dL_dcov3D[4],
+        0.5f * dL_dcov3D[2], 0.5f * dL_dcov3D[4], dL_dcov3D[5]);
+    mat3 dL_dM = m3_mul(m3_scale(2.0f, M), dL_dSigma);   /* 2.0f * M * dL_dSigma, left to right */
+    mat3 Rt = m3_transpose(R);
+    mat3 dL_dMt = m3_transpose(dL_dM);
+    for (int k = 0; k < 3; k++)   /* glm::dot(a,b) = a.x*b.x + a.y*b.y + a.z*b.z */
+        dL_dscale[k] = Rt.m[k][0] * dL_dMt.m[k][0] + Rt.m[k][1] * dL_dMt.m[k][1] + Rt.m[k][2] * dL_dMt.m[k][2];
+    for (int k = 0; k < 3; k++)
+        for (int q = 0; q < 3; q++) dL_dMt.m[k][q] *= s[k];
+#define D(a, b) dL_dMt.m[a][b]
+    dL_drot[0] = 2 * z * (D(0, 1) - D(1, 0)) + 2 * y * (D(2, 0) - D(0, 2)) + 2 * x * (D(1, 2) - D(2, 1));
+    dL_drot[1] = 2 * y * (D(1, 0) + D(0, 1)) + 2 * z * (D(2, 0) + D(0, 2)) + 2 * r * (D(1, 2) - D(2, 1)) - 4 * x * (D(2, 2) + D(1, 1));
+    dL_drot[2] = 2 * x * (D(1, 0) + D(0, 1)) + 2 * r * (D(2, 0) - D(0, 2)) + 2 * z * (D(1, 2) + D(2, 1)) - 4 * y * (D(2, 2) + D(0, 0));
+    dL_drot[3] = 2 * r * (D(0, 1) - D(1, 0)) + 2 * x * (D(2, 0) + D(0, 2)) + 2 * y * (D(1, 2) + D(2, 1)) - 4 * z * (D(1, 1) + D(0, 0));
+#undef D
+}
+
+/*
+ * Backward of the per-Gaussian preprocess: computeCov2DCUDA (backward.cu:144-274) followed by
+ * preprocessCUDA (backward.cu:346-412), colours-precomputed path.  Outputs must be zero-initialised by the caller
+ * (rasterize_points.cu:158-167); Gaussians with radii == 0 are skipped.
+ */
+void ago_preprocess_backward(int P, int W, int H, const float* means3D, const int* radii,
+                             const float* scales, const float* rotations, float scale_modifier,
+                             const float* cov3Ds, const float* view, const float* proj,
+                             float tan_fovx, float tan_fovy,
+                             const float* dL_dmean2D /*[P,3]*/, const float* dL_dconics /*[P,4]*/,
+                             const float* dL_ddepth /*[P]*/,
+                             float* dL_dmeans /*[P,3]*/, float* dL_dcov /*[P,6]*/,
+                             float* dL_dscale /*[P,3]*/, float* dL_drot /*[P,4]*/)
+{
+    const float h_y = H / (2.0f * tan_fovy);
+    const float h_x = W / (2.0f * tan_fovx);
+    for (int idx = 0; idx < P; idx++) {
+        if (!(radii[idx] > 0)) continue;
+        /* ---- computeCov2DCUDA ---- */
+        const float* cov3D = cov3Ds + 6 * idx;
+        const float* mean = means3D + 3 * idx;
+        float dL_dconic[3] = { dL_dconics[4 * idx], dL_dconics[4 * idx + 1], dL_dconics[4 * idx + 3] };
+        float t[3];
+        transform_point_4x3(mean, view, t);
+        const float limx = 1.3f * tan_fovx;
+        const float limy = 1.3f * tan_fovy;
+        const float txtz = t[0] / t[2];
+        const float tytz = t[1] / t[2];
+        t[0] = fminf_(limx, fmaxf_(-limx, txtz)) * t[2];
+        t[1] = fminf_(limy, fmaxf_(-limy, tytz)) * t[2];
+        const float x_grad_mul = (txtz < -limx || txtz > limx) ? 0 : 1;
+        const float y_grad_mul = (tytz < -limy || tytz > limy) ? 0 : 1;
+
+        mat3 J = m3_cols(h_x / t[2], 0.0f, -(h_x * t[0]) / (t[2] * t[2]),
+                         0.0f, h_y / t[2], -(h_y * t[1]) / (t[2] * t[2]),
+                         0, 0, 0);
+        mat3 Wm = m3_cols(view[0], view[4], view[8], view[1], view[5], view[9], view[2], view[6], view[10]);
+        mat3 Vrk = m3_cols(cov3D[0], cov3D[1], cov3D[2], cov3D[1], cov3D[3], cov3D[4], cov3D[2], cov3D[4], cov3D[5]);
+        mat3 T = m3_mul(Wm, J);
+        mat3 cov2D = m3_mul(m3_mul(m3_transpose(T), m3_transpose(Vrk)), T);
+        float a = cov2D.m[0][0] += 0.3f;
+        float b = cov2D.m[0][1];
+        float c = cov2D.m[1][1] += 0.3f;
+        float denom = a * c - b * b;
+        float dL_da = 0, dL_db = 0, dL_dc = 0;
+        float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+        if (denom2inv != 0) {
+            dL_da = denom2inv * (-c * c * dL_dconic[0] + 2 * b * c * dL_dconic[1] + (denom - a * c) * dL_dconic[2]);
+            dL_dc = denom2inv * (-a * a * dL_dconic[2] + 2 * a * b * dL_dconic[1] + (denom - a * c) * dL_dconic[0]);
+            dL_db = denom2inv * 2 * (b * c * dL_dconic[0] - (denom + 2 * b * b) * dL_dconic[1] + a * b * dL_dconic[2]);
+#define TT(i, j) T.m[i][j]
+            dL_dcov[6 * idx + 0] = (TT(0, 0) * TT(0, 0) * dL_da + TT(0, 0) * TT(1, 0) * dL_db + TT(1, 0) * TT(1, 0) * dL_dc);
+            dL_dcov[6 * idx + 3] = (TT(0, 1) * TT(0, 1) * dL_da + TT(0, 1) * TT(1, 1) * dL_db + TT(1, 1) * TT(1, 1) * dL_dc);
+            dL_dcov[6 * idx + 5] = (TT(0, 2) * TT(0, 2) * dL_da + TT(0, 2) * TT(1, 2) * dL_db + TT(1, 2) * TT(1, 2) * dL_dc);
+            dL_dcov[6 * idx + 1] = 2 * TT(0, 0) * TT(0, 1) * dL_da + (TT(0, 0) * TT(1, 1) + TT(0, 1) * TT(1, 0)) * dL_db + 2 * TT(1, 0) * TT(1, 1) * dL_dc;
+            dL_dcov[6 * idx + 2] = 2 * TT(0, 0) * TT(0, 2) * dL_da + (TT(0, 0) * TT(1, 2) + TT(0, 2) * TT(1, 0)) * dL_db + 2 * TT(1, 0) * TT(1, 2) * dL_dc;
+            dL_dcov[6 * idx + 4] = 2 * TT(0, 2) * TT(0, 1) * dL_da + (TT(0, 1) * TT(1, 2) + TT(0, 2) * TT(1, 1)) * dL_db + 2 * TT(1, 1) * TT(1, 2) * dL_dc;
+        } else {
+            for (int i = 0; i < 6; i++) dL_dcov[6 * idx + i] = 0;
+        }
+#define VV(i, j) Vrk.m[i][j]
+        float dL_dT00 = 2 * (TT(0, 0) * VV(0, 0) + TT(0, 1) * VV(0, 1) + TT(0, 2) * VV(0, 2)) * dL_da +
+                        (TT(1, 0) * VV(0, 0) + TT(1, 1) * VV(0, 1) + TT(1, 2) * VV(0, 2)) * dL_db;
+        float dL_dT01 = 2 * (TT(0, 0) * VV(1, 0) + TT(0, 1) * VV(1, 1) + TT(0, 2) * VV(1, 2)) * dL_da +
+                        (TT(1, 0) * VV(1, 0) + TT(1, 1) * VV(1, 1) + TT(1, 2) * VV(1, 2)) * dL_db;
+        float dL_dT02 = 2 * (TT(0, 0) * VV(2, 0) + TT(0, 1) * VV(2, 1) + TT(0, 2) * VV(2, 2)) * dL_da +
+                        (TT(1, 0) * VV(2, 0) + TT(1, 1) * VV(2, 1) + TT(1, 2) * VV(2, 2)) * dL_db;
+        float dL_dT10 = 2 * (TT(1, 0) * VV(0, 0) + TT(1, 1) * VV(0, 1) + TT(1, 2) * VV(0, 2)) * dL_dc +
+                        (TT(0, 0) * VV(0, 0) + TT(0, 1) * VV(0, 1) + TT(0, 2) * VV(0, 2)) * dL_db;
+        float dL_dT11 = 2 * (TT(1, 0) * VV(1, 0) + TT(1, 1) * VV(1, 1) + TT(1, 2) * VV(1, 2)) * dL_dc +
+                        (TT(0, 0) * VV(1, 0) + TT(0, 1) * VV(1, 1) + TT(0, 2) * VV(1, 2)) * dL_db;
+        float dL_dT12 = 2 * (TT(1, 0) * VV(2, 0) + TT(1, 1) * VV(2, 1) + TT(1, 2) * VV(2, 2)) * dL_dc +
+                        (TT(0, 0) * VV(2, 0) + TT(0, 1) * VV(2, 1) + TT(0, 2) * VV(2, 2)) * dL_db;
+#undef VV
+#undef TT
+        float dL_dJ00 = Wm.m[0][0] * dL_dT00 + Wm.m[0][1] * dL_dT01 + Wm.m[0][2] * dL_dT02;
+        float dL_dJ02 = Wm.m[2][0] * dL_dT00 + Wm.m[2][1] * dL_dT01 + Wm.m[2][2] * dL_dT02;
+        float dL_dJ11 = Wm.m[1][0] * dL_dT10 + Wm.m[1][1] * dL_dT11 + Wm.m[1][2] * dL_dT12;
+        float dL_dJ12 = Wm.m[2][0] * dL_dT10 + Wm.m[2][1] * dL_dT11 + Wm.m[2][2] * dL_dT12;
+        float tz = 1.f / t[2];
+        float tz2 = tz * tz;
+        float tz3 = tz2 * tz;
+        float dL_dtx = x_grad_mul * -h_x * tz2 * dL_dJ02;
+        float dL_dty = y_grad_mul * -h_y * tz2 * dL_dJ12;
+        float dL_dtz = -h_x * tz2 * dL_dJ00 - h_y * tz2 * dL_dJ11 + (2 * h_x * t[0]) * tz3 * dL_dJ02 + (2 * h_y * t[1]) * tz3 * dL_dJ12;
+        /* transformVec4x3Transpose, auxiliary.h:89-97 */
+        float dm[3] = {
+            view[0] * dL_dtx + view[1] * dL_dty + view[2] * dL_dtz,
+            view[4] * dL_dtx + view[5] * dL_dty + view[6] * dL_dtz,
+            view[8] * dL_dtx + view[9] * dL_dty + view[10] * dL_dtz };
+        dL_dmeans[3 * idx + 0] = dm[0];
+        dL_dmeans[3 * idx + 1] = dm[1];
+        dL_dmeans[3 * idx + 2] = dm[2];
+
+        /* ---- preprocessCUDA (backward) ---- */
+        const float* m = mean;
+        float m_hom[4];
+        transform_point_4x4(m, proj, m_hom);
+        float m_w = 1.0f / (m_hom[3] + 0.0000001f);
+        float mul1 = (proj[0] * m[0] + proj[4] * m[1] + proj[8] * m[2] + proj[12]) * m_w * m_w;
+        float mul2 = (proj[1] * m[0] + proj[5] * m[1] + proj[9] * m[2] + proj[13]) * m_w * m_w;
+        const float g2x = dL_dmean2D[3 * idx + 0], g2y = dL_dmean2D[3 * idx + 1];
+        float d1[3];
+        d1[0] = (proj[0] * m_w - proj[3] * mul1) * g2x + (proj[1] * m_w - proj[3] * mul2) * g2y;
+        d1[1] = (proj[4] * m_w - proj[7] * mul1) * g2x + (proj[5] * m_w - proj[7] * mul2) * g2y;
+        d1[2] = (proj[8] * m_w - proj[11] * mul1) * g2x + (proj[9] * m_w - proj[11] * mul2) * g2y;
+        for (int k = 0; k < 3; k++) dL_dmeans[3 * idx + k] += d1[k];
+        float mul3 = view[2] * m[0] + view[6] * m[1] + view[10] * m[2] + view[14];
+        float d2[3];
+        d2[0] = (view[2] - view[3] * mul3) * dL_ddepth[idx];
+        d2[1] = (view[6] - view[7] * mul3) * dL_ddepth[idx];
+        d2[2] = (view[10] - view[11] * mul3) * dL_ddepth[idx];
+        for (int k = 0; k < 3; k++) dL_dmeans[3 * idx + k] += d2[k];
+        if (scales)
+            compute_cov3d_backward(scales + 3 * idx, scale_modifier, rotations + 4 * idx, dL_dcov + 6 * idx,
+                                   dL_dscale + 3 * idx, dL_drot + 4 * idx);
+    }
+}
