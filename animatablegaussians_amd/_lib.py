@@ -72,6 +72,9 @@ SYMBOLS = [
     ("ag_raster_forward_render", ctypes.c_int, [ctypes.POINTER(AgRasterForwardArgs), c_i32, c_vp]),
     ("ag_raster_backward", ctypes.c_int, [ctypes.POINTER(AgRasterBackwardArgs), c_vp]),
     ("ag_raster_mark_visible", ctypes.c_int, [c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    ("ag_prof_kernel_name", ctypes.c_char_p, [c_i32]),
+    ("ag_prof_enable", ctypes.c_int, [ctypes.c_uint32]),
+    ("ag_prof_collect", ctypes.c_int, [ctypes.POINTER(c_i32), ctypes.POINTER(c_f)]),
     ("ag_debug_wave_reduce16", ctypes.c_int, [c_vp, c_vp, c_vp]),
 ]
 
@@ -99,6 +102,24 @@ def lib() -> ctypes.CDLL:
             raise AgNativeError(f"libag_hip.so ABI version {L.ag_abi_version()} != 1")
         _lib = L
     return _lib
+
+
+AG_K_COUNT = 7
+
+
+def prof_enable(kernel_ids) -> None:
+    mask = 0
+    for k in kernel_ids:
+        mask |= 1 << int(k)
+    check(lib().ag_prof_enable(mask), "ag_prof_enable")
+
+
+def prof_collect():
+    """{kernel name: (launches, total ms)} for the launches bracketed since the last collect."""
+    n = (c_i32 * AG_K_COUNT)()
+    ms = (c_f * AG_K_COUNT)()
+    check(lib().ag_prof_collect(n, ms), "ag_prof_collect")
+    return {lib().ag_prof_kernel_name(i).decode(): (int(n[i]), float(ms[i])) for i in range(AG_K_COUNT)}
 
 
 def check(rc: int, what: str) -> None:

@@ -3,6 +3,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <mutex>
+#include <vector>
 
 #include "ag_common.h"
 
@@ -23,6 +24,38 @@ int check_hip(hipError_t e, const char* what)
     if (e == hipSuccess) return AG_OK;
     set_error("%s: %s", what, hipGetErrorString(e));
     return AG_ERR_HIP;
+}
+
+// ---- kernel timing log ---------------------------------------------------------------------------------------
+static uint32_t g_prof_mask = 0;
+struct ProfRec { int id; hipEvent_t a, b; };
+static std::vector<ProfRec> g_prof_log;
+static std::vector<hipEvent_t> g_prof_pool;
+static std::mutex g_prof_mu;
+
+static hipEvent_t prof_event()
+{
+    if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+void prof_begin(int id, hipStream_t s)
+{
+    if (!(g_prof_mask & (1u << id))) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    ProfRec r{ id, prof_event(), prof_event() };
+    (void)hipEventRecord(r.a, s);
+    g_prof_log.push_back(r);
+}
+
+void prof_end(int id, hipStream_t s)
+{
+    if (!(g_prof_mask & (1u << id))) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (size_t i = g_prof_log.size(); i-- > 0;)
+        if (g_prof_log[i].id == id) { (void)hipEventRecord(g_prof_log[i].b, s); break; }
 }
 
 // One pinned word per thread for the num_rendered read-back (the reference's blocking cudaMemcpy,
@@ -148,6 +181,37 @@ int ag_raster_backward(const AgRasterBackwardArgs* a, void* stream)
     int rc;
     if ((rc = launch_blend_backward(*a, s))) return rc;
     return launch_preprocess_backward(*a, s);
+}
+
+const char* ag_prof_kernel_name(int32_t id)
+{
+    static const char* names[AG_K_COUNT] = { "preprocess_kernel", "tile_scan_kernel", "scatter_kernel", "tile_sort_kernel",
+                                             "blend_forward_kernel", "blend_backward_kernel", "preprocess_backward_kernel" };
+    return (id >= 0 && id < AG_K_COUNT) ? names[id] : "";
+}
+
+int ag_prof_enable(uint32_t mask)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_mask = mask;
+    return AG_OK;
+}
+
+int ag_prof_collect(int32_t* launches, float* total_ms)
+{
+    if (!launches || !total_ms) return AG_ERR_INVALID_ARGUMENT;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (int i = 0; i < AG_K_COUNT; i++) { launches[i] = 0; total_ms[i] = 0.f; }
+    int rc = AG_OK;
+    for (auto& r : g_prof_log) {
+        float ms = 0.f;
+        if (hipEventSynchronize(r.b) != hipSuccess || hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) rc = AG_ERR_HIP;
+        else { launches[r.id]++; total_ms[r.id] += ms; }
+        g_prof_pool.push_back(r.a);
+        g_prof_pool.push_back(r.b);
+    }
+    g_prof_log.clear();
+    return rc;
 }
 
 int ag_debug_wave_reduce16(const float* in, float* out, void* stream)

@@ -62,11 +62,11 @@ int launch_tile_scan(const AgRasterForwardArgs& a, hipStream_t s)
     const int gx = (a.W + kTileX - 1) / kTileX, gy = (a.H + kTileY - 1) / kTileY;
     char* ib = aligned_base(a.image_buffer);
     ImageLayout il((size_t)a.W, (size_t)a.H);
-    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, gx * gy,
+    { ProfScope ps(AG_K_TILE_SCAN, s); hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, gx * gy,
                        reinterpret_cast<const uint32_t*>(ib + il.tile_count),
                        reinterpret_cast<uint32_t*>(ib + il.cursor),
                        reinterpret_cast<uint2*>(ib + il.ranges),
-                       reinterpret_cast<uint32_t*>(ib + il.num_rendered));
+                       reinterpret_cast<uint32_t*>(ib + il.num_rendered)); }
     return check_hip(hipGetLastError(), "tile_scan_kernel");
 }
 
@@ -182,11 +182,11 @@ int launch_bin_sort(const AgRasterForwardArgs& a, int R, hipStream_t s)
     BinLayout bl((size_t)R);
     uint64_t* keys = reinterpret_cast<uint64_t*>(bb + bl.keys);
     uint32_t* point_list = reinterpret_cast<uint32_t*>(bb + bl.point_list);
-    hipLaunchKernelGGL(scatter_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, a.P, gx, gy, a.radii,
-                       reinterpret_cast<const GaussRec*>(gb + gl.rec), reinterpret_cast<uint32_t*>(ib + il.cursor), keys);
+    { ProfScope ps(AG_K_SCATTER, s); hipLaunchKernelGGL(scatter_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, a.P, gx, gy, a.radii,
+                       reinterpret_cast<const GaussRec*>(gb + gl.rec), reinterpret_cast<uint32_t*>(ib + il.cursor), keys); }
     if (check_hip(hipGetLastError(), "scatter_kernel")) return AG_ERR_HIP;
-    hipLaunchKernelGGL(tile_sort_kernel, dim3(gx * gy), dim3(256), 0, s,
-                       reinterpret_cast<const uint2*>(ib + il.ranges), keys, point_list);
+    { ProfScope ps(AG_K_TILE_SORT, s); hipLaunchKernelGGL(tile_sort_kernel, dim3(gx * gy), dim3(256), 0, s,
+                       reinterpret_cast<const uint2*>(ib + il.ranges), keys, point_list); }
     return check_hip(hipGetLastError(), "tile_sort_kernel");
 }
 

@@ -273,7 +273,7 @@ int launch_blend_backward(const AgRasterBackwardArgs& a, hipStream_t s)
     p.accum = reinterpret_cast<float*>(aligned_base(a.accum_buffer));
     if (check_hip(hipMemsetAsync(p.accum, 0, (size_t)a.P * kAccumFloats * sizeof(float), s), "memset accum")) return AG_ERR_HIP;
     if (a.num_rendered <= 0) return AG_OK;
-    hipLaunchKernelGGL(blend_backward_kernel, dim3(p.T), dim3(256), 0, s, p);
+    { ProfScope ps(AG_K_BLEND_BACKWARD, s); hipLaunchKernelGGL(blend_backward_kernel, dim3(p.T), dim3(256), 0, s, p); }
     return check_hip(hipGetLastError(), "blend_backward_kernel");
 }
 

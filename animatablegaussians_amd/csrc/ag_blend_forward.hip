@@ -140,7 +140,7 @@ int launch_blend_forward(const AgRasterForwardArgs& a, int R, hipStream_t s)
     p.bg = a.bg;
     p.out_color = a.out_color; p.out_depth = a.out_depth; p.out_alpha = a.out_alpha;
     p.n_contrib = reinterpret_cast<uint32_t*>(ib + il.n_contrib);
-    hipLaunchKernelGGL(blend_forward_kernel, dim3(p.T), dim3(256), 0, s, p);
+    { ProfScope ps(AG_K_BLEND_FORWARD, s); hipLaunchKernelGGL(blend_forward_kernel, dim3(p.T), dim3(256), 0, s, p); }
     return check_hip(hipGetLastError(), "blend_forward_kernel");
 }
 

@@ -79,6 +79,15 @@ inline __host__ __device__ char* aligned_base(const void* p)
 }
 
 void set_error(const char* fmt, ...);
+
+// Optional event bracketing of kernel launches (ag_prof_* in the ABI).  Usage: { ProfScope ps(AG_K_X, stream); launch; }
+void prof_begin(int kernel_id, hipStream_t s);
+void prof_end(int kernel_id, hipStream_t s);
+struct ProfScope {
+    int id; hipStream_t s;
+    ProfScope(int id_, hipStream_t s_) : id(id_), s(s_) { prof_begin(id, s); }
+    ~ProfScope() { prof_end(id, s); }
+};
 int check_hip(hipError_t e, const char* what);
 
 // launchers (one per translation unit)

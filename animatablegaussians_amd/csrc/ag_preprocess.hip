@@ -212,7 +212,7 @@ int launch_preprocess(const AgRasterForwardArgs& a, hipStream_t s)
     p.tile_count = reinterpret_cast<uint32_t*>(ib + il.tile_count);
     const size_t T = (size_t)p.gx * p.gy;
     if (check_hip(hipMemsetAsync(p.tile_count, 0, T * sizeof(uint32_t), s), "memset tile_count")) return AG_ERR_HIP;
-    hipLaunchKernelGGL(preprocess_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, p);
+    { ProfScope ps(AG_K_PREPROCESS, s); hipLaunchKernelGGL(preprocess_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, p); }
     return check_hip(hipGetLastError(), "preprocess_kernel");
 }
 

@@ -235,7 +235,7 @@ int launch_preprocess_backward(const AgRasterBackwardArgs& a, hipStream_t s)
     p.dL_dmeans2D = a.dL_dmeans2D; p.dL_dcolors = a.dL_dcolors; p.dL_dopacity = a.dL_dopacity;
     p.dL_dmeans3D = a.dL_dmeans3D; p.dL_dcov3D = a.dL_dcov3D; p.dL_dscales = a.dL_dscales;
     p.dL_drotations = a.dL_drotations;
-    hipLaunchKernelGGL(preprocess_backward_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, p);
+    { ProfScope ps(AG_K_PREPROCESS_BACKWARD, s); hipLaunchKernelGGL(preprocess_backward_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, p); }
     return check_hip(hipGetLastError(), "preprocess_backward_kernel");
 }
 

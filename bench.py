@@ -1,0 +1,228 @@
+#!/usr/bin/env python
+"""Headline benchmark: rendered views/sec (forward + backward) at 1024x1024 over ~250 k Gaussians.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload = BASELINE.json configs[1] ("avatarrex_zzr: 512^2 front/back maps (~250k Gaussians), 1 view @1024^2,
+1xMI355X fwd+bwd"), synthetic: animatablegaussians_amd.synth.avatar_map_gaussians() (268 348 Gaussians on the
+reference's 1024x2048 front|back canvas) seen from 8 free-view cameras (f = 1100, 2.5 m).  One step = one view
+through the public operator surface (GaussianRasterizer forward, torch.autograd backward with resident random
+upstream gradients): preprocess -> tile counts/scan -> scatter -> per-tile sort -> blend, then blend backward ->
+preprocess backward.  All inputs are resident in HBM before the timed region.
+
+Multi-GPU: views are sharded over ranks (weak scaling: every rank renders K views of the same Gaussians).  The
+exchange step of view-sharded rendering is the sum over views of the per-Gaussian attribute gradients (14 floats per
+Gaussian, 15 MB) -- one RCCL all-reduce per step, issued on a side stream and overlapped with the next view.
+
+The JSON line also carries
+  roofline     : dominant kernel (blend backward), ALGORITHMIC bytes/launch (8T + 44R + 28WH + 40P)
+                 / its HIP-event duration measured live in the timed region, against 8 TB/s HBM3E;
+  cpu_baseline : the CPU oracle (a restatement of the reference's CUDA kernels -- the reference has no CPU
+                 rasterizer) timed on this box's host cores on a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle timing (profiling runs)")
+    ap.add_argument("--breakdown", action="store_true", help="add a per-kernel HIP-event breakdown pass")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from animatablegaussians_amd import _lib, camera, synth
+    from animatablegaussians_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    # ---- synthetic scene, resident on the GPU -------------------------------------------------------------------
+    W = H = 1024
+    av = synth.avatar_map_gaussians()
+    P = av["means3D"].shape[0]
+    cams_np = synth.free_view_cameras(8, img=W)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    means3D = t(av["means3D"]).requires_grad_(True)
+    scales = t(av["scales"]).requires_grad_(True)
+    rotations = t(av["rotations"]).requires_grad_(True)
+    opacities = t(av["opacities"]).requires_grad_(True)
+    colors = t(av["colors"]).requires_grad_(True)
+    leaves = [means3D, scales, rotations, opacities, colors]
+    bg = t(av["bg"])
+    settings = []
+    for c in cams_np:
+        cm = camera.camera_from_intr_extr(c["extr"], c["intr"], W, H)
+        settings.append(GaussianRasterizationSettings(
+            image_height=H, image_width=W, tanfovx=cm["tanfovx"], tanfovy=cm["tanfovy"], bg=bg, scale_modifier=1.0,
+            viewmatrix=t(cm["viewmatrix"]), projmatrix=t(cm["projmatrix"]), sh_degree=0, campos=t(cm["campos"]),
+            prefiltered=False, debug=False))
+    rasterizers = [GaussianRasterizer(s) for s in settings]
+    up = synth.upstream_grads(W, H, 12345 + rank)
+    g_color, g_depth, g_alpha = t(up["dL_dcolor"]), t(up["dL_ddepth"]), t(up["dL_dalpha"])
+    comm_stream = torch.cuda.Stream(dev) if world > 1 else None
+    grad_pack = torch.zeros((P, 14), device=dev) if world > 1 else None
+    R_seen = []
+
+    def step(i: int):
+        r = rasterizers[(i * world + rank) % len(rasterizers)]     # this rank's view of the step
+        means2D = torch.zeros_like(means3D, requires_grad=True)
+        color, radii, depth, alpha = r(means3D=means3D, means2D=means2D, opacities=opacities, shs=None,
+                                       colors_precomp=colors, scales=scales, rotations=rotations, cov3D_precomp=None)
+        torch.autograd.backward([color, depth, alpha], [g_color, g_depth, g_alpha])
+        if world > 1:
+            # exchange step of view sharding: sum the per-Gaussian attribute gradients over the views of this step
+            comm_stream.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(comm_stream):
+                torch.cat([means3D.grad, scales.grad, rotations.grad, opacities.grad, colors.grad], dim=1, out=grad_pack)
+                dist.all_reduce(grad_pack)
+        for leaf in leaves:
+            leaf.grad = None
+
+    def sync_all():
+        if world > 1:
+            torch.cuda.current_stream(dev).wait_stream(comm_stream)
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    # ---- warm-up, then the timed region -----------------------------------------------------------------------
+    for i in range(args.warmup):
+        step(i)
+    sync_all()
+    DOM = 5  # AG_K_BLEND_BACKWARD: bracket the dominant kernel with HIP events on its own launch stream
+    _lib.prof_enable([DOM])
+    sync_all()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    prof = _lib.prof_collect()
+    _lib.prof_enable([])
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # instance count of the views this rank rendered (data-dependent: read back from one extra untimed pass)
+    from animatablegaussians_amd.rasterizer import native_rasterize_gaussians
+    empty = torch.Tensor([])
+    with torch.no_grad():
+        for v in range(len(settings)):
+            s = settings[v]
+            R_seen.append(native_rasterize_gaussians(s.bg, means3D, colors, opacities, scales, rotations, 1.0, empty,
+                                                     s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy, H, W, empty, 0,
+                                                     s.campos, False, False)[0])
+    views_of_rank = [(i * world + rank) % len(settings) for i in range(args.warmup, args.warmup + args.steps)]
+    R_mean = float(np.mean([R_seen[v] for v in views_of_rank]))
+
+    breakdown = None
+    if args.breakdown and rank == 0:
+        _lib.prof_enable(range(_lib.AG_K_COUNT))
+        for i in range(min(args.steps, 64)):
+            step(i)
+        sync_all() if world == 1 else torch.cuda.synchronize(dev)
+        bd = _lib.prof_collect()
+        _lib.prof_enable([])
+        breakdown = {k: round(1e3 * ms / max(n, 1), 2) for k, (n, ms) in bd.items()}
+
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    T_tiles = ((W + 15) // 16) * ((H + 15) // 16)
+    n_dom, ms_dom = prof["blend_backward_kernel"]
+    dom_us = 1e3 * ms_dom / max(n_dom, 1)
+    alg_dom = 8 * T_tiles + 44 * R_mean + 28 * W * H + 40 * P          # bytes per launch (bwd blend)
+    alg_step = 392 * P + 132 * R_mean + 52 * W * H + 24 * T_tiles       # whole raster fwd+bwd
+    achieved = alg_dom / (dom_us * 1e-6) / 1e9 if dom_us > 0 else 0.0
+    value = args.gpus * args.steps / elapsed
+    ms_per_step = 1e3 * elapsed / args.steps
+
+    out = {
+        "metric": "rendered views/sec (fwd+bwd) @1024^2, ~250k Gaussians",
+        "value": round(value, 2), "unit": "views/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": "BASELINE configs[1]: avatar front|back map, 1 view @1024x1024 per step, rasterizer fwd+bwd "
+                        "through GaussianRasterizer + autograd",
+            "gaussians": P, "instances_per_view": int(R_mean), "tiles": T_tiles, "views": len(settings),
+            "parallelism": "1 process" if world == 1 else f"view-sharded x{world}, RCCL all-reduce of per-Gaussian grads (14 f32 each)",
+        },
+        "roofline": {
+            "kernel": "blend_backward_kernel", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+            "algorithmic_bytes_per_launch": int(alg_dom), "avg_launch_us": round(dom_us, 2), "launches_timed": n_dom,
+            "whole_step_algorithmic_GBps": round(alg_step / (ms_per_step * 1e-3) / 1e9, 2),
+            "note": "VALU/LDS/atomic-bound kernel reported against HBM as SURVEY.md 8(d) prescribes",
+        },
+    }
+    if breakdown is not None:
+        out["kernels_us"] = breakdown
+
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(av, cams_np, up, W, H)
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(av, cams_np, up, W, H, max_seconds: float = 25.0):
+    """The CPU oracle (oracle/raster_oracle.c: scalar C restatement of forward.cu / backward.cu, OpenMP over tiles
+    for the two blend loops) on the same scene and upstream gradients, views 0.. until ~max_seconds are spent."""
+    import numpy as np
+    from animatablegaussians_amd import camera
+    from oracle import raster_oracle as ro
+    cores = os.cpu_count() or 1
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    ro.lib()
+    done, t0 = 0, time.perf_counter()
+    for c in cams_np:
+        cm = camera.camera_from_intr_extr(c["extr"], c["intr"], W, H)
+        st = ro.forward(av["means3D"], av["colors"], av["opacities"], av["scales"], av["rotations"], av["bg"],
+                        cm["viewmatrix"], cm["projmatrix"], cm["tanfovx"], cm["tanfovy"], W, H, want_fragile=False)
+        ro.backward(st, av["means3D"], av["colors"], av["scales"], av["rotations"], av["bg"], cm["viewmatrix"],
+                    cm["projmatrix"], cm["tanfovx"], cm["tanfovy"], up["dL_dcolor"], up["dL_ddepth"], up["dL_dalpha"],
+                    f32_accum=True)
+        done += 1
+        if time.perf_counter() - t0 > max_seconds:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": round(done / dt, 4), "unit": "views/s", "cores": cores, "kind": "port",
+            "sample": f"{done} of the 8 views of the same scene, fwd+bwd, {dt:.1f} s wall; per-Gaussian stages "
+                      f"single-threaded, blend loops OpenMP x{cores}"}
+
+
+if __name__ == "__main__":
+    main()

@@ -159,6 +159,26 @@ int ag_raster_mark_visible(int32_t P, const float* means3D, const float* viewmat
                            uint8_t* present, void* stream);
 
 /*
+ * Kernel timing hooks (bench.py).  ag_prof_enable(mask) makes every subsequent launch of a kernel whose bit is set
+ * in `mask` be bracketed by a pair of HIP events recorded on the launch stream; ag_prof_collect synchronises those
+ * events and returns, per kernel id, the number of bracketed launches and their summed duration in milliseconds,
+ * then clears the log.  mask == 0 (the default) disables recording entirely.
+ */
+enum AgKernelId {
+    AG_K_PREPROCESS = 0,
+    AG_K_TILE_SCAN = 1,
+    AG_K_SCATTER = 2,
+    AG_K_TILE_SORT = 3,
+    AG_K_BLEND_FORWARD = 4,
+    AG_K_BLEND_BACKWARD = 5,
+    AG_K_PREPROCESS_BACKWARD = 6,
+    AG_K_COUNT = 7
+};
+const char* ag_prof_kernel_name(int32_t kernel_id);
+int ag_prof_enable(uint32_t kernel_mask);
+int ag_prof_collect(int32_t* launches /*[AG_K_COUNT]*/, float* total_ms /*[AG_K_COUNT]*/);
+
+/*
  * Test hook (tests/ only): runs the wave64 transposed butterfly reduction used by the blend backward on one
  * wavefront.  in: [64 lanes][16 values] floats, out: [64] floats; out[l] = sum over lanes of in[.][(l >> 2) & 15].
  */

@@ -25,6 +25,9 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #define BLOCK_X 16
 #define BLOCK_Y 16
@@ -424,10 +427,31 @@ void ago_render_backward(int P, int W, int H, const uint32_t* ranges, const uint
     const int gx = (W + BLOCK_X - 1) / BLOCK_X, gy = (H + BLOCK_Y - 1) / BLOCK_Y;
     const float ddelx_dx = (float)(0.5 * W);
     const float ddely_dy = (float)(0.5 * H);
-    double* acc = (double*)calloc((size_t)(P > 0 ? P : 1) * 10, sizeof(double));
-    double* aabs = (double*)calloc((size_t)(P > 0 ? P : 1) * 10, sizeof(double));
-    for (int ty = 0; ty < gy; ty++)
-        for (int tx = 0; tx < gx; tx++) {
+    /* Tiles are distributed over OpenMP threads (bench.py's cpu_baseline leg); each thread owns private
+       accumulators that are folded in thread order afterwards.  With one thread (OMP_NUM_THREADS=1, what the
+       golden fixtures were generated with) this is exactly the sequential order documented above. */
+    const size_t NA = (size_t)(P > 0 ? P : 1) * 10;
+    double* acc = (double*)calloc(NA, sizeof(double));
+    double* aabs = (double*)calloc(NA, sizeof(double));
+    int nthreads = 1;
+#ifdef _OPENMP
+    nthreads = omp_get_max_threads();
+#endif
+    double** tacc_all = (double**)calloc((size_t)nthreads, sizeof(double*));
+    double** tabs_all = (double**)calloc((size_t)nthreads, sizeof(double*));
+#pragma omp parallel num_threads(nthreads)
+    {
+        int tid = 0;
+#ifdef _OPENMP
+        tid = omp_get_thread_num();
+#endif
+        double* tacc = (nthreads == 1) ? acc : (double*)calloc(NA, sizeof(double));
+        double* tabs = (nthreads == 1) ? aabs : (double*)calloc(NA, sizeof(double));
+        tacc_all[tid] = tacc;
+        tabs_all[tid] = tabs;
+#pragma omp for schedule(static, 1)
+        for (int tile = 0; tile < gx * gy; tile++) {
+            const int ty = tile / gx, tx = tile % gx;
             const uint32_t r0 = ranges[2 * (ty * gx + tx)], r1 = ranges[2 * (ty * gx + tx) + 1];
             for (int ly = 0; ly < BLOCK_Y; ly++)
                 for (int lx = 0; lx < BLOCK_X; lx++) {
@@ -494,12 +518,26 @@ void ago_render_backward(int P, int W, int H, const uint32_t* ranges, const uint
                         term[4] = -0.5f * gdy * dy * dL_dG;
                         term[5] = G * dL_dopa;
                         for (int q = 0; q < 10; q++) {
-                            ACC(acc[10 * (size_t)id + q], term[q]);
-                            aabs[10 * (size_t)id + q] += fabs((double)term[q]);
+                            ACC(tacc[10 * (size_t)id + q], term[q]);
+                            tabs[10 * (size_t)id + q] += fabs((double)term[q]);
                         }
                     }
                 }
         }
+    }
+    if (nthreads > 1)
+        for (int t = 0; t < nthreads; t++) {
+            if (!tacc_all[t]) continue;
+            for (size_t i = 0; i < NA; i++) {
+                if (f32_accum) acc[i] = (double)(float)((float)acc[i] + (float)tacc_all[t][i]);
+                else acc[i] += tacc_all[t][i];
+                aabs[i] += tabs_all[t][i];
+            }
+            free(tacc_all[t]);
+            free(tabs_all[t]);
+        }
+    free(tacc_all);
+    free(tabs_all);
     for (int id = 0; id < P; id++) {
         const double* a = acc + 10 * (size_t)id;
         dL_dmean2D[3 * id + 0] += (float)a[0];
