@@ -30,16 +30,17 @@ def focal2fov(focal: float, pixels: int) -> float:
 def projection_matrix(znear: float, zfar: float, K: np.ndarray, img_w: int, img_h: int) -> np.ndarray:
     """Off-centre perspective matrix from intrinsics, float32 (``utils/graphics_utils.py:60-80``, K branch)."""
     K = np.asarray(K, dtype=f32)
-    near_fx = f32(znear) / K[0, 0]
-    near_fy = f32(znear) / K[1, 1]
+    # `python_float / tensor` is evaluated by torch as reciprocal(tensor) * float32(python_float)
+    near_fx = f32(f32(1.0) / K[0, 0]) * f32(znear)
+    near_fy = f32(f32(1.0) / K[1, 1]) * f32(znear)
     left = -(f32(img_w) - K[0, 2]) * near_fx
     right = K[0, 2] * near_fx
     bottom = (K[1, 2] - f32(img_h)) * near_fy
     top = K[1, 2] * near_fy
     P = np.zeros((4, 4), dtype=f32)
     z_sign = 1.0
-    P[0, 0] = f32(2.0 * znear) / (right - left)
-    P[1, 1] = f32(2.0 * znear) / (top - bottom)
+    P[0, 0] = f32(f32(1.0) / (right - left)) * f32(2.0 * znear)
+    P[1, 1] = f32(f32(1.0) / (top - bottom)) * f32(2.0 * znear)
     P[0, 2] = (right + left) / (right - left)
     P[1, 2] = (top + bottom) / (top - bottom)
     P[3, 2] = z_sign

@@ -55,6 +55,30 @@ def test_forward_config1_bitexact_and_images(P, img):
     h.assert_image_parity(gpu, ref)
 
 
+@pytest.mark.parametrize("name", ["raster_random_p1500_128", "raster_ragged_p800_100x60_cov3d"])
+def test_against_reference_golden_fixtures(name):
+    """HIP path vs the fixtures produced by the reference's own code (tests/golden/make_golden.py)."""
+    from test_oracle_cpu import load_golden
+    scene, cam, st_ref, g_ref = load_golden(name)
+    gpu = h.gpu_native_forward(scene, cam)
+    ref = dict(st_ref, fragile=h.oracle_forward(scene, cam)["fragile"])
+    if scene.get("cov3D_precomp") is not None:
+        ref["cov3D"] = np.where((st_ref["radii"] > 0)[:, None], scene["cov3D_precomp"], 0).astype(np.float32)
+    _bitexact(gpu, ref)
+    h.assert_image_parity(gpu, ref)
+    # gradients on the golden's saved alpha map: accumulators vs the golden (fp32 sums of the same terms in the
+    # reference's sequential order) with the summation-order slack measured by the oracle
+    from oracle import raster_oracle as ro
+    keep = (~ref["fragile"].astype(bool)).astype(np.float32)[None]
+    grads = {k: np.ascontiguousarray(scene[k] * keep) for k in ("dL_dcolor", "dL_ddepth", "dL_dalpha")}
+    acc = ro.backward_blend(st_ref, scene["colors"], scene["bg"], grads["dL_dcolor"], grads["dL_ddepth"], grads["dL_dalpha"])
+    got = h.gpu_native_backward(gpu, grads, alphas=st_ref["alpha"])
+    h.assert_accum_parity(got, acc)
+    if not ref["fragile"].any():   # no masked pixel: the golden gradients themselves are directly comparable
+        for k in ("dL_dmeans3D", "dL_dcov3D") + (("dL_dscales", "dL_drotations") if scene.get("scales") is not None else ()):
+            h.assert_rows_close(got[k], g_ref[k], k, rtol=1e-3, row_rtol=1e-4)
+
+
 def test_forward_cov3d_precomp_path():
     scene = synth.random_gaussians(P=2000)
     cam = h.cam_of(scene)
@@ -162,7 +186,9 @@ def _check_backward(scene, cam):
     h.assert_rows_close(got["dL_dcov3D"], pre["dL_dcov3D"], "dL_dcov3D")
     if scene.get("scales") is not None:
         h.assert_rows_close(got["dL_dscales"], pre["dL_dscales"], "dL_dscales")
-        h.assert_rows_close(got["dL_drotations"], pre["dL_drotations"], "dL_drotations")
+        # quaternion chain rule: sums of +-2 q_i s_j dL/dM_jk products that largely cancel, so the slack is relative to
+        # the row's largest entry, three times looser than for the other rows
+        h.assert_rows_close(got["dL_drotations"], pre["dL_drotations"], "dL_drotations", row_rtol=3e-5)
     vis = ref["radii"] > 0
     for k in ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dscales", "dL_drotations"):
         assert not got[k][~vis].any(), f"{k} must be zero for culled Gaussians"
