@@ -87,41 +87,83 @@ __device__ __forceinline__ void get_rect_i(float px, float py, int max_radius, i
     x1o = (uint32_t)min(gx, x1); y1o = (uint32_t)min(gy, y1);
 }
 
+constexpr int kWinBins = 2048;   // same workgroup tile window as the preprocess kernel
+
 __global__ void __launch_bounds__(256) scatter_kernel(int P, int gx, int gy, const int* __restrict__ radii,
                                                      const GaussRec* __restrict__ rec, uint32_t* __restrict__ cursor,
                                                      uint64_t* __restrict__ keys)
 {
+    // Slots are handed out per (workgroup, tile): instances are counted in an LDS histogram over the workgroup's
+    // tile window, one global atomic per touched tile reserves the workgroup's block of the tile segment, and the
+    // rank inside the block comes from a second pass of LDS atomics.  Order inside a segment is arbitrary (the sort
+    // fixes it), so this is equivalent to one global atomic per instance at a fraction of the contention.
+    __shared__ int s_win[4];
+    __shared__ uint32_t s_hist[kWinBins];
+    __shared__ uint32_t s_base[kWinBins];
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= P) return;
-    const int rad = radii[idx];
-    if (rad <= 0) return;
-    const float px = rec[idx].x, py = rec[idx].y;
-    const uint32_t dbits = __float_as_uint(rec[idx].depth);
-    uint32_t x0, y0, x1, y1;
-    get_rect_i(px, py, rad, gx, gy, x0, y0, x1, y1);
-    const uint64_t key = ((uint64_t)dbits << 32) | (uint32_t)idx;
-    for (uint32_t y = y0; y < y1; y++)
-        for (uint32_t x = x0; x < x1; x++) {
-            const uint32_t pos = atomicAdd(&cursor[y * (uint32_t)gx + x], 1u);
-            keys[pos] = key;
+    if (threadIdx.x == 0) { s_win[0] = 0x7fffffff; s_win[1] = 0x7fffffff; s_win[2] = 0; s_win[3] = 0; }
+    __syncthreads();
+    uint32_t x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+    uint64_t key = 0;
+    const int rad = (idx < P) ? radii[idx] : 0;
+    if (rad > 0) {
+        const float px = rec[idx].x, py = rec[idx].y;
+        const uint32_t dbits = __float_as_uint(rec[idx].depth);
+        get_rect_i(px, py, rad, gx, gy, x0, y0, x1, y1);
+        key = ((uint64_t)dbits << 32) | (uint32_t)idx;
+        atomicMin(&s_win[0], (int)x0); atomicMin(&s_win[1], (int)y0);
+        atomicMax(&s_win[2], (int)x1); atomicMax(&s_win[3], (int)y1);
+    }
+    __syncthreads();
+    const int wx0 = s_win[0], wy0 = s_win[1];
+    const int bw = s_win[2] - wx0, bh = s_win[3] - wy0;
+    if (bw <= 0 || bh <= 0) return;
+    const int nb = bw * bh;
+    if (nb <= kWinBins) {
+        for (int i = threadIdx.x; i < nb; i += 256) s_hist[i] = 0u;
+        __syncthreads();
+        for (uint32_t y = y0; y < y1; y++)
+            for (uint32_t x = x0; x < x1; x++) atomicAdd(&s_hist[((int)y - wy0) * bw + ((int)x - wx0)], 1u);
+        __syncthreads();
+        for (int i = threadIdx.x; i < nb; i += 256) {
+            const uint32_t c = s_hist[i];
+            if (c) s_base[i] = atomicAdd(&cursor[(uint32_t)(wy0 + i / bw) * (uint32_t)gx + (uint32_t)(wx0 + i % bw)], c);
+            s_hist[i] = 0u;
         }
+        __syncthreads();
+        for (uint32_t y = y0; y < y1; y++)
+            for (uint32_t x = x0; x < x1; x++) {
+                const int li = ((int)y - wy0) * bw + ((int)x - wx0);
+                const uint32_t r = atomicAdd(&s_hist[li], 1u);
+                keys[s_base[li] + r] = key;
+            }
+    } else {
+        for (uint32_t y = y0; y < y1; y++)
+            for (uint32_t x = x0; x < x1; x++) {
+                const uint32_t pos = atomicAdd(&cursor[y * (uint32_t)gx + x], 1u);
+                keys[pos] = key;
+            }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // 4. per-tile sort.  Bitonic network in the all-ascending ("flip + disperse") form: every compare-exchange moves
 //    the minimum to the lower index, so virtual +inf padding above n never moves and needs no storage.
+//    Two size classes share the code: tiles up to 2048 entries sort in 16 KiB of LDS with 256 threads (several
+//    workgroups per CU), tiles up to 16384 entries in 128 KiB with 1024 threads; anything larger (never reached by
+//    avatar-sized splats) runs the same network directly on its global-memory segment.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int kSortLdsCap = 4096;  // 32 KiB of LDS per workgroup; avatar tiles top out near 1.5-4.5 k entries
-
-template <typename KeyPtr>
-__device__ __forceinline__ void bitonic_sort(KeyPtr sk, uint32_t n, uint32_t m /* pow2 >= n */, int tid, int nthreads)
+template <int NT, typename KeyPtr>
+__device__ __forceinline__ void bitonic_sort(KeyPtr sk, uint32_t n, uint32_t m /* pow2 >= n */, int tid)
 {
+    const uint32_t half = m >> 1;
     for (uint32_t k = 2; k <= m; k <<= 1) {
-        // flip
-        const uint32_t hk = k >> 1;
-        for (uint32_t t = tid; t < (m >> 1); t += nthreads) {
-            const uint32_t blk = t / hk, off = t - blk * hk;
-            const uint32_t i = blk * k + off, p = blk * k + k - 1 - off;
+        const uint32_t hk = k >> 1, lk = __builtin_ctz(hk);
+        // flip: i and its mirror image inside the k-block
+#pragma unroll 4
+        for (uint32_t t = tid; t < half; t += NT) {
+            const uint32_t blk = t >> lk, off = t & (hk - 1);
+            const uint32_t i = (blk << (lk + 1)) + off, p = (blk << (lk + 1)) + k - 1 - off;
             if (p < n) {
                 const uint64_t a = sk[i], b = sk[p];
                 if (a > b) { sk[i] = b; sk[p] = a; }
@@ -129,7 +171,8 @@ __device__ __forceinline__ void bitonic_sort(KeyPtr sk, uint32_t n, uint32_t m /
         }
         __syncthreads();
         for (uint32_t j = k >> 2; j > 0; j >>= 1) {
-            for (uint32_t t = tid; t < (m >> 1); t += nthreads) {
+#pragma unroll 4
+            for (uint32_t t = tid; t < half; t += NT) {
                 const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), p = i + j;
                 if (p < n) {
                     const uint64_t a = sk[i], b = sk[p];
@@ -141,32 +184,32 @@ __device__ __forceinline__ void bitonic_sort(KeyPtr sk, uint32_t n, uint32_t m /
     }
 }
 
-__global__ void __launch_bounds__(256) tile_sort_kernel(const uint2* __restrict__ ranges, uint64_t* __restrict__ keys,
-                                                       uint32_t* __restrict__ point_list)
+constexpr int kSortSmallCap = 2048;    // 16 KiB LDS, 256 threads
+constexpr int kSortLargeCap = 16384;   // 128 KiB LDS, 1024 threads
+
+template <int NT, int CAP, bool LARGE>
+__global__ void __launch_bounds__(NT) tile_sort_kernel(const uint2* __restrict__ ranges, uint64_t* __restrict__ keys,
+                                                      uint32_t* __restrict__ point_list)
 {
-    __shared__ uint64_t sk[kSortLdsCap];
+    extern __shared__ __attribute__((aligned(16))) uint64_t sk[];
     const uint2 rg = ranges[blockIdx.x];
     const uint32_t n = rg.y - rg.x;
-    if (n == 0) return;
+    // size classes: the small kernel takes (0, kSortSmallCap], the large one everything above
+    if (LARGE ? (n <= (uint32_t)kSortSmallCap) : (n == 0 || n > (uint32_t)kSortSmallCap)) return;
     const int tid = threadIdx.x;
     uint64_t* seg = keys + rg.x;
     uint32_t m = 2;
     while (m < n) m <<= 1;
-    if (n <= (uint32_t)kSortLdsCap) {
-        for (uint32_t i = tid; i < n; i += 256) sk[i] = seg[i];
+    if (n <= (uint32_t)CAP) {
+        for (uint32_t i = tid; i < n; i += NT) sk[i] = seg[i];
         __syncthreads();
-        bitonic_sort(sk, n, m, tid, 256);
-        for (uint32_t i = tid; i < n; i += 256) {
-            const uint64_t k = sk[i];
-            seg[i] = k;
-            point_list[rg.x + i] = (uint32_t)k;
-        }
+        bitonic_sort<NT>(sk, n, m, tid);
+        for (uint32_t i = tid; i < n; i += NT) point_list[rg.x + i] = (uint32_t)sk[i];
     } else {
-        // Oversized tile (never reached by avatar-sized splats): same network directly on the global segment.
         // All waves of a workgroup share one CU and its L1, so workgroup barriers order the exchanges.
         __syncthreads();
-        bitonic_sort(seg, n, m, tid, 256);
-        for (uint32_t i = tid; i < n; i += 256) point_list[rg.x + i] = (uint32_t)seg[i];
+        bitonic_sort<NT>(seg, n, m, tid);
+        for (uint32_t i = tid; i < n; i += NT) point_list[rg.x + i] = (uint32_t)seg[i];
     }
 }
 
@@ -185,8 +228,21 @@ int launch_bin_sort(const AgRasterForwardArgs& a, int R, hipStream_t s)
     { ProfScope ps(AG_K_SCATTER, s); hipLaunchKernelGGL(scatter_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, a.P, gx, gy, a.radii,
                        reinterpret_cast<const GaussRec*>(gb + gl.rec), reinterpret_cast<uint32_t*>(ib + il.cursor), keys); }
     if (check_hip(hipGetLastError(), "scatter_kernel")) return AG_ERR_HIP;
-    { ProfScope ps(AG_K_TILE_SORT, s); hipLaunchKernelGGL(tile_sort_kernel, dim3(gx * gy), dim3(256), 0, s,
-                       reinterpret_cast<const uint2*>(ib + il.ranges), keys, point_list); }
+    const uint2* ranges = reinterpret_cast<const uint2*>(ib + il.ranges);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_sort_kernel<1024, kSortLargeCap, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, kSortLargeCap * 8), "sort LDS attr"))
+            return AG_ERR_HIP;
+        attr_set = true;
+    }
+    {
+        ProfScope ps(AG_K_TILE_SORT, s);
+        hipLaunchKernelGGL((tile_sort_kernel<256, kSortSmallCap, false>), dim3(gx * gy), dim3(256), kSortSmallCap * 8, s,
+                           ranges, keys, point_list);
+        hipLaunchKernelGGL((tile_sort_kernel<1024, kSortLargeCap, true>), dim3(gx * gy), dim3(1024), kSortLargeCap * 8, s,
+                           ranges, keys, point_list);
+    }
     return check_hip(hipGetLastError(), "tile_sort_kernel");
 }
 

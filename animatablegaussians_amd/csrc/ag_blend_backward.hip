@@ -94,7 +94,7 @@ __device__ __forceinline__ float wave_reduce16_transposed(float (&v)[16], int la
 __global__ void __launch_bounds__(256) blend_backward_kernel(BlendBwdParams p)
 {
     __shared__ float4 slab[4][64 * 3];
-    __shared__ float gslab[4][64 * 16];
+    __shared__ float gslab[4][16 * 65];
 
     const int tile = blockIdx.x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -134,102 +134,114 @@ __global__ void __launch_bounds__(256) blend_backward_kernel(BlendBwdParams p)
     float acc_r = 0.f, acc_g = 0.f, acc_b = 0.f, acc_d = 0.f, acc_a = 0.f;
     float last_alpha = 0.f, last_r = 0.f, last_g = 0.f, last_b = 0.f, last_d = 0.f;
 
-    // entries [range.x, range.x + wmax) back to front, 64 per batch; lane 0 takes the rearmost entry of the batch
+    // entries [range.x, range.x + wmax) back to front, 64 per batch; lane 0 takes the rearmost entry of the batch.
+    // Same software pipeline as the forward: the gathers of the next batch fly while this one is processed.
+    constexpr int GS = 65;   // padded row stride of the per-batch gradient slab: [16 values][64 splats]
+    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
+    uint32_t id = 0;
+    {
+        const uint32_t take0 = wmax < 64u ? wmax : 64u;
+        if ((uint32_t)lane < take0) {
+            id = p.point_list[range.x + wmax - 1u - (uint32_t)lane];
+            const float4* src = reinterpret_cast<const float4*>(p.rec + id);
+            r0 = src[0]; r1 = src[1]; r2 = src[2];
+        }
+    }
     for (uint32_t remaining = wmax; remaining > 0;) {
         const uint32_t take = remaining < 64u ? remaining : 64u;
         const uint32_t top = range.x + remaining;  // one past the rearmost entry of this batch
         remaining -= take;
-        bool keep = false;
-        float4 r0, r1, r2;
-        uint32_t id = 0;
-        if ((uint32_t)lane < take) {
-            const uint32_t k = top - 1u - (uint32_t)lane;
-            id = p.point_list[k];
-            const float4* src = reinterpret_cast<const float4*>(p.rec + id);
-            r0 = src[0];
-            r1 = src[1];
-            r2 = src[2];
-            const float ddx = fmaxf(fmaxf(qx0f - r0.x, r0.x - qx1f), 0.f);
-            const float ddy = fmaxf(fmaxf(qy0f - r0.y, r0.y - qy1f), 0.f);
-            keep = (ddx * ddx + ddy * ddy) <= r2.z;
-            r2.z = __uint_as_float(k - range.x + 1u);  // 1-based list position
-            r2.w = __uint_as_float(id);
-        }
+        const float ddx = fmaxf(fmaxf(qx0f - r0.x, r0.x - qx1f), 0.f);
+        const float ddy = fmaxf(fmaxf(qy0f - r0.y, r0.y - qy1f), 0.f);
+        const bool keep = ((uint32_t)lane < take) && ((ddx * ddx + ddy * ddy) <= r2.z);
         const unsigned long long mask = __ballot(keep);
-        if (mask == 0ull) continue;
         const int slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
         if (keep) {
             my[slot * 3 + 0] = r0;
             my[slot * 3 + 1] = r1;
-            my[slot * 3 + 2] = r2;
+            // b, depth, 1-based list position, Gaussian index
+            my[slot * 3 + 2] = make_float4(r2.x, r2.y, __uint_as_float(top - (uint32_t)lane - range.x), __uint_as_float(id));
+        }
+        // prefetch the next (nearer) batch
+        {
+            const uint32_t take_n = remaining < 64u ? remaining : 64u;
+            if ((uint32_t)lane < take_n) {
+                id = p.point_list[range.x + remaining - 1u - (uint32_t)lane];
+                const float4* src = reinterpret_cast<const float4*>(p.rec + id);
+                r0 = src[0]; r1 = src[1]; r2 = src[2];
+            }
         }
         const int cnt = __popcll(mask);
         __builtin_amdgcn_wave_barrier();
+        if (cnt == 0) continue;
 
+        float4 a = my[0], b = my[1], c = my[2];
         for (int j = 0; j < cnt; j++) {
-            const float4 a = my[j * 3 + 0];  // x, y, ca, cb
-            const float4 b = my[j * 3 + 1];  // cc, op, r, g
-            const float4 c = my[j * 3 + 2];  // b, depth, pos, id
+            const int jn = (j + 1 < cnt) ? j + 1 : j;
+            float4 na = my[jn * 3 + 0], nb = my[jn * 3 + 1], nc = my[jn * 3 + 2];
+            __builtin_amdgcn_sched_barrier(0);
+            // a: x, y, ca, cb   b: cc, op, r, g   c: b, depth, pos, id
             const uint32_t pos1 = __float_as_uint(c.z);
             const float dx = a.x - pxf, dy = a.y - pyf;
             const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
             const float G = __builtin_amdgcn_exp2f(power * 1.4426950408889634f);
             const float alpha = fminf(0.99f, b.y * G);
             const bool act = (pos1 <= last_contributor) && (power <= 0.0f) && (alpha >= 1.0f / 255.0f);
-            float v[16];
-#pragma unroll
-            for (int i = 0; i < 16; i++) v[i] = 0.f;
-            if (act) {
-                const float one_m_alpha = 1.f - alpha;
-                T = T / one_m_alpha;
-                const float wgt = alpha * T;
-                const float one_m_last = 1.f - last_alpha;
-                acc_r = last_alpha * last_r + one_m_last * acc_r;
-                acc_g = last_alpha * last_g + one_m_last * acc_g;
-                acc_b = last_alpha * last_b + one_m_last * acc_b;
-                acc_d = last_alpha * last_d + one_m_last * acc_d;
-                acc_a = last_alpha + one_m_last * acc_a;
-                last_r = b.z; last_g = b.w; last_b = c.x; last_d = c.y;
-                float dL_dopa = (b.z - acc_r) * gr + (b.w - acc_g) * gg + (c.x - acc_b) * gb;
-                dL_dopa += (c.y - acc_d) * gd;
-                dL_dopa += (1.f - acc_a) * ga;
-                dL_dopa *= T;
-                last_alpha = alpha;
-                dL_dopa += (-T_final / one_m_alpha) * bg_dot;
-                const float dL_dG = b.y * dL_dopa;
-                const float gdx = G * dx, gdy = G * dy;
-                const float dG_ddelx = -gdx * a.z - gdy * a.w;
-                const float dG_ddely = -gdy * b.x - gdx * a.w;
-                v[A_M2X] = dL_dG * dG_ddelx * ddelx_dx;
-                v[A_M2Y] = dL_dG * dG_ddely * ddely_dy;
-                v[A_CONX] = -0.5f * gdx * dx * dL_dG;
-                v[A_CONY] = -0.5f * gdx * dy * dL_dG;
-                v[A_CONW] = -0.5f * gdy * dy * dL_dG;
-                v[A_OPAC] = G * dL_dopa;
-                v[A_COLR] = wgt * gr;
-                v[A_COLG] = wgt * gg;
-                v[A_COLB] = wgt * gb;
-                v[A_DEPTH] = wgt * gd;
-            }
             if (__any(act)) {
+                float v[16];
+#pragma unroll
+                for (int i = 0; i < 16; i++) v[i] = 0.f;
+                if (act) {
+                    const float one_m_alpha = 1.f - alpha;
+                    T = T / one_m_alpha;
+                    const float wgt = alpha * T;
+                    const float one_m_last = 1.f - last_alpha;
+                    acc_r = last_alpha * last_r + one_m_last * acc_r;
+                    acc_g = last_alpha * last_g + one_m_last * acc_g;
+                    acc_b = last_alpha * last_b + one_m_last * acc_b;
+                    acc_d = last_alpha * last_d + one_m_last * acc_d;
+                    acc_a = last_alpha + one_m_last * acc_a;
+                    last_r = b.z; last_g = b.w; last_b = c.x; last_d = c.y;
+                    float dL_dopa = (b.z - acc_r) * gr + (b.w - acc_g) * gg + (c.x - acc_b) * gb;
+                    dL_dopa += (c.y - acc_d) * gd;
+                    dL_dopa += (1.f - acc_a) * ga;
+                    dL_dopa *= T;
+                    last_alpha = alpha;
+                    dL_dopa += (-T_final / one_m_alpha) * bg_dot;
+                    const float dL_dG = b.y * dL_dopa;
+                    const float gdx = G * dx, gdy = G * dy;
+                    const float dG_ddelx = -gdx * a.z - gdy * a.w;
+                    const float dG_ddely = -gdy * b.x - gdx * a.w;
+                    v[A_M2X] = dL_dG * dG_ddelx * ddelx_dx;
+                    v[A_M2Y] = dL_dG * dG_ddely * ddely_dy;
+                    v[A_CONX] = -0.5f * gdx * dx * dL_dG;
+                    v[A_CONY] = -0.5f * gdx * dy * dL_dG;
+                    v[A_CONW] = -0.5f * gdy * dy * dL_dG;
+                    v[A_OPAC] = G * dL_dopa;
+                    v[A_COLR] = wgt * gr;
+                    v[A_COLG] = wgt * gg;
+                    v[A_COLB] = wgt * gb;
+                    v[A_DEPTH] = wgt * gd;
+                }
                 const float tot = wave_reduce16_transposed(v, lane);
                 // value slot 15 is unused by the gradients: it carries the "this quad touched the splat" flag
-                if ((lane & 3) == 0) myg[j * 16 + (lane >> 2)] = (lane == 60) ? 1.f : tot;
+                if ((lane & 3) == 0) myg[(lane >> 2) * GS + j] = (lane == 60) ? 1.f : tot;
             } else if (lane == 0) {
-                myg[j * 16 + 15] = 0.f;
+                myg[15 * GS + j] = 0.f;
             }
+            asm volatile("" : "+v"(na.x), "+v"(na.y), "+v"(na.z), "+v"(na.w), "+v"(nb.x), "+v"(nb.y), "+v"(nb.z),
+                         "+v"(nb.w), "+v"(nc.x), "+v"(nc.y), "+v"(nc.z), "+v"(nc.w));
+            a = na; b = nb; c = nc;
         }
         __builtin_amdgcn_wave_barrier();
 
-        // flush: lane j owns compacted splat j
-        if (lane < cnt) {
-            const float* row = myg + lane * 16;
-            if (row[15] != 0.f) {
-                const uint32_t gid = __float_as_uint(my[lane * 3 + 2].w);
-                float* dst = p.accum + (size_t)gid * kAccumFloats;
+        // flush: lane j owns compacted splat j; slab rows are bank-conflict free for both the 16-lane column write above
+        // and this 64-lane row read (stride 65 floats)
+        if (lane < cnt && myg[15 * GS + lane] != 0.f) {
+            const uint32_t gid = __float_as_uint(my[lane * 3 + 2].w);
+            float* dst = p.accum + (size_t)gid * kAccumFloats;
 #pragma unroll
-                for (int i = 0; i < 10; i++) atomicAdd(dst + i, row[i]);
-            }
+            for (int i = 0; i < 10; i++) atomicAdd(dst + i, myg[i * GS + lane]);
         }
         __builtin_amdgcn_wave_barrier();
     }

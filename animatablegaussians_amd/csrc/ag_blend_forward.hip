@@ -38,7 +38,7 @@ struct BlendFwdParams {
 
 __global__ void __launch_bounds__(256) blend_forward_kernel(BlendFwdParams p)
 {
-    __shared__ float4 slab[4][64 * 3];
+    __shared__ float4 slab[4][68 * 3];
 
     const int tile = blockIdx.x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -55,52 +55,76 @@ __global__ void __launch_bounds__(256) blend_forward_kernel(BlendFwdParams p)
     uint32_t last = 0;
     bool done = !inside;
 
+    // Software pipeline over 64-entry batches: while batch b is culled/compacted and blended, the (dependent)
+    // point_list -> record gathers of batch b+1 are already in flight; hipcc waits for them at their first use,
+    // i.e. at the top of the next iteration.  With ~2.5 resident waves per SIMD nothing else would hide that latency.
+    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = make_float4(0.f, 0.f, -1.f, 0.f);
+    if (range.x + lane < range.y) {
+        const float4* src = reinterpret_cast<const float4*>(p.rec + p.point_list[range.x + lane]);
+        r0 = src[0]; r1 = src[1]; r2 = src[2];
+    }
     for (uint32_t base = range.x; base < range.y; base += 64) {
         if (__all(done)) break;
         const uint32_t k = base + lane;
-        bool keep = false;
-        float4 r0, r1, r2;
-        if (k < range.y) {
-            const uint32_t id = p.point_list[k];
-            const float4* src = reinterpret_cast<const float4*>(p.rec + id);
-            r0 = src[0];  // x, y, ca, cb
-            r1 = src[1];  // cc, op, r, g
-            r2 = src[2];  // b, depth, r2cut, pad
-            const float ddx = fmaxf(fmaxf(qx0f - r0.x, r0.x - qx1f), 0.f);
-            const float ddy = fmaxf(fmaxf(qy0f - r0.y, r0.y - qy1f), 0.f);
-            keep = (ddx * ddx + ddy * ddy) <= r2.z;
-        }
+        // cull against this wave's 8x8 quad (r2.z = r2cut; lanes past the end carry r2cut = -1)
+        const float ddx = fmaxf(fmaxf(qx0f - r0.x, r0.x - qx1f), 0.f);
+        const float ddy = fmaxf(fmaxf(qy0f - r0.y, r0.y - qy1f), 0.f);
+        const bool keep = (k < range.y) && ((ddx * ddx + ddy * ddy) <= r2.z);
         const unsigned long long mask = __ballot(keep);
-        if (mask == 0ull) continue;
         const int slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
         if (keep) {
-            r2.z = __uint_as_float(k - range.x + 1u);  // 1-based list position ("contributor")
             my[slot * 3 + 0] = r0;
             my[slot * 3 + 1] = r1;
-            my[slot * 3 + 2] = r2;
+            my[slot * 3 + 2] = make_float4(r2.x, r2.y, __uint_as_float(k - range.x + 1u), 0.f);  // 1-based list position
+        }
+        // prefetch the next batch
+        const uint32_t kn = k + 64;
+        if (kn < range.y) {
+            const float4* src = reinterpret_cast<const float4*>(p.rec + p.point_list[kn]);
+            r0 = src[0]; r1 = src[1]; r2 = src[2];
         }
         const int cnt = __popcll(mask);
+        // pad the compacted batch to a multiple of 4 with inert records (opacity 0 -> alpha 0 -> never a candidate)
+        if (lane < 4) {
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            my[(cnt + lane) * 3 + 0] = z;
+            my[(cnt + lane) * 3 + 1] = z;
+            my[(cnt + lane) * 3 + 2] = z;
+        }
         __builtin_amdgcn_wave_barrier();
-
-        for (int j = 0; j < cnt; j++) {
-            const float4 a = my[j * 3 + 0];
-            const float4 b = my[j * 3 + 1];
-            const float4 c = my[j * 3 + 2];
-            const float dx = a.x - pxf, dy = a.y - pyf;
-            const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
-            const float alpha = fminf(0.99f, b.y * __builtin_amdgcn_exp2f(power * 1.4426950408889634f));
-            bool act = !done && (power <= 0.0f) && (alpha >= 1.0f / 255.0f);
-            const float test_T = T * (1.0f - alpha);
-            if (act && test_T < 0.0001f) { done = true; act = false; }
-            if (act) {
-                const float w = alpha * T;
-                Cr += b.z * w;
-                Cg += b.w * w;
-                Cb += c.x * w;
-                Dd += c.y * w;
+        // Four entries per trip: their conic/exp evaluations are independent, which gives a wave that is alone on
+        // its SIMD (the long-list tail of the kernel) instruction-level parallelism; only the short T recurrence is
+        // serial.
+        for (int j = 0; j < cnt; j += 4) {
+            float4 a[4], b[4], c[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                a[u] = my[(j + u) * 3 + 0];
+                b[u] = my[(j + u) * 3 + 1];
+                c[u] = my[(j + u) * 3 + 2];
+            }
+            float power[4], alpha[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const float dx = a[u].x - pxf, dy = a[u].y - pyf;
+                power[u] = -0.5f * (a[u].z * dx * dx + b[u].x * dy * dy) - a[u].w * dx * dy;
+                alpha[u] = fminf(0.99f, b[u].y * __builtin_amdgcn_exp2f(power[u] * 1.4426950408889634f));
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const bool cand = !done && (power[u] <= 0.0f) && (alpha[u] >= 1.0f / 255.0f);
+                const float test_T = T * (1.0f - alpha[u]);
+                const bool stop = cand && (test_T < 0.0001f);
+                const bool act = cand && !stop;
+                done = done || stop;
+                const float w = act ? alpha[u] * T : 0.f;
+                Cr += b[u].z * w;
+                Cg += b[u].w * w;
+                Cb += c[u].x * w;
+                Dd += c[u].y * w;
                 Wsum += w;
-                T = test_T;
-                last = __float_as_uint(c.z);
+                T = act ? test_T : T;
+                last = act ? __float_as_uint(c[u].z) : last;
             }
         }
         __builtin_amdgcn_wave_barrier();

@@ -63,6 +63,8 @@ __device__ __forceinline__ void get_rect(float px, float py, int max_radius, int
     x1o = (uint32_t)min(gx, x1); y1o = (uint32_t)min(gy, y1);
 }
 
+constexpr int kWinBins = 2048;   // tile-window histogram bins per workgroup (8 KiB of LDS)
+
 struct PreParams {
     int P, W, H, gx, gy;
     float tan_fovx, tan_fovy, focal_x, focal_y, scale_modifier;
@@ -83,8 +85,15 @@ struct PreParams {
 
 __global__ void __launch_bounds__(256) preprocess_kernel(PreParams p)
 {
+    // Workgroup-local tile histogram: the 256 Gaussians of a workgroup are neighbours on the canonical map, so
+    // their tile rects fall into a small window of the tile grid.  Instances are counted with LDS atomics inside that
+    // window and flushed with ONE global atomic per (workgroup, tile): ~20x fewer same-address global atomics than
+    // one per instance (which serialise in L2 at ~5 M/s per address and cost 190 us at avatar scale).
+    __shared__ int s_win[4];             // min x, min y, max x, max y (tile units, max exclusive)
+    __shared__ uint32_t s_hist[kWinBins];
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= p.P) return;
+    if (threadIdx.x == 0) { s_win[0] = 0x7fffffff; s_win[1] = 0x7fffffff; s_win[2] = 0; s_win[3] = 0; }
+    __syncthreads();
 
     // wave-uniform camera: scalar loads
     float V[16], Pm[16];
@@ -93,11 +102,14 @@ __global__ void __launch_bounds__(256) preprocess_kernel(PreParams p)
 
     int my_radii = 0;
     uint32_t touched = 0;
-    const float ox = p.means3D[3 * idx + 0], oy = p.means3D[3 * idx + 1], oz = p.means3D[3 * idx + 2];
+    uint32_t rx0 = 0, ry0 = 0, rx1 = 0, ry1 = 0;
+    const bool valid = idx < p.P;
+    const int sidx = valid ? idx : 0;
+    const float ox = p.means3D[3 * sidx + 0], oy = p.means3D[3 * sidx + 1], oz = p.means3D[3 * sidx + 2];
 
     // near-plane cull only (auxiliary.h:154)
     const float vz = V[2] * ox + V[6] * oy + V[10] * oz + V[14];
-    if (vz > 0.2f) {
+    if (valid && vz > 0.2f) {
         const float hx = Pm[0] * ox + Pm[4] * oy + Pm[8] * oz + Pm[12];
         const float hy = Pm[1] * ox + Pm[5] * oy + Pm[9] * oz + Pm[13];
         const float hw = Pm[3] * ox + Pm[7] * oy + Pm[11] * oz + Pm[15];
@@ -179,13 +191,36 @@ __global__ void __launch_bounds__(256) preprocess_kernel(PreParams p)
                 g.r2cut = r2;
                 g.pad = 0.f;
                 p.rec[idx] = g;
-                for (uint32_t y = y0; y < y1; y++)
-                    for (uint32_t x = x0; x < x1; x++) atomicAdd(&p.tile_count[y * (uint32_t)p.gx + x], 1u);
+                rx0 = x0; ry0 = y0; rx1 = x1; ry1 = y1;
+                atomicMin(&s_win[0], (int)x0); atomicMin(&s_win[1], (int)y0);
+                atomicMax(&s_win[2], (int)x1); atomicMax(&s_win[3], (int)y1);
             }
         }
     }
-    p.radii[idx] = my_radii;
-    p.tiles_touched[idx] = touched;
+    if (valid) {
+        p.radii[idx] = my_radii;
+        p.tiles_touched[idx] = touched;
+    }
+    __syncthreads();
+    const int wx0 = s_win[0], wy0 = s_win[1];
+    const int bw = s_win[2] - wx0, bh = s_win[3] - wy0;
+    if (bw <= 0 || bh <= 0) return;                       // nothing visible in this workgroup (uniform)
+    const int nb = bw * bh;
+    if (nb <= kWinBins) {
+        for (int i = threadIdx.x; i < nb; i += 256) s_hist[i] = 0u;
+        __syncthreads();
+        for (uint32_t y = ry0; y < ry1; y++)
+            for (uint32_t x = rx0; x < rx1; x++) atomicAdd(&s_hist[((int)y - wy0) * bw + ((int)x - wx0)], 1u);
+        __syncthreads();
+        for (int i = threadIdx.x; i < nb; i += 256) {
+            const uint32_t c = s_hist[i];
+            if (c) atomicAdd(&p.tile_count[(uint32_t)(wy0 + i / bw) * (uint32_t)p.gx + (uint32_t)(wx0 + i % bw)], c);
+        }
+    } else {
+        // spatially incoherent input (e.g. randomly ordered Gaussians): plain per-instance atomics
+        for (uint32_t y = ry0; y < ry1; y++)
+            for (uint32_t x = rx0; x < rx1; x++) atomicAdd(&p.tile_count[y * (uint32_t)p.gx + x], 1u);
+    }
 }
 
 int launch_preprocess(const AgRasterForwardArgs& a, hipStream_t s)
