@@ -59,7 +59,18 @@ class AgRasterScratchLayout(ctypes.Structure):
         "bin_point_list_off", "bin_keys_off")]
 
 
-# every symbol include/ag_raster.h declares: (name, restype, argtypes)
+class AgGatherArgs(ctypes.Structure):
+    _fields_ = [("N", c_i32), ("S", c_i32)] + [(n, c_vp) for n in (
+        "pix", "position_map", "other_map", "color_map", "xyz", "opacity_raw", "scaling_raw", "rotation_raw",
+        "positions", "opacity", "scales", "rotations", "colors")]
+
+
+class AgLbsArgs(ctypes.Structure):
+    _fields_ = [("N", c_i32), ("J", c_i32)] + [(n, c_vp) for n in (
+        "lbs", "jnt_mats", "positions", "rotations", "out_positions", "out_rotations")]
+
+
+# every symbol include/*.h declares: (name, restype, argtypes)
 SYMBOLS = [
     ("ag_abi_version", ctypes.c_int, []),
     ("ag_last_error", ctypes.c_char_p, []),
@@ -76,6 +87,11 @@ SYMBOLS = [
     ("ag_prof_enable", ctypes.c_int, [ctypes.c_uint32]),
     ("ag_prof_collect", ctypes.c_int, [ctypes.POINTER(c_i32), ctypes.POINTER(c_f)]),
     ("ag_debug_wave_reduce16", ctypes.c_int, [c_vp, c_vp, c_vp]),
+    # include/ag_avatar.h
+    ("ag_gather_activate_forward", ctypes.c_int, [ctypes.POINTER(AgGatherArgs), c_vp]),
+    ("ag_gather_activate_backward", ctypes.c_int, [ctypes.POINTER(AgGatherArgs), c_vp, c_vp, c_vp, c_vp]),
+    ("ag_lbs_forward", ctypes.c_int, [ctypes.POINTER(AgLbsArgs), c_vp]),
+    ("ag_lbs_backward", ctypes.c_int, [ctypes.POINTER(AgLbsArgs), c_vp, c_vp, c_vp]),
 ]
 
 _lib = None

@@ -1,0 +1,126 @@
+"""Autograd operators over the per-Gaussian assembly and skinning kernels (``include/ag_avatar.h``).
+
+``gather_activate`` is the fused equivalent of ``AvatarNet.get_positions`` + ``get_others`` + ``get_colors`` applied to
+already-computed StyleUNet outputs (reference ``network/avatar.py:93-124``); ``lbs_transform`` is
+``AvatarNet.transform_cano2live`` (``network/avatar.py:84-91``).  Python only allocates and passes pointers.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _stream(dev):
+    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def _chk(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not t.is_cuda or t.dtype != torch.float32:
+        raise RuntimeError(f"{name} must be a float32 GPU tensor")
+    return t.contiguous()
+
+
+def mask_to_pix(mask: torch.Tensor) -> torch.Tensor:
+    """[S, 2S] bool canvas mask -> ascending int32 pixel list (the order ``canvas[mask]`` enumerates)."""
+    return torch.nonzero(mask.reshape(-1), as_tuple=False).reshape(-1).to(torch.int32).contiguous()
+
+
+class _GatherActivate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, position_map, other_map, color_map, pix, xyz, opacity_raw, scaling_raw, rotation_raw):
+        L = _lib.lib()
+        position_map, other_map, color_map = (_chk(position_map, "position_map"), _chk(other_map, "other_map"),
+                                              _chk(color_map, "color_map"))
+        xyz, opacity_raw = _chk(xyz, "xyz"), _chk(opacity_raw, "opacity_raw")
+        scaling_raw, rotation_raw = _chk(scaling_raw, "scaling_raw"), _chk(rotation_raw, "rotation_raw")
+        S = int(position_map.shape[-1])
+        if tuple(position_map.shape) != (1, 6, S, S) or tuple(other_map.shape) != (1, 16, S, S) or tuple(color_map.shape) != (1, 6, S, S):
+            raise RuntimeError("expected maps of shape [1,6,S,S], [1,16,S,S], [1,6,S,S]")
+        N, dev = int(pix.numel()), position_map.device
+        f = dict(dtype=torch.float32, device=dev)
+        out = [torch.empty((N, c), **f) for c in (3, 1, 3, 4, 3)]
+        a = _lib.AgGatherArgs()
+        a.N, a.S = N, S
+        a.pix = _p(pix)
+        a.position_map, a.other_map, a.color_map = _p(position_map), _p(other_map), _p(color_map)
+        a.xyz, a.opacity_raw, a.scaling_raw, a.rotation_raw = _p(xyz), _p(opacity_raw), _p(scaling_raw), _p(rotation_raw)
+        a.positions, a.opacity, a.scales, a.rotations, a.colors = (_p(t) for t in out)
+        with torch.cuda.device(dev):
+            _lib.check(L.ag_gather_activate_forward(ctypes.byref(a), _stream(dev)), "ag_gather_activate_forward")
+        ctx.save_for_backward(position_map, other_map, color_map, pix, xyz, opacity_raw, scaling_raw, rotation_raw)
+        return tuple(out)
+
+    @staticmethod
+    def backward(ctx, g_pos, g_opa, g_sca, g_rot, g_col):
+        L = _lib.lib()
+        position_map, other_map, color_map, pix, xyz, opacity_raw, scaling_raw, rotation_raw = ctx.saved_tensors
+        dev = position_map.device
+        N, S = int(pix.numel()), int(position_map.shape[-1])
+        grads = [(_chk(g, "grad") if g is not None else torch.zeros((N, c), dtype=torch.float32, device=dev))
+                 for g, c in ((g_pos, 3), (g_opa, 1), (g_sca, 3), (g_rot, 4), (g_col, 3))]
+        a = _lib.AgGatherArgs()
+        a.N, a.S = N, S
+        a.pix = _p(pix)
+        a.position_map, a.other_map, a.color_map = _p(position_map), _p(other_map), _p(color_map)
+        a.xyz, a.opacity_raw, a.scaling_raw, a.rotation_raw = _p(xyz), _p(opacity_raw), _p(scaling_raw), _p(rotation_raw)
+        a.positions, a.opacity, a.scales, a.rotations, a.colors = (_p(t) for t in grads)
+        gp, go, gc = (torch.empty_like(m) for m in (position_map, other_map, color_map))
+        with torch.cuda.device(dev):
+            _lib.check(L.ag_gather_activate_backward(ctypes.byref(a), _p(gp), _p(go), _p(gc), _stream(dev)),
+                       "ag_gather_activate_backward")
+        # the canonical Gaussian parameters are not optimised by the reference trainer (GaussianModel is not an
+        # nn.Module, main_avatar.py:55-58 only collects avatar_net.parameters()): no gradient is produced for them
+        return gp, go, gc, None, None, None, None, None
+
+
+def gather_activate(position_map, other_map, color_map, pix, xyz, opacity_raw, scaling_raw, rotation_raw):
+    """-> (positions [N,3], opacity [N,1], scales [N,3], rotations [N,4], colors [N,3])."""
+    return _GatherActivate.apply(position_map, other_map, color_map, pix, xyz, opacity_raw, scaling_raw, rotation_raw)
+
+
+class _LbsTransform(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, positions, rotations, lbs, jnt_mats):
+        L = _lib.lib()
+        positions, rotations = _chk(positions, "positions"), _chk(rotations, "rotations")
+        lbs, jnt_mats = _chk(lbs, "lbs"), _chk(jnt_mats, "jnt_mats")
+        N, J, dev = int(positions.shape[0]), int(lbs.shape[1]), positions.device
+        if tuple(jnt_mats.shape) != (J, 4, 4) or lbs.shape[0] != N or tuple(rotations.shape) != (N, 4):
+            raise RuntimeError("expected positions [N,3], rotations [N,4], lbs [N,J], jnt_mats [J,4,4]")
+        out_p, out_r = torch.empty_like(positions), torch.empty_like(rotations)
+        a = _lib.AgLbsArgs()
+        a.N, a.J = N, J
+        a.lbs, a.jnt_mats, a.positions, a.rotations = _p(lbs), _p(jnt_mats), _p(positions), _p(rotations)
+        a.out_positions, a.out_rotations = _p(out_p), _p(out_r)
+        with torch.cuda.device(dev):
+            _lib.check(L.ag_lbs_forward(ctypes.byref(a), _stream(dev)), "ag_lbs_forward")
+        ctx.save_for_backward(positions, rotations, lbs, jnt_mats)
+        return out_p, out_r
+
+    @staticmethod
+    def backward(ctx, g_p, g_r):
+        L = _lib.lib()
+        positions, rotations, lbs, jnt_mats = ctx.saved_tensors
+        N, J, dev = int(positions.shape[0]), int(lbs.shape[1]), positions.device
+        g_p = _chk(g_p, "grad") if g_p is not None else torch.zeros_like(positions)
+        g_r = _chk(g_r, "grad") if g_r is not None else torch.zeros_like(rotations)
+        dp, dr = torch.empty_like(positions), torch.empty_like(rotations)
+        a = _lib.AgLbsArgs()
+        a.N, a.J = N, J
+        a.lbs, a.jnt_mats, a.positions, a.rotations = _p(lbs), _p(jnt_mats), _p(positions), _p(rotations)
+        a.out_positions, a.out_rotations = _p(g_p), _p(g_r)
+        with torch.cuda.device(dev):
+            _lib.check(L.ag_lbs_backward(ctypes.byref(a), _p(dp), _p(dr), _stream(dev)), "ag_lbs_backward")
+        return dp, dr, None, None   # lbs weights and joint matrices are data, not parameters
+
+
+def lbs_transform(positions, rotations, lbs, jnt_mats):
+    """-> (live positions [N,3], live rotations [N,4])."""
+    return _LbsTransform.apply(positions, rotations, lbs, jnt_mats)

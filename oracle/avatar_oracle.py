@@ -1,0 +1,97 @@
+"""CPU oracle (torch fp32 + autograd) of the per-Gaussian assembly and skinning steps.  TEST INFRASTRUCTURE ONLY.
+
+Restates, with plain torch ops on the CPU,
+  * ``AvatarNet.get_positions / get_others / get_colors``  (reference ``network/avatar.py:93-124``): re-layout of the
+    StyleUNet output ``[1, 2C, S, S]`` into the ``[S, 2S, C]`` front|back canvas, boolean-mask gather, and the
+    activations ``0.05*delta + xyz``, ``sigmoid``, ``exp``, ``F.normalize`` (``gaussians/gaussian_model.py:53-61``);
+  * ``AvatarNet.transform_cano2live`` (``network/avatar.py:84-91``): linear-blend skinning of positions and rotations.
+
+The backward oracle is ``torch.autograd`` of exactly these ops -- that IS the reference's backward for this stage.
+
+PARITY UNPINNED for the two pytorch3d helpers: ``pytorch3d.transforms.quaternion_to_matrix`` /
+``matrix_to_quaternion`` (pytorch3d == 0.7.4, ``requirements.txt:9``) are third-party code that is absent from
+/root/reference and not installable here; they are restated below from the published 0.7.4 algorithm
+(``transforms/rotation_conversions.py``: ``two_s = 2/|q|^2``; four ``sqrt(max(0, 1 +- m00 +- m11 +- m22))`` candidates,
+arg-max row, division by ``2*max(q_abs, 0.1)``, no sign standardisation).  Everything else in this file is pinned by
+the reference's own Python, which these functions mirror line by line.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+
+def quaternion_to_matrix(quaternions: torch.Tensor) -> torch.Tensor:
+    r, i, j, k = torch.unbind(quaternions, -1)
+    two_s = 2.0 / (quaternions * quaternions).sum(-1)
+    o = torch.stack(
+        (
+            1 - two_s * (j * j + k * k),
+            two_s * (i * j - k * r),
+            two_s * (i * k + j * r),
+            two_s * (i * j + k * r),
+            1 - two_s * (i * i + k * k),
+            two_s * (j * k - i * r),
+            two_s * (i * k - j * r),
+            two_s * (j * k + i * r),
+            1 - two_s * (i * i + j * j),
+        ),
+        -1,
+    )
+    return o.reshape(quaternions.shape[:-1] + (3, 3))
+
+
+def _sqrt_positive_part(x: torch.Tensor) -> torch.Tensor:
+    ret = torch.zeros_like(x)
+    positive_mask = x > 0
+    ret[positive_mask] = torch.sqrt(x[positive_mask])
+    return ret
+
+
+def matrix_to_quaternion(matrix: torch.Tensor) -> torch.Tensor:
+    batch_dim = matrix.shape[:-2]
+    m00, m01, m02, m10, m11, m12, m20, m21, m22 = torch.unbind(matrix.reshape(batch_dim + (9,)), dim=-1)
+    q_abs = _sqrt_positive_part(
+        torch.stack(
+            [1.0 + m00 + m11 + m22, 1.0 + m00 - m11 - m22, 1.0 - m00 + m11 - m22, 1.0 - m00 - m11 + m22], dim=-1))
+    quat_by_rijk = torch.stack(
+        [
+            torch.stack([q_abs[..., 0] ** 2, m21 - m12, m02 - m20, m10 - m01], dim=-1),
+            torch.stack([m21 - m12, q_abs[..., 1] ** 2, m10 + m01, m02 + m20], dim=-1),
+            torch.stack([m02 - m20, m10 + m01, q_abs[..., 2] ** 2, m12 + m21], dim=-1),
+            torch.stack([m10 - m01, m20 + m02, m21 + m12, q_abs[..., 3] ** 2], dim=-1),
+        ],
+        dim=-2,
+    )
+    flr = torch.tensor(0.1).to(dtype=q_abs.dtype, device=q_abs.device)
+    quat_candidates = quat_by_rijk / (2.0 * q_abs[..., None].max(flr))
+    return quat_candidates[F.one_hot(q_abs.argmax(dim=-1), num_classes=4) > 0.5, :].reshape(batch_dim + (4,))
+
+
+def canvas(net_out: torch.Tensor, C: int) -> torch.Tensor:
+    """[1, 2C, S, S] -> [S, 2S, C] (front | back along W), network/avatar.py:95-96,108-109,121-122."""
+    front, back = torch.split(net_out, [C, C], 1)
+    return torch.cat([front, back], 3)[0].permute(1, 2, 0)
+
+
+def gather_activate(position_map, other_map, color_map, mask, xyz, opacity_raw, scaling_raw, rotation_raw):
+    """get_positions + get_others + get_colors on already-computed network outputs.
+
+    Returns (positions [N,3], opacity [N,1], scales [N,3], rotations [N,4], colors [N,3])."""
+    positions = 0.05 * canvas(position_map, 3)[mask] + xyz
+    others = canvas(other_map, 8)[mask]
+    o, s, r = torch.split(others, [1, 3, 4], 1)
+    opacity = torch.sigmoid(o + opacity_raw)
+    scales = torch.exp(s + scaling_raw)
+    rotations = F.normalize(r + rotation_raw)
+    colors = canvas(color_map, 3)[mask]
+    return positions, opacity, scales, rotations, colors
+
+
+def transform_cano2live(positions, rotations, lbs, jnt_mats):
+    """network/avatar.py:84-91."""
+    pt_mats = torch.einsum('nj,jxy->nxy', lbs, jnt_mats)
+    live_pos = torch.einsum('nxy,ny->nx', pt_mats[..., :3, :3], positions) + pt_mats[..., :3, 3]
+    rot_mats = quaternion_to_matrix(rotations)
+    rot_mats = torch.einsum('nxy,nyz->nxz', pt_mats[..., :3, :3], rot_mats)
+    return live_pos, matrix_to_quaternion(rot_mats)

@@ -1,0 +1,123 @@
+"""GPU parity of the gather/activation and LBS kernels against the torch-CPU oracle (oracle/avatar_oracle.py).
+
+fp32 tolerance: 1e-5 relative to the row magnitude for forward values (a handful of fused fp32 ops; the LBS blend is a
+55-term dot product whose summation order differs from the oracle's BLAS matmul), 1e-4 for gradients."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _synthetic(S=256, J=55, seed=0):
+    import torch
+    from animatablegaussians_amd import synth
+    g = torch.Generator().manual_seed(seed)
+    m = synth.body_mask(S)
+    mask = torch.from_numpy(np.concatenate([m, m[:, ::-1]], axis=1).copy())
+    N = int(mask.sum())
+    d = dict(
+        mask=mask,
+        position_map=torch.randn(1, 6, S, S, generator=g),
+        other_map=torch.randn(1, 16, S, S, generator=g) * 0.5,
+        color_map=torch.rand(1, 6, S, S, generator=g),
+        xyz=torch.randn(N, 3, generator=g) * 0.5,
+        opacity_raw=torch.randn(N, 1, generator=g),
+        scaling_raw=torch.randn(N, 3, generator=g) * 0.3 - 5.0,
+        rotation_raw=torch.nn.functional.normalize(torch.randn(N, 4, generator=g)),
+    )
+    w = torch.softmax(torch.randn(N, J, generator=g) * 4, dim=1)
+    top = torch.topk(w, 4, dim=1)
+    lbs = torch.zeros_like(w).scatter_(1, top.indices, top.values)
+    d["lbs"] = lbs / lbs.sum(1, keepdim=True)
+    # random rigid joint transforms: rotations <= 30 deg, translations <= 5 cm
+    ax = torch.nn.functional.normalize(torch.randn(J, 3, generator=g))
+    ang = torch.rand(J, generator=g) * (np.pi / 6)
+    K = torch.zeros(J, 3, 3)
+    K[:, 0, 1], K[:, 0, 2], K[:, 1, 0], K[:, 1, 2], K[:, 2, 0], K[:, 2, 1] = -ax[:, 2], ax[:, 1], ax[:, 2], -ax[:, 0], -ax[:, 1], ax[:, 0]
+    Rm = torch.eye(3)[None] + torch.sin(ang)[:, None, None] * K + (1 - torch.cos(ang))[:, None, None] * (K @ K)
+    A = torch.eye(4)[None].repeat(J, 1, 1)
+    A[:, :3, :3] = Rm
+    A[:, :3, 3] = (torch.rand(J, 3, generator=g) - 0.5) * 0.1
+    d["jnt_mats"] = A
+    return d
+
+
+def _close(got, ref, name, rtol):
+    got, ref = got.detach().cpu().double().numpy(), ref.detach().double().numpy()
+    d = np.abs(got - ref)
+    lim = rtol * np.maximum(np.abs(ref), np.abs(ref).max(axis=-1, keepdims=True) if ref.ndim > 1 else np.abs(ref)) + 1e-7
+    assert np.isfinite(got).all(), name
+    assert (d <= lim).all(), f"{name}: max diff {d.max():.3e}, worst ratio {(d / lim).max():.2f}"
+
+
+def test_gather_activate_forward_backward():
+    import torch
+    from animatablegaussians_amd import avatar_ops as ops
+    from oracle import avatar_oracle as ao
+    d = _synthetic()
+    maps = [d[k].clone().requires_grad_(True) for k in ("position_map", "other_map", "color_map")]
+    ref = ao.gather_activate(*maps, d["mask"], d["xyz"], d["opacity_raw"], d["scaling_raw"], d["rotation_raw"])
+    g = torch.Generator().manual_seed(1)
+    ups = [torch.randn(r.shape, generator=g) for r in ref]
+    torch.autograd.backward(list(ref), ups)
+
+    gm = [d[k].cuda().requires_grad_(True) for k in ("position_map", "other_map", "color_map")]
+    pix = ops.mask_to_pix(d["mask"].cuda())
+    got = ops.gather_activate(*gm, pix, d["xyz"].cuda(), d["opacity_raw"].cuda(), d["scaling_raw"].cuda(), d["rotation_raw"].cuda())
+    for name, a, b in zip(("positions", "opacity", "scales", "rotations", "colors"), got, ref):
+        _close(a, b, name, 1e-5)
+    torch.autograd.backward(list(got), [u.cuda() for u in ups])
+    for name, a, b in zip(("dL_dposition_map", "dL_dother_map", "dL_dcolor_map"), gm, maps):
+        ga, gb = a.grad.cpu(), b.grad
+        assert torch.equal(ga == 0, gb == 0) or (ga[gb == 0].abs().max() == 0), name + ": gradient outside the mask"
+        np.testing.assert_allclose(ga.numpy(), gb.numpy(), rtol=1e-4, atol=1e-6, err_msg=name)
+
+
+@pytest.mark.parametrize("J", [55, 24])
+def test_lbs_forward_backward(J):
+    import torch
+    from animatablegaussians_amd import avatar_ops as ops
+    from oracle import avatar_oracle as ao
+    d = _synthetic(J=J, seed=2)
+    N = d["xyz"].shape[0]
+    g = torch.Generator().manual_seed(3)
+    pos = (torch.randn(N, 3, generator=g) * 0.5).requires_grad_(True)
+    rot = torch.nn.functional.normalize(torch.randn(N, 4, generator=g)).requires_grad_(True)
+    rp, rr = ao.transform_cano2live(pos, rot, d["lbs"], d["jnt_mats"])
+    up, ur = torch.randn(N, 3, generator=g), torch.randn(N, 4, generator=g)
+    torch.autograd.backward([rp, rr], [up, ur])
+
+    gpos, grot = pos.detach().cuda().requires_grad_(True), rot.detach().cuda().requires_grad_(True)
+    gp, gr = ops.lbs_transform(gpos, grot, d["lbs"].cuda(), d["jnt_mats"].cuda())
+    _close(gp, rp, "live positions", 1e-5)
+    _close(gr, rr, "live rotations", 1e-5)
+    # blended matrices are not orthonormal: the output quaternions are generally NOT unit (the rasterizer consumes them raw)
+    assert (gr.detach().norm(dim=1) - 1).abs().max() > 1e-4
+    torch.autograd.backward([gp, gr], [up.cuda(), ur.cuda()])
+    _close(gpos.grad, pos.grad, "dL_dpositions", 1e-4)
+    _close(grot.grad, rot.grad, "dL_drotations", 1e-4)
+
+
+def test_lbs_all_matrix_to_quaternion_branches():
+    """Force each of the four arg-max candidates of matrix_to_quaternion (rotations by ~180 deg about x, y, z and a
+    small one) plus the 0.1 floor (a strongly shrunk blend)."""
+    import torch
+    from animatablegaussians_amd import avatar_ops as ops
+    from oracle import avatar_oracle as ao
+    qs = torch.tensor([[1.0, 0.02, 0.01, 0.03], [0.02, 1.0, 0.03, 0.01], [0.01, 0.02, 1.0, 0.03], [0.03, 0.01, 0.02, 1.0]])
+    qs = torch.nn.functional.normalize(qs).repeat(16, 1)
+    N = qs.shape[0]
+    lbs = torch.zeros(N, 3)
+    lbs[:, 0] = 1.0
+    lbs[N // 2:, 0] = 0.004          # shrinks M3 so every q_abs candidate falls under the 0.1 floor... (identity * 0.004)
+    A = torch.eye(4)[None].repeat(3, 1, 1)
+    pos = torch.randn(N, 3)
+    rot = qs.clone().requires_grad_(True)
+    rp, rr = ao.transform_cano2live(pos, rot, lbs, A)
+    up = torch.randn(N, 4)
+    rr.backward(up)
+    grot = qs.clone().cuda().requires_grad_(True)
+    gp, gr = ops.lbs_transform(pos.cuda(), grot, lbs.cuda(), A.cuda())
+    _close(gr, rr, "rotations", 1e-5)
+    gr.backward(up.cuda())
+    _close(grot.grad, rot.grad, "dL_drotations", 1e-4)
