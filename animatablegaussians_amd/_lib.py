@@ -92,6 +92,9 @@ SYMBOLS = [
     ("ag_gather_activate_backward", ctypes.c_int, [ctypes.POINTER(AgGatherArgs), c_vp, c_vp, c_vp, c_vp]),
     ("ag_lbs_forward", ctypes.c_int, [ctypes.POINTER(AgLbsArgs), c_vp]),
     ("ag_lbs_backward", ctypes.c_int, [ctypes.POINTER(AgLbsArgs), c_vp, c_vp, c_vp]),
+    # include/ag_styleunet.h
+    ("ag_fused_bias_act", ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_f, c_f, ctypes.c_int64, ctypes.c_int64, c_i32, c_vp]),
+    ("ag_upfirdn2d", ctypes.c_int, [c_vp, c_vp, c_vp] + [c_i32] * 13 + [c_vp]),
 ]
 
 _lib = None

@@ -1,0 +1,150 @@
+// fused bias + activation and upfirdn2d (FIR resampling) for the StyleUNet (gfx950).
+//
+// Replaces network/styleunet/fused_bias_act_kernel.cu:18-104 and upfirdn2d_kernel.cu:49-368 (see
+// include/ag_styleunet.h).  Both are pure streaming operators, HBM-bound:
+//   fused_bias_act: 4 B in (+4 B ref) + 4 B out per element; float4-vectorised grid-stride loop;
+//   upfirdn2d     : one output element per thread, x-fastest so a wave writes 256 contiguous bytes and its <= 16 taps
+//                   read overlapping contiguous spans that stay in L1/L2 (each input element feeds <= kh*kw/(up^2)
+//                   outputs); the <= 4x4 FIR taps sit in LDS.
+#include "ag_common.h"
+#include "../../include/ag_styleunet.h"
+
+namespace ag {
+
+__device__ __forceinline__ float bias_act_one(float x, float ref, int mode, float alpha)
+{
+    switch (mode) {
+    case 12: case 32: return 0.0f;
+    case 30: return (x > 0.0f) ? x : x * alpha;
+    case 31: return (ref > 0.0f) ? x : x * alpha;
+    default: return x;   // 10, 11 and the reference's `default:`
+    }
+}
+
+__global__ void __launch_bounds__(256) fused_bias_act_kernel(float* __restrict__ out, const float* __restrict__ x,
+                                                            const float* __restrict__ bias, const float* __restrict__ ref,
+                                                            int mode, float alpha, float scale, long long size_x,
+                                                            long long step_b, int size_b, int vec_ok)
+{
+    const long long stride = (long long)gridDim.x * 256;
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (vec_ok) {
+        // step_b % 4 == 0 and 16-byte aligned pointers: the four lanes of a float4 share one bias element
+        const long long n4 = size_x >> 2;
+        for (; i < n4; i += stride) {
+            const float4 v = reinterpret_cast<const float4*>(x)[i];
+            const float b = bias ? bias[((i << 2) / step_b) % size_b] : 0.0f;
+            float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ref) r = reinterpret_cast<const float4*>(ref)[i];
+            float4 o;
+            o.x = bias_act_one(v.x + b, r.x, mode, alpha) * scale;
+            o.y = bias_act_one(v.y + b, r.y, mode, alpha) * scale;
+            o.z = bias_act_one(v.z + b, r.z, mode, alpha) * scale;
+            o.w = bias_act_one(v.w + b, r.w, mode, alpha) * scale;
+            reinterpret_cast<float4*>(out)[i] = o;
+        }
+        // tail (size_x % 4) handled by the scalar loop below on the remaining elements
+        i = (n4 << 2) + (long long)blockIdx.x * 256 + threadIdx.x;
+    }
+    for (; i < size_x; i += stride) {
+        const float b = bias ? bias[(i / step_b) % size_b] : 0.0f;
+        out[i] = bias_act_one(x[i] + b, ref ? ref[i] : 0.0f, mode, alpha) * scale;
+    }
+}
+
+__device__ __forceinline__ int floor_div(int a, int b)
+{
+    int c = a / b;
+    if (c * b > a) c--;
+    return c;
+}
+
+struct UpfirdnParams {
+    int up_x, up_y, down_x, down_y, pad_x0, pad_y0;
+    int major, in_h, in_w, kernel_h, kernel_w, out_h, out_w;
+};
+
+constexpr int kMaxTaps = 1024;
+
+__global__ void __launch_bounds__(256) upfirdn2d_kernel(float* __restrict__ out, const float* __restrict__ input,
+                                                       const float* __restrict__ kernel, UpfirdnParams p)
+{
+    __shared__ float taps[kMaxTaps];
+    const int ntaps = p.kernel_h * p.kernel_w;
+    for (int i = threadIdx.x; i < ntaps; i += 256) taps[i] = kernel[i];
+    __syncthreads();
+    const long long total = (long long)p.major * p.out_h * p.out_w;
+    for (long long o = (long long)blockIdx.x * 256 + threadIdx.x; o < total; o += (long long)gridDim.x * 256) {
+        const int out_x = (int)(o % p.out_w);
+        const long long t = o / p.out_w;
+        const int out_y = (int)(t % p.out_h);
+        const long long mj = t / p.out_h;
+        // first contributing input row/col and the kernel tap that meets it (upfirdn2d_kernel.cu:62-81)
+        const int mid_y = out_y * p.down_y + p.up_y - 1 - p.pad_y0;
+        const int in_y = min(max(floor_div(mid_y, p.up_y), 0), p.in_h);
+        const int h = min(max(floor_div(mid_y + p.kernel_h, p.up_y), 0), p.in_h) - in_y;
+        const int kernel_y = mid_y + p.kernel_h - (in_y + 1) * p.up_y;
+        const int mid_x = out_x * p.down_x + p.up_x - 1 - p.pad_x0;
+        const int in_x = min(max(floor_div(mid_x, p.up_x), 0), p.in_w);
+        const int w = min(max(floor_div(mid_x + p.kernel_w, p.up_x), 0), p.in_w) - in_x;
+        const int kernel_x = mid_x + p.kernel_w - (in_x + 1) * p.up_x;
+        const float* xp = input + (mj * p.in_h + in_y) * p.in_w + in_x;
+        float v = 0.0f;
+        for (int y = 0; y < h; y++) {
+            const float* kp = taps + (kernel_y - y * p.up_y) * p.kernel_w + kernel_x;
+            for (int x = 0; x < w; x++) v += xp[(long long)y * p.in_w + x] * kp[-x * p.up_x];
+        }
+        out[o] = v;
+    }
+}
+
+}  // namespace ag
+
+using namespace ag;
+
+extern "C" {
+
+int ag_fused_bias_act(float* out, const float* x, const float* bias, const float* ref, int32_t act, int32_t grad,
+                      float alpha, float scale, int64_t size_x, int64_t step_b, int32_t size_b, void* stream)
+{
+    if (size_x < 0 || (size_x > 0 && (!out || !x))) { set_error("bad fused_bias_act arguments"); return AG_ERR_INVALID_ARGUMENT; }
+    if (size_x == 0) return AG_OK;
+    if (bias && (size_b <= 0 || step_b <= 0)) { set_error("bias given but size_b/step_b invalid"); return AG_ERR_INVALID_ARGUMENT; }
+    if (!bias || size_b <= 0) { bias = nullptr; size_b = 1; step_b = 1; }
+    const int mode = act * 10 + grad;
+    const auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    const int vec_ok = (step_b % 4 == 0 || !bias) && al(out) && al(x) && (!ref || al(ref));
+    long long work = vec_ok ? (size_x + 3) / 4 : size_x;
+    int blocks = (int)((work + 255) / 256);
+    if (blocks > 4096) blocks = 4096;   // grid-stride: ~16 workgroups per CU
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(fused_bias_act_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), out, x, bias,
+                       ref, mode, alpha, scale, (long long)size_x, (long long)step_b, (int)size_b, vec_ok);
+    return check_hip(hipGetLastError(), "fused_bias_act_kernel");
+}
+
+int ag_upfirdn2d(float* out, const float* input, const float* kernel, int32_t major, int32_t in_h, int32_t in_w,
+                 int32_t kernel_h, int32_t kernel_w, int32_t up_x, int32_t up_y, int32_t down_x, int32_t down_y,
+                 int32_t pad_x0, int32_t pad_x1, int32_t pad_y0, int32_t pad_y1, void* stream)
+{
+    if (major < 0 || in_h <= 0 || in_w <= 0 || kernel_h <= 0 || kernel_w <= 0 || up_x <= 0 || up_y <= 0 || down_x <= 0 ||
+        down_y <= 0 || kernel_h * kernel_w > kMaxTaps) {
+        set_error("bad upfirdn2d sizes");
+        return AG_ERR_INVALID_ARGUMENT;
+    }
+    UpfirdnParams p;
+    p.up_x = up_x; p.up_y = up_y; p.down_x = down_x; p.down_y = down_y; p.pad_x0 = pad_x0; p.pad_y0 = pad_y0;
+    p.major = major; p.in_h = in_h; p.in_w = in_w; p.kernel_h = kernel_h; p.kernel_w = kernel_w;
+    p.out_h = (in_h * up_y + pad_y0 + pad_y1 - kernel_h + down_y) / down_y;
+    p.out_w = (in_w * up_x + pad_x0 + pad_x1 - kernel_w + down_x) / down_x;
+    if (p.out_h <= 0 || p.out_w <= 0) { set_error("upfirdn2d output would be empty (%d x %d)", p.out_h, p.out_w); return AG_ERR_INVALID_ARGUMENT; }
+    if (major == 0) return AG_OK;
+    if (!out || !input || !kernel) { set_error("null pointer"); return AG_ERR_INVALID_ARGUMENT; }
+    const long long total = (long long)major * p.out_h * p.out_w;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(upfirdn2d_kernel, dim3((int)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), out, input, kernel, p);
+    return check_hip(hipGetLastError(), "upfirdn2d_kernel");
+}
+
+}  // extern "C"

@@ -13,7 +13,7 @@ FAST="-ffp-contract=fast"
 compile() { # src flags
   local src="$1"; shift
   local obj="$OBJ/$(basename "${src%.hip}").o"
-  if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ "$HERE/ag_common.h" -nt "$obj" ] || [ "$HERE/../../include/ag_raster.h" -nt "$obj" ] || [ "$HERE/../../include/ag_avatar.h" -nt "$obj" ]; then
+  if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ "$HERE/ag_common.h" -nt "$obj" ] || [ "$HERE/../../include/ag_raster.h" -nt "$obj" ] || [ "$HERE/../../include/ag_avatar.h" -nt "$obj" ] || [ "$HERE/../../include/ag_styleunet.h" -nt "$obj" ]; then
     echo "hipcc $(basename "$src") $*"
     "$HIPCC" $COMMON "$@" -c "$src" -o "$obj"
   fi
@@ -25,6 +25,7 @@ compile "$HERE/ag_blend_forward.hip" $FAST &
 compile "$HERE/ag_blend_backward.hip" $FAST &
 compile "$HERE/ag_preprocess_backward.hip" $FAST &
 compile "$HERE/ag_avatar.hip" $FAST &
+compile "$HERE/ag_styleunet_ops.hip" $FAST &
 wait
 "$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT/libag_hip.so" "$OBJ"/*.o
 echo "built $OUT/libag_hip.so"

@@ -1,0 +1,45 @@
+/*
+ * ag_styleunet.h — C ABI of the StyleUNet element-wise / FIR operators (libag_hip.so).
+ *
+ * Drop-in for the two native extension modules the reference's network/styleunet imports as top-level modules:
+ *   `fused`      fused.fused_bias_act(input, bias, refer, act, grad, alpha, scale)
+ *                network/styleunet/fused_bias_act.cpp:17-31, fused_bias_act_kernel.cu:18-104
+ *   `upfirdn2d`  upfirdn2d.upfirdn2d(input, kernel, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1)
+ *                network/styleunet/upfirdn2d.cpp:17-31, upfirdn2d_kernel.cu:49-368
+ * Device pointers, fp32, contiguous; 0 on success (codes in ag_raster.h).
+ */
+#ifndef AG_STYLEUNET_H
+#define AG_STYLEUNET_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/*
+ * out[i] = scale * f(x[i] + bias[(i / step_b) % size_b], ref[i])
+ *   act 1 (linear): grad 0/1 -> x            ; grad 2 -> 0
+ *   act 3 (lrelu) : grad 0 -> x > 0 ? x : alpha x ; grad 1 -> ref > 0 ? x : alpha x ; grad 2 -> 0
+ * bias == NULL or size_b == 0: no bias.  ref == NULL: ref = 0.  step_b = product of the dimensions after dim 1.
+ * Any other (act, grad) pair behaves like act 1 / grad 0, as the reference's `default:` label does.
+ */
+int ag_fused_bias_act(float* out, const float* x, const float* bias, const float* ref, int32_t act, int32_t grad,
+                      float alpha, float scale, int64_t size_x, int64_t step_b, int32_t size_b, void* stream);
+
+/*
+ * input [major, in_h, in_w] (the reference's [major, in_h, in_w, minor = 1]), kernel [kernel_h, kernel_w]:
+ * zero-insert upsampling by (up_y, up_x), padding (negative = cropping), correlation with the FLIPPED kernel,
+ * decimation by (down_y, down_x).  out [major, out_h, out_w] with
+ *   out_h = (in_h*up_y + pad_y0 + pad_y1 - kernel_h + down_y) / down_y   (same for w).
+ * Returns AG_ERR_INVALID_ARGUMENT when the output would be empty.
+ */
+int ag_upfirdn2d(float* out, const float* input, const float* kernel, int32_t major, int32_t in_h, int32_t in_w,
+                 int32_t kernel_h, int32_t kernel_w, int32_t up_x, int32_t up_y, int32_t down_x, int32_t down_y,
+                 int32_t pad_x0, int32_t pad_x1, int32_t pad_y0, int32_t pad_y1, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AG_STYLEUNET_H */
