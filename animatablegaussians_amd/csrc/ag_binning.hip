@@ -22,12 +22,16 @@ namespace ag {
 // ---------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024) tile_scan_kernel(int T, const uint32_t* __restrict__ tile_count,
                                                         uint32_t* __restrict__ cursor, uint2* __restrict__ ranges,
-                                                        uint32_t* __restrict__ num_rendered)
+                                                        uint32_t* __restrict__ num_rendered,
+                                                        uint4* __restrict__ tile_order, uint32_t* __restrict__ queue)
 {
     __shared__ uint32_t wave_sums[16];
     __shared__ uint32_t carry_s;
+    __shared__ uint32_t cls_hist[34], cls_off[34];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) carry_s = 0;
+    if (tid < 2 * kQueues) queue[tid] = 0;
+    if (tid < 34) cls_hist[tid] = 0;
     __syncthreads();
     for (int base = 0; base < T; base += 1024) {
         const int t = base + tid;
@@ -49,12 +53,25 @@ __global__ void __launch_bounds__(1024) tile_scan_kernel(int T, const uint32_t* 
             const uint32_t start = incl - c;
             cursor[t] = start;
             ranges[t] = c ? make_uint2(start, incl) : make_uint2(0u, 0u);  // empty tiles keep the memset value
+            atomicAdd(&cls_hist[32 - __clz(c)], 1u);                       // size class = bit length of the count
         }
         __syncthreads();
         if (tid == 1023) carry_s = incl;
         __syncthreads();
     }
-    if (tid == 0) *num_rendered = carry_s;
+    if (tid == 0) { num_rendered[0] = carry_s; num_rendered[1] = (uint32_t)T - cls_hist[0]; }   // instances, non-empty tiles
+    // Work order for the persistent blend kernels: tiles by descending size class (longest-processing-time first),
+    // empty tiles last.  Order inside a class is arbitrary.
+    if (tid == 0) {
+        uint32_t acc = 0;
+        for (int cls = 33; cls >= 0; cls--) { cls_off[cls] = acc; acc += cls_hist[cls]; }
+    }
+    __syncthreads();
+    for (int t = tid; t < T; t += 1024) {
+        const uint32_t cls = 32 - __clz(tile_count[t]);
+        const uint2 rg = ranges[t];   // written above by this workgroup (barriers in between)
+        tile_order[atomicAdd(&cls_off[cls], 1u)] = make_uint4((uint32_t)t, rg.x, rg.y, 0u);
+    }
 }
 
 int launch_tile_scan(const AgRasterForwardArgs& a, hipStream_t s)
@@ -66,7 +83,9 @@ int launch_tile_scan(const AgRasterForwardArgs& a, hipStream_t s)
                        reinterpret_cast<const uint32_t*>(ib + il.tile_count),
                        reinterpret_cast<uint32_t*>(ib + il.cursor),
                        reinterpret_cast<uint2*>(ib + il.ranges),
-                       reinterpret_cast<uint32_t*>(ib + il.num_rendered)); }
+                       reinterpret_cast<uint32_t*>(ib + il.num_rendered),
+                       reinterpret_cast<uint4*>(ib + il.tile_order),
+                       reinterpret_cast<uint32_t*>(ib + il.queue)); }
     return check_hip(hipGetLastError(), "tile_scan_kernel");
 }
 

@@ -4,25 +4,29 @@
 // T_final = 1 - alpha_out with T recovered by division, the depth and alpha-output gradient terms, the background
 // term, no gradient gate at the 0.99 alpha clamp, dL_dmean2D in NDC-scaled units (x 0.5 W, x 0.5 H).
 //
-// The reference issues 10 global float atomicAdds per (pixel, Gaussian) pair.  Here (wave64, CDNA4):
-//   * four independent waves per 16x16 tile, one 8x8 pixel quad each, same staging/cull/compaction as the forward
-//     (ag_blend_forward.hip), but walking the tile list from the back and starting at the quad's largest
-//     n_contrib, so the forward's early termination is inherited;
-//   * for each surviving splat the 10 per-pixel partial gradients are summed over the 64 lanes by a TRANSPOSED
-//     butterfly: v_permlane32_swap / v_permlane16_swap exchange register halves so that each step halves the number
-//     of live values while doubling the lanes summed (16 -> 8 -> 4 -> 2 -> 1 registers), then two quad-perm adds.
-//     35 VALU ops for all 10 sums instead of 70 for ten independent DPP reductions; afterwards lane l holds the
-//     total of value (l >> 2) & 15;
-//   * the per-splat totals are parked in the wave's LDS slab and flushed once per 64-entry batch with one lane per
-//     splat: ten atomic instructions per batch, all landing in that splat's single 64-byte accumulator line.
-// Global atomics drop from 10 per (pixel, splat) to 10 per (quad, splat).
+// Same decomposition as the forward (ag_blend_forward.hip): persistent 8-wave workgroups own 8x4-pixel regions,
+// statically assigned longest-list-first; the tile list is culled 512 entries at a time against the region (rearmost
+// first, only up to the region's largest n_contrib) and compacted in processing order into LDS; inside a wave each
+// 16-lane DPP row is one pixel and its lanes are 16 consecutive entries of the back-to-front walk.  The reference's
+// three serial recurrences become row scans:
+//   T_e      = T / prod_{i<=e} (1 - alpha_i)                          inclusive product scan (the divisions of :534)
+//   behind_e = g_{e-1}( ... g_0(behind_0)),  g_i(S) = alpha_i c_i + (1 - alpha_i) S
+//                                                                      exclusive scan of affine maps (A, B[5]) for the
+//                                                                      colour / depth / alpha "accum_rec" of :541-565
+// after which the ten gradient terms of all 16 entries are independent.  The terms of the wave's 4 pixels are summed
+// with two register-exchange stages (v_permlane32_swap, v_permlane16_swap: 10 -> 5 -> 3 registers), added into a
+// per-chunk LDS accumulator [10][512] with ds_add_f32 (8 waves share it), and flushed once per chunk with one global
+// atomic per (region, splat, component) into the splat's 64-byte accumulator line.  The reference issues the same ten
+// atomics per (pixel, splat).
+#include <cstdlib>
 #include "ag_common.h"
 
 namespace ag {
 
 struct BlendBwdParams {
-    int W, H, gx, T;
-    const uint2* __restrict__ ranges;
+    int W, H, gx, T, dbg;
+    const uint4* __restrict__ tile_order;
+    const uint32_t* __restrict__ counts;
     const uint32_t* __restrict__ point_list;
     const GaussRec* __restrict__ rec;
     const float* __restrict__ bg;
@@ -45,6 +49,23 @@ __device__ __forceinline__ float dpp(float v)
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
 }
 
+template <int N>
+__device__ __forceinline__ float row_shr(float v, float fill)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), AG_DPP_ROW_SHR(N), 0xf, 0xf, false));
+}
+
+template <int N>
+__device__ __forceinline__ float row_shr0(float v)   // zero fill: foldable into the DPP operand of an FMA
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), AG_DPP_ROW_SHR(N), 0xf, 0xf, true));
+}
+
+__device__ __forceinline__ float row_read(float v, int lane, int k)   // value of lane k of this lane's 16-lane row
+{
+    return __shfl(v, (lane & 48) + k, 64);
+}
+
 __device__ __forceinline__ void swap32(float& a, float& b)
 {
     // lanes 32-63 of a <-> lanes 0-31 of b
@@ -61,20 +82,21 @@ __device__ __forceinline__ void swap16(float& a, float& b)
     b = __uint_as_float(r[1]);
 }
 
-// Sum each of v[0..15] over the 64 lanes; on return lane l holds the total of v[(l >> 2) & 15].
+// Sum each of v[0..15] over the 64 lanes; on return lane l holds the total of v[(l >> 2) & 15].  (Used by the
+// wave-per-quad variant of this kernel and kept as a tested building block: tests/test_raster_gpu.py.)
 __device__ __forceinline__ float wave_reduce16_transposed(float (&v)[16], int lane)
 {
     float s[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         swap32(v[i], v[i + 8]);
-        s[i] = v[i] + v[i + 8];  // lanes <32: value i, lanes >=32: value i+8
+        s[i] = v[i] + v[i + 8];
     }
     float u[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         swap16(s[i], s[i + 4]);
-        u[i] = s[i] + s[i + 4];  // row r: value i + 4*(r&1) + 8*(r>>1)
+        u[i] = s[i] + s[i + 4];
     }
     float w[2];
 #pragma unroll
@@ -91,123 +113,188 @@ __device__ __forceinline__ float wave_reduce16_transposed(float (&v)[16], int la
     return x;
 }
 
-__global__ void __launch_bounds__(256) blend_backward_kernel(BlendBwdParams p)
+#ifndef BWD_WAVES_PER_SIMD
+#define BWD_WAVES_PER_SIMD 4
+#endif
+constexpr int kSub = 64;                 // compacted entries blended between two flushes of the per-wave partial sums
+constexpr int kPartStride = kSub + 4;
+
+__global__ void __launch_bounds__(kBlendThreads, BWD_WAVES_PER_SIMD) blend_backward_kernel(BlendBwdParams p)
 {
-    __shared__ float4 slab[4][64 * 3];
-    __shared__ float gslab[4][16 * 65];
+    constexpr int NW = kBlendThreads / 64;
+    __shared__ float4 s_rec[kChunk * 3];
+    __shared__ float s_part[kBlendThreads / 64][10][kPartStride];   // per-wave sums over its 4 pixels: plain stores, no LDS atomics
+    __shared__ uint32_t s_gid[kChunk];
+    __shared__ int s_wave_cnt[2][NW];
+    __shared__ uint32_t s_wave_max[NW];
 
-    const int tile = blockIdx.x;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int tile_x = tile % p.gx, tile_y = tile / p.gx;
-    const int qx0 = tile_x * kTileX + (wave & 1) * 8, qy0 = tile_y * kTileY + (wave >> 1) * 8;
-    const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
-    const bool inside = px < p.W && py < p.H;
-    const float pxf = (float)px, pyf = (float)py;
-    const float qx0f = (float)qx0, qy0f = (float)qy0, qx1f = (float)(qx0 + 7), qy1f = (float)(qy0 + 7);
-    const uint2 range = p.ranges[tile];
-    float4* my = slab[wave];
-    float* myg = gslab[wave];
-
-    const int pix = p.W * py + px;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int row = lane >> 4, e = lane & 15;
+    const uint32_t n_active = p.counts[1];
     const size_t HW = (size_t)p.W * p.H;
-    uint32_t last_contributor = 0;
-    float T_final = 0.f, gr = 0.f, gg = 0.f, gb = 0.f, gd = 0.f, ga = 0.f;
-    if (inside) {
-        last_contributor = p.n_contrib[pix];
-        T_final = 1.0f - p.alphas[pix];
-        gr = p.dL_dpix[pix];
-        gg = p.dL_dpix[HW + pix];
-        gb = p.dL_dpix[2 * HW + pix];
-        gd = p.dL_ddepth[pix];
-        ga = p.dL_dalpha[pix];
-    }
-    const float bg_dot = p.bg[0] * gr + p.bg[1] * gg + p.bg[2] * gb;
     const float ddelx_dx = 0.5f * (float)p.W, ddely_dy = 0.5f * (float)p.H;
+    const float bg0 = p.bg[0], bg1 = p.bg[1], bg2 = p.bg[2];
 
-    // largest n_contrib of the quad: nothing behind it contributed to any of these pixels
-    uint32_t wmax = last_contributor;
+    ItemIter it(blockIdx.x, gridDim.x, n_active);
+    uint32_t tr, rg;
+    bool have = it.next(tr, rg);
+    uint4 hdr = make_uint4(0u, 0u, 0u, 0u);
+    if (have) { hdr = p.tile_order[tr]; hdr.w = rg; }
+    lds_barrier();
+
+    while (have) {
+        uint32_t tr_n, rg_n;
+        const bool have_n = it.next(tr_n, rg_n);
+        uint4 hdr_n = make_uint4(0u, 0u, 0u, 0u);
+        if (have_n) { hdr_n = p.tile_order[tr_n]; hdr_n.w = rg_n; }
+
+        const int tile = (int)hdr.x, reg = (int)hdr.w;
+        const uint32_t rbeg = hdr.y;
+        const int tile_x = tile % p.gx, tile_y = tile / p.gx;
+        const int rx0 = tile_x * kTileX + (reg & 1) * kRegW, ry0 = tile_y * kTileY + (reg >> 1) * kRegH;
+        const int pi = wave * 4 + row;
+        // the wave's 4 pixels form a 2x2 block (better coherence of the per-wave early-outs than a 4x1 strip)
+        const int px = rx0 + (wave & 3) * 2 + (row & 1), py = ry0 + (wave >> 2) * 2 + (row >> 1);
+        const bool inside = px < p.W && py < p.H;
+        const float pxf = (float)px, pyf = (float)py;
+        const float qx0f = (float)rx0, qy0f = (float)ry0, qx1f = (float)(rx0 + kRegW - 1), qy1f = (float)(ry0 + kRegH - 1);
+
+        // per-pixel constants (row-uniform)
+        const int pix = p.W * py + px;
+        uint32_t last_contributor = 0;
+        float T_final = 0.f, gr = 0.f, gg = 0.f, gb = 0.f, gd = 0.f, ga = 0.f;
+        if (inside) {
+            last_contributor = p.n_contrib[pix];
+            T_final = 1.0f - p.alphas[pix];
+            gr = p.dL_dpix[pix];
+            gg = p.dL_dpix[HW + pix];
+            gb = p.dL_dpix[2 * HW + pix];
+            gd = p.dL_ddepth[pix];
+            ga = p.dL_dalpha[pix];
+        }
+        const float bg_dot = bg0 * gr + bg1 * gg + bg2 * gb;
+
+        // nothing behind the region's largest n_contrib contributed to any of its pixels
+        uint32_t wmax = last_contributor;
 #pragma unroll
-    for (int d = 32; d > 0; d >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, d, 64));
-    if (wmax == 0) return;
+        for (int d = 32; d > 0; d >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, d, 64));
+        if (lane == 0) s_wave_max[wave] = wmax;
+        lds_barrier();
+#pragma unroll
+        for (int w = 0; w < NW; w++) wmax = max(wmax, s_wave_max[w]);
+        const uint32_t rend = rbeg + wmax;   // walk [rbeg, rend) from the back
 
-    float T = T_final;
-    float acc_r = 0.f, acc_g = 0.f, acc_b = 0.f, acc_d = 0.f, acc_a = 0.f;
-    float last_alpha = 0.f, last_r = 0.f, last_g = 0.f, last_b = 0.f, last_d = 0.f;
+        // row state of the back-to-front walk
+        float T = T_final;                                   // transmittance behind the entries processed so far
+        float S_r = 0.f, S_g = 0.f, S_b = 0.f, S_d = 0.f, S_a = 0.f;   // blended colour/depth/alpha behind them
 
-    // entries [range.x, range.x + wmax) back to front, 64 per batch; lane 0 takes the rearmost entry of the batch.
-    // Same software pipeline as the forward: the gathers of the next batch fly while this one is processed.
-    constexpr int GS = 65;   // padded row stride of the per-batch gradient slab: [16 values][64 splats]
-    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
-    uint32_t id = 0;
-    {
-        const uint32_t take0 = wmax < 64u ? wmax : 64u;
-        if ((uint32_t)lane < take0) {
-            id = p.point_list[range.x + wmax - 1u - (uint32_t)lane];
-            const float4* src = reinterpret_cast<const float4*>(p.rec + id);
-            r0 = src[0]; r1 = src[1]; r2 = src[2];
-        }
-    }
-    for (uint32_t remaining = wmax; remaining > 0;) {
-        const uint32_t take = remaining < 64u ? remaining : 64u;
-        const uint32_t top = range.x + remaining;  // one past the rearmost entry of this batch
-        remaining -= take;
-        const float ddx = fmaxf(fmaxf(qx0f - r0.x, r0.x - qx1f), 0.f);
-        const float ddy = fmaxf(fmaxf(qy0f - r0.y, r0.y - qy1f), 0.f);
-        const bool keep = ((uint32_t)lane < take) && ((ddx * ddx + ddy * ddy) <= r2.z);
-        const unsigned long long mask = __ballot(keep);
-        const int slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-        if (keep) {
-            my[slot * 3 + 0] = r0;
-            my[slot * 3 + 1] = r1;
-            // b, depth, 1-based list position, Gaussian index
-            my[slot * 3 + 2] = make_float4(r2.x, r2.y, __uint_as_float(top - (uint32_t)lane - range.x), __uint_as_float(id));
-        }
-        // prefetch the next (nearer) batch
+        // staging pipeline (records one chunk ahead, indices two chunks ahead); thread t takes entry rend-1-t-c*512
+        uint32_t id_cur = 0, id_next = 0;
+        float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
         {
-            const uint32_t take_n = remaining < 64u ? remaining : 64u;
-            if ((uint32_t)lane < take_n) {
-                id = p.point_list[range.x + remaining - 1u - (uint32_t)lane];
-                const float4* src = reinterpret_cast<const float4*>(p.rec + id);
+            const uint32_t o0 = (uint32_t)tid, o1 = o0 + kChunk;
+            if (o0 < wmax) id_cur = p.point_list[rend - 1u - o0];
+            if (o1 < wmax) id_next = p.point_list[rend - 1u - o1];
+            if (o0 < wmax) {
+                const float4* src = reinterpret_cast<const float4*>(p.rec + id_cur);
                 r0 = src[0]; r1 = src[1]; r2 = src[2];
             }
         }
-        const int cnt = __popcll(mask);
-        __builtin_amdgcn_wave_barrier();
-        if (cnt == 0) continue;
+        bool keep;
+        {
+            const float ddx = fmaxf(fmaxf(qx0f - r0.x, r0.x - qx1f), 0.f);
+            const float ddy = fmaxf(fmaxf(qy0f - r0.y, r0.y - qy1f), 0.f);
+            keep = ((uint32_t)tid < wmax) && ((ddx * ddx + ddy * ddy) <= r2.z);
+        }
+        unsigned long long mask = __ballot(keep);
+        if (lane == 0) s_wave_cnt[0][wave] = __popcll(mask);
+        lds_barrier();
 
-        float4 a = my[0], b = my[1], c = my[2];
-        for (int j = 0; j < cnt; j++) {
-            const int jn = (j + 1 < cnt) ? j + 1 : j;
-            float4 na = my[jn * 3 + 0], nb = my[jn * 3 + 1], nc = my[jn * 3 + 2];
-            __builtin_amdgcn_sched_barrier(0);
-            // a: x, y, ca, cb   b: cc, op, r, g   c: b, depth, pos, id
-            const uint32_t pos1 = __float_as_uint(c.z);
-            const float dx = a.x - pxf, dy = a.y - pyf;
-            const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
-            const float G = __builtin_amdgcn_exp2f(power * 1.4426950408889634f);
-            const float alpha = fminf(0.99f, b.y * G);
-            const bool act = (pos1 <= last_contributor) && (power <= 0.0f) && (alpha >= 1.0f / 255.0f);
-            if (__any(act)) {
-                float v[16];
+        int cpar = 0;
+        for (uint32_t done_entries = 0; done_entries < wmax; done_entries += kChunk, cpar ^= 1) {
+            // ---- ordered compaction (processing order = back to front) ----
+            const uint32_t o = done_entries + (uint32_t)tid;        // offset from the back
+            const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+            int off = 0, K = 0;
 #pragma unroll
-                for (int i = 0; i < 16; i++) v[i] = 0.f;
-                if (act) {
-                    const float one_m_alpha = 1.f - alpha;
-                    T = T / one_m_alpha;
-                    const float wgt = alpha * T;
-                    const float one_m_last = 1.f - last_alpha;
-                    acc_r = last_alpha * last_r + one_m_last * acc_r;
-                    acc_g = last_alpha * last_g + one_m_last * acc_g;
-                    acc_b = last_alpha * last_b + one_m_last * acc_b;
-                    acc_d = last_alpha * last_d + one_m_last * acc_d;
-                    acc_a = last_alpha + one_m_last * acc_a;
-                    last_r = b.z; last_g = b.w; last_b = c.x; last_d = c.y;
-                    float dL_dopa = (b.z - acc_r) * gr + (b.w - acc_g) * gg + (c.x - acc_b) * gb;
-                    dL_dopa += (c.y - acc_d) * gd;
-                    dL_dopa += (1.f - acc_a) * ga;
-                    dL_dopa *= T;
-                    last_alpha = alpha;
-                    dL_dopa += (-T_final / one_m_alpha) * bg_dot;
+            for (int w = 0; w < NW; w++) {
+                const int c = s_wave_cnt[cpar][w];
+                off += (w < wave) ? c : 0;
+                K += c;
+            }
+            if (keep) {
+                const int slot = off + rank;
+                s_rec[slot * 3 + 0] = r0;
+                s_rec[slot * 3 + 1] = r1;
+                s_rec[slot * 3 + 2] = make_float4(r2.x, r2.y, __uint_as_float(wmax - o), 0.f);   // b, depth, 1-based list position
+                s_gid[slot] = id_cur;
+            }
+            const uint32_t on = o + kChunk, onn = on + kChunk;
+            id_cur = id_next;
+            if (on < wmax) {
+                const float4* src = reinterpret_cast<const float4*>(p.rec + id_next);
+                r0 = src[0]; r1 = src[1]; r2 = src[2];
+            }
+            if (onn < wmax) id_next = p.point_list[rend - 1u - onn];
+            lds_barrier();
+
+            // ---- kSub compacted entries at a time: 16 entries per step per pixel row, then flush ----
+            for (int sb = 0; sb < K; sb += kSub) {
+            const int sub_n = min(kSub, K - sb);
+            for (int s0 = sb; s0 < ((p.dbg & 4) ? sb : sb + sub_n); s0 += 16) {
+                const int idx = s0 + e;
+                const bool ev = idx < K;
+                const int ci = ev ? idx : (K - 1);
+                const float4 a = s_rec[ci * 3 + 0];   // x, y, conic a, conic b
+                const float4 b = s_rec[ci * 3 + 1];   // conic c, opacity, r, g
+                const float4 c = s_rec[ci * 3 + 2];   // b, depth, position
+                const float dx = a.x - pxf, dy = a.y - pyf;
+                const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
+                const float G = __builtin_amdgcn_exp2f(power * 1.4426950408889634f);
+                const float alpha = fminf(0.99f, b.y * G);
+                const bool act = ev && (__float_as_uint(c.z) <= last_contributor) && (power <= 0.0f) && (alpha >= 1.0f / 255.0f);
+                const int vbase = (row == 0) ? 0 : (row == 1) ? 3 : (row == 2) ? 5 : 8;
+                float* part = &s_part[wave][vbase][idx - sb];
+                if (!__any(act)) {
+                    if (ev) { part[0] = 0.f; part[kPartStride] = 0.f; if (!(row & 1)) part[2 * kPartStride] = 0.f; }
+                    continue;
+                }
+                const float fac = act ? (1.0f - alpha) : 1.0f;
+                // affine maps g_e(S) = A S + B, A = fac, B = alpha * c (0 when inactive); inclusive row scan
+                const float al = act ? alpha : 0.f;
+                float A = fac, Br = al * b.z, Bg = al * b.w, Bb = al * c.x, Bd = al * c.y, Ba = al;
+#define AG_SCAN_STEP(N)                                                                      \
+                {                                                                            \
+                    const float Ap = row_shr<N>(A, 1.0f);                                    \
+                    Br = fmaf(row_shr0<N>(Br), A, Br);                                       \
+                    Bg = fmaf(row_shr0<N>(Bg), A, Bg);                                       \
+                    Bb = fmaf(row_shr0<N>(Bb), A, Bb);                                       \
+                    Bd = fmaf(row_shr0<N>(Bd), A, Bd);                                       \
+                    Ba = fmaf(row_shr0<N>(Ba), A, Ba);                                       \
+                    A *= Ap;                                                                 \
+                }
+                if (!(p.dbg & 32)) { AG_SCAN_STEP(1) AG_SCAN_STEP(2) AG_SCAN_STEP(4) AG_SCAN_STEP(8) }
+#undef AG_SCAN_STEP
+                // A is now prod_{i<=e} fac_i: T in front of entry e; exclusive maps give the blend behind entry e
+                const float Tin = T * __builtin_amdgcn_rcpf(A);
+                const float Aex = row_shr<1>(A, 1.0f);
+                const float beh_r = fmaf(Aex, S_r, row_shr0<1>(Br));
+                const float beh_g = fmaf(Aex, S_g, row_shr0<1>(Bg));
+                const float beh_b = fmaf(Aex, S_b, row_shr0<1>(Bb));
+                const float beh_d = fmaf(Aex, S_d, row_shr0<1>(Bd));
+                const float beh_a = fmaf(Aex, S_a, row_shr0<1>(Ba));
+
+                // the ten per-(pixel, entry) terms; inactive lanes contribute exact zeros through `m`
+                float v[10];
+                {
+                    const float m = act ? 1.f : 0.f;
+                    float dL_dopa = (b.z - beh_r) * gr + (b.w - beh_g) * gg + (c.x - beh_b) * gb;
+                    dL_dopa += (c.y - beh_d) * gd;
+                    dL_dopa += (1.f - beh_a) * ga;
+                    dL_dopa *= Tin;
+                    dL_dopa += (-T_final * __builtin_amdgcn_rcpf(fac)) * bg_dot;
+                    dL_dopa *= m;
+                    const float wgt = al * Tin;            // al is 0 on inactive lanes
                     const float dL_dG = b.y * dL_dopa;
                     const float gdx = G * dx, gdy = G * dy;
                     const float dG_ddelx = -gdx * a.z - gdy * a.w;
@@ -223,27 +310,63 @@ __global__ void __launch_bounds__(256) blend_backward_kernel(BlendBwdParams p)
                     v[A_COLB] = wgt * gb;
                     v[A_DEPTH] = wgt * gd;
                 }
-                const float tot = wave_reduce16_transposed(v, lane);
-                // value slot 15 is unused by the gradients: it carries the "this quad touched the splat" flag
-                if ((lane & 3) == 0) myg[(lane >> 2) * GS + j] = (lane == 60) ? 1.f : tot;
-            } else if (lane == 0) {
-                myg[15 * GS + j] = 0.f;
-            }
-            asm volatile("" : "+v"(na.x), "+v"(na.y), "+v"(na.z), "+v"(na.w), "+v"(nb.x), "+v"(nb.y), "+v"(nb.z),
-                         "+v"(nb.w), "+v"(nc.x), "+v"(nc.y), "+v"(nc.z), "+v"(nc.w));
-            a = na; b = nb; c = nc;
-        }
-        __builtin_amdgcn_wave_barrier();
+                // carry for the next step: state behind entry 15 of this step
+                if (!(p.dbg & 16)) {
+                T = row_read(Tin, lane, 15);
+                const float A15 = row_read(A, lane, 15);
+                S_r = fmaf(A15, S_r, row_read(Br, lane, 15));
+                S_g = fmaf(A15, S_g, row_read(Bg, lane, 15));
+                S_b = fmaf(A15, S_b, row_read(Bb, lane, 15));
+                S_d = fmaf(A15, S_d, row_read(Bd, lane, 15));
+                S_a = fmaf(A15, S_a, row_read(Ba, lane, 15));
+                }
 
-        // flush: lane j owns compacted splat j; slab rows are bank-conflict free for both the 16-lane column write above
-        // and this 64-lane row read (stride 65 floats)
-        if (lane < cnt && myg[15 * GS + lane] != 0.f) {
-            const uint32_t gid = __float_as_uint(my[lane * 3 + 2].w);
-            float* dst = p.accum + (size_t)gid * kAccumFloats;
+                // sum the 4 pixels (rows) of this wave per entry column: 10 -> 5 -> 3 registers
+                if (p.dbg & 8) { if (ev) part[0] = v[0] + v[1] + v[2] + v[3] + v[4] + v[5] + v[6] + v[7] + v[8] + v[9]; continue; }
+                float s[6];
 #pragma unroll
-            for (int i = 0; i < 10; i++) atomicAdd(dst + i, myg[i * GS + lane]);
+                for (int i = 0; i < 5; i++) {
+                    swap32(v[i], v[i + 5]);
+                    s[i] = v[i] + v[i + 5];      // rows 0,1: value i ; rows 2,3: value i+5
+                }
+                s[5] = 0.f;
+                float u[3];
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+                    swap16(s[i], s[i + 3]);
+                    u[i] = s[i] + s[i + 3];      // row 0: value i, row 1: value i+3, row 2: value i+5, row 3: value i+8
+                }
+                if (ev) { part[0] = u[0]; part[kPartStride] = u[1]; if (!(row & 1)) part[2 * kPartStride] = u[2]; }
+            }
+            lds_barrier();   // partial sums of this sub-chunk complete
+            // flush: lane = (entry, component) with the 16 accumulator slots of one splat in 16 ADJACENT lanes, so one wave
+            // instruction touches 4 whole 64-byte accumulator lines instead of 64 different ones (the atomic units work
+            // per line request); 512 threads cover 32 entries per pass.  Exact zeros are skipped.
+#pragma unroll
+            for (int pass = 0; pass < kSub / 32; pass++) {
+                const int ent = pass * 32 + (tid >> 4), comp = tid & 15;
+                if (ent < sub_n && comp < 10) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int w = 0; w < NW; w++) acc += s_part[w][comp][ent];
+                    if (acc != 0.f && !(p.dbg & 1)) atomicAdd(p.accum + (size_t)s_gid[sb + ent] * kAccumFloats + comp, acc);
+                }
+            }
+            lds_barrier();   // s_part reusable
+            }
+
+            // ---- cull of the next chunk ----
+            {
+                const float ddx = fmaxf(fmaxf(qx0f - r0.x, r0.x - qx1f), 0.f);
+                const float ddy = fmaxf(fmaxf(qy0f - r0.y, r0.y - qy1f), 0.f);
+                keep = (on < wmax) && ((ddx * ddx + ddy * ddy) <= r2.z);
+            }
+            mask = __ballot(keep);
+            if (lane == 0) s_wave_cnt[cpar ^ 1][wave] = __popcll(mask);
+            lds_barrier();   // s_rec / s_gid reusable, next counts visible
         }
-        __builtin_amdgcn_wave_barrier();
+        hdr = hdr_n;
+        have = have_n;
     }
 }
 
@@ -265,6 +388,7 @@ int launch_debug_wave_reduce16(const float* in, float* out, hipStream_t s)
 int launch_blend_backward(const AgRasterBackwardArgs& a, hipStream_t s)
 {
     BlendBwdParams p;
+    p.dbg = getenv("AG_DBG_BWD") ? atoi(getenv("AG_DBG_BWD")) : 0;
     p.W = a.W; p.H = a.H;
     p.gx = (a.W + kTileX - 1) / kTileX;
     const int gy = (a.H + kTileY - 1) / kTileY;
@@ -274,7 +398,8 @@ int launch_blend_backward(const AgRasterBackwardArgs& a, hipStream_t s)
     GeomLayout gl((size_t)a.P);
     ImageLayout il((size_t)a.W, (size_t)a.H);
     BinLayout bl((size_t)a.num_rendered);
-    p.ranges = reinterpret_cast<const uint2*>(ib + il.ranges);
+    p.tile_order = reinterpret_cast<const uint4*>(ib + il.tile_order);
+    p.counts = reinterpret_cast<const uint32_t*>(ib + il.num_rendered);
     p.rec = reinterpret_cast<const GaussRec*>(gb + gl.rec);
     p.point_list = a.num_rendered > 0
         ? reinterpret_cast<const uint32_t*>(aligned_base(a.binning_buffer) + bl.point_list) : nullptr;
@@ -285,7 +410,9 @@ int launch_blend_backward(const AgRasterBackwardArgs& a, hipStream_t s)
     p.accum = reinterpret_cast<float*>(aligned_base(a.accum_buffer));
     if (check_hip(hipMemsetAsync(p.accum, 0, (size_t)a.P * kAccumFloats * sizeof(float), s), "memset accum")) return AG_ERR_HIP;
     if (a.num_rendered <= 0) return AG_OK;
-    { ProfScope ps(AG_K_BLEND_BACKWARD, s); hipLaunchKernelGGL(blend_backward_kernel, dim3(p.T), dim3(256), 0, s, p); }
+    const long long items = (long long)p.T * kRegionsPerTile;
+    const int grid = (int)(items < 768 ? items : 768);   // 3 workgroups of 8 waves per CU (46 KiB of LDS each)
+    { ProfScope ps(AG_K_BLEND_BACKWARD, s); hipLaunchKernelGGL(blend_backward_kernel, dim3(grid), dim3(kBlendThreads), 0, s, p); }
     return check_hip(hipGetLastError(), "blend_backward_kernel");
 }
 

@@ -8,27 +8,35 @@
 //   n_contrib = 1-based list position of the last accumulated entry
 //   out = C + T bg ; out_alpha = A (accumulated weight, not 1 - T) ; out_depth = D
 //
-// MI355X mapping (not the reference's 256-thread lock-step block):
-//   * one workgroup per 16x16 tile, but its four wave64s are INDEPENDENT: wave w owns the 8x8 pixel quad
-//     (w&1, w>>1) and walks the tile's sorted list on its own, 64 entries at a time (lane = list entry);
-//   * while staging, each lane tests its entry against the quad with the record's conservative cut-off radius
-//     (r2cut, see ag_preprocess.hip) and the survivors are ballot-compacted into a wave-private LDS slab, so the
-//     inner loop only visits splats that can reach alpha >= 1/255 somewhere in the quad (a radius-4 splat touches
-//     ~1.7 of a tile's 4 quads).  Culled entries still count in n_contrib because the list position travels with
-//     the record;
-//   * the inner loop reads one record per iteration as three uniform-address ds_read_b128 (LDS broadcast), no
-//     workgroup barrier anywhere; a wave leaves as soon as all of its 64 pixels are saturated.
-// Bound: VALU (about 30 ops per (splat, quad) pair) + LDS broadcast; HBM traffic is the compulsory
-// 52 B/instance + 24 B/pixel.
+// The reference walks a tile's list serially per pixel (one 256-thread block per tile, one Gaussian at a time).  With
+// an avatar only 300-650 of 4096 tiles are non-empty and side views put 6000 entries in one tile, so that serial chain
+// -- not throughput -- sets the kernel time.  This kernel breaks the chain in two places:
+//   * PIXELS: a tile is split into 8 regions of 8x4 pixels, each owned by one 8-wave workgroup; persistent workgroups
+//     pull (tile, region) items from a global queue ordered longest-list-first (tile_scan_kernel).
+//   * LIST ENTRIES: inside a wave, each 16-lane DPP row is ONE pixel and its 16 lanes are 16 CONSECUTIVE list entries.
+//     The transmittance is a prefix product: T_before(e) = T * prod_{i<e} (1 - alpha_i) over the contributing entries,
+//     computed with a 4-step DPP row scan; the reference's early stop is "the first entry with T_before*(1-alpha) <
+//     1e-4", found with a ballot + count-trailing-zeros, everything behind it is masked off.  Per 16 entries a wave
+//     issues ~50 VALU ops instead of ~45 per entry.
+// Staging: the workgroup culls the tile list 512 entries at a time against its region with the record's conservative
+// cut-off radius (r2cut, ag_preprocess.hip), compacts the survivors IN LIST ORDER into LDS (wave ballots + an 8-entry
+// prefix), and prefetches the next 512 while blending.  Culled entries still count in n_contrib: the list position
+// travels with the record.  Results differ from a serial evaluation only by the association of the transmittance
+// product (a few ulp).
+// Bound: VALU + LDS; HBM traffic is the compulsory 52 B/instance (x8 regions, served by L2) + 24 B/pixel.
+#include <cstdlib>
 #include "ag_common.h"
 
 namespace ag {
 
 struct BlendFwdParams {
-    int W, H, gx, T;
+    int W, H, gx, T, dbg;
     const uint2* __restrict__ ranges;
     const uint32_t* __restrict__ point_list;
     const GaussRec* __restrict__ rec;
+    const uint4* __restrict__ tile_order;
+    const uint32_t* __restrict__ counts;   // [0] instances, [1] non-empty tiles
+    uint32_t* __restrict__ queue;
     const float* __restrict__ bg;
     float* __restrict__ out_color;
     float* __restrict__ out_depth;
@@ -36,115 +44,219 @@ struct BlendFwdParams {
     uint32_t* __restrict__ n_contrib;
 };
 
-__global__ void __launch_bounds__(256) blend_forward_kernel(BlendFwdParams p)
+#define AG_ROW_SHR(n) (0x110 + (n))
+
+template <int N>
+__device__ __forceinline__ float row_shr(float v, float fill)
 {
-    __shared__ float4 slab[4][68 * 3];
+    // lane l of each 16-lane row receives lane l-N of the same row; the first N lanes receive `fill`
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), AG_ROW_SHR(N), 0xf, 0xf, false));
+}
 
-    const int tile = blockIdx.x;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int tile_x = tile % p.gx, tile_y = tile / p.gx;
-    const int qx0 = tile_x * kTileX + (wave & 1) * 8, qy0 = tile_y * kTileY + (wave >> 1) * 8;
-    const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
-    const bool inside = px < p.W && py < p.H;
-    const float pxf = (float)px, pyf = (float)py;
-    const float qx0f = (float)qx0, qy0f = (float)qy0, qx1f = (float)(qx0 + 7), qy1f = (float)(qy0 + 7);
-    const uint2 range = p.ranges[tile];
-    float4* my = slab[wave];
+__device__ __forceinline__ float row_inclusive_product(float x)
+{
+    x *= row_shr<1>(x, 1.0f);
+    x *= row_shr<2>(x, 1.0f);
+    x *= row_shr<4>(x, 1.0f);
+    x *= row_shr<8>(x, 1.0f);
+    return x;
+}
 
-    float T = 1.0f, Cr = 0.f, Cg = 0.f, Cb = 0.f, Dd = 0.f, Wsum = 0.f;
-    uint32_t last = 0;
-    bool done = !inside;
+__device__ __forceinline__ float row_total(float x)   // sum over the row, valid in lane 15 of the row
+{
+    x += row_shr<1>(x, 0.0f);
+    x += row_shr<2>(x, 0.0f);
+    x += row_shr<4>(x, 0.0f);
+    x += row_shr<8>(x, 0.0f);
+    return x;
+}
 
-    // Software pipeline over 64-entry batches: while batch b is culled/compacted and blended, the (dependent)
-    // point_list -> record gathers of batch b+1 are already in flight; hipcc waits for them at their first use,
-    // i.e. at the top of the next iteration.  With ~2.5 resident waves per SIMD nothing else would hide that latency.
-    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = make_float4(0.f, 0.f, -1.f, 0.f);
-    if (range.x + lane < range.y) {
-        const float4* src = reinterpret_cast<const float4*>(p.rec + p.point_list[range.x + lane]);
-        r0 = src[0]; r1 = src[1]; r2 = src[2];
-    }
-    for (uint32_t base = range.x; base < range.y; base += 64) {
-        if (__all(done)) break;
-        const uint32_t k = base + lane;
-        // cull against this wave's 8x8 quad (r2.z = r2cut; lanes past the end carry r2cut = -1)
-        const float ddx = fmaxf(fmaxf(qx0f - r0.x, r0.x - qx1f), 0.f);
-        const float ddy = fmaxf(fmaxf(qy0f - r0.y, r0.y - qy1f), 0.f);
-        const bool keep = (k < range.y) && ((ddx * ddx + ddy * ddy) <= r2.z);
-        const unsigned long long mask = __ballot(keep);
-        const int slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-        if (keep) {
-            my[slot * 3 + 0] = r0;
-            my[slot * 3 + 1] = r1;
-            my[slot * 3 + 2] = make_float4(r2.x, r2.y, __uint_as_float(k - range.x + 1u), 0.f);  // 1-based list position
+__device__ __forceinline__ float row_read(float v, int lane, int k)   // value of lane k of this lane's row
+{
+    return __shfl(v, (lane & 48) + k, 64);
+}
+
+__global__ void __launch_bounds__(kBlendThreads) blend_forward_kernel(BlendFwdParams p)
+{
+    constexpr int NW = kBlendThreads / 64;
+    __shared__ float4 s_rec[kChunk * 3];
+    __shared__ int s_wave_cnt[2][NW];
+    __shared__ int s_wave_done[NW];
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int row = lane >> 4, e = lane & 15;
+    const uint32_t n_active = p.counts[1];
+
+    // Empty tiles (the tail of the work order) only need their background: static share, no queue traffic.
+    for (uint32_t t = n_active + blockIdx.x; t < ((p.dbg & 8) ? 0u : (uint32_t)p.T); t += gridDim.x) {
+        const int tile = (int)p.tile_order[t].x;
+        const int px = (tile % p.gx) * kTileX + (tid & 15), py = (tile / p.gx) * kTileY + (tid >> 4);
+        if (tid < kTileX * kTileY && px < p.W && py < p.H) {
+            const int pix = p.W * py + px;
+            const size_t HW = (size_t)p.W * p.H;
+            p.n_contrib[pix] = 0;
+            p.out_color[pix] = p.bg[0];
+            p.out_color[HW + pix] = p.bg[1];
+            p.out_color[2 * HW + pix] = p.bg[2];
+            p.out_alpha[pix] = 0.f;
+            p.out_depth[pix] = 0.f;
         }
-        // prefetch the next batch
-        const uint32_t kn = k + 64;
-        if (kn < range.y) {
-            const float4* src = reinterpret_cast<const float4*>(p.rec + p.point_list[kn]);
-            r0 = src[0]; r1 = src[1]; r2 = src[2];
-        }
-        const int cnt = __popcll(mask);
-        // pad the compacted batch to a multiple of 4 with inert records (opacity 0 -> alpha 0 -> never a candidate)
-        if (lane < 4) {
-            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-            my[(cnt + lane) * 3 + 0] = z;
-            my[(cnt + lane) * 3 + 1] = z;
-            my[(cnt + lane) * 3 + 2] = z;
-        }
-        __builtin_amdgcn_wave_barrier();
-        // Four entries per trip: their conic/exp evaluations are independent, which gives a wave that is alone on
-        // its SIMD (the long-list tail of the kernel) instruction-level parallelism; only the short T recurrence is
-        // serial.
-        for (int j = 0; j < cnt; j += 4) {
-            float4 a[4], b[4], c[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                a[u] = my[(j + u) * 3 + 0];
-                b[u] = my[(j + u) * 3 + 1];
-                c[u] = my[(j + u) * 3 + 2];
-            }
-            float power[4], alpha[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const float dx = a[u].x - pxf, dy = a[u].y - pyf;
-                power[u] = -0.5f * (a[u].z * dx * dx + b[u].x * dy * dy) - a[u].w * dx * dy;
-                alpha[u] = fminf(0.99f, b[u].y * __builtin_amdgcn_exp2f(power[u] * 1.4426950408889634f));
-            }
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const bool cand = !done && (power[u] <= 0.0f) && (alpha[u] >= 1.0f / 255.0f);
-                const float test_T = T * (1.0f - alpha[u]);
-                const bool stop = cand && (test_T < 0.0001f);
-                const bool act = cand && !stop;
-                done = done || stop;
-                const float w = act ? alpha[u] * T : 0.f;
-                Cr += b[u].z * w;
-                Cg += b[u].w * w;
-                Cb += c[u].x * w;
-                Dd += c[u].y * w;
-                Wsum += w;
-                T = act ? test_T : T;
-                last = act ? __float_as_uint(c[u].z) : last;
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
     }
 
-    if (inside) {
-        const int pix = p.W * py + px;
-        const size_t HW = (size_t)p.W * p.H;
-        p.n_contrib[pix] = last;
-        p.out_color[pix] = Cr + T * p.bg[0];
-        p.out_color[HW + pix] = Cg + T * p.bg[1];
-        p.out_color[2 * HW + pix] = Cb + T * p.bg[2];
-        p.out_alpha[pix] = Wsum;
-        p.out_depth[pix] = Dd;
+    // Static work assignment (see ItemIter); the descriptor of item i+1 is fetched while item i is blended.
+    ItemIter it(blockIdx.x, gridDim.x, n_active);
+    uint32_t tr, rg;
+    bool have = it.next(tr, rg);
+    uint4 hdr = make_uint4(0u, 0u, 0u, 0u);
+    if (have) { hdr = p.tile_order[tr]; hdr.w = rg; }
+
+    while (have) {
+        uint32_t tr_n, rg_n;
+        const bool have_n = it.next(tr_n, rg_n);
+        uint4 hdr_n = make_uint4(0u, 0u, 0u, 0u);
+        if (have_n) { hdr_n = p.tile_order[tr_n]; hdr_n.w = rg_n; }
+
+        const int tile = (int)hdr.x, reg = (int)hdr.w;
+        const uint2 range = make_uint2(hdr.y, hdr.z);
+        const int tile_x = tile % p.gx, tile_y = tile / p.gx;
+        const int rx0 = tile_x * kTileX + (reg & 1) * kRegW, ry0 = tile_y * kTileY + (reg >> 1) * kRegH;
+        const int pi = wave * 4 + row;                          // pixel of this row inside the region
+        // the wave's 4 pixels form a 2x2 block (better coherence of the per-wave early-outs than a 4x1 strip)
+        const int px = rx0 + (wave & 3) * 2 + (row & 1), py = ry0 + (wave >> 2) * 2 + (row >> 1);
+        const bool inside = px < p.W && py < p.H;
+        const float pxf = (float)px, pyf = (float)py;
+        const float qx0f = (float)rx0, qy0f = (float)ry0, qx1f = (float)(rx0 + kRegW - 1), qy1f = (float)(ry0 + kRegH - 1);
+
+        float T = 1.0f, Cr = 0.f, Cg = 0.f, Cb = 0.f, Dd = 0.f, Ws = 0.f;   // T: row-uniform; sums: per-lane partials
+        uint32_t last = 0;
+        bool done = !inside;                                                // row-uniform
+
+        // staging pipeline: records one chunk ahead, list indices two chunks ahead
+        uint32_t id_next = 0;
+        float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
+        {
+            const uint32_t k0 = range.x + tid, k1 = k0 + kChunk;
+            uint32_t id0 = 0;
+            if (k0 < range.y && !(p.dbg & 32)) id0 = p.point_list[k0];
+            if (k1 < range.y && !(p.dbg & 32)) id_next = p.point_list[k1];
+            if (k0 < range.y && !(p.dbg & 32)) {
+                const float4* src = reinterpret_cast<const float4*>(p.rec + id0);
+                r0 = src[0]; r1 = src[1]; r2 = src[2];
+            }
+        }
+        // cull of chunk 0
+        bool keep;
+        {
+            const float ddx = fmaxf(fmaxf(qx0f - r0.x, r0.x - qx1f), 0.f);
+            const float ddy = fmaxf(fmaxf(qy0f - r0.y, r0.y - qy1f), 0.f);
+            keep = (range.x + tid < range.y) && ((ddx * ddx + ddy * ddy) <= r2.z);
+        }
+        unsigned long long mask = __ballot(keep);
+        if (lane == 0) { s_wave_cnt[0][wave] = __popcll(mask); s_wave_done[wave] = 0; }
+        lds_barrier();
+
+        int cpar = 0;
+        for (uint32_t base = range.x; base < ((p.dbg & 16) ? range.x : range.y); base += kChunk, cpar ^= 1) {
+            // ---- ordered compaction of the survivors into LDS ----
+            const uint32_t k = base + tid;
+            const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+            int off = 0, K = 0;
+#pragma unroll
+            for (int w = 0; w < NW; w++) {
+                const int c = s_wave_cnt[cpar][w];
+                off += (w < wave) ? c : 0;
+                K += c;
+            }
+            if (keep) {
+                const int slot = off + rank;
+                s_rec[slot * 3 + 0] = r0;
+                s_rec[slot * 3 + 1] = r1;
+                s_rec[slot * 3 + 2] = make_float4(r2.x, r2.y, __uint_as_float(k - range.x + 1u), 0.f);  // b, depth, 1-based position
+            }
+            // issue the gathers of chunk c+1 and the index loads of chunk c+2; both are consumed after the blend
+            const uint32_t kn = k + kChunk, knn = kn + kChunk;
+            if (kn < range.y && !(p.dbg & 2)) {
+                const float4* src = reinterpret_cast<const float4*>(p.rec + id_next);
+                r0 = src[0]; r1 = src[1]; r2 = src[2];
+            }
+            if (knn < range.y && !(p.dbg & 2)) id_next = p.point_list[knn];
+            lds_barrier();
+
+            // ---- blend: 16 entries per step per pixel row ----
+            for (int s0 = 0; s0 < ((p.dbg & 1) ? 0 : K); s0 += 16) {
+                if (__all(done)) break;
+                const int idx = s0 + e;
+                const bool ev = idx < K;
+                const int ci = ev ? idx : (K - 1);
+                const float4 a = s_rec[ci * 3 + 0];   // x, y, conic a, conic b
+                const float4 b = s_rec[ci * 3 + 1];   // conic c, opacity, r, g
+                const float4 c = s_rec[ci * 3 + 2];   // b, depth, position
+                const float dx = a.x - pxf, dy = a.y - pyf;
+                const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
+                const float alpha = fminf(0.99f, b.y * __builtin_amdgcn_exp2f(power * 1.4426950408889634f));
+                const bool valid = ev && !done && (power <= 0.0f) && (alpha >= 1.0f / 255.0f);
+                const float fac = valid ? (1.0f - alpha) : 1.0f;
+                const float pin = row_inclusive_product(fac);
+                const float Tb = T * row_shr<1>(pin, 1.0f);          // transmittance in front of entry e
+                const float testT = T * pin;                         // ... and behind it
+                const bool stop = valid && (testT < 0.0001f);
+                const uint32_t rowbits = (uint32_t)(__ballot(stop) >> (lane & 48)) & 0xffffu;
+                const int f = rowbits ? __builtin_ctz(rowbits) : 16; // first stopping entry of this pixel
+                const bool act = valid && (e < f);
+                const float w = act ? alpha * Tb : 0.f;
+                Cr += b.z * w;
+                Cg += b.w * w;
+                Cb += c.x * w;
+                Dd += c.y * w;
+                Ws += w;
+                last = act ? __float_as_uint(c.z) : last;
+                // row state for the next step: T in front of the stopping entry, or behind entry 15
+                const bool stopped = f < 16;
+                T = row_read(stopped ? Tb : testT, lane, stopped ? f : 15);
+                done = done || stopped;
+            }
+
+            // ---- cull of the next chunk (its records have landed by now) + completion vote ----
+            {
+                const float ddx = fmaxf(fmaxf(qx0f - r0.x, r0.x - qx1f), 0.f);
+                const float ddy = fmaxf(fmaxf(qy0f - r0.y, r0.y - qy1f), 0.f);
+                keep = (kn < range.y) && ((ddx * ddx + ddy * ddy) <= r2.z);
+            }
+            mask = __ballot(keep);
+            const int wdone = __all(done);
+            if (lane == 0) { s_wave_cnt[cpar ^ 1][wave] = __popcll(mask); s_wave_done[wave] = wdone; }
+            lds_barrier();   // counts + votes visible, s_rec free for the next compaction
+            int all_done = 1;
+#pragma unroll
+            for (int w = 0; w < NW; w++) all_done &= s_wave_done[w];
+            if (all_done) break;
+        }
+
+        // ---- per-pixel totals (lane 15 of each row) and output ----
+        Cr = row_total(Cr); Cg = row_total(Cg); Cb = row_total(Cb); Dd = row_total(Dd); Ws = row_total(Ws);
+        uint32_t lm = last;   // positions grow with e and with the step: the row maximum is the last contributor
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) lm = max(lm, (uint32_t)__shfl_up((int)lm, d, 16));
+        if (inside && e == 15) {
+            const int pix = p.W * py + px;
+            const size_t HW = (size_t)p.W * p.H;
+            p.n_contrib[pix] = lm;
+            p.out_color[pix] = Cr + T * p.bg[0];
+            p.out_color[HW + pix] = Cg + T * p.bg[1];
+            p.out_color[2 * HW + pix] = Cb + T * p.bg[2];
+            p.out_alpha[pix] = Ws;
+            p.out_depth[pix] = Dd;
+        }
+        lds_barrier();   // s_rec / counters reusable
+        hdr = hdr_n;
+        have = have_n;
     }
 }
 
 int launch_blend_forward(const AgRasterForwardArgs& a, int R, hipStream_t s)
 {
     BlendFwdParams p;
+    p.dbg = getenv("AG_DBG") ? atoi(getenv("AG_DBG")) : 0;
     p.W = a.W; p.H = a.H;
     p.gx = (a.W + kTileX - 1) / kTileX;
     const int gy = (a.H + kTileY - 1) / kTileY;
@@ -161,10 +273,16 @@ int launch_blend_forward(const AgRasterForwardArgs& a, int R, hipStream_t s)
     } else {
         p.point_list = nullptr;  // every range is (0,0): never dereferenced
     }
+    p.tile_order = reinterpret_cast<const uint4*>(ib + il.tile_order);
+    p.queue = reinterpret_cast<uint32_t*>(ib + il.queue);
+    p.counts = reinterpret_cast<const uint32_t*>(ib + il.num_rendered);
     p.bg = a.bg;
     p.out_color = a.out_color; p.out_depth = a.out_depth; p.out_alpha = a.out_alpha;
     p.n_contrib = reinterpret_cast<uint32_t*>(ib + il.n_contrib);
-    { ProfScope ps(AG_K_BLEND_FORWARD, s); hipLaunchKernelGGL(blend_forward_kernel, dim3(p.T), dim3(256), 0, s, p); }
+    // persistent grid: 4 workgroups of 8 waves per CU fill the 32 wave slots of each of the 256 CUs
+    const long long items = (long long)p.T * kRegionsPerTile;
+    const int grid = (int)(items < 1024 ? items : 1024);
+    { ProfScope ps(AG_K_BLEND_FORWARD, s); hipLaunchKernelGGL(blend_forward_kernel, dim3(grid), dim3(kBlendThreads), 0, s, p); }
     return check_hip(hipGetLastError(), "blend_forward_kernel");
 }
 

@@ -30,6 +30,42 @@ static_assert(sizeof(GaussRec) == 48, "GaussRec must be 48 bytes");
 constexpr int kAccumFloats = 16;
 enum AccumSlot { A_M2X = 0, A_M2Y, A_CONX, A_CONY, A_CONW, A_OPAC, A_COLR, A_COLG, A_COLB, A_DEPTH };
 
+// Blend kernels: a workgroup of 8 waves owns an 8x4 pixel region (8 regions per 16x16 tile); each wave blends
+// 4 pixels (one per 16-lane DPP row) x 16 list entries per step.
+constexpr int kRegW = 8, kRegH = 4, kRegionsPerTile = (kTileX / kRegW) * (kTileY / kRegH);
+constexpr int kBlendThreads = 512;
+constexpr int kChunk = 512;   // tile-list entries culled cooperatively per pass (one per thread)
+constexpr int kQueues = 8;    // one work-queue head per XCD: a single L2 atomic word saturates near 88 pops/us
+
+// Work distribution of the persistent blend kernels: STATIC.  (A global work queue was measured first: returning
+// atomics on a few hot words sustain only ~5-10 pops/us on this part, 100+ us per frame for ~5000 items.)
+// Tiles are ranked longest-list-first by tile_scan_kernel.  Workgroup b sits on XCD b % 8 (observed dispatcher
+// placement, used for speed only) and is the (b / 8)-th workgroup of that XCD.  XCD x owns tile ranks x, x+8, x+16, ...
+// and ALL regions of those tiles, so the workgroups that gather one tile's list share an L2; inside the XCD the
+// (tile, region) items are dealt round-robin, which with the longest-first order is the usual LPT balance.
+struct ItemIter {
+    uint32_t i, stride, x, n_active;
+    __device__ __forceinline__ ItemIter(uint32_t block, uint32_t grid, uint32_t n_active_)
+        : i(block / kQueues), stride((grid + kQueues - 1 - (block % kQueues)) / kQueues), x(block % kQueues), n_active(n_active_) {}
+    // next (tile rank, region) of this workgroup; false when exhausted
+    __device__ __forceinline__ bool next(uint32_t& tile_rank, uint32_t& region)
+    {
+        tile_rank = (i / kRegionsPerTile) * kQueues + x;
+        region = i % kRegionsPerTile;
+        i += stride;
+        return tile_rank < n_active;
+    }
+};
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a workgroup-scope release fence, which on
+// gfx950 makes every wave wait for the acknowledgement of its outstanding global stores/atomics (vmcnt(0)) -- and, because
+// vmcnt retires in order, for any prefetch issued before them.  The blend kernels exchange data between waves through
+// LDS only (global memory is written with fire-and-forget stores/atomics), so they use this instead.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 inline __host__ __device__ size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct GeomLayout {
@@ -46,7 +82,7 @@ struct GeomLayout {
 };
 
 struct ImageLayout {
-    size_t ranges, tile_count, cursor, n_contrib, num_rendered, total;
+    size_t ranges, tile_count, cursor, n_contrib, num_rendered, tile_order, queue, total;
     __host__ __device__ ImageLayout(size_t W, size_t H)
     {
         const size_t T = ((W + kTileX - 1) / kTileX) * ((H + kTileY - 1) / kTileY);
@@ -56,6 +92,8 @@ struct ImageLayout {
         cursor = o;        o = align_up(o + T * sizeof(uint32_t), 256);
         n_contrib = o;     o = align_up(o + W * H * sizeof(uint32_t), 256);
         num_rendered = o;  o = align_up(o + 16, 256);
+        tile_order = o;    o = align_up(o + T * 4 * sizeof(uint32_t), 256);   // uint4 {tile, begin, end, 0}, longest list first
+        queue = o;         o = align_up(o + 64, 256);                     // work-queue heads: [0..7] forward, [8..15] backward (one per XCD)
         total = o + 256;
     }
 };

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Builds libag_hip.so for gfx950 (cross-compiles without a GPU).  Output: animatablegaussians_amd/lib/libag_hip.so
-set -euo pipefail
+set -eo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 OUT="$HERE/../lib"
 OBJ="$HERE/../lib/obj"
@@ -15,6 +15,7 @@ compile() { # src flags
   local obj="$OBJ/$(basename "${src%.hip}").o"
   if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ "$HERE/ag_common.h" -nt "$obj" ] || [ "$HERE/../../include/ag_raster.h" -nt "$obj" ] || [ "$HERE/../../include/ag_avatar.h" -nt "$obj" ] || [ "$HERE/../../include/ag_styleunet.h" -nt "$obj" ]; then
     echo "hipcc $(basename "$src") $*"
+    rm -f "$obj"
     "$HIPCC" $COMMON "$@" -c "$src" -o "$obj"
   fi
 }
@@ -26,6 +27,8 @@ compile "$HERE/ag_blend_backward.hip" $FAST &
 compile "$HERE/ag_preprocess_backward.hip" $FAST &
 compile "$HERE/ag_avatar.hip" $FAST &
 compile "$HERE/ag_styleunet_ops.hip" $FAST &
-wait
+fail=0
+for job in $(jobs -p); do wait "$job" || fail=1; done
+if [ "$fail" -ne 0 ]; then echo "build.sh: compilation failed" >&2; exit 1; fi
 "$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT/libag_hip.so" "$OBJ"/*.o
 echo "built $OUT/libag_hip.so"
