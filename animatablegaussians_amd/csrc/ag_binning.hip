@@ -166,69 +166,127 @@ __global__ void __launch_bounds__(256) scatter_kernel(int P, int gx, int gy, con
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// 4. per-tile sort.  Bitonic network in the all-ascending ("flip + disperse") form: every compare-exchange moves
-//    the minimum to the lower index, so virtual +inf padding above n never moves and needs no storage.
-//    Two size classes share the code: tiles up to 2048 entries sort in 16 KiB of LDS with 256 threads (several
-//    workgroups per CU), tiles up to 16384 entries in 128 KiB with 1024 threads; anything larger (never reached by
-//    avatar-sized splats) runs the same network directly on its global-memory segment.
+// 4. per-tile sort of the u64 keys (depth_bits << 32 | gaussian_index; unique, so any correct sort gives THE order).
+//    Merge sort in LDS: each thread sorts 8 keys in registers (19-comparator network), then log2(n/8) rounds of pairwise
+//    run merges between two LDS buffers, every thread producing 8 consecutive outputs of its pair after a merge-path
+//    binary search.  10 rounds with ~30 dependent LDS reads each for an 8192-entry tile, against 91 barrier-separated
+//    compare-exchange stages of a bitonic network.  Two size classes: <= 2048 entries (256 threads, 32 KiB LDS) and
+//    <= 8192 (1024 threads, 128 KiB LDS).  Larger tiles (never reached by avatar-sized splats) fall back to an
+//    all-ascending bitonic network run directly on the global segment by one workgroup.
 // ---------------------------------------------------------------------------------------------------------
-template <int NT, typename KeyPtr>
-__device__ __forceinline__ void bitonic_sort(KeyPtr sk, uint32_t n, uint32_t m /* pow2 >= n */, int tid)
+__device__ __forceinline__ void cswap(uint64_t& a, uint64_t& b)
+{
+    const uint64_t lo = a < b ? a : b, hi = a < b ? b : a;
+    a = lo; b = hi;
+}
+
+__device__ __forceinline__ void sort8(uint64_t (&v)[8])
+{
+    cswap(v[0], v[1]); cswap(v[2], v[3]); cswap(v[4], v[5]); cswap(v[6], v[7]);
+    cswap(v[0], v[2]); cswap(v[1], v[3]); cswap(v[4], v[6]); cswap(v[5], v[7]);
+    cswap(v[1], v[2]); cswap(v[5], v[6]); cswap(v[0], v[4]); cswap(v[3], v[7]);
+    cswap(v[1], v[5]); cswap(v[2], v[6]);
+    cswap(v[1], v[4]); cswap(v[3], v[6]);
+    cswap(v[2], v[4]); cswap(v[3], v[5]);
+    cswap(v[3], v[4]);
+}
+
+constexpr uint64_t kKeyInf = ~0ull;
+constexpr int kSortSmallCap = 2048;   // 256 threads x 8 keys
+constexpr int kSortLargeCap = 8192;   // 1024 threads x 8 keys
+
+template <typename KeyPtr>
+__device__ __forceinline__ void bitonic_sort_global(KeyPtr sk, uint32_t n, uint32_t m, int tid, int nthreads)
 {
     const uint32_t half = m >> 1;
     for (uint32_t k = 2; k <= m; k <<= 1) {
         const uint32_t hk = k >> 1, lk = __builtin_ctz(hk);
-        // flip: i and its mirror image inside the k-block
-#pragma unroll 4
-        for (uint32_t t = tid; t < half; t += NT) {
+        for (uint32_t t = tid; t < half; t += nthreads) {
             const uint32_t blk = t >> lk, off = t & (hk - 1);
             const uint32_t i = (blk << (lk + 1)) + off, p = (blk << (lk + 1)) + k - 1 - off;
-            if (p < n) {
-                const uint64_t a = sk[i], b = sk[p];
-                if (a > b) { sk[i] = b; sk[p] = a; }
-            }
+            if (p < n) { const uint64_t a = sk[i], b = sk[p]; if (a > b) { sk[i] = b; sk[p] = a; } }
         }
         __syncthreads();
         for (uint32_t j = k >> 2; j > 0; j >>= 1) {
-#pragma unroll 4
-            for (uint32_t t = tid; t < half; t += NT) {
+            for (uint32_t t = tid; t < half; t += nthreads) {
                 const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), p = i + j;
-                if (p < n) {
-                    const uint64_t a = sk[i], b = sk[p];
-                    if (a > b) { sk[i] = b; sk[p] = a; }
-                }
+                if (p < n) { const uint64_t a = sk[i], b = sk[p]; if (a > b) { sk[i] = b; sk[p] = a; } }
             }
             __syncthreads();
         }
     }
 }
 
-constexpr int kSortSmallCap = 2048;    // 16 KiB LDS, 256 threads
-constexpr int kSortLargeCap = 16384;   // 128 KiB LDS, 1024 threads
-
-template <int NT, int CAP, bool LARGE>
-__global__ void __launch_bounds__(NT) tile_sort_kernel(const uint2* __restrict__ ranges, uint64_t* __restrict__ keys,
-                                                      uint32_t* __restrict__ point_list)
+// Workgroups walk the non-empty tiles in tile_scan_kernel's longest-first order with a grid stride, so only as many
+// workgroups are launched as can be resident (the 128 KiB class would otherwise queue 4096 one-per-CU launches).
+template <int NT, bool LARGE>
+__global__ void __launch_bounds__(NT) tile_sort_kernel(const uint4* __restrict__ tile_order, const uint32_t* __restrict__ counts,
+                                                      uint64_t* __restrict__ keys, uint32_t* __restrict__ point_list)
 {
-    extern __shared__ __attribute__((aligned(16))) uint64_t sk[];
-    const uint2 rg = ranges[blockIdx.x];
-    const uint32_t n = rg.y - rg.x;
-    // size classes: the small kernel takes (0, kSortSmallCap], the large one everything above
-    if (LARGE ? (n <= (uint32_t)kSortSmallCap) : (n == 0 || n > (uint32_t)kSortSmallCap)) return;
+    extern __shared__ __attribute__((aligned(16))) uint64_t sk[];   // two buffers of NT * 8 keys
+    constexpr uint32_t CAP = NT * 8;
+    const uint32_t n_active = counts[1];
     const int tid = threadIdx.x;
+    for (uint32_t rank = blockIdx.x; rank < n_active; rank += gridDim.x) {
+    const uint4 wd = tile_order[rank];
+    const uint2 rg = make_uint2(wd.y, wd.z);
+    const uint32_t n = rg.y - rg.x;
+    // size classes: the small kernel takes (0, kSortSmallCap], the large one everything above.  The order is by
+    // descending bit length of n, so once the large kernel meets a tile below 2048 entries it is done.
+    if (LARGE) { if (n < 2048u) break; if (n <= (uint32_t)kSortSmallCap) continue; }
+    else if (n > (uint32_t)kSortSmallCap) continue;
     uint64_t* seg = keys + rg.x;
-    uint32_t m = 2;
-    while (m < n) m <<= 1;
-    if (n <= (uint32_t)CAP) {
-        for (uint32_t i = tid; i < n; i += NT) sk[i] = seg[i];
-        __syncthreads();
-        bitonic_sort<NT>(sk, n, m, tid);
-        for (uint32_t i = tid; i < n; i += NT) point_list[rg.x + i] = (uint32_t)sk[i];
-    } else {
-        // All waves of a workgroup share one CU and its L1, so workgroup barriers order the exchanges.
-        __syncthreads();
-        bitonic_sort<NT>(seg, n, m, tid);
+    __syncthreads();   // LDS buffers of the previous tile are free
+    if (n > CAP) {
+        uint32_t m = 2;
+        while (m < n) m <<= 1;
+        bitonic_sort_global(seg, n, m, tid, NT);   // workgroup barriers order the exchanges (one CU, one L1)
         for (uint32_t i = tid; i < n; i += NT) point_list[rg.x + i] = (uint32_t)seg[i];
+        continue;
+    }
+    uint64_t* bufA = sk;
+    uint64_t* bufB = sk + CAP;
+    // 1. 8 keys per thread, sorted in registers; slots past n hold +inf and simply stay at the top
+    uint64_t v[8];
+    const uint32_t base = (uint32_t)tid * 8u;
+#pragma unroll
+    for (int i = 0; i < 8; i++) v[i] = (base + i < n) ? seg[base + i] : kKeyInf;
+    sort8(v);
+    if (base < n) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) bufA[base + i] = v[i];
+    }
+    __syncthreads();
+    // 2. merge rounds over the first n8 = ceil(n / 8) * 8 slots
+    const uint32_t n8 = (n + 7u) & ~7u;
+    for (uint32_t L = 8; L < n8; L <<= 1) {
+        if (base < n8) {
+            const uint32_t ps = base & ~(2u * L - 1u);          // start of this thread's run pair
+            const uint32_t o = base - ps;                        // first output index inside the merged pair
+            const uint32_t lx = min(L, n8 - ps);                 // |X|
+            const uint32_t ly = (ps + L < n8) ? min(L, n8 - ps - L) : 0u;   // |Y|
+            const uint64_t* X = bufA + ps;
+            const uint64_t* Y = bufA + ps + L;
+            // merge path: smallest i with X[i] > Y[o - i - 1] (keys are unique)
+            uint32_t lo = (o > ly) ? o - ly : 0u, hi = min(o, lx);
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (X[mid] < Y[o - mid - 1]) lo = mid + 1; else hi = mid;
+            }
+            uint32_t i = lo, j = o - lo;
+            uint64_t xv = (i < lx) ? X[i] : kKeyInf, yv = (j < ly) ? Y[j] : kKeyInf;
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const bool takex = xv <= yv;
+                bufB[base + r] = takex ? xv : yv;
+                if (takex) { i++; xv = (i < lx) ? X[i] : kKeyInf; }
+                else       { j++; yv = (j < ly) ? Y[j] : kKeyInf; }
+            }
+        }
+        __syncthreads();
+        uint64_t* t = bufA; bufA = bufB; bufB = t;
+    }
+    for (uint32_t i = tid; i < n; i += NT) point_list[rg.x + i] = (uint32_t)bufA[i];
     }
 }
 
@@ -247,20 +305,21 @@ int launch_bin_sort(const AgRasterForwardArgs& a, int R, hipStream_t s)
     { ProfScope ps(AG_K_SCATTER, s); hipLaunchKernelGGL(scatter_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, a.P, gx, gy, a.radii,
                        reinterpret_cast<const GaussRec*>(gb + gl.rec), reinterpret_cast<uint32_t*>(ib + il.cursor), keys); }
     if (check_hip(hipGetLastError(), "scatter_kernel")) return AG_ERR_HIP;
-    const uint2* ranges = reinterpret_cast<const uint2*>(ib + il.ranges);
     static bool attr_set = false;
+    constexpr size_t kSmallLds = 2ull * kSortSmallCap * sizeof(uint64_t), kLargeLds = 2ull * kSortLargeCap * sizeof(uint64_t);
     if (!attr_set) {
-        if (check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_sort_kernel<1024, kSortLargeCap, true>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, kSortLargeCap * 8), "sort LDS attr"))
+        if (check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_sort_kernel<1024, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLargeLds), "sort LDS attr"))
             return AG_ERR_HIP;
         attr_set = true;
     }
     {
         ProfScope ps(AG_K_TILE_SORT, s);
-        hipLaunchKernelGGL((tile_sort_kernel<256, kSortSmallCap, false>), dim3(gx * gy), dim3(256), kSortSmallCap * 8, s,
-                           ranges, keys, point_list);
-        hipLaunchKernelGGL((tile_sort_kernel<1024, kSortLargeCap, true>), dim3(gx * gy), dim3(1024), kSortLargeCap * 8, s,
-                           ranges, keys, point_list);
+        const uint4* order = reinterpret_cast<const uint4*>(ib + il.tile_order);
+        const uint32_t* counts = reinterpret_cast<const uint32_t*>(ib + il.num_rendered);
+        const int T = gx * gy;
+        hipLaunchKernelGGL((tile_sort_kernel<256, false>), dim3(T < 1280 ? T : 1280), dim3(256), kSmallLds, s, order, counts, keys, point_list);
+        hipLaunchKernelGGL((tile_sort_kernel<1024, true>), dim3(T < 256 ? T : 256), dim3(1024), kLargeLds, s, order, counts, keys, point_list);
     }
     return check_hip(hipGetLastError(), "tile_sort_kernel");
 }
