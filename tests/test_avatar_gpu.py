@@ -121,3 +121,65 @@ def test_lbs_all_matrix_to_quaternion_branches():
     _close(gr, rr, "rotations", 1e-5)
     gr.backward(up.cuda())
     _close(grot.grad, rot.grad, "dL_drotations", 1e-4)
+
+
+def test_avatar_render_core_end_to_end():
+    """maps -> gather/activations -> LBS -> render3 -> rasterizer, forward and backward, against the composition of the
+    torch oracle (assembly + skinning) with the C rasterizer oracle."""
+    import torch
+    import helpers as h
+    from animatablegaussians_amd import camera
+    from animatablegaussians_amd.avatar import AvatarRenderCore
+    from oracle import avatar_oracle as ao
+    from oracle import raster_oracle as ro
+    S, W = 256, 256
+    d = _synthetic(S=S, seed=7)
+    # canonical points on a body-sized sheet so the camera sees them; small scales
+    N = d["xyz"].shape[0]
+    vv, uu = torch.nonzero(d["mask"], as_tuple=True)
+    front = uu < S
+    ul = torch.where(front, uu, 2 * S - 1 - uu).float()
+    d["xyz"] = torch.stack([(ul + 0.5 - S / 2) * (2.0 / S), (S / 2 - (vv.float() + 0.5)) * (2.0 / S),
+                            torch.where(front, 0.05, -0.05) * torch.ones(N)], 1)
+    d["scaling_raw"] = torch.full((N, 3), float(np.log(2.0 / S)))
+    d["position_map"] = d["position_map"] * 0.2
+    d["jnt_mats"][:, :3, 3] *= 0.2
+    extr = torch.from_numpy(camera.calc_front_mv(np.zeros(3, np.float32), tar_pos=(0.0, 0.0, 2.5)))
+    intr = torch.tensor([[275.0, 0, W / 2], [0, 275.0, W / 2], [0, 0, 1]])
+    bg = torch.tensor([0.2, 0.5, 0.8])
+    # ---- oracle: forward ----
+    maps = [d[k].clone().requires_grad_(True) for k in ("position_map", "other_map", "color_map")]
+    pos, opa, sca, rot, col = ao.gather_activate(*maps, d["mask"], d["xyz"], d["opacity_raw"], d["scaling_raw"], d["rotation_raw"])
+    lpos, lrot = ao.transform_cano2live(pos, rot, d["lbs"], d["jnt_mats"])
+    cm = camera.camera_from_intr_extr(extr.numpy(), intr.numpy(), W, W)
+    npy = lambda t: t.detach().numpy()  # noqa: E731
+    st = ro.forward(npy(lpos), npy(col), npy(opa), npy(sca), npy(lrot), bg.numpy(), cm["viewmatrix"], cm["projmatrix"],
+                    cm["tanfovx"], cm["tanfovy"], W, W)
+    assert st["num_rendered"] > 5000
+    frag = st["fragile"].astype(bool)
+    # ---- GPU: forward ----
+    core = AvatarRenderCore(d["mask"].cuda(), d["xyz"].cuda(), d["opacity_raw"].cuda(), d["scaling_raw"].cuda(),
+                            d["rotation_raw"].cuda(), d["lbs"].cuda())
+    gm = [d[k].cuda().requires_grad_(True) for k in ("position_map", "other_map", "color_map")]
+    out = core(*gm, d["jnt_mats"].cuda(), extr.cuda(), intr.cuda(), W, W, bg.cuda())
+    rgb = out["rgb_map"].detach().cpu().numpy().transpose(2, 0, 1)
+    err = np.abs(rgb - st["color"])[:, ~frag]
+    assert err.max() <= 2e-4, f"rgb differs by {err.max()}"       # 1e-4 raster bar + upstream fp32 op-order noise
+    np.testing.assert_allclose(out["offset"].detach().cpu().numpy(), npy(pos - d["xyz"]), rtol=1e-5, atol=1e-7)
+    # ---- backward: same masked upstream gradients on both sides ----
+    g = torch.Generator().manual_seed(9)
+    keep = torch.from_numpy((~frag).astype(np.float32))
+    g_rgb = torch.randn(W, W, 3, generator=g) * keep[..., None]
+    g_msk = torch.randn(W, W, 1, generator=g) * keep[..., None]
+    torch.autograd.backward([out["rgb_map"], out["mask_map"]], [g_rgb.cuda(), g_msk.cuda()])
+    gr = ro.backward(st, npy(lpos), npy(col), npy(sca), npy(lrot), bg.numpy(), cm["viewmatrix"], cm["projmatrix"], cm["tanfovx"],
+                     cm["tanfovy"], g_rgb.permute(2, 0, 1).contiguous().numpy(), np.zeros((1, W, W), np.float32),
+                     g_msk.permute(2, 0, 1).contiguous().numpy())
+    T = torch.from_numpy
+    torch.autograd.backward([lpos, lrot, sca, opa, col],
+                            [T(gr["dL_dmeans3D"]), T(gr["dL_drotations"]), T(gr["dL_dscales"]), T(gr["dL_dopacity"]), T(gr["dL_dcolors"])])
+    for name, a, b in zip(("position_map", "other_map", "color_map"), gm, maps):
+        ga, gb = a.grad.cpu().numpy(), b.grad.numpy()
+        dd = np.abs(ga - gb)
+        lim = 2e-3 * np.abs(gb) + 2e-4 * np.abs(gb).max()          # coarse: forward-rounding conditioning (DESIGN.md)
+        assert (dd > lim).mean() < 2e-3, f"dL/d{name}: {(dd > lim).mean():.2e} of elements off, max {dd.max():.3e}"
