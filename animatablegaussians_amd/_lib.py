@@ -70,6 +70,10 @@ class AgLbsArgs(ctypes.Structure):
         "lbs", "jnt_mats", "positions", "rotations", "out_positions", "out_rotations")]
 
 
+class AgConvDesc(ctypes.Structure):
+    _fields_ = [(n, c_i32) for n in ("kind", "Cin", "Cout", "H", "W", "k", "stride", "padding")]
+
+
 # every symbol include/*.h declares: (name, restype, argtypes)
 SYMBOLS = [
     ("ag_abi_version", ctypes.c_int, []),
@@ -95,6 +99,12 @@ SYMBOLS = [
     # include/ag_styleunet.h
     ("ag_fused_bias_act", ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_f, c_f, ctypes.c_int64, ctypes.c_int64, c_i32, c_vp]),
     ("ag_upfirdn2d", ctypes.c_int, [c_vp, c_vp, c_vp] + [c_i32] * 13 + [c_vp]),
+    # include/ag_conv.h
+    ("ag_conv_output_size", ctypes.c_int, [ctypes.POINTER(AgConvDesc), ctypes.POINTER(c_i32), ctypes.POINTER(c_i32)]),
+    ("ag_conv_workspace_bytes", c_sz, [ctypes.POINTER(AgConvDesc)]),
+    ("ag_conv_forward", ctypes.c_int, [ctypes.POINTER(AgConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    ("ag_conv_backward_input", ctypes.c_int, [ctypes.POINTER(AgConvDesc), c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    ("ag_conv_backward_weight", ctypes.c_int, [ctypes.POINTER(AgConvDesc), c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
 ]
 
 _lib = None

@@ -1,0 +1,109 @@
+"""``conv2d`` / ``conv_transpose2d`` with the signatures of the reference's ``network/styleunet/conv2d_gradfix.py:22-75``,
+backed by the MFMA kernels of ``libag_hip.so`` (``include/ag_conv.h``): forward, input gradient and weight gradient are
+all ours (no MIOpen / cuDNN call on this path).
+
+Supported = what the product uses (batch 1, groups 1): conv2d k in {1,3,4}, stride 1|2, zero padding; conv_transpose2d
+3x3 stride 2 padding 0.  Anything else raises -- there is no fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import _lib
+
+AG_CONV, AG_CONV_TRANSPOSE = 0, 1
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream(dev):
+    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def _desc(kind, Cin, Cout, H, W, k, stride, padding):
+    d = _lib.AgConvDesc()
+    d.kind, d.Cin, d.Cout, d.H, d.W, d.k, d.stride, d.padding = kind, Cin, Cout, H, W, k, stride, padding
+    return d
+
+
+def _workspace(d, dev):
+    n = _lib.lib().ag_conv_workspace_bytes(ctypes.byref(d))
+    return torch.empty((n,), dtype=torch.uint8, device=dev), n
+
+
+class _Conv(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, bias, out_scale, kind, stride, padding):
+        L = _lib.lib()
+        if x.dim() != 4 or x.shape[0] != 1:
+            raise RuntimeError("MFMA conv path: batch must be 1 (the product renders one pose per step)")
+        if not (x.is_cuda and w.is_cuda) or x.dtype != torch.float32 or w.dtype != torch.float32:
+            raise RuntimeError("MFMA conv path: float32 GPU tensors only")
+        x, w = x.contiguous(), w.contiguous()
+        _, Cin, H, W = x.shape
+        k = int(w.shape[-1])
+        Cout = int(w.shape[0] if kind == AG_CONV else w.shape[1])
+        if (kind == AG_CONV and w.shape[1] != Cin) or (kind == AG_CONV_TRANSPOSE and w.shape[0] != Cin) or w.shape[-2] != k:
+            raise RuntimeError("weight shape does not match the input channels / square kernel")
+        d = _desc(kind, Cin, Cout, H, W, k, stride, padding)
+        oh, ow = ctypes.c_int32(), ctypes.c_int32()
+        _lib.check(L.ag_conv_output_size(ctypes.byref(d), ctypes.byref(oh), ctypes.byref(ow)), "ag_conv_output_size")
+        y = torch.empty((1, Cout, oh.value, ow.value), dtype=torch.float32, device=x.device)
+        ws, n = _workspace(d, x.device)
+        b = bias.contiguous() if bias is not None else None
+        sc = out_scale.contiguous() if out_scale is not None else None
+        with torch.cuda.device(x.device):
+            _lib.check(L.ag_conv_forward(ctypes.byref(d), _p(x), _p(w), _p(sc), _p(b), _p(y), _p(ws), n, _stream(x.device)),
+                       "ag_conv_forward")
+        ctx.save_for_backward(x, w, sc)
+        ctx.cfg = (kind, stride, padding, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        L = _lib.lib()
+        x, w, sc = ctx.saved_tensors
+        kind, stride, padding, has_bias = ctx.cfg
+        _, Cin, H, W = x.shape
+        k = int(w.shape[-1])
+        Cout = int(w.shape[0] if kind == AG_CONV else w.shape[1])
+        d = _desc(kind, Cin, Cout, H, W, k, stride, padding)
+        gy = gy.contiguous()
+        gbias = gy.sum((0, 2, 3)) if has_bias else None
+        gscale = None
+        if sc is not None:
+            # y = conv * s + b: the conv result is not stored; recover d/ds from y would need it, so out_scale is treated as
+            # a constant of this node (ModulatedConv2d differentiates its demodulation coefficients through `weight`)
+            gy = gy * sc.view(1, -1, 1, 1)
+        ws, n = _workspace(d, x.device)
+        gx = gw = None
+        with torch.cuda.device(x.device):
+            if ctx.needs_input_grad[0]:
+                gx = torch.empty_like(x)
+                _lib.check(L.ag_conv_backward_input(ctypes.byref(d), _p(gy), _p(w), _p(gx), _p(ws), n, _stream(x.device)),
+                           "ag_conv_backward_input")
+            if ctx.needs_input_grad[1]:
+                gw = torch.empty_like(w)
+                _lib.check(L.ag_conv_backward_weight(ctypes.byref(d), _p(x), _p(gy), _p(gw), _p(ws), n, _stream(x.device)),
+                           "ag_conv_backward_weight")
+        return gx, gw, gbias, gscale, None, None, None
+
+
+def _one(v):
+    return int(v[0]) if isinstance(v, (tuple, list)) else int(v)
+
+
+def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, out_scale=None):
+    if _one(dilation) != 1 or groups != 1:
+        raise RuntimeError("MFMA conv path: dilation 1 and groups 1 only")
+    return _Conv.apply(input, weight, bias, out_scale, AG_CONV, _one(stride), _one(padding))
+
+
+def conv_transpose2d(input, weight, bias=None, stride=1, padding=0, output_padding=0, groups=1, dilation=1, out_scale=None):
+    if _one(dilation) != 1 or groups != 1 or _one(output_padding) != 0:
+        raise RuntimeError("MFMA conv path: dilation 1, groups 1, output_padding 0 only")
+    return _Conv.apply(input, weight, bias, out_scale, AG_CONV_TRANSPOSE, _one(stride), _one(padding))

@@ -152,7 +152,6 @@ __global__ void __launch_bounds__(kBlendThreads, BWD_WAVES_PER_SIMD) blend_backw
         const uint32_t rbeg = hdr.y;
         const int tile_x = tile % p.gx, tile_y = tile / p.gx;
         const int rx0 = tile_x * kTileX + (reg & 1) * kRegW, ry0 = tile_y * kTileY + (reg >> 1) * kRegH;
-        const int pi = wave * 4 + row;
         // the wave's 4 pixels form a 2x2 block (better coherence of the per-wave early-outs than a 4x1 strip)
         const int px = rx0 + (wave & 3) * 2 + (row & 1), py = ry0 + (wave >> 2) * 2 + (row >> 1);
         const bool inside = px < p.W && py < p.H;

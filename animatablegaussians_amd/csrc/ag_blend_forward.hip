@@ -120,7 +120,6 @@ __global__ void __launch_bounds__(kBlendThreads) blend_forward_kernel(BlendFwdPa
         const uint2 range = make_uint2(hdr.y, hdr.z);
         const int tile_x = tile % p.gx, tile_y = tile / p.gx;
         const int rx0 = tile_x * kTileX + (reg & 1) * kRegW, ry0 = tile_y * kTileY + (reg >> 1) * kRegH;
-        const int pi = wave * 4 + row;                          // pixel of this row inside the region
         // the wave's 4 pixels form a 2x2 block (better coherence of the per-wave early-outs than a 4x1 strip)
         const int px = rx0 + (wave & 3) * 2 + (row & 1), py = ry0 + (wave >> 2) * 2 + (row >> 1);
         const bool inside = px < p.W && py < p.H;

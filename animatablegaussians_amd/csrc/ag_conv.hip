@@ -1,0 +1,512 @@
+// MFMA convolutions for the StyleUNet, batch 1, fp32 (gfx950).  See include/ag_conv.h.
+//
+// Replaces the cuDNN calls behind network/styleunet/conv2d_gradfix.py (conv2d / conv_transpose2d) and their
+// backward.  Every variant is one of two implicit GEMMs on v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32
+// accumulate; 157 TF peak = the fp32 vector rate, but it leaves the VALU free for the gather arithmetic):
+//
+//   gather-conv  Y[m][gy, gx] = sum_{c, t} At[(c, t)][m] * Xin[c][gy*sy + dy_t][gx*sx + dx_t]
+//       forward conv (any stride/pad), input gradient of a stride-1 conv (taps mirrored), input gradient of a transposed
+//       conv (= stride-2 conv) and -- split into the 4 output-parity classes so no zero taps are multiplied -- the
+//       stride-2 transposed conv forward and the input gradient of a stride-2 conv.  At is the weight tensor re-packed
+//       K-major [K = C*taps][M] by a small kernel, so the A tile streams in with full 512-byte rows.
+//   wgrad        dW[m][(c, t)] = sum_{gy, gx} A[m][gy, gx] * Xin[c][gy*sy + dy_t][gx*sx + dx_t]      (split-K + atomics)
+//
+// Tile: 128 x 128 outputs per 256-thread workgroup (2 x 2 waves, each 64 x 64 = 2 x 2 MFMA blocks, 64 accumulator
+// VGPRs), BK = 16, operands staged through LDS K-major ([k][m], [k][n]) so an MFMA operand fetch is one conflict-free
+// ds_read_b32 per lane; global->register loads of tile k+1 are issued before the 32 MFMAs of tile k and written to
+// the other LDS buffer after them (one barrier per K step).
+#include "ag_common.h"
+#include "../../include/ag_conv.h"
+
+namespace ag {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 128, BK = 16;
+constexpr int LDA = BM + 4, LDB = BN + 4;   // +4 floats: keeps float4 stores 16-B aligned, shifts rows across banks
+constexpr int kMaxTaps = 16;
+
+struct GatherProblem {
+    const float* xin;      // [Cg][Hg][Wg]
+    const float* At;       // [Kpad][Mpad]
+    float* yout;           // [M][OHf][OWf]
+    const float* out_scale;
+    const float* bias;
+    int Cg, Hg, Wg;
+    int M, Mpad, OHf, OWf;
+    int gh, gw, y0, ys, x0, xs;     // class grid -> output coordinates
+    int sy, sx, ntaps;
+    int K, Kpad;
+    int dy[kMaxTaps], dx[kMaxTaps];
+};
+
+__device__ __forceinline__ void mma_tile(const float* __restrict__ As, const float* __restrict__ Bs, int wm, int wn, int lane,
+                                         f32x16 (&acc)[2][2])
+{
+    const int r = lane & 31, kh = lane >> 5;
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; kk++) {
+        const float a0 = As[(2 * kk + kh) * LDA + wm * 64 + r];
+        const float a1 = As[(2 * kk + kh) * LDA + wm * 64 + 32 + r];
+        const float b0 = Bs[(2 * kk + kh) * LDB + wn * 64 + r];
+        const float b1 = Bs[(2 * kk + kh) * LDB + wn * 64 + 32 + r];
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// gather-conv
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) gather_conv_kernel(GatherProblem p)
+{
+    __shared__ __attribute__((aligned(16))) float As[2][BK * LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int N = p.gh * p.gw;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+
+    // B loader: this thread owns output column n_loc for the whole kernel and rows khalf, khalf+2, ... of each K tile
+    const int n_loc = tid & (BN - 1), khalf = tid >> 7;
+    const int n = n0 + n_loc;
+    const bool n_ok = n < N;
+    const int gy = n_ok ? n / p.gw : 0, gx = n_ok ? n - (n / p.gw) * p.gw : 0;
+    const int iy0 = gy * p.sy, ix0 = gx * p.sx;
+    const size_t plane = (size_t)p.Hg * p.Wg;
+    // A loader: rows ka, ka + 8 ; columns [mq, mq + 4)
+    const int ka = tid >> 5, mq = (tid & 31) * 4;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    float4 ra[2];
+    float rb[BK / 2];
+    // running (channel, tap) of this thread's first B row of the current tile
+    int c_cur = khalf / p.ntaps, t_cur = khalf % p.ntaps;
+
+    auto load_tile = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+            ra[j] = *reinterpret_cast<const float4*>(p.At + (size_t)(k0 + ka + 8 * j) * p.Mpad + m0 + mq);
+        int c = c_cur, t = t_cur;
+#pragma unroll
+        for (int j = 0; j < BK / 2; j++) {
+            const int iy = iy0 + p.dy[t], ix = ix0 + p.dx[t];
+            const bool ok = n_ok && (c < p.Cg) && (iy >= 0) && (iy < p.Hg) && (ix >= 0) && (ix < p.Wg);
+            rb[j] = ok ? p.xin[(size_t)c * plane + (size_t)iy * p.Wg + ix] : 0.f;
+            t += 2;
+            while (t >= p.ntaps) { t -= p.ntaps; c++; }
+        }
+        // advance the running (channel, tap) by BK rows for the next tile
+        t_cur += BK % p.ntaps; c_cur += BK / p.ntaps;
+        if (t_cur >= p.ntaps) { t_cur -= p.ntaps; c_cur++; }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 2; j++) *reinterpret_cast<float4*>(&As[buf][(ka + 8 * j) * LDA + mq]) = ra[j];
+#pragma unroll
+        for (int j = 0; j < BK / 2; j++) Bs[buf][(khalf + 2 * j) * LDB + n_loc] = rb[j];
+    };
+
+    const int nkt = p.Kpad / BK;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; kt++) {
+        const bool more = kt + 1 < nkt;
+        if (more) load_tile((kt + 1) * BK);
+        mma_tile(As[kt & 1], Bs[kt & 1], wm, wn, lane, acc);
+        if (more) store_tile((kt + 1) & 1);
+        __syncthreads();
+    }
+
+    // epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    const int col = lane & 31, rbase = 4 * (lane >> 5);
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int nn = n0 + wn * 64 + j * 32 + col;
+            if (nn >= N) continue;
+            const int oy = nn / p.gw, ox = nn - oy * p.gw;
+            const size_t opix = (size_t)(p.y0 + oy * p.ys) * p.OWf + (p.x0 + ox * p.xs);
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + rbase;
+                if (m < p.M) {
+                    float v = acc[i][j][r];
+                    if (p.out_scale) v *= p.out_scale[m];
+                    if (p.bias) v += p.bias[m];
+                    p.yout[(size_t)m * p.OHf * p.OWf + opix] = v;
+                }
+            }
+        }
+}
+
+// weight re-pack: At[(c, t)][m] = w[c * stride_c + m * stride_m + tapoff[t]], zero padded to [Kpad][Mpad]
+struct PackProblem {
+    const float* w;
+    float* At;
+    int C, M, Mpad, ntaps, K, Kpad;
+    long long stride_c, stride_m;
+    int tapoff[kMaxTaps];
+};
+
+__global__ void __launch_bounds__(256) pack_weights_kernel(PackProblem p)
+{
+    const long long total = (long long)p.Kpad * p.Mpad;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int kk = (int)(i / p.Mpad), m = (int)(i - (long long)kk * p.Mpad);
+        float v = 0.f;
+        if (kk < p.K && m < p.M) {
+            const int c = kk / p.ntaps, t = kk - c * p.ntaps;
+            v = p.w[c * p.stride_c + m * p.stride_m + p.tapoff[t]];
+        }
+        p.At[i] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// wgrad: C[m][(c, t)] += sum over a slice of pixels of A[m][pix] * Xin[c][gy*sy + dy_t][gx*sx + dx_t]
+// ------------------------------------------------------------------------------------------------------------------
+struct WgradProblem {
+    const float* a;        // [Mw][gh * gw]
+    const float* xin;      // [Cg][Hg][Wg]
+    float* c;              // [Mw][Cg * ntaps], zero-initialised
+    int Mw, Cg, Hg, Wg, gh, gw, sy, sx, ntaps;
+    int ksplit_len;        // pixels per split (multiple of BK)
+    int dy[kMaxTaps], dx[kMaxTaps];
+};
+
+__global__ void __launch_bounds__(256) wgrad_kernel(WgradProblem p)
+{
+    __shared__ __attribute__((aligned(16))) float As[2][BK * LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int Kp = p.gh * p.gw, Nw = p.Cg * p.ntaps;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int kbeg = blockIdx.z * p.ksplit_len, kend = min(Kp, kbeg + p.ksplit_len);
+    if (kbeg >= kend) return;
+
+    // A loader: row am (and am + 64), 4 consecutive pixels aq..aq+3   (A is pixel-contiguous)
+    const int am = tid >> 2, aq = (tid & 3) * 4;
+    // B loader: pixel row bk = tid & 15 of the tile, columns bn, bn + 16, ... (8 per thread); lanes run along pixels
+    const int bk = tid & 15, bn = tid >> 4;
+    const size_t plane = (size_t)p.Hg * p.Wg;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    float ra[2][4];
+    float rb[8];
+    // per-thread column descriptors (channel, tap offsets) are fixed for the whole kernel
+    int col_c[8], col_dy[8], col_dx[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int nn = n0 + bn + 16 * j;
+        const int c = nn / p.ntaps, t = nn - c * p.ntaps;
+        col_c[j] = (nn < Nw) ? c : -1;
+        col_dy[j] = p.dy[t];
+        col_dx[j] = p.dx[t];
+    }
+
+    auto load_tile = [&](int k0) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int m = m0 + am + 64 * h;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int k = k0 + aq + q;
+                ra[h][q] = (m < p.Mw && k < kend) ? p.a[(size_t)m * Kp + k] : 0.f;
+            }
+        }
+        const int k = k0 + bk;
+        const bool k_ok = k < kend;
+        const int gy = k_ok ? k / p.gw : 0, gx = k_ok ? k - (k / p.gw) * p.gw : 0;
+        const int iy0 = gy * p.sy, ix0 = gx * p.sx;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int iy = iy0 + col_dy[j], ix = ix0 + col_dx[j];
+            const bool ok = k_ok && (col_c[j] >= 0) && (iy >= 0) && (iy < p.Hg) && (ix >= 0) && (ix < p.Wg);
+            rb[j] = ok ? p.xin[(size_t)col_c[j] * plane + (size_t)iy * p.Wg + ix] : 0.f;
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) As[buf][(aq + q) * LDA + am + 64 * h] = ra[h][q];
+#pragma unroll
+        for (int j = 0; j < 8; j++) Bs[buf][bk * LDB + bn + 16 * j] = rb[j];
+    };
+
+    const int nkt = (kend - kbeg + BK - 1) / BK;
+    load_tile(kbeg);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; kt++) {
+        const bool more = kt + 1 < nkt;
+        if (more) load_tile(kbeg + (kt + 1) * BK);
+        mma_tile(As[kt & 1], Bs[kt & 1], wm, wn, lane, acc);
+        if (more) store_tile((kt + 1) & 1);
+        __syncthreads();
+    }
+
+    const int col = lane & 31, rbase = 4 * (lane >> 5);
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int nn = n0 + wn * 64 + j * 32 + col;
+            if (nn >= Nw) continue;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + rbase;
+                if (m < p.Mw) atomicAdd(p.c + (size_t)m * Nw + nn, acc[i][j][r]);   // 32 lanes = 128 contiguous bytes
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------------------------
+static int round_up(int v, int a) { return (v + a - 1) / a * a; }
+
+static int validate(const AgConvDesc* d)
+{
+    if (!d) { set_error("null conv descriptor"); return AG_ERR_INVALID_ARGUMENT; }
+    if (d->Cin <= 0 || d->Cout <= 0 || d->H <= 0 || d->W <= 0 || d->k <= 0 || d->k * d->k > kMaxTaps) {
+        set_error("bad conv sizes");
+        return AG_ERR_INVALID_ARGUMENT;
+    }
+    if (d->kind == AG_CONV) {
+        if ((d->stride != 1 && d->stride != 2) || d->padding < 0) { set_error("conv2d: stride must be 1 or 2, padding >= 0"); return AG_ERR_UNSUPPORTED; }
+        if ((d->H + 2 * d->padding - d->k) < 0 || (d->W + 2 * d->padding - d->k) < 0) { set_error("conv2d: kernel larger than padded input"); return AG_ERR_INVALID_ARGUMENT; }
+    } else if (d->kind == AG_CONV_TRANSPOSE) {
+        if (d->stride != 2 || d->padding != 0) { set_error("conv_transpose2d: only stride 2, padding 0"); return AG_ERR_UNSUPPORTED; }
+    } else {
+        set_error("unknown conv kind");
+        return AG_ERR_INVALID_ARGUMENT;
+    }
+    return AG_OK;
+}
+
+static void out_size(const AgConvDesc* d, int& OH, int& OW)
+{
+    if (d->kind == AG_CONV) {
+        OH = (d->H + 2 * d->padding - d->k) / d->stride + 1;
+        OW = (d->W + 2 * d->padding - d->k) / d->stride + 1;
+    } else {
+        OH = (d->H - 1) * 2 + d->k;
+        OW = (d->W - 1) * 2 + d->k;
+    }
+}
+
+// One gather-conv launch = one tap subset.  `taps` lists (ky, kx) of the subset.
+struct TapSet { int n; int ky[kMaxTaps], kx[kMaxTaps]; };
+
+static int launch_pack(const float* w, float* At, int C, int M, int Mpad, int K, int Kpad, long long stride_c, long long stride_m,
+                       const TapSet& ts, int k, hipStream_t s)
+{
+    PackProblem pp;
+    pp.w = w; pp.At = At; pp.C = C; pp.M = M; pp.Mpad = Mpad; pp.ntaps = ts.n; pp.K = K; pp.Kpad = Kpad;
+    pp.stride_c = stride_c; pp.stride_m = stride_m;
+    for (int t = 0; t < ts.n; t++) pp.tapoff[t] = ts.ky[t] * k + ts.kx[t];
+    const long long total = (long long)Kpad * Mpad;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, s, pp);
+    return check_hip(hipGetLastError(), "pack_weights_kernel");
+}
+
+static int launch_gather(GatherProblem& gp, hipStream_t s)
+{
+    const int N = gp.gh * gp.gw;
+    if (N <= 0) return AG_OK;
+    dim3 grid((N + BN - 1) / BN, gp.Mpad / BM);
+    hipLaunchKernelGGL(gather_conv_kernel, grid, dim3(256), 0, s, gp);
+    return check_hip(hipGetLastError(), "gather_conv_kernel");
+}
+
+}  // namespace ag
+
+using namespace ag;
+
+extern "C" {
+
+int ag_conv_output_size(const AgConvDesc* d, int32_t* OH, int32_t* OW)
+{
+    int rc = validate(d);
+    if (rc) return rc;
+    int oh, ow;
+    out_size(d, oh, ow);
+    if (OH) *OH = oh;
+    if (OW) *OW = ow;
+    return AG_OK;
+}
+
+size_t ag_conv_workspace_bytes(const AgConvDesc* d)
+{
+    if (validate(d)) return 0;
+    const int Cmax = d->Cin > d->Cout ? d->Cin : d->Cout;
+    // packed weights of all tap subsets together: (C * k*k rounded per subset) x (M rounded to BM)
+    const size_t kk = (size_t)round_up(Cmax * d->k * d->k, BK) + 4 * BK;
+    return kk * (size_t)round_up(Cmax, BM) * sizeof(float) + 256;
+}
+
+// Shared by forward / backward-input: which GEMM(s) to run.
+//   mode 0: plain gather with all taps (sy = sx = stride_in), tap offset = sign * k - pad_off
+//   mode 1: 4 output-parity classes of a stride-2 "scatter" (transposed conv forward, or input gradient of a stride-2 conv)
+static int run_gather_family(const AgConvDesc* d, bool backward_input, const float* xin, const float* w, const float* out_scale,
+                             const float* bias, float* yout, void* workspace, size_t workspace_bytes, hipStream_t s)
+{
+    int OH, OW;
+    out_size(d, OH, OW);
+    const int k = d->k, k2 = k * k;
+    if (workspace_bytes < ag_conv_workspace_bytes(d) || !workspace) { set_error("conv workspace too small"); return AG_ERR_SCRATCH_TOO_SMALL; }
+    float* At = reinterpret_cast<float*>(aligned_base(workspace));
+
+    GatherProblem gp;
+    gp.out_scale = out_scale; gp.bias = bias; gp.yout = yout; gp.xin = xin;
+    const bool conv = d->kind == AG_CONV;
+    // input of the GEMM / output of the GEMM in tensor terms
+    int Cg, Hg, Wg, M, OHf, OWf;
+    long long stride_c, stride_m;
+    if (!backward_input) { Cg = d->Cin; Hg = d->H; Wg = d->W; M = d->Cout; OHf = OH; OWf = OW; }
+    else                 { Cg = d->Cout; Hg = OH; Wg = OW; M = d->Cin; OHf = d->H; OWf = d->W; }
+    // weight layout: conv [Cout][Cin][k][k], transposed conv [Cin][Cout][k][k]
+    const long long s_co = conv ? (long long)d->Cin * k2 : k2, s_ci = conv ? k2 : (long long)d->Cout * k2;
+    stride_c = backward_input ? s_co : s_ci;
+    stride_m = backward_input ? s_ci : s_co;
+    gp.Cg = Cg; gp.Hg = Hg; gp.Wg = Wg; gp.M = M; gp.Mpad = round_up(M, BM); gp.OHf = OHf; gp.OWf = OWf;
+
+    // "gather" cases: forward conv, input gradient of a transposed conv (a stride-2 conv over dy), input gradient of a
+    // stride-1 conv (taps mirrored).  "scatter" cases (stride 2): transposed conv forward, input gradient of a stride-2 conv.
+    const bool scatter = (conv && backward_input && d->stride == 2) || (!conv && !backward_input);
+    if (!scatter) {
+        TapSet ts; ts.n = k2;
+        for (int ky = 0; ky < k; ky++) for (int kx = 0; kx < k; kx++) { ts.ky[ky * k + kx] = ky; ts.kx[ky * k + kx] = kx; }
+        gp.ntaps = k2; gp.K = Cg * k2; gp.Kpad = round_up(gp.K, BK);
+        gp.gh = OHf; gp.gw = OWf; gp.y0 = 0; gp.ys = 1; gp.x0 = 0; gp.xs = 1;
+        if (conv && !backward_input) {                 // y[oy] <- x[oy*s - p + ky]
+            gp.sy = gp.sx = d->stride;
+            for (int t = 0; t < k2; t++) { gp.dy[t] = ts.ky[t] - d->padding; gp.dx[t] = ts.kx[t] - d->padding; }
+        } else if (conv) {                             // stride-1 conv, dx[iy] <- dy[iy + p - ky]
+            gp.sy = gp.sx = 1;
+            for (int t = 0; t < k2; t++) { gp.dy[t] = d->padding - ts.ky[t]; gp.dx[t] = d->padding - ts.kx[t]; }
+        } else {                                       // transposed conv, dx[iy] <- dy[2 iy + ky]
+            gp.sy = gp.sx = 2;
+            for (int t = 0; t < k2; t++) { gp.dy[t] = ts.ky[t]; gp.dx[t] = ts.kx[t]; }
+        }
+        gp.At = At;
+        int rc = launch_pack(w, At, Cg, M, gp.Mpad, gp.K, gp.Kpad, stride_c, stride_m, ts, k, s);
+        if (rc) return rc;
+        return launch_gather(gp, s);
+    }
+    // scatter with stride 2: output coordinate o = 2*i + ky - poff  (poff = padding for the conv gradient, 0 for convT).
+    // Class (qy, qx) = parity of the output coordinate; it receives only taps with ky = (o + poff) mod 2, from
+    // input i = (o + poff - ky) / 2 = g + (q + poff - ky) / 2 with o = q + 2 g.
+    const int poff = conv ? d->padding : 0;
+    size_t at_off = 0;
+    for (int qy = 0; qy < 2; qy++)
+        for (int qx = 0; qx < 2; qx++) {
+            TapSet ts; ts.n = 0;
+            for (int ky = 0; ky < k; ky++) {
+                if (((qy + poff - ky) & 1) != 0) continue;
+                for (int kx = 0; kx < k; kx++) {
+                    if (((qx + poff - kx) & 1) != 0) continue;
+                    ts.ky[ts.n] = ky; ts.kx[ts.n] = kx; ts.n++;
+                }
+            }
+            gp.gh = (OHf - qy + 1) / 2; gp.gw = (OWf - qx + 1) / 2;
+            gp.y0 = qy; gp.ys = 2; gp.x0 = qx; gp.xs = 2;
+            if (gp.gh <= 0 || gp.gw <= 0) continue;
+            if (ts.n == 0) {
+                // no tap reaches this class (possible for k = 1): the outputs are out_scale*0 + bias; handled by a
+                // degenerate GEMM with K = one zero-padded tile
+                ts.n = 1; ts.ky[0] = 0; ts.kx[0] = 0;
+                gp.ntaps = 1; gp.K = 0; gp.Kpad = BK;
+            } else {
+                gp.ntaps = ts.n; gp.K = Cg * ts.n; gp.Kpad = round_up(gp.K, BK);
+            }
+            gp.sy = gp.sx = 1;
+            for (int t = 0; t < ts.n; t++) { gp.dy[t] = (qy + poff - ts.ky[t]) / 2; gp.dx[t] = (qx + poff - ts.kx[t]) / 2; }
+            // floor division for negative odd numerators never happens: numerators are even by construction
+            gp.At = At + at_off;
+            int rc = launch_pack(w, At + at_off, Cg, M, gp.Mpad, gp.K, gp.Kpad, stride_c, stride_m, ts, k, s);
+            if (rc) return rc;
+            if ((rc = launch_gather(gp, s))) return rc;
+            at_off += (size_t)gp.Kpad * gp.Mpad;
+        }
+    return AG_OK;
+}
+
+int ag_conv_forward(const AgConvDesc* d, const float* x, const float* w, const float* out_scale, const float* bias, float* y,
+                    void* workspace, size_t workspace_bytes, void* stream)
+{
+    int rc = validate(d);
+    if (rc) return rc;
+    if (!x || !w || !y) { set_error("null conv tensor"); return AG_ERR_INVALID_ARGUMENT; }
+    return run_gather_family(d, false, x, w, out_scale, bias, y, workspace, workspace_bytes, reinterpret_cast<hipStream_t>(stream));
+}
+
+int ag_conv_backward_input(const AgConvDesc* d, const float* dy, const float* w, float* dx, void* workspace,
+                           size_t workspace_bytes, void* stream)
+{
+    int rc = validate(d);
+    if (rc) return rc;
+    if (!dy || !w || !dx) { set_error("null conv tensor"); return AG_ERR_INVALID_ARGUMENT; }
+    return run_gather_family(d, true, dy, w, nullptr, nullptr, dx, workspace, workspace_bytes, reinterpret_cast<hipStream_t>(stream));
+}
+
+int ag_conv_backward_weight(const AgConvDesc* d, const float* x, const float* dy, float* dw, void* workspace,
+                            size_t workspace_bytes, void* stream)
+{
+    (void)workspace; (void)workspace_bytes;
+    int rc = validate(d);
+    if (rc) return rc;
+    if (!x || !dy || !dw) { set_error("null conv tensor"); return AG_ERR_INVALID_ARGUMENT; }
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    int OH, OW;
+    out_size(d, OH, OW);
+    const int k = d->k, k2 = k * k;
+    WgradProblem wp;
+    if (d->kind == AG_CONV) {      // dw[co][(ci,t)] = sum_o dy[co][o] * x[ci][o*s - p + k]
+        wp.a = dy; wp.xin = x; wp.Mw = d->Cout; wp.Cg = d->Cin; wp.Hg = d->H; wp.Wg = d->W; wp.gh = OH; wp.gw = OW;
+        wp.sy = wp.sx = d->stride;
+        for (int t = 0; t < k2; t++) { wp.dy[t] = t / k - d->padding; wp.dx[t] = t % k - d->padding; }
+    } else {                       // dw[ci][(co,t)] = sum_i x[ci][i] * dy[co][2 i + k]
+        wp.a = x; wp.xin = dy; wp.Mw = d->Cin; wp.Cg = d->Cout; wp.Hg = OH; wp.Wg = OW; wp.gh = d->H; wp.gw = d->W;
+        wp.sy = wp.sx = 2;
+        for (int t = 0; t < k2; t++) { wp.dy[t] = t / k; wp.dx[t] = t % k; }
+    }
+    wp.c = dw; wp.ntaps = k2;
+    const int Kp = wp.gh * wp.gw, Nw = wp.Cg * k2;
+    const int tiles = ((Nw + BN - 1) / BN) * ((wp.Mw + BM - 1) / BM);
+    int splits = (2048 + tiles - 1) / tiles;                 // aim at ~8 workgroups per CU
+    const int max_splits = (Kp + 4 * BK - 1) / (4 * BK);     // at least 4 K tiles per split
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    wp.ksplit_len = round_up((Kp + splits - 1) / splits, BK);
+    splits = (Kp + wp.ksplit_len - 1) / wp.ksplit_len;
+    if ((rc = check_hip(hipMemsetAsync(dw, 0, (size_t)wp.Mw * Nw * sizeof(float), s), "memset dw"))) return rc;
+    dim3 grid((Nw + BN - 1) / BN, (wp.Mw + BM - 1) / BM, splits);
+    hipLaunchKernelGGL(wgrad_kernel, grid, dim3(256), 0, s, wp);
+    return check_hip(hipGetLastError(), "wgrad_kernel");
+}
+
+}  // extern "C"

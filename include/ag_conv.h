@@ -1,0 +1,63 @@
+/*
+ * ag_conv.h — C ABI of the MFMA convolution kernels for the StyleUNet (libag_hip.so), batch 1, fp32.
+ *
+ * Boundary B4 of SURVEY.md: replaces the cuDNN calls behind network/styleunet/conv2d_gradfix.py:22-75
+ * (conv2d / conv_transpose2d, reached from dual_styleunet.py:114,239-298).  Only the configurations that occur in
+ * the product are supported: conv2d k x k (k = 1, 3, 4) with stride 1 or 2 and any zero padding, and
+ * conv_transpose2d 3x3 stride 2 padding 0; groups = batch = 1 (the reference's grouped call with groups = batch
+ * is the same thing at batch 1).
+ *
+ * All three GEMM-shaped problems of a convolution run on v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32
+ * accumulation): forward, input gradient (= a gather-convolution with re-packed weights) and weight gradient.
+ * Device pointers, contiguous NCHW without the batch dimension; 0 on success (codes in ag_raster.h).
+ */
+#ifndef AG_CONV_H
+#define AG_CONV_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum AgConvKind {
+    AG_CONV = 0,            /* y = conv2d(x, w [Cout,Cin,k,k], stride, padding) */
+    AG_CONV_TRANSPOSE = 1   /* y = conv_transpose2d(x, w [Cin,Cout,k,k], stride 2, padding 0): OH = (H-1)*2 + k */
+} AgConvKind;
+
+typedef struct AgConvDesc {
+    int32_t kind;          /* AgConvKind */
+    int32_t Cin, Cout;
+    int32_t H, W;          /* input spatial size */
+    int32_t k;             /* square kernel size */
+    int32_t stride;        /* 1 or 2 (AG_CONV_TRANSPOSE: 2) */
+    int32_t padding;       /* AG_CONV only */
+} AgConvDesc;
+
+/* Output spatial size of the described convolution. */
+int ag_conv_output_size(const AgConvDesc* d, int32_t* OH, int32_t* OW);
+
+/* Bytes of scratch the three entry points need (re-packed weights / transposed operands). */
+size_t ag_conv_workspace_bytes(const AgConvDesc* d);
+
+/*
+ * y [Cout, OH, OW] = conv(x [Cin, H, W], w) * out_scale[co] + bias[co]
+ * out_scale / bias may be NULL (1 / 0).  out_scale is the demodulation coefficient hook of ModulatedConv2d
+ * (dual_styleunet.py:246-250); bias the EqualConv2d bias (:114-120).
+ */
+int ag_conv_forward(const AgConvDesc* d, const float* x, const float* w, const float* out_scale, const float* bias,
+                    float* y, void* workspace, size_t workspace_bytes, void* stream);
+
+/* dx [Cin, H, W] = d(loss)/dx given dy [Cout, OH, OW] (dy already multiplied by out_scale if one was used). */
+int ag_conv_backward_input(const AgConvDesc* d, const float* dy, const float* w, float* dx, void* workspace,
+                           size_t workspace_bytes, void* stream);
+
+/* dw (same shape as w) = d(loss)/dw given x and dy.  dw is overwritten. */
+int ag_conv_backward_weight(const AgConvDesc* d, const float* x, const float* dy, float* dw, void* workspace,
+                            size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AG_CONV_H */
