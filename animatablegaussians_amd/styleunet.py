@@ -1,0 +1,278 @@
+"""DualStyleUNet on the MI355X kernels: the pose-conditioned generator the avatar uses three
+times per step (``network/avatar.py:34-36``), rebuilt as a flat, table-driven network over
+
+  * ``conv.conv2d`` / ``conv.conv_transpose2d``  -- MFMA fp32 implicit-GEMM kernels (include/ag_conv.h)
+  * ``styleunet_ops.upfirdn2d_nchw``             -- FIR resampling (include/ag_styleunet.h)
+  * ``styleunet_ops.fused_leaky_relu``           -- bias + leaky-ReLU * sqrt(2)
+
+It is numerically the reference's ``network/styleunet/dual_styleunet.py:DualStyleUNet`` at batch 1 with a single style
+vector (the only way ``network/avatar.py:94,107,120`` calls it) and takes the reference's checkpoints:
+``load_reference_state_dict`` accepts the ``state_dict`` of the reference module key for key (FIR / Haar kernels are
+constants here, every learnable tensor and the fixed noise maps are loaded).  The arithmetic order of the modulated
+convolution follows the reference's fused branch (``dual_styleunet.py:254-298``): the modulated, demodulated weight is
+formed first and then convolved, so results agree to fp32 summation-order noise.
+
+Small glue (the 512-wide mapping / modulation GEMVs, weight modulation, noise and skip additions, channel concat) is
+plain torch tensor algebra on the GPU; all convolutions, FIR filters and activations are this package's HIP kernels.
+There is no CPU path.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+
+from . import conv as agc
+from .styleunet_ops import fused_leaky_relu, upfirdn2d_nchw
+
+_SQRT2 = 2 ** 0.5
+
+
+def _fir(taps, gain=1.0):
+    k = torch.tensor(taps, dtype=torch.float32)
+    k = k[None, :] * k[:, None]
+    k /= k.sum()
+    return k * gain
+
+
+def _haar():
+    a = 1 / (2 ** 0.5)
+    lo, hi = torch.tensor([[a, a]]), torch.tensor([[-a, a]])
+    # dual_styleunet.py:374-384
+    return {"ll": lo.T * lo, "lh": hi.T * lo, "hl": lo.T * hi, "hh": hi.T * hi}
+
+
+class DualStyleUNet(torch.nn.Module):
+    """Encoder (pose map -> 6 feature levels) + two style-modulated decoders (front / back maps)."""
+
+    def __init__(self, inp_size=512, inp_ch=3, out_ch=3, out_size=1024, style_dim=512, n_mlp=2, middle_size=8,
+                 channel_multiplier=2, blur_kernel=(1, 3, 3, 1), lr_mlp=0.01):
+        super().__init__()
+        if tuple(blur_kernel) != (1, 3, 3, 1):
+            raise ValueError("only the [1,3,3,1] blur kernel of the product is supported")
+        cm = channel_multiplier
+        ch = {4: 512, 8: 512, 16: 512, 32: 512, 64: 256 * cm, 128: 128 * cm, 256: 64 * cm, 512: 32 * cm, 1024: 16 * cm}
+        self.inp_size, self.inp_ch, self.out_ch, self.out_size = inp_size, inp_ch, out_ch, out_size
+        self.style_dim, self.n_mlp, self.lr_mlp = style_dim, n_mlp, lr_mlp
+        log_in, log_mid, log_out = int(math.log2(inp_size)), int(math.log2(middle_size)), int(math.log2(out_size)) - 1
+        self._ref_names = {}
+
+        # ---- learnable tensors, under the reference's state_dict names --------------------------------------------
+        for i in range(n_mlp):
+            self._param(f"style.{i + 1}.weight", torch.randn(style_dim, style_dim) / lr_mlp)
+            self._param(f"style.{i + 1}.bias", torch.zeros(style_dim))
+
+        c0 = ch[inp_size // 2]
+        self._conv_layer_params("conv_in", inp_ch, c0, 3, downsample=True)
+        self._conv_layer_params("comb_convs.0", 2 * c0, c0, 3)
+        self.enc = []                       # (level index, in channels, out channels)
+        cin = c0
+        for n, i in enumerate(range(log_in - 2, log_mid - 1, -1)):
+            cout = ch[2 ** i]
+            self._conv_layer_params(f"from_rgbs.{n}.conv", inp_ch, cin, 1)
+            self._conv_layer_params(f"cond_convs.{n}.conv1", cin, cin, 3)
+            self._conv_layer_params(f"cond_convs.{n}.conv2", cin, cout, 3, downsample=True)
+            self._conv_layer_params(f"comb_convs.{n + 1}", cout * (2 if i > log_mid else 1), cout, 3)
+            self.enc.append((n, cin, cout))
+            cin = cout
+        self.n_comb = len(self.enc) + 1
+
+        self.dec = []                       # (stage, in channels, out channels)
+        cin = ch[middle_size]
+        for n, i in enumerate(range(log_mid + 1, log_out + 1)):
+            cout = ch[2 ** i]
+            for b in (1, 2):
+                self._styled_conv_params(f"convs{b}.{2 * n}", cin, cout)
+                self._styled_conv_params(f"convs{b}.{2 * n + 1}", cout, cout)
+                self._param(f"to_rgbs{b}.{n}.conv.weight", torch.randn(1, out_ch * 4, cout, 1, 1))
+                self._param(f"to_rgbs{b}.{n}.conv.modulation.weight", torch.randn(cout, style_dim))
+                self._param(f"to_rgbs{b}.{n}.conv.modulation.bias", torch.ones(cout))
+                self._param(f"to_rgbs{b}.{n}.bias", torch.zeros(1, out_ch * 4, 1, 1))
+            self.dec.append((n, cin, cout))
+            cin = cout
+        self.num_layers = 2 * len(self.dec)
+        self.n_latent = log_out * 2 - (log_mid * 2 - 1) + 1
+        for layer in range(self.num_layers):
+            res = 2 ** ((layer + 2 * (log_mid + 1)) // 2)
+            self.register_buffer(self._attr(f"noises.noise_{layer}"), torch.randn(1, 1, res, res))
+
+        # ---- constant filters ---------------------------------------------------------------------------------
+        self.register_buffer("_k_blur", _fir(blur_kernel), persistent=False)           # Blur before stride-2 conv, Downsample
+        self.register_buffer("_k_blur_up", _fir(blur_kernel, 4.0), persistent=False)   # Blur after conv_transpose, Upsample
+        for name, k in _haar().items():
+            self.register_buffer("_dwt_" + name, k.contiguous(), persistent=False)
+            self.register_buffer("_iwt_" + name, (-k if name in ("lh", "hl") else k).contiguous(), persistent=False)
+
+    # ---- parameter bookkeeping ------------------------------------------------------------------------------------
+    @staticmethod
+    def _attr(ref_name):
+        return ref_name.replace(".", "__")
+
+    def _param(self, ref_name, value):
+        self.register_parameter(self._attr(ref_name), torch.nn.Parameter(value))
+        self._ref_names[ref_name] = self._attr(ref_name)
+
+    def _p(self, ref_name):
+        return getattr(self, self._attr(ref_name))
+
+    def _conv_layer_params(self, prefix, cin, cout, k, downsample=False):
+        # ConvLayer = [Blur] + EqualConv2d(bias=False) + FusedLeakyReLU(bias)   (dual_styleunet.py:326-371)
+        base = 1 if downsample else 0
+        self._param(f"{prefix}.{base}.weight", torch.randn(cout, cin, k, k))
+        self._param(f"{prefix}.{base + 1}.bias", torch.zeros(cout))
+
+    def _styled_conv_params(self, prefix, cin, cout):
+        self._param(f"{prefix}.conv.weight", torch.randn(1, cout, cin, 3, 3))
+        self._param(f"{prefix}.conv.modulation.weight", torch.randn(cin, self.style_dim))
+        self._param(f"{prefix}.conv.modulation.bias", torch.ones(cin))
+        self._param(f"{prefix}.noise.weight", torch.zeros(1))
+        self._param(f"{prefix}.activate.bias", torch.zeros(cout))
+
+    def reference_state_dict(self):
+        """Learnable tensors + noise maps under the reference module's state_dict keys."""
+        sd = {ref: getattr(self, attr).detach() for ref, attr in self._ref_names.items()}
+        for layer in range(self.num_layers):
+            sd[f"noises.noise_{layer}"] = getattr(self, self._attr(f"noises.noise_{layer}"))
+        return sd
+
+    @torch.no_grad()
+    def load_reference_state_dict(self, sd, strict=True):
+        """Load the ``state_dict`` of the reference's DualStyleUNet.  Its constant buffers (``*.kernel``, ``*.ll`` ...)
+        are recomputed here and ignored; anything else unknown or missing raises when ``strict``."""
+        const_suffix = (".kernel", ".ll", ".lh", ".hl", ".hh")
+        seen = set()
+        for key, value in sd.items():
+            if key.endswith(const_suffix):
+                continue
+            attr = self._attr(key)
+            if key in self._ref_names or key.startswith("noises.noise_") and hasattr(self, attr):
+                dst = getattr(self, attr)
+                if tuple(dst.shape) != tuple(value.shape):
+                    raise RuntimeError(f"{key}: checkpoint shape {tuple(value.shape)} != {tuple(dst.shape)}")
+                dst.copy_(value)
+                seen.add(key)
+            elif strict:
+                raise RuntimeError(f"unexpected key in reference state_dict: {key}")
+        missing = [k for k in self._ref_names if k not in seen]
+        if strict and missing:
+            raise RuntimeError(f"missing keys in reference state_dict: {missing[:5]}{' ...' if len(missing) > 5 else ''}")
+
+    # ---- building blocks ------------------------------------------------------------------------------------------
+    def _conv_layer(self, x, prefix, downsample=False):
+        base = 1 if downsample else 0
+        w = self._p(f"{prefix}.{base}.weight")
+        k = w.shape[-1]
+        w = w * (1 / math.sqrt(w.shape[1] * k * k))                      # EqualConv2d scale (:100-114)
+        if downsample:
+            x = upfirdn2d_nchw(x, self._k_blur, pad=(2, 2))              # p = (4 - 2) + (k - 1), k = 3 (:339-345)
+            x = agc.conv2d(x, w, stride=2, padding=0)
+        else:
+            x = agc.conv2d(x, w, stride=1, padding=k // 2)
+        return fused_leaky_relu(x, self._p(f"{prefix}.{base + 1}.bias"))
+
+    def _modulated_weight(self, prefix, w_latent, demodulate):
+        w = self._p(f"{prefix}.weight")                                  # [1, Cout, Cin, k, k]
+        mw, mb = self._p(f"{prefix}.modulation.weight"), self._p(f"{prefix}.modulation.bias")
+        style = F.linear(w_latent, mw * (1 / math.sqrt(mw.shape[1])), bias=mb * 1.0)    # EqualLinear, lr_mul 1 (:152-155)
+        k = w.shape[-1]
+        weight = (1 / math.sqrt(w.shape[2] * k * k)) * w * style.view(1, 1, -1, 1, 1)  # (:254-255)
+        if demodulate:
+            demod = torch.rsqrt(weight.pow(2).sum([2, 3, 4]) + 1e-8)
+            weight = weight * demod.view(1, -1, 1, 1, 1)
+        return weight[0]                                                  # [Cout, Cin, k, k]
+
+    def _styled_conv(self, x, prefix, w_latent, noise, upsample):
+        weight = self._modulated_weight(f"{prefix}.conv", w_latent, True)
+        if upsample:
+            x = agc.conv_transpose2d(x, weight.transpose(0, 1).contiguous(), stride=2, padding=0)
+            x = upfirdn2d_nchw(x, self._k_blur_up, pad=(1, 1))           # p = (4 - 2) - (3 - 1) = 0 -> pad (1, 1) (:188-193)
+        else:
+            x = agc.conv2d(x, weight, stride=1, padding=1)
+        if noise is None:
+            noise = torch.randn(1, 1, x.shape[2], x.shape[3], device=x.device, dtype=x.dtype)
+        x = x + self._p(f"{prefix}.noise.weight") * noise                # NoiseInjection (:301-311)
+        return fused_leaky_relu(x, self._p(f"{prefix}.activate.bias"))
+
+    def _haar_split(self, x):                                             # HaarTransform (:387-403)
+        return torch.cat([upfirdn2d_nchw(x, getattr(self, "_dwt_" + n), down=2) for n in ("ll", "lh", "hl", "hh")], 1)
+
+    def _haar_merge(self, x):                                             # InverseHaarTransform (:406-425)
+        parts = x.chunk(4, 1)
+        out = None
+        for part, n in zip(parts, ("ll", "lh", "hl", "hh")):
+            y = upfirdn2d_nchw(part, getattr(self, "_iwt_" + n), up=2, pad=(1, 0, 1, 0))
+            out = y if out is None else out + y
+        return out
+
+    def _to_rgb(self, x, prefix, w_latent, skip):
+        weight = self._modulated_weight(f"{prefix}.conv", w_latent, False)
+        out = agc.conv2d(x, weight, stride=1, padding=0) + self._p(f"{prefix}.bias")
+        if skip is not None:
+            s = self._haar_merge(skip)
+            s = upfirdn2d_nchw(s, self._k_blur_up, up=2, pad=(2, 1))     # Upsample (:32-50)
+            out = out + self._haar_split(s)
+        return out
+
+    def get_latent(self, z):
+        """Mapping network: PixelNorm + n_mlp x EqualLinear(lr_mul, fused leaky ReLU)  (:594-610)."""
+        x = z * torch.rsqrt(torch.mean(z ** 2, dim=1, keepdim=True) + 1e-8)
+        for i in range(self.n_mlp):
+            w = self._p(f"style.{i + 1}.weight")
+            x = F.linear(x, w * ((1 / math.sqrt(w.shape[1])) * self.lr_mlp))
+            x = fused_leaky_relu(x, self._p(f"style.{i + 1}.bias") * self.lr_mlp)
+        return x
+
+    def encode(self, condition_img):
+        """Pose map [1, inp_ch, S, S] -> feature levels, finest first  (:854-864)."""
+        img = condition_img
+        out = self._conv_layer(img, "conv_in", downsample=True)
+        levels = [out]
+        for n, _, _ in self.enc:
+            img = upfirdn2d_nchw(img, self._k_blur, down=2, pad=(1, 1))                  # Downsample (:53-71)
+            out = self._conv_layer(img, f"from_rgbs.{n}.conv") + out                      # FromRGB, use_wt=False (:455-468)
+            out = self._conv_layer(out, f"cond_convs.{n}.conv1")
+            out = self._conv_layer(out, f"cond_convs.{n}.conv2", downsample=True)
+            levels.append(out)
+        return levels
+
+    def decode(self, branch, levels, w_latent, noise, view_feature=None):
+        """One decoder (branch 1 = front map, 2 = back map)  (:869-905)."""
+        skip = out = None
+        for n, _, _ in self.dec:
+            if n == 0:
+                out = self._conv_layer(levels[-1], f"comb_convs.{self.n_comb - 1}")
+            elif n < self.n_comb:
+                out = self._conv_layer(torch.cat([out, levels[-1 - n]], 1), f"comb_convs.{self.n_comb - 1 - n}")
+            out = self._styled_conv(out, f"convs{branch}.{2 * n}", w_latent, noise[2 * n], True)
+            out = self._styled_conv(out, f"convs{branch}.{2 * n + 1}", w_latent, noise[2 * n + 1], False)
+            skip = self._to_rgb(out, f"to_rgbs{branch}.{n}", w_latent, skip)
+            if view_feature is not None and n == 4:
+                if view_feature.shape[-2:] != out.shape[-2:]:
+                    view_feature = F.interpolate(view_feature, out.shape[-2:], mode="bilinear")
+                out = out + view_feature
+        return self._haar_merge(skip)
+
+    def forward(self, styles, condition_img, cond=None, return_latents=False, inject_index=None, truncation=1,
+                truncation_latent=None, input_is_latent=False, noise=None, randomize_noise=True, view_feature1=None,
+                view_feature2=None):
+        """Same call as the reference (:616-911); returns ``(images [1, 2*out_ch, out_size, out_size], latent|None)``."""
+        if cond is not None or truncation < 1 or len(styles) != 1 or inject_index is not None:
+            raise RuntimeError("DualStyleUNet (MI355X path): one style vector, no conditioning / truncation / style mixing")
+        if condition_img.shape[0] != 1 or styles[0].shape[0] != 1:
+            raise RuntimeError("DualStyleUNet (MI355X path): batch 1")
+        if not condition_img.is_cuda:
+            raise RuntimeError("DualStyleUNet (MI355X path) runs on the GPU only")
+        w_latent = styles[0] if input_is_latent else self.get_latent(styles[0])
+        if w_latent.dim() == 3:
+            w_latent = w_latent[:, 0]
+        if noise is None:
+            noise = [None] * self.num_layers if randomize_noise else \
+                [getattr(self, self._attr(f"noises.noise_{i}")) for i in range(self.num_layers)]
+        levels = self.encode(condition_img)
+        image1 = self.decode(1, levels, w_latent, noise, view_feature1)
+        image2 = self.decode(2, levels, w_latent, noise, view_feature2)
+        images = torch.cat([image1, image2], 1)
+        if return_latents:
+            return images, w_latent.unsqueeze(1).repeat(1, self.n_latent, 1)
+        return images, None

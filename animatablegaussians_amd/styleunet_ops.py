@@ -74,3 +74,87 @@ def upfirdn2d(input: torch.Tensor, kernel: torch.Tensor, up_x: int, up_y: int, d
     if minor != 1:
         out = out.reshape(major, minor, out_h, out_w).permute(0, 2, 3, 1).contiguous()
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Differentiable NCHW front ends (what network/styleunet/fused_act.py:79-138 and upfirdn2d.py:35-184 wrap around the
+# two raw ops).  First-order gradients only: the avatar trainer has no gradient-penalty term, so the reference's
+# double-backward Functions (fused_act.py:35-76, upfirdn2d.py:35-103) are never differentiated on the product path.
+# ---------------------------------------------------------------------------------------------------------------------
+_EMPTY = {}
+
+
+def _empty(dev):
+    e = _EMPTY.get(dev)
+    if e is None:
+        e = _EMPTY[dev] = torch.empty(0, dtype=torch.float32, device=dev)
+    return e
+
+
+class _FusedLeakyReLU(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, bias, negative_slope, scale):
+        e = _empty(x.device)
+        out = fused_bias_act(x.contiguous(), bias if bias is not None else e, e, 3, 0, negative_slope, scale)
+        ctx.save_for_backward(out)
+        ctx.cfg = (bias is not None, negative_slope, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, gy):
+        (out,) = ctx.saved_tensors
+        has_bias, slope, scale = ctx.cfg
+        e = _empty(gy.device)
+        # the sign of the saved OUTPUT selects the slope (act=3, grad=1: fused_bias_act_kernel.cu:41)
+        gx = fused_bias_act(gy.contiguous(), e, out, 3, 1, slope, scale)
+        gb = None
+        if has_bias:
+            dims = [0] + list(range(2, gx.dim()))
+            gb = gx.sum(dims)
+        return gx, gb, None, None
+
+
+def fused_leaky_relu(input, bias=None, negative_slope=0.2, scale=2 ** 0.5):
+    """leaky_relu(input + bias[None, :, None, None]) * scale  (fused_act.py:117-138)."""
+    return _FusedLeakyReLU.apply(input, bias, float(negative_slope), float(scale))
+
+
+def _out_size(n, up, down, p0, p1, k):
+    return (n * up + p0 + p1 - k + down) // down
+
+
+class _UpFirDn2d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, kernel, up, down, pad):
+        n, c, h, w = x.shape
+        kh, kw = kernel.shape
+        px0, px1, py0, py1 = pad
+        oh, ow = _out_size(h, up[1], down[1], py0, py1, kh), _out_size(w, up[0], down[0], px0, px1, kw)
+        y = upfirdn2d(x.reshape(n * c, h, w, 1).contiguous(), kernel, up[0], up[1], down[0], down[1], px0, px1, py0, py1)
+        ctx.save_for_backward(kernel)
+        ctx.cfg = (up, down, pad, (n, c, h, w), (oh, ow))
+        return y.view(n, c, oh, ow)
+
+    @staticmethod
+    def backward(ctx, gy):
+        (kernel,) = ctx.saved_tensors
+        up, down, (px0, px1, py0, py1), (n, c, h, w), (oh, ow) = ctx.cfg
+        kh, kw = kernel.shape
+        # adjoint of (zero-stuff by up, pad, FIR, decimate by down) = the same pipeline with up/down exchanged, the
+        # kernel flipped, and pads chosen so that the output has the input's size (upfirdn2d.py:131-136)
+        gx0, gy0 = kw - px0 - 1, kh - py0 - 1
+        gx1 = w * up[0] - ow * down[0] + px0 - up[0] + 1
+        gy1 = h * up[1] - oh * down[1] + py0 - up[1] + 1
+        g = upfirdn2d(gy.reshape(n * c, oh, ow, 1).contiguous(), torch.flip(kernel, [0, 1]).contiguous(), down[0], down[1],
+                      up[0], up[1], gx0, gx1, gy0, gy1)
+        return g.view(n, c, h, w), None, None, None, None
+
+
+def upfirdn2d_nchw(input, kernel, up=1, down=1, pad=(0, 0)):
+    """``upfirdn2d(input [N,C,H,W], kernel, up, down, pad)`` of upfirdn2d.py:168-184 (pad of 2 = same for x and y)."""
+    up = (up, up) if isinstance(up, int) else tuple(up)
+    down = (down, down) if isinstance(down, int) else tuple(down)
+    pad = tuple(pad)
+    if len(pad) == 2:
+        pad = (pad[0], pad[1], pad[0], pad[1])
+    return _UpFirDn2d.apply(input, kernel, up, down, pad)

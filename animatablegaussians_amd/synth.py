@@ -115,3 +115,44 @@ def free_view_cameras(n_views: int = 8, img: int = 1024, focal: float = 1100.0, 
         intr = np.array([[focal, 0, img / 2], [0, focal, img / 2], [0, 0, 1]], f32)
         cams.append({"extr": extr, "intr": intr, "img_w": img, "img_h": img})
     return cams
+
+
+def named_fill(state: Dict[str, object], seed: int = SEED) -> Dict[str, object]:
+    """Deterministic synthetic values for a network's tensors, a pure function of (name, shape, seed): the same
+    numbers can be produced wherever the names are known (the reference module in the build container, this package
+    on the GPU box), which is how the StyleUNet parity fixture pins a 74M-parameter network without shipping weights.
+
+    Scales follow the reference's initialisers (randn weights, randn/lr_mul mapping weights come out of the shapes
+    alone), with small non-zero biases / noise strengths so that every path contributes."""
+    import zlib
+
+    import torch
+
+    out = {}
+    for name, t in state.items():
+        if name.endswith((".kernel", ".ll", ".lh", ".hl", ".hh")):
+            continue
+        g = torch.Generator().manual_seed((zlib.crc32(name.encode()) ^ seed) & 0x7FFFFFFF)
+        v = torch.randn(tuple(t.shape), generator=g, dtype=torch.float32)
+        if name.startswith("style.") and name.endswith(".weight"):
+            v = v * 100.0                                  # randn / lr_mlp
+        elif name.endswith("modulation.bias"):
+            v = 1.0 + 0.1 * v
+        elif name.endswith(".bias") or name.endswith("noise.weight"):
+            v = 0.1 * v
+        out[name] = v
+    return out
+
+
+def pose_map(S: int = 512, seed: int = SEED):
+    """Smooth synthetic position map [1, 3, S, S] inside a body-shaped mask (stand-in for smpl_pos_map)."""
+    import torch
+
+    rng = np.random.default_rng(seed + 77)
+    yy, xx = np.meshgrid(np.linspace(-1, 1, S, dtype=np.float32), np.linspace(-1, 1, S, dtype=np.float32), indexing="ij")
+    chans = []
+    for c in range(3):
+        a = rng.uniform(0.5, 3.0, 4).astype(np.float32)
+        chans.append(0.5 * np.sin(a[0] * xx + a[1]) * np.cos(a[2] * yy + a[3]) + 0.1 * xx * (c - 1))
+    m = (np.abs(xx) < 0.8) & (np.abs(yy) < 0.9)
+    return torch.from_numpy((np.stack(chans) * m[None]).astype(np.float32))[None]
