@@ -21,6 +21,7 @@
 namespace ag {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: HIP's float4 struct in arrays defeats SROA (scratch spills)
 
 constexpr int BM = 128, BN = 128, BK = 16;
 constexpr int LDA = BM + 4, LDB = BN + 4;   // +4 floats: keeps float4 stores 16-B aligned, shifts rows across banks
@@ -28,15 +29,17 @@ constexpr int kMaxTaps = 16;
 
 struct GatherProblem {
     const float* xin;      // [Cg][Hg][Wg]
-    const float* At;       // [Kpad][Mpad]
+    const float* At;       // [Kpad][Mpad], K index = tap * Cpad + channel
     float* yout;           // [M][OHf][OWf]
     const float* out_scale;
     const float* bias;
-    int Cg, Hg, Wg;
+    int Cg, Cpad, Hg, Wg;  // Cpad = channels rounded up to BK: every K tile lies inside one tap
     int M, Mpad, OHf, OWf;
     int gh, gw, y0, ys, x0, xs;     // class grid -> output coordinates
     int sy, sx, ntaps;
-    int K, Kpad;
+    int Kpad;              // ntaps * Cpad
+    int kt_per_split;      // K tiles per blockIdx.z slice (gridDim.z == 1: all of them)
+    float* partial;        // gridDim.z > 1: raw accumulators go to partial[z][Mpad][N] and reduce_splits_kernel finishes
     int dy[kMaxTaps], dx[kMaxTaps];
 };
 
@@ -60,22 +63,33 @@ __device__ __forceinline__ void mma_tile(const float* __restrict__ As, const flo
 // ------------------------------------------------------------------------------------------------------------------
 // gather-conv
 // ------------------------------------------------------------------------------------------------------------------
+// K is ordered tap-major (k = tap * Cpad + channel), so the 16 rows of a K tile are 16 consecutive channels of ONE tap:
+// the tap (and with it the input offset and the padding test) is a wave-uniform scalar per tile, each thread keeps the
+// 16-bit in-bounds mask of its output pixel over the taps, and the 8 gathers of a tile are unconditional loads from
+// `pixel + tap offset + channel * plane` (address and value selected, no branches) -- all in flight under the MFMAs.
 __global__ void __launch_bounds__(256) gather_conv_kernel(GatherProblem p)
 {
     __shared__ __attribute__((aligned(16))) float As[2][BK * LDA];
     __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int N = p.gh * p.gw;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
 
     // B loader: this thread owns output column n_loc for the whole kernel and rows khalf, khalf+2, ... of each K tile
-    const int n_loc = tid & (BN - 1), khalf = tid >> 7;
+    const int n_loc = tid & (BN - 1), khalf = wave >> 1;
     const int n = n0 + n_loc;
     const bool n_ok = n < N;
     const int gy = n_ok ? n / p.gw : 0, gx = n_ok ? n - (n / p.gw) * p.gw : 0;
     const int iy0 = gy * p.sy, ix0 = gx * p.sx;
     const size_t plane = (size_t)p.Hg * p.Wg;
+    uint32_t vmask = 0;
+    for (int t = 0; t < p.ntaps; t++) {
+        const int iy = iy0 + p.dy[t], ix = ix0 + p.dx[t];
+        if (n_ok && iy >= 0 && iy < p.Hg && ix >= 0 && ix < p.Wg) vmask |= 1u << t;
+    }
+    const long long pix = (long long)iy0 * p.Wg + ix0;
     // A loader: rows ka, ka + 8 ; columns [mq, mq + 4)
     const int ka = tid >> 5, mq = (tid & 31) * 4;
 
@@ -87,42 +101,46 @@ __global__ void __launch_bounds__(256) gather_conv_kernel(GatherProblem p)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-    float4 ra[2];
-    float rb[BK / 2];
-    // running (channel, tap) of this thread's first B row of the current tile
-    int c_cur = khalf / p.ntaps, t_cur = khalf % p.ntaps;
+    const int nkt_all = p.Kpad / BK, ctiles = p.Cpad / BK;
+    const int kt_beg = blockIdx.z * p.kt_per_split, kt_end = min(nkt_all, kt_beg + p.kt_per_split);
+    int t_cur = kt_beg / ctiles, c0_cur = (kt_beg - t_cur * ctiles) * BK;   // wave-uniform (tap, first channel) of the next tile to load
 
-    auto load_tile = [&](int k0) {
+    f32x4 ra[2];
+    float rb[BK / 2];
+    uint32_t rb_ok = 0;     // bit j: rb[j] is a real sample (else padding -> 0); applied when the tile is written to LDS so
+                            // that nothing consumes the loads before the MFMAs of the current tile have been issued
+    auto load_tile = [&](int kt) {
 #pragma unroll
         for (int j = 0; j < 2; j++)
-            ra[j] = *reinterpret_cast<const float4*>(p.At + (size_t)(k0 + ka + 8 * j) * p.Mpad + m0 + mq);
-        int c = c_cur, t = t_cur;
+            ra[j] = *reinterpret_cast<const f32x4*>(p.At + (size_t)(kt * BK + ka + 8 * j) * p.Mpad + m0 + mq);
+        const bool tap_ok = (vmask >> t_cur) & 1u;
+        const long long off = pix + (long long)p.dy[t_cur] * p.Wg + p.dx[t_cur];
+        rb_ok = 0;
 #pragma unroll
         for (int j = 0; j < BK / 2; j++) {
-            const int iy = iy0 + p.dy[t], ix = ix0 + p.dx[t];
-            const bool ok = n_ok && (c < p.Cg) && (iy >= 0) && (iy < p.Hg) && (ix >= 0) && (ix < p.Wg);
-            rb[j] = ok ? p.xin[(size_t)c * plane + (size_t)iy * p.Wg + ix] : 0.f;
-            t += 2;
-            while (t >= p.ntaps) { t -= p.ntaps; c++; }
+            const int c = c0_cur + khalf + 2 * j;
+            const bool ok = tap_ok && (c < p.Cg);
+            const long long o = ok ? (long long)c * (long long)plane + off : 0ll;
+            rb[j] = p.xin[o];
+            rb_ok |= ok ? (1u << j) : 0u;
         }
-        // advance the running (channel, tap) by BK rows for the next tile
-        t_cur += BK % p.ntaps; c_cur += BK / p.ntaps;
-        if (t_cur >= p.ntaps) { t_cur -= p.ntaps; c_cur++; }
+        c0_cur += BK;
+        if (c0_cur == p.Cpad) { c0_cur = 0; t_cur++; }
     };
     auto store_tile = [&](int buf) {
 #pragma unroll
-        for (int j = 0; j < 2; j++) *reinterpret_cast<float4*>(&As[buf][(ka + 8 * j) * LDA + mq]) = ra[j];
+        for (int j = 0; j < 2; j++) *reinterpret_cast<f32x4*>(&As[buf][(ka + 8 * j) * LDA + mq]) = ra[j];
 #pragma unroll
-        for (int j = 0; j < BK / 2; j++) Bs[buf][(khalf + 2 * j) * LDB + n_loc] = rb[j];
+        for (int j = 0; j < BK / 2; j++) Bs[buf][(khalf + 2 * j) * LDB + n_loc] = ((rb_ok >> j) & 1u) ? rb[j] : 0.f;
     };
 
-    const int nkt = p.Kpad / BK;
-    load_tile(0);
+    const int nkt = kt_end - kt_beg;
+    load_tile(kt_beg);
     store_tile(0);
     __syncthreads();
     for (int kt = 0; kt < nkt; kt++) {
         const bool more = kt + 1 < nkt;
-        if (more) load_tile((kt + 1) * BK);
+        if (more) load_tile(kt_beg + kt + 1);
         mma_tile(As[kt & 1], Bs[kt & 1], wm, wn, lane, acc);
         if (more) store_tile((kt + 1) & 1);
         __syncthreads();
@@ -130,32 +148,68 @@ __global__ void __launch_bounds__(256) gather_conv_kernel(GatherProblem p)
 
     // epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
     const int col = lane & 31, rbase = 4 * (lane >> 5);
+    if (gridDim.z > 1) {
+        float* part = p.partial + (size_t)blockIdx.z * p.Mpad * N;
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int nn = n0 + wn * 64 + j * 32 + col;
+                if (nn >= N) continue;
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + rbase;
+                    part[(size_t)m * N + nn] = acc[i][j][r];
+                }
+            }
+        return;
+    }
+    int nn[2];
+    size_t opix[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        nn[j] = n0 + wn * 64 + j * 32 + col;
+        const int q = min(nn[j], N - 1);
+        const int oy = q / p.gw, ox = q - oy * p.gw;
+        opix[j] = (size_t)(p.y0 + oy * p.ys) * p.OWf + (p.x0 + ox * p.xs);
+    }
+    const bool has_scale = p.out_scale != nullptr, has_bias = p.bias != nullptr;
 #pragma unroll
     for (int i = 0; i < 2; i++)
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const int nn = n0 + wn * 64 + j * 32 + col;
-            if (nn >= N) continue;
-            const int oy = nn / p.gw, ox = nn - oy * p.gw;
-            const size_t opix = (size_t)(p.y0 + oy * p.ys) * p.OWf + (p.x0 + ox * p.xs);
+        for (int r = 0; r < 16; r++) {
+            const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + rbase;
+            if (m >= p.M) continue;
+            const float sc = has_scale ? p.out_scale[m] : 1.f, bi = has_bias ? p.bias[m] : 0.f;
+            float* row = p.yout + (size_t)m * p.OHf * p.OWf;
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + rbase;
-                if (m < p.M) {
-                    float v = acc[i][j][r];
-                    if (p.out_scale) v *= p.out_scale[m];
-                    if (p.bias) v += p.bias[m];
-                    p.yout[(size_t)m * p.OHf * p.OWf + opix] = v;
-                }
-            }
+            for (int j = 0; j < 2; j++)
+                if (nn[j] < N) row[opix[j]] = acc[i][j][r] * sc + bi;
         }
+}
+
+// split-K finish: y = (sum_z partial[z][m][n]) * out_scale[m] + bias[m], in a fixed order (deterministic)
+__global__ void __launch_bounds__(256) reduce_splits_kernel(GatherProblem p, int splits)
+{
+    const int N = p.gh * p.gw;
+    const long long total = (long long)p.M * N;
+    const size_t zstride = (size_t)p.Mpad * N;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int m = (int)(i / N), nn = (int)(i - (long long)m * N);
+        float v = 0.f;
+        for (int z = 0; z < splits; z++) v += p.partial[z * zstride + i];
+        if (p.out_scale) v *= p.out_scale[m];
+        if (p.bias) v += p.bias[m];
+        const int oy = nn / p.gw, ox = nn - oy * p.gw;
+        p.yout[(size_t)m * p.OHf * p.OWf + (size_t)(p.y0 + oy * p.ys) * p.OWf + (p.x0 + ox * p.xs)] = v;
+    }
 }
 
 // weight re-pack: At[(c, t)][m] = w[c * stride_c + m * stride_m + tapoff[t]], zero padded to [Kpad][Mpad]
 struct PackProblem {
     const float* w;
     float* At;
-    int C, M, Mpad, ntaps, K, Kpad;
+    int C, Cpad, M, Mpad, ntaps, Kpad;
     long long stride_c, stride_m;
     int tapoff[kMaxTaps];
 };
@@ -165,11 +219,9 @@ __global__ void __launch_bounds__(256) pack_weights_kernel(PackProblem p)
     const long long total = (long long)p.Kpad * p.Mpad;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int kk = (int)(i / p.Mpad), m = (int)(i - (long long)kk * p.Mpad);
+        const int t = kk / p.Cpad, c = kk - t * p.Cpad;
         float v = 0.f;
-        if (kk < p.K && m < p.M) {
-            const int c = kk / p.ntaps, t = kk - c * p.ntaps;
-            v = p.w[c * p.stride_c + m * p.stride_m + p.tapoff[t]];
-        }
+        if (c < p.C && m < p.M) v = p.w[c * p.stride_c + m * p.stride_m + p.tapoff[t]];
         p.At[i] = v;
     }
 }
@@ -319,11 +371,11 @@ static void out_size(const AgConvDesc* d, int& OH, int& OW)
 // One gather-conv launch = one tap subset.  `taps` lists (ky, kx) of the subset.
 struct TapSet { int n; int ky[kMaxTaps], kx[kMaxTaps]; };
 
-static int launch_pack(const float* w, float* At, int C, int M, int Mpad, int K, int Kpad, long long stride_c, long long stride_m,
+static int launch_pack(const float* w, float* At, int C, int Cpad, int M, int Mpad, int Kpad, long long stride_c, long long stride_m,
                        const TapSet& ts, int k, hipStream_t s)
 {
     PackProblem pp;
-    pp.w = w; pp.At = At; pp.C = C; pp.M = M; pp.Mpad = Mpad; pp.ntaps = ts.n; pp.K = K; pp.Kpad = Kpad;
+    pp.w = w; pp.At = At; pp.C = C; pp.Cpad = Cpad; pp.M = M; pp.Mpad = Mpad; pp.ntaps = ts.n; pp.Kpad = Kpad;
     pp.stride_c = stride_c; pp.stride_m = stride_m;
     for (int t = 0; t < ts.n; t++) pp.tapoff[t] = ts.ky[t] * k + ts.kx[t];
     const long long total = (long long)Kpad * Mpad;
@@ -333,13 +385,40 @@ static int launch_pack(const float* w, float* At, int C, int M, int Mpad, int K,
     return check_hip(hipGetLastError(), "pack_weights_kernel");
 }
 
-static int launch_gather(GatherProblem& gp, hipStream_t s)
+// Split-K policy.  A 128 x 128 tile per workgroup leaves the chip idle when M * N is small (the 512-channel layers at
+// 8^2 .. 64^2 have 4 .. 128 tiles for 256 CUs) and the K loop (up to 576 tiles) becomes the critical path; slices of K go
+// to blockIdx.z until ~3 workgroups per CU exist, each keeping >= 4 K tiles, partial sums capped at kMaxPartialBytes.
+constexpr size_t kMaxPartialBytes = size_t(96) << 20;
+static int choose_splits(int Mpad, int N, int Kpad)
+{
+    const long long tiles = (long long)((N + BN - 1) / BN) * (Mpad / BM);
+    const int nkt = Kpad / BK;
+    if (tiles >= 512 || nkt < 8) return 1;
+    long long s = (768 + tiles - 1) / tiles;
+    if (s > nkt / 4) s = nkt / 4;
+    const long long cap = (long long)(kMaxPartialBytes / ((size_t)Mpad * N * sizeof(float)));
+    if (s > cap) s = cap;
+    return s < 2 ? 1 : (int)s;
+}
+
+static int launch_gather(GatherProblem& gp, float* partial, hipStream_t s)
 {
     const int N = gp.gh * gp.gw;
     if (N <= 0) return AG_OK;
-    dim3 grid((N + BN - 1) / BN, gp.Mpad / BM);
+    const int nkt = gp.Kpad / BK;
+    int splits = choose_splits(gp.Mpad, N, gp.Kpad);
+    gp.kt_per_split = (nkt + splits - 1) / splits;
+    splits = (nkt + gp.kt_per_split - 1) / gp.kt_per_split;
+    gp.partial = splits > 1 ? partial : nullptr;
+    dim3 grid((N + BN - 1) / BN, gp.Mpad / BM, splits);
     hipLaunchKernelGGL(gather_conv_kernel, grid, dim3(256), 0, s, gp);
-    return check_hip(hipGetLastError(), "gather_conv_kernel");
+    int rc = check_hip(hipGetLastError(), "gather_conv_kernel");
+    if (rc || splits == 1) return rc;
+    const long long total = (long long)gp.M * N;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(reduce_splits_kernel, dim3(blocks), dim3(256), 0, s, gp, splits);
+    return check_hip(hipGetLastError(), "reduce_splits_kernel");
 }
 
 }  // namespace ag
@@ -359,13 +438,18 @@ int ag_conv_output_size(const AgConvDesc* d, int32_t* OH, int32_t* OW)
     return AG_OK;
 }
 
+static size_t packed_bytes(const AgConvDesc* d)
+{
+    const int Cmax = d->Cin > d->Cout ? d->Cin : d->Cout;
+    const size_t kk = (size_t)round_up(Cmax, BK) * (d->k * d->k + 4);   // all tap subsets together (+ degenerate classes)
+    return align_up(kk * (size_t)round_up(Cmax, BM) * sizeof(float), 256);
+}
+
 size_t ag_conv_workspace_bytes(const AgConvDesc* d)
 {
     if (validate(d)) return 0;
-    const int Cmax = d->Cin > d->Cout ? d->Cin : d->Cout;
-    // packed weights of all tap subsets together: (C * k*k rounded per subset) x (M rounded to BM)
-    const size_t kk = (size_t)round_up(Cmax * d->k * d->k, BK) + 4 * BK;
-    return kk * (size_t)round_up(Cmax, BM) * sizeof(float) + 256;
+    // packed weights of all tap subsets together + split-K partial sums (choose_splits keeps them under the cap)
+    return packed_bytes(d) + kMaxPartialBytes + 512;
 }
 
 // Shared by forward / backward-input: which GEMM(s) to run.
@@ -379,6 +463,7 @@ static int run_gather_family(const AgConvDesc* d, bool backward_input, const flo
     const int k = d->k, k2 = k * k;
     if (workspace_bytes < ag_conv_workspace_bytes(d) || !workspace) { set_error("conv workspace too small"); return AG_ERR_SCRATCH_TOO_SMALL; }
     float* At = reinterpret_cast<float*>(aligned_base(workspace));
+    float* partial = reinterpret_cast<float*>(aligned_base(workspace) + packed_bytes(d));
 
     GatherProblem gp;
     gp.out_scale = out_scale; gp.bias = bias; gp.yout = yout; gp.xin = xin;
@@ -400,7 +485,7 @@ static int run_gather_family(const AgConvDesc* d, bool backward_input, const flo
     if (!scatter) {
         TapSet ts; ts.n = k2;
         for (int ky = 0; ky < k; ky++) for (int kx = 0; kx < k; kx++) { ts.ky[ky * k + kx] = ky; ts.kx[ky * k + kx] = kx; }
-        gp.ntaps = k2; gp.K = Cg * k2; gp.Kpad = round_up(gp.K, BK);
+        gp.ntaps = k2; gp.Cpad = round_up(Cg, BK); gp.Kpad = k2 * gp.Cpad;
         gp.gh = OHf; gp.gw = OWf; gp.y0 = 0; gp.ys = 1; gp.x0 = 0; gp.xs = 1;
         if (conv && !backward_input) {                 // y[oy] <- x[oy*s - p + ky]
             gp.sy = gp.sx = d->stride;
@@ -413,9 +498,9 @@ static int run_gather_family(const AgConvDesc* d, bool backward_input, const flo
             for (int t = 0; t < k2; t++) { gp.dy[t] = ts.ky[t]; gp.dx[t] = ts.kx[t]; }
         }
         gp.At = At;
-        int rc = launch_pack(w, At, Cg, M, gp.Mpad, gp.K, gp.Kpad, stride_c, stride_m, ts, k, s);
+        int rc = launch_pack(w, At, Cg, gp.Cpad, M, gp.Mpad, gp.Kpad, stride_c, stride_m, ts, k, s);
         if (rc) return rc;
-        return launch_gather(gp, s);
+        return launch_gather(gp, partial, s);
     }
     // scatter with stride 2: output coordinate o = 2*i + ky - poff  (poff = padding for the conv gradient, 0 for convT).
     // Class (qy, qx) = parity of the output coordinate; it receives only taps with ky = (o + poff) mod 2, from
@@ -435,21 +520,21 @@ static int run_gather_family(const AgConvDesc* d, bool backward_input, const flo
             gp.gh = (OHf - qy + 1) / 2; gp.gw = (OWf - qx + 1) / 2;
             gp.y0 = qy; gp.ys = 2; gp.x0 = qx; gp.xs = 2;
             if (gp.gh <= 0 || gp.gw <= 0) continue;
+            gp.Cg = Cg;
             if (ts.n == 0) {
                 // no tap reaches this class (possible for k = 1): the outputs are out_scale*0 + bias; handled by a
-                // degenerate GEMM with K = one zero-padded tile
+                // degenerate GEMM over one all-zero K tile (zero channels)
                 ts.n = 1; ts.ky[0] = 0; ts.kx[0] = 0;
-                gp.ntaps = 1; gp.K = 0; gp.Kpad = BK;
-            } else {
-                gp.ntaps = ts.n; gp.K = Cg * ts.n; gp.Kpad = round_up(gp.K, BK);
+                gp.Cg = 0;
             }
+            gp.ntaps = ts.n; gp.Cpad = round_up(Cg, BK); gp.Kpad = ts.n * gp.Cpad;
             gp.sy = gp.sx = 1;
             for (int t = 0; t < ts.n; t++) { gp.dy[t] = (qy + poff - ts.ky[t]) / 2; gp.dx[t] = (qx + poff - ts.kx[t]) / 2; }
             // floor division for negative odd numerators never happens: numerators are even by construction
             gp.At = At + at_off;
-            int rc = launch_pack(w, At + at_off, Cg, M, gp.Mpad, gp.K, gp.Kpad, stride_c, stride_m, ts, k, s);
+            int rc = launch_pack(w, At + at_off, gp.Cg, gp.Cpad, M, gp.Mpad, gp.Kpad, stride_c, stride_m, ts, k, s);
             if (rc) return rc;
-            if ((rc = launch_gather(gp, s))) return rc;
+            if ((rc = launch_gather(gp, partial, s))) return rc;
             at_off += (size_t)gp.Kpad * gp.Mpad;
         }
     return AG_OK;
