@@ -17,6 +17,7 @@ from typing import Dict, Optional
 import numpy as np
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from . import avatar_ops as ops
 from .gaussian_renderer import render3
@@ -72,3 +73,204 @@ class AvatarRenderCore(nn.Module):
         r = render3(g, bg_color, extr, intr, img_w, img_h)
         return {'rgb_map': r['render'].permute(1, 2, 0), 'mask_map': r['mask'].permute(1, 2, 0), 'offset': offset,
                 'depth_map': r['depth'].permute(1, 2, 0), 'posed_gaussians': g}
+
+
+def _knn3_log_scale(points: np.ndarray) -> np.ndarray:
+    """``log sqrt(clamp_min(mean squared distance to the 3 nearest neighbours, 1e-7))`` -- the scale initialiser of
+    ``GaussianModel.create_from_pcd`` (gaussians/gaussian_model.py:170-171; pytorch3d ``knn_points(K=4)[..., 1:]``).
+    Init-time only, on the host (scipy k-d tree)."""
+    from scipy.spatial import cKDTree
+    d, _ = cKDTree(points).query(points, k=4)
+    dist2 = np.maximum((d[:, 1:].astype(np.float64) ** 2).mean(-1), 1e-7)
+    return np.log(np.sqrt(dist2)).astype(np.float32)
+
+
+class AvatarNet(nn.Module):
+    """Re-host of the reference's ``network.avatar.AvatarNet`` (``network/avatar.py:16-239``) on this package's kernels:
+    three ``DualStyleUNet`` (position / other / colour), the view-direction encoder, the fused per-Gaussian assembly,
+    LBS and the rasterizer.  ``render(items, bg_color)`` takes the same ``items`` dict (``smpl_pos_map``,
+    ``cano2live_jnt_mats``, ``extr``, ``intr``, ``img_w``, ``img_h``) and returns the same dict (``rgb_map``,
+    ``mask_map``, ``offset``, ``pos_map`` [+ ``cano_tex_map``, ``posed_gaussians`` in eval mode]).
+
+    Differences, all deliberate: the per-subject assets are passed in as tensors (``cano_smpl_map`` [S, 2S, 3],
+    ``lbs`` [N, J], optional ``cano_nml_map``) instead of being read with OpenCV from ``config.opt`` -- the EXR loader
+    is SURVEY.md §8(f)-3; eval-time hand fusion (``:183-200``) is §8(f)-4 and raises.  ``load_reference_state_dict``
+    takes the reference's ``net.pt['avatar_net']`` dict key for key.
+    """
+
+    def __init__(self, opt: Optional[dict] = None, *, cano_smpl_map: torch.Tensor, lbs: torch.Tensor,
+                 cano_nml_map: Optional[torch.Tensor] = None, device="cuda"):
+        super().__init__()
+        from .styleunet import DualStyleUNet
+        opt = dict(opt or {})
+        self.opt = opt
+        self.random_style = opt.get('random_style', False)
+        self.with_viewdirs = opt.get('with_viewdirs', True) and cano_nml_map is not None
+        self.max_sh_degree = 0
+        dev = torch.device(device)
+
+        cano_smpl_map = cano_smpl_map.to(torch.float32)
+        mask = torch.linalg.norm(cano_smpl_map, dim=-1) > 0.                                  # :28
+        init_points = cano_smpl_map[mask]                                                       # :29
+        N = init_points.shape[0]
+        if lbs.shape[0] != N:
+            raise ValueError(f"lbs has {lbs.shape[0]} rows, the canonical map has {N} valid pixels")
+        log_scale = torch.from_numpy(_knn3_log_scale(init_points.cpu().numpy()))
+        rot = torch.zeros(N, 4)
+        rot[:, 0] = 1.0
+        self.core = AvatarRenderCore(mask.to(dev), init_points.to(dev), torch.full((N, 1), float(np.log(0.1 / 0.9))).to(dev),
+                                     log_scale[:, None].repeat(1, 3).to(dev), rot.to(dev), lbs.to(dev), self.max_sh_degree)
+        self.register_buffer("cano_smpl_mask", mask.to(dev), persistent=False)
+        self.map_shape = tuple(cano_smpl_map.shape[:2])
+
+        self.color_net = DualStyleUNet(inp_size=512, inp_ch=3, out_ch=3, out_size=1024, style_dim=512, n_mlp=2)     # :34-36
+        self.position_net = DualStyleUNet(inp_size=512, inp_ch=3, out_ch=3, out_size=1024, style_dim=512, n_mlp=2)
+        self.other_net = DualStyleUNet(inp_size=512, inp_ch=3, out_ch=8, out_size=1024, style_dim=512, n_mlp=2)
+        style = torch.ones(1, 512, dtype=torch.float32) / np.sqrt(512)                                             # :38-40
+        for n in ("color_style", "position_style", "other_style"):
+            self.register_buffer(n, style.clone(), persistent=False)
+
+        if self.with_viewdirs:
+            nml = cano_nml_map.to(torch.float32)
+            self.register_buffer("cano_nmls", nml[mask].to(dev), persistent=False)                                 # :45
+            # viewdir_net = Conv2d(1, 64, 4, 2, 1) + LeakyReLU(0.2) + Conv2d(64, 128, 4, 2, 1)  (:46-50); torch's default
+            # Conv2d initialisation (kaiming_uniform(a=sqrt 5) weights, uniform(+-1/sqrt(fan_in)) biases)
+            for idx, (cin, cout) in ((0, (1, 64)), (2, (64, 128))):
+                bound = 1 / np.sqrt(cin * 16)
+                self.register_parameter(f"viewdir_net__{idx}__weight", nn.Parameter((torch.rand(cout, cin, 4, 4) * 2 - 1) * bound))
+                self.register_parameter(f"viewdir_net__{idx}__bias", nn.Parameter((torch.rand(cout) * 2 - 1) * bound))
+        self.to(dev)
+
+    # ---- construction helpers -------------------------------------------------------------------------------------
+    @classmethod
+    def synthetic(cls, opt: Optional[dict] = None, S: int = 1024, J: int = 55, seed: int = 31359, device="cuda") -> "AvatarNet":
+        """The synthetic subject of SURVEY.md 8d config 3 (``synth.avatar_map_gaussians`` canvas, 4-sparse LBS weights)."""
+        from . import synth
+        av = synth.avatar_map_gaussians(S)
+        mask = av["mask"]
+        cano = np.zeros(mask.shape + (3,), np.float32)
+        pts = av["means3D"].astype(np.float32).copy()
+        pts[np.linalg.norm(pts, axis=-1) == 0] += 1e-6          # the mask is recovered from |xyz| > 0
+        cano[mask] = pts
+        nml = np.zeros_like(cano)
+        nml[..., 2] = 1.0
+        nml[:, S:, 2] = -1.0                                    # front canvas faces +z, back canvas -z
+        nml *= mask[..., None]
+        rs = np.random.RandomState(seed)
+        N = pts.shape[0]
+        w = rs.normal(0, 1, (N, J)) * 4
+        w = np.exp(w - w.max(1, keepdims=True))
+        idx = np.argsort(-w, axis=1)[:, :4]
+        lbs = np.zeros_like(w)
+        np.put_along_axis(lbs, idx, np.take_along_axis(w, idx, 1), 1)
+        lbs /= lbs.sum(1, keepdims=True)
+        return cls(opt, cano_smpl_map=torch.from_numpy(cano), lbs=torch.from_numpy(lbs.astype(np.float32)),
+                   cano_nml_map=torch.from_numpy(nml), device=device)
+
+    @torch.no_grad()
+    def load_reference_state_dict(self, sd, strict=True):
+        """``sd`` = the reference's ``AvatarNet.state_dict()`` (``net.pt['avatar_net']``, main_avatar.py:778-786)."""
+        per_net = {"color_net": {}, "position_net": {}, "other_net": {}}
+        for key, value in sd.items():
+            head, _, rest = key.partition(".")
+            if head in per_net:
+                per_net[head][rest] = value
+            elif head == "viewdir_net" and self.with_viewdirs:
+                getattr(self, "viewdir_net__" + rest.replace(".", "__")).copy_(value)
+            elif strict and head != "viewdir_net":
+                raise RuntimeError(f"unexpected key in reference state_dict: {key}")
+        for name, part in per_net.items():
+            getattr(self, name).load_reference_state_dict(part, strict=strict)
+
+    # ---- the reference's methods ----------------------------------------------------------------------------------
+    @property
+    def init_points(self):
+        return self.core.xyz
+
+    @property
+    def lbs(self):
+        return self.core.lbs
+
+    def _blend_points(self, jnt_mats, vectors=None):
+        """(no grad) LBS of the canonical points, optionally of direction vectors with the rotation part (:127-129,151-152)."""
+        pt_mats = torch.einsum('nj,jxy->nxy', self.core.lbs, jnt_mats)
+        pts = torch.einsum('nxy,ny->nx', pt_mats[..., :3, :3], self.core.xyz) + pt_mats[..., :3, 3]
+        if vectors is None:
+            return pts, None
+        return pts, torch.einsum('nxy,ny->nx', pt_mats[..., :3, :3], vectors)
+
+    @torch.no_grad()
+    def get_pose_map(self, items):
+        """Live position map [6, S/2, S/2] from ``cano2live_jnt_mats_woRoot``  (:149-159)."""
+        live_pts, _ = self._blend_points(items['cano2live_jnt_mats_woRoot'])
+        H, W = self.map_shape
+        live = torch.zeros(H, W, 3, device=live_pts.device)
+        live[self.cano_smpl_mask] = live_pts
+        live = live.permute(2, 0, 1)[:, ::2, ::2]                  # F.interpolate(scale 0.5, 'nearest') == every 2nd sample
+        live = torch.cat(torch.split(live, [W // 4, W // 4], 2), 0).contiguous()
+        items.update({'smpl_pos_map': live})
+        return live
+
+    def get_viewdir_feat(self, items):
+        """Cosine between surface normal and view direction, as two [1, 128, S/8, S/8] feature maps  (:126-147)."""
+        from . import conv as agc
+        from .styleunet_ops import fused_leaky_relu
+        with torch.no_grad():
+            live_pts, live_nmls = self._blend_points(items['cano2live_jnt_mats'], self.cano_nmls)
+            extr = items['extr']
+            cam_pos = -torch.matmul(torch.linalg.inv(extr[:3, :3]), extr[:3, 3])
+            viewdirs = F.normalize(cam_pos[None] - live_pts, dim=-1, eps=1e-3)
+            if self.training:
+                viewdirs = viewdirs + torch.randn_like(viewdirs) * 0.1
+            viewdirs = F.normalize(viewdirs, dim=-1, eps=1e-3)
+            cosine = (live_nmls * viewdirs).sum(-1)
+            H, W = self.map_shape
+            vmap = torch.zeros(H, W, device=cosine.device)
+            vmap[self.cano_smpl_mask] = cosine
+            vmap = vmap[None, None, ::2, ::2]
+            front, back = (t.contiguous() for t in torch.split(vmap, [W // 4, W // 4], -1))
+        weight = self.opt.get('weight_viewdirs', 1.)
+        feats = []
+        for v in (front, back):
+            h = agc.conv2d(v, self.viewdir_net__0__weight, bias=self.viewdir_net__0__bias, stride=2, padding=1)
+            h = fused_leaky_relu(h, None, 0.2, 1.0)
+            h = agc.conv2d(h, self.viewdir_net__2__weight, bias=self.viewdir_net__2__bias, stride=2, padding=1)
+            feats.append(weight * h)
+        return feats[0], feats[1]
+
+    def get_maps(self, pose_map, front_viewdirs=None, back_viewdirs=None):
+        """The three StyleUNet evaluations of ``get_positions`` / ``get_others`` / ``get_colors``  (:93-124), raw maps."""
+        x = pose_map[None].contiguous()
+        position_map, _ = self.position_net([self.position_style], x, randomize_noise=False)
+        other_map, _ = self.other_net([self.other_style], x, randomize_noise=False)
+        color_style = torch.rand_like(self.color_style) if self.random_style and self.training else self.color_style
+        color_map, _ = self.color_net([color_style], x, randomize_noise=False, view_feature1=front_viewdirs,
+                                      view_feature2=back_viewdirs)
+        return position_map, other_map, color_map
+
+    @staticmethod
+    def _canvas(m):
+        """[1, 2C, S, S] network output -> [S, 2S, C] front|back canvas (the layout ``pos_map`` / ``cano_tex_map`` have)."""
+        c = m.shape[1] // 2
+        return torch.cat([m[:, :c], m[:, c:]], 3)[0].permute(1, 2, 0)
+
+    def render(self, items, bg_color=(0., 0., 0.), use_pca=False, use_vae=False):
+        dev = self.core.xyz.device
+        bg = torch.as_tensor(np.asarray(bg_color), dtype=torch.float32).to(dev)
+        assert not (use_pca and use_vae), "Cannot use both PCA and VAE!"
+        key = 'smpl_pos_map_pca' if use_pca else 'smpl_pos_map_vae' if use_vae else 'smpl_pos_map'
+        pose_map = items[key][:3]
+        if (not self.training) and self.opt.get('fix_hand', False):
+            raise NotImplementedError("eval-time hand fusion (network/avatar.py:183-200) is outside the render hot path")
+        front_vd, back_vd = self.get_viewdir_feat(items) if self.with_viewdirs else (None, None)
+        position_map, other_map, color_map = self.get_maps(pose_map, front_vd, back_vd)
+        g = self.core.assemble(position_map, other_map, color_map)
+        offset = g['positions'] - self.core.xyz                                                                   # :211
+        g['positions'], g['rotations'] = ops.lbs_transform(g['positions'], g['rotations'], self.core.lbs,
+                                                           items['cano2live_jnt_mats'])
+        r = render3(g, bg, items['extr'], items['intr'], items['img_w'], items['img_h'])
+        ret = {'rgb_map': r['render'].permute(1, 2, 0), 'mask_map': r['mask'].permute(1, 2, 0), 'offset': offset,
+               'pos_map': self._canvas(position_map)}
+        if not self.training:
+            ret.update({'cano_tex_map': self._canvas(color_map), 'posed_gaussians': g})
+        return ret

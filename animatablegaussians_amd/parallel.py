@@ -49,3 +49,83 @@ class GradSync:
         for p in self.params:
             p.grad = self.flat[off:off + p.numel()].view_as(p).clone()
             off += p.numel()
+
+
+class BucketedGradSync:
+    """Data-parallel gradient exchange for the networks (223.7 M fp32 = 895 MB per step), overlapped with
+    the backward pass.
+
+    * All gradients live in ONE flat buffer; every ``param.grad`` is a view into it, so nothing is packed or unpacked.
+    * The buffer is cut into buckets of ``bucket_bytes`` following the REVERSE registration order (the order autograd
+      finishes them in); a post-accumulate hook counts finished parameters and launches the bucket's all-reduce
+      (async, on the collective's own stream) the moment its last gradient lands -- the remaining backward keeps
+      running on the compute stream.
+    * xGMI is point-to-point (7 links x ~153 GB/s per GPU) and ring collectives are per-link bound, so buckets are few
+      and large (default 128 MB: ~7 collectives per step) rather than DDP's 25 MB.
+
+    Usage per step: ``sync.zero()`` -> forward/backward (hooks fire) -> ``sync.finish()`` -> optimizer step.
+    Works on any backend (``nccl`` = RCCL on the GPU node, ``gloo`` in the CPU tests); with world size 1 it only
+    provides the flat gradient storage."""
+
+    def __init__(self, params: Sequence[torch.nn.Parameter], bucket_bytes: int = 128 << 20, average: bool = True):
+        self.params = [p for p in params if p.requires_grad]
+        self.average = average
+        n = sum(p.numel() for p in self.params)
+        dev = self.params[0].device
+        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        # reverse order: the last-registered parameters (decoder heads) get their gradients first
+        order = list(reversed(self.params))
+        self.buckets = []          # [start, end) element ranges of the flat buffer
+        self._bucket_of = {}
+        self._pending_init = []
+        off, b_start, b_count = 0, 0, 0
+        cap = max(1, bucket_bytes // 4)
+        for p in order:
+            if off - b_start >= cap:
+                self.buckets.append((b_start, off))
+                self._pending_init.append(b_count)
+                b_start, b_count = off, 0
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            self._bucket_of[p] = len(self.buckets)
+            off += p.numel()
+            b_count += 1
+        self.buckets.append((b_start, off))
+        self._pending_init.append(b_count)
+        self._pending = list(self._pending_init)
+        self._works = []
+        self._world = dist.get_world_size() if dist.is_initialized() else 1
+        self._handles = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+
+    def zero(self):
+        """Start of a step: clear the flat gradient buffer and re-arm the buckets."""
+        self.flat.zero_()
+        self._pending = list(self._pending_init)
+        self._works = []
+
+    def _on_grad(self, p):
+        # autograd accumulated into the existing .grad view in place; guard against it having been replaced
+        if p.grad.data_ptr() < self.flat.data_ptr() or p.grad.data_ptr() >= self.flat.data_ptr() + self.flat.numel() * 4:
+            raise RuntimeError("a parameter's .grad was re-allocated; use BucketedGradSync.zero(), not zero_grad(set_to_none=True)")
+        b = self._bucket_of[p]
+        self._pending[b] -= 1
+        if self._pending[b] == 0 and self._world > 1:
+            s, e = self.buckets[b]
+            self._works.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, async_op=True))
+
+    def finish(self):
+        """End of backward: launch buckets whose parameters received no gradient this step, wait, average."""
+        if self._world > 1:
+            for b, left in enumerate(self._pending):
+                if left > 0:
+                    s, e = self.buckets[b]
+                    self._works.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, async_op=True))
+                    self._pending[b] = 0
+            for w in self._works:
+                w.wait()
+            self._works = []
+            if self.average:
+                self.flat /= self._world
+
+    def close(self):
+        for h in self._handles:
+            h.remove()

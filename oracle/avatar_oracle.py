@@ -95,3 +95,38 @@ def transform_cano2live(positions, rotations, lbs, jnt_mats):
     rot_mats = quaternion_to_matrix(rotations)
     rot_mats = torch.einsum('nxy,nyz->nxz', pt_mats[..., :3, :3], rot_mats)
     return live_pos, matrix_to_quaternion(rot_mats)
+
+
+def get_pose_map(cano_smpl_map, mask, lbs, jnt_mats_wo_root):
+    """network/avatar.py:149-159, literally (einsum blend, scatter into the canvas, F.interpolate 0.5 'nearest', split
+    front|back and stack on the channel axis) -> [6, S/2, S/2]."""
+    init_points = cano_smpl_map[mask]
+    pt_mats = torch.einsum('nj,jxy->nxy', lbs, jnt_mats_wo_root)
+    live_pts = torch.einsum('nxy,ny->nx', pt_mats[..., :3, :3], init_points) + pt_mats[..., :3, 3]
+    live_pos_map = torch.zeros_like(cano_smpl_map)
+    live_pos_map[mask] = live_pts
+    live_pos_map = F.interpolate(live_pos_map.permute(2, 0, 1)[None], None, [0.5, 0.5], mode='nearest')[0]
+    half = live_pos_map.shape[2] // 2
+    return torch.cat(torch.split(live_pos_map, [half, half], 2), 0)
+
+
+def get_viewdir_feat(cano_smpl_map, cano_nml_map, mask, lbs, jnt_mats, extr, w0, b0, w2, b2, weight_viewdirs=1.0):
+    """network/avatar.py:126-147 in eval mode (no view-direction jitter); viewdir_net = Conv2d(1,64,4,2,1) +
+    LeakyReLU(0.2) + Conv2d(64,128,4,2,1) (:46-50) with the given weights."""
+    init_points, cano_nmls = cano_smpl_map[mask], cano_nml_map[mask]
+    pt_mats = torch.einsum('nj,jxy->nxy', lbs, jnt_mats)
+    live_pts = torch.einsum('nxy,ny->nx', pt_mats[..., :3, :3], init_points) + pt_mats[..., :3, 3]
+    live_nmls = torch.einsum('nxy,ny->nx', pt_mats[..., :3, :3], cano_nmls)
+    cam_pos = -torch.matmul(torch.linalg.inv(extr[:3, :3]), extr[:3, 3])
+    viewdirs = F.normalize(cam_pos[None] - live_pts, dim=-1, eps=1e-3)
+    viewdirs = F.normalize(viewdirs, dim=-1, eps=1e-3)
+    viewdirs = (live_nmls * viewdirs).sum(-1)
+    viewdirs_map = torch.zeros(*cano_nml_map.shape[:2]).to(viewdirs)
+    viewdirs_map[mask] = viewdirs
+    viewdirs_map = F.interpolate(viewdirs_map[None, None], None, 0.5, 'nearest')
+    half = viewdirs_map.shape[-1] // 2
+    outs = []
+    for v in torch.split(viewdirs_map, [half, half], -1):
+        h = F.leaky_relu(F.conv2d(v, w0, b0, stride=2, padding=1), 0.2)
+        outs.append(weight_viewdirs * F.conv2d(h, w2, b2, stride=2, padding=1))
+    return outs[0], outs[1]

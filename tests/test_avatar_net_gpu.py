@@ -1,0 +1,128 @@
+"""AvatarNet re-host (SURVEY.md §8 B5, rows a4-a6 glue) on the GPU.
+
+The three DualStyleUNets, the assembly / LBS kernels and the rasterizer each have their own parity tests; this file
+checks the wiring around them against literal restatements of network/avatar.py (oracle/avatar_oracle.py):
+pose-map and view-direction producers, the composition inside render(), state_dict loading, and that a training-mode
+backward reaches every learnable tensor."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _items(net, S=1024, seed=3):
+    import torch
+    from animatablegaussians_amd import camera
+    g = torch.Generator().manual_seed(seed)
+    J = net.lbs.shape[1]
+    ax = torch.nn.functional.normalize(torch.randn(J, 3, generator=g))
+    ang = torch.rand(J, generator=g) * (np.pi / 6)
+    K = torch.zeros(J, 3, 3)
+    K[:, 0, 1], K[:, 0, 2], K[:, 1, 0], K[:, 1, 2], K[:, 2, 0], K[:, 2, 1] = -ax[:, 2], ax[:, 1], ax[:, 2], -ax[:, 0], -ax[:, 1], ax[:, 0]
+    Rm = torch.eye(3)[None] + torch.sin(ang)[:, None, None] * K + (1 - torch.cos(ang))[:, None, None] * (K @ K)
+    A = torch.eye(4)[None].repeat(J, 1, 1)
+    A[:, :3, :3] = Rm
+    A[:, :3, 3] = (torch.rand(J, 3, generator=g) - 0.5) * 0.02
+    extr = torch.from_numpy(camera.calc_front_mv(np.zeros(3, np.float32), tar_pos=(0.0, 0.0, 2.5)))
+    intr = torch.tensor([[1100.0, 0, S / 2], [0, 1100.0, S / 2], [0, 0, 1]])
+    return {'cano2live_jnt_mats': A.cuda(), 'cano2live_jnt_mats_woRoot': A.cuda(), 'extr': extr.cuda(), 'intr': intr.cuda(),
+            'img_w': S, 'img_h': S}
+
+
+@pytest.fixture(scope="module")
+def net():
+    import torch
+    from animatablegaussians_amd.avatar import AvatarNet
+    torch.manual_seed(31359)
+    return AvatarNet.synthetic({'with_viewdirs': True})
+
+
+def test_pose_map_and_viewdir_features_match_reference_formulation(net):
+    import torch
+    from animatablegaussians_amd import synth
+    from oracle import avatar_oracle as ao
+    items = _items(net)
+    S = 1024
+    mask = net.cano_smpl_mask.cpu()
+    cano = torch.zeros(S, 2 * S, 3)
+    cano[mask] = net.init_points.cpu()
+    nml = torch.zeros(S, 2 * S, 3)
+    nml[mask] = net.cano_nmls.cpu()
+    A = items['cano2live_jnt_mats'].cpu()
+    ref_pose = ao.get_pose_map(cano, mask, net.lbs.cpu(), A)
+    got_pose = net.get_pose_map(items)
+    assert got_pose.shape == (6, 512, 512) and items['smpl_pos_map'] is got_pose
+    np.testing.assert_allclose(got_pose.cpu().numpy(), ref_pose.numpy(), rtol=1e-5, atol=1e-6)
+
+    net.eval()
+    w = [getattr(net, f"viewdir_net__{i}__{k}").detach().cpu() for i in (0, 2) for k in ("weight", "bias")]
+    ref_f, ref_b = ao.get_viewdir_feat(cano, nml, mask, net.lbs.cpu(), A, items['extr'].cpu(), *w)
+    got_f, got_b = net.get_viewdir_feat(items)
+    assert got_f.shape == (1, 128, 128, 128)
+    for got, ref in ((got_f, ref_f), (got_b, ref_b)):
+        np.testing.assert_allclose(got.detach().cpu().numpy(), ref.numpy(), rtol=1e-4, atol=1e-5 * float(ref.abs().max()))
+    del synth
+
+
+def test_render_composes_the_verified_pieces_and_trains(net):
+    import torch
+    from animatablegaussians_amd import avatar_ops as ops
+    from animatablegaussians_amd.gaussian_renderer import render3
+    items = _items(net)
+    net.get_pose_map(items)
+    net.eval()
+    with torch.no_grad():
+        out = net.render(items, bg_color=(0.1, 0.2, 0.3))
+        assert set(out) == {'rgb_map', 'mask_map', 'offset', 'pos_map', 'cano_tex_map', 'posed_gaussians'}
+        assert out['rgb_map'].shape == (1024, 1024, 3) and out['mask_map'].shape == (1024, 1024, 1)
+        assert out['pos_map'].shape == (1024, 2048, 3) and out['cano_tex_map'].shape == (1024, 2048, 3)
+        # the same computation from its parts
+        fv, bv = net.get_viewdir_feat(items)
+        pm, om, cm = net.get_maps(items['smpl_pos_map'][:3], fv, bv)
+        g = net.core.assemble(pm, om, cm)
+        np.testing.assert_array_equal((g['positions'] - net.init_points).cpu().numpy(), out['offset'].cpu().numpy())
+        # pos_map is the raw position canvas: positions = 0.05 * canvas[mask] + xyz  (network/avatar.py:97-101)
+        np.testing.assert_allclose((0.05 * out['pos_map'][net.cano_smpl_mask] + net.init_points).cpu().numpy(),
+                                   g['positions'].cpu().numpy(), rtol=1e-6, atol=1e-7)
+        g['positions'], g['rotations'] = ops.lbs_transform(g['positions'], g['rotations'], net.lbs, items['cano2live_jnt_mats'])
+        r = render3(g, torch.tensor([0.1, 0.2, 0.3]).cuda(), items['extr'], items['intr'], 1024, 1024)
+        np.testing.assert_array_equal(r['render'].permute(1, 2, 0).cpu().numpy(), out['rgb_map'].cpu().numpy())
+        cover = float((out['mask_map'] > 0.5).float().mean())
+        assert 0.03 < cover < 0.6, cover                                   # the subject is in view
+
+    # training mode: one loss, every learnable tensor receives a finite, not-all-zero gradient
+    net.train()
+    out = net.render(items, bg_color=(0., 0., 0.))
+    assert set(out) == {'rgb_map', 'mask_map', 'offset', 'pos_map'}
+    target = torch.rand(1024, 1024, 3, generator=torch.Generator().manual_seed(5)).cuda()
+    loss = (out['rgb_map'] - target).abs().mean() + 0.005 * torch.linalg.norm(out['offset'], dim=-1).mean()
+    loss.backward()
+    dead = []
+    for name, p in net.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), name
+        if float(p.grad.abs().max()) == 0.0:
+            dead.append(name)
+    # the two wavelet-skip ToRGB paths of the coarsest stages still reach the output; nothing may be disconnected
+    assert not dead, dead[:10]
+    net.zero_grad(set_to_none=True)
+
+
+def test_reference_state_dict_roundtrip(net):
+    import torch
+    sd = {}
+    for prefix in ("color_net", "position_net", "other_net"):
+        for k, v in getattr(net, prefix).reference_state_dict().items():
+            sd[f"{prefix}.{k}"] = v.detach().clone() + 1.0
+        sd[f"{prefix}.conv_in.0.kernel"] = torch.zeros(4, 4)
+    for i in (0, 2):
+        for k in ("weight", "bias"):
+            sd[f"viewdir_net.{i}.{k}"] = getattr(net, f"viewdir_net__{i}__{k}").detach().clone() + 1.0
+    before = float(net.color_net._p("style.1.bias").detach().sum())
+    net.load_reference_state_dict(sd)
+    assert abs(float(net.color_net._p("style.1.bias").detach().sum()) - (before + 512)) < 1e-2
+    with pytest.raises(RuntimeError):
+        net.load_reference_state_dict({**sd, "bogus.weight": torch.zeros(1)})
+    # restore
+    for k in sd:
+        sd[k] = sd[k] - 1.0
+    net.load_reference_state_dict(sd)

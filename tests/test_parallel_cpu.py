@@ -57,3 +57,61 @@ def test_views_of_rank_partition():
         got = sorted(sum((views_of_rank(16, r, world) for r in range(world)), []))
         assert got == list(range(16))
         assert max(len(views_of_rank(16, r, world)) for r in range(world)) == 16 // world
+
+
+def _bucket_worker(rank, world, port, out):
+    """Two replicas of a small MLP, different data per rank: after BucketedGradSync the gradients equal the mean of the
+    two single-rank gradients, buckets fire during backward, and a parameter without gradient does not stall finish()."""
+    from animatablegaussians_amd.parallel import BucketedGradSync
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(16, 64), torch.nn.ReLU(), torch.nn.Linear(64, 64), torch.nn.ReLU(),
+                              torch.nn.Linear(64, 8))
+    unused = torch.nn.Parameter(torch.ones(5))
+    params = list(net.parameters()) + [unused]
+    sync = BucketedGradSync(params, bucket_bytes=1024)          # several buckets
+    assert len(sync.buckets) >= 3
+
+    def data(r):
+        g = torch.Generator().manual_seed(100 + r)
+        return torch.randn(32, 16, generator=g), torch.randn(32, 8, generator=g)
+
+    ok = True
+    for step in range(2):                                       # two steps: zero() re-arms the buckets
+        sync.zero()
+        x, y = data(rank + 10 * step)
+        ((net(x) - y) ** 2).mean().backward()
+        sync.finish()
+        got = [p.grad.clone() for p in net.parameters()]
+        # reference: plain autograd on both ranks' data, averaged
+        want = None
+        for r in range(world):
+            ref = [p.detach().clone().requires_grad_(True) for p in net.parameters()]
+            xr, yr = data(r + 10 * step)
+            h = torch.relu(torch.nn.functional.linear(xr, ref[0], ref[1]))
+            h = torch.relu(torch.nn.functional.linear(h, ref[2], ref[3]))
+            ((torch.nn.functional.linear(h, ref[4], ref[5]) - yr) ** 2).mean().backward()
+            gs = [p.grad for p in ref]
+            want = gs if want is None else [a + b for a, b in zip(want, gs)]
+        want = [w / world for w in want]
+        ok = ok and all(torch.allclose(a, b, rtol=1e-5, atol=1e-7) for a, b in zip(got, want))
+        ok = ok and bool((unused.grad == 0).all())
+        ok = ok and all(p.grad.data_ptr() >= sync.flat.data_ptr() for p in params)   # still views of the flat buffer
+    out[rank] = bool(ok)
+    sync.close()
+    dist.destroy_process_group()
+
+
+def test_bucketed_grad_sync_gloo_world2():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    out = ctx.Manager().dict()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert dict(out) == {0: True, 1: True}
