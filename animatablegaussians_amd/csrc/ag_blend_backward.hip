@@ -24,7 +24,7 @@
 namespace ag {
 
 struct BlendBwdParams {
-    int W, H, gx, T, dbg;
+    int W, H, gx, T;
     const uint4* __restrict__ tile_order;
     const uint32_t* __restrict__ counts;
     const uint32_t* __restrict__ point_list;
@@ -240,7 +240,7 @@ __global__ void __launch_bounds__(kBlendThreads, BWD_WAVES_PER_SIMD) blend_backw
             // ---- kSub compacted entries at a time: 16 entries per step per pixel row, then flush ----
             for (int sb = 0; sb < K; sb += kSub) {
             const int sub_n = min(kSub, K - sb);
-            for (int s0 = sb; s0 < ((p.dbg & 4) ? sb : sb + sub_n); s0 += 16) {
+            for (int s0 = sb; s0 < sb + sub_n; s0 += 16) {
                 const int idx = s0 + e;
                 const bool ev = idx < K;
                 const int ci = ev ? idx : (K - 1);
@@ -272,7 +272,7 @@ __global__ void __launch_bounds__(kBlendThreads, BWD_WAVES_PER_SIMD) blend_backw
                     Ba = fmaf(row_shr0<N>(Ba), A, Ba);                                       \
                     A *= Ap;                                                                 \
                 }
-                if (!(p.dbg & 32)) { AG_SCAN_STEP(1) AG_SCAN_STEP(2) AG_SCAN_STEP(4) AG_SCAN_STEP(8) }
+                AG_SCAN_STEP(1) AG_SCAN_STEP(2) AG_SCAN_STEP(4) AG_SCAN_STEP(8)
 #undef AG_SCAN_STEP
                 // A is now prod_{i<=e} fac_i: T in front of entry e; exclusive maps give the blend behind entry e
                 const float Tin = T * __builtin_amdgcn_rcpf(A);
@@ -310,7 +310,6 @@ __global__ void __launch_bounds__(kBlendThreads, BWD_WAVES_PER_SIMD) blend_backw
                     v[A_DEPTH] = wgt * gd;
                 }
                 // carry for the next step: state behind entry 15 of this step
-                if (!(p.dbg & 16)) {
                 T = row_read(Tin, lane, 15);
                 const float A15 = row_read(A, lane, 15);
                 S_r = fmaf(A15, S_r, row_read(Br, lane, 15));
@@ -318,10 +317,8 @@ __global__ void __launch_bounds__(kBlendThreads, BWD_WAVES_PER_SIMD) blend_backw
                 S_b = fmaf(A15, S_b, row_read(Bb, lane, 15));
                 S_d = fmaf(A15, S_d, row_read(Bd, lane, 15));
                 S_a = fmaf(A15, S_a, row_read(Ba, lane, 15));
-                }
 
                 // sum the 4 pixels (rows) of this wave per entry column: 10 -> 5 -> 3 registers
-                if (p.dbg & 8) { if (ev) part[0] = v[0] + v[1] + v[2] + v[3] + v[4] + v[5] + v[6] + v[7] + v[8] + v[9]; continue; }
                 float s[6];
 #pragma unroll
                 for (int i = 0; i < 5; i++) {
@@ -348,7 +345,7 @@ __global__ void __launch_bounds__(kBlendThreads, BWD_WAVES_PER_SIMD) blend_backw
                     float acc = 0.f;
 #pragma unroll
                     for (int w = 0; w < NW; w++) acc += s_part[w][comp][ent];
-                    if (acc != 0.f && !(p.dbg & 1)) atomicAdd(p.accum + (size_t)s_gid[sb + ent] * kAccumFloats + comp, acc);
+                    if (acc != 0.f) atomicAdd(p.accum + (size_t)s_gid[sb + ent] * kAccumFloats + comp, acc);
                 }
             }
             lds_barrier();   // s_part reusable
@@ -387,7 +384,6 @@ int launch_debug_wave_reduce16(const float* in, float* out, hipStream_t s)
 int launch_blend_backward(const AgRasterBackwardArgs& a, hipStream_t s)
 {
     BlendBwdParams p;
-    p.dbg = getenv("AG_DBG_BWD") ? atoi(getenv("AG_DBG_BWD")) : 0;
     p.W = a.W; p.H = a.H;
     p.gx = (a.W + kTileX - 1) / kTileX;
     const int gy = (a.H + kTileY - 1) / kTileY;

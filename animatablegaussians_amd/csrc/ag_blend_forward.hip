@@ -30,7 +30,7 @@
 namespace ag {
 
 struct BlendFwdParams {
-    int W, H, gx, T, dbg;
+    int W, H, gx, T;
     const uint2* __restrict__ ranges;
     const uint32_t* __restrict__ point_list;
     const GaussRec* __restrict__ rec;
@@ -88,7 +88,7 @@ __global__ void __launch_bounds__(kBlendThreads) blend_forward_kernel(BlendFwdPa
     const uint32_t n_active = p.counts[1];
 
     // Empty tiles (the tail of the work order) only need their background: static share, no queue traffic.
-    for (uint32_t t = n_active + blockIdx.x; t < ((p.dbg & 8) ? 0u : (uint32_t)p.T); t += gridDim.x) {
+    for (uint32_t t = n_active + blockIdx.x; t < (uint32_t)p.T; t += gridDim.x) {
         const int tile = (int)p.tile_order[t].x;
         const int px = (tile % p.gx) * kTileX + (tid & 15), py = (tile / p.gx) * kTileY + (tid >> 4);
         if (tid < kTileX * kTileY && px < p.W && py < p.H) {
@@ -136,9 +136,9 @@ __global__ void __launch_bounds__(kBlendThreads) blend_forward_kernel(BlendFwdPa
         {
             const uint32_t k0 = range.x + tid, k1 = k0 + kChunk;
             uint32_t id0 = 0;
-            if (k0 < range.y && !(p.dbg & 32)) id0 = p.point_list[k0];
-            if (k1 < range.y && !(p.dbg & 32)) id_next = p.point_list[k1];
-            if (k0 < range.y && !(p.dbg & 32)) {
+            if (k0 < range.y) id0 = p.point_list[k0];
+            if (k1 < range.y) id_next = p.point_list[k1];
+            if (k0 < range.y) {
                 const float4* src = reinterpret_cast<const float4*>(p.rec + id0);
                 r0 = src[0]; r1 = src[1]; r2 = src[2];
             }
@@ -155,7 +155,7 @@ __global__ void __launch_bounds__(kBlendThreads) blend_forward_kernel(BlendFwdPa
         lds_barrier();
 
         int cpar = 0;
-        for (uint32_t base = range.x; base < ((p.dbg & 16) ? range.x : range.y); base += kChunk, cpar ^= 1) {
+        for (uint32_t base = range.x; base < range.y; base += kChunk, cpar ^= 1) {
             // ---- ordered compaction of the survivors into LDS ----
             const uint32_t k = base + tid;
             const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
@@ -174,15 +174,15 @@ __global__ void __launch_bounds__(kBlendThreads) blend_forward_kernel(BlendFwdPa
             }
             // issue the gathers of chunk c+1 and the index loads of chunk c+2; both are consumed after the blend
             const uint32_t kn = k + kChunk, knn = kn + kChunk;
-            if (kn < range.y && !(p.dbg & 2)) {
+            if (kn < range.y) {
                 const float4* src = reinterpret_cast<const float4*>(p.rec + id_next);
                 r0 = src[0]; r1 = src[1]; r2 = src[2];
             }
-            if (knn < range.y && !(p.dbg & 2)) id_next = p.point_list[knn];
+            if (knn < range.y) id_next = p.point_list[knn];
             lds_barrier();
 
             // ---- blend: 16 entries per step per pixel row ----
-            for (int s0 = 0; s0 < ((p.dbg & 1) ? 0 : K); s0 += 16) {
+            for (int s0 = 0; s0 < K; s0 += 16) {
                 if (__all(done)) break;
                 const int idx = s0 + e;
                 const bool ev = idx < K;
@@ -255,7 +255,6 @@ __global__ void __launch_bounds__(kBlendThreads) blend_forward_kernel(BlendFwdPa
 int launch_blend_forward(const AgRasterForwardArgs& a, int R, hipStream_t s)
 {
     BlendFwdParams p;
-    p.dbg = getenv("AG_DBG") ? atoi(getenv("AG_DBG")) : 0;
     p.W = a.W; p.H = a.H;
     p.gx = (a.W + kTileX - 1) / kTileX;
     const int gy = (a.H + kTileY - 1) / kTileY;

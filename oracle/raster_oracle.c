@@ -437,6 +437,7 @@ void ago_render_backward(int P, int W, int H, const uint32_t* ranges, const uint
 #ifdef _OPENMP
     nthreads = omp_get_max_threads();
 #endif
+    if (f32_accum) nthreads = 1;   /* the reference's sequential atomic order is only defined single-threaded */
     double** tacc_all = (double**)calloc((size_t)nthreads, sizeof(double*));
     double** tabs_all = (double**)calloc((size_t)nthreads, sizeof(double*));
 #pragma omp parallel num_threads(nthreads)
