@@ -89,9 +89,13 @@ __global__ void __launch_bounds__(256) gather_conv_kernel(GatherProblem p)
         const int iy = iy0 + p.dy[t], ix = ix0 + p.dx[t];
         if (n_ok && iy >= 0 && iy < p.Hg && ix >= 0 && ix < p.Wg) vmask |= 1u << t;
     }
-    const long long pix = (long long)iy0 * p.Wg + ix0;
+    // Address split that keeps the per-tile VALU work near zero: the channel (and the A row block) advance through a
+    // wave-uniform 64-bit base (SALU), the pixel / tap part is a 32-bit per-thread element offset, so every gather is
+    // `global_load_dword v, v_off, s[base]`.
+    const int pix = iy0 * p.Wg + ix0;                         // may be "negative-reaching" only for taps masked out by vmask
     // A loader: rows ka, ka + 8 ; columns [mq, mq + 4)
     const int ka = tid >> 5, mq = (tid & 31) * 4;
+    const uint32_t a_off0 = (uint32_t)(ka * p.Mpad + m0 + mq), a_off1 = a_off0 + 8u * (uint32_t)p.Mpad;
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -107,31 +111,35 @@ __global__ void __launch_bounds__(256) gather_conv_kernel(GatherProblem p)
 
     f32x4 ra[2];
     float rb[BK / 2];
-    uint32_t rb_ok = 0;     // bit j: rb[j] is a real sample (else padding -> 0); applied when the tile is written to LDS so
-                            // that nothing consumes the loads before the MFMAs of the current tile have been issued
+    bool rb_tap_ok = false; // rb[] are real samples for this thread's pixel (else spatial padding -> 0) and
+    uint32_t rb_cmask = 0;  // bit j: row j is a real channel (else channel padding -> 0, wave-uniform).  Both are applied when
+                            // the tile is written to LDS so that nothing consumes the loads before the MFMAs of the current
+                            // tile have been issued
     auto load_tile = [&](int kt) {
-#pragma unroll
-        for (int j = 0; j < 2; j++)
-            ra[j] = *reinterpret_cast<const f32x4*>(p.At + (size_t)(kt * BK + ka + 8 * j) * p.Mpad + m0 + mq);
-        const bool tap_ok = (vmask >> t_cur) & 1u;
-        const long long off = pix + (long long)p.dy[t_cur] * p.Wg + p.dx[t_cur];
-        rb_ok = 0;
+        const float* a_base = p.At + (size_t)kt * BK * p.Mpad;                  // uniform
+        ra[0] = *reinterpret_cast<const f32x4*>(a_base + a_off0);
+        ra[1] = *reinterpret_cast<const f32x4*>(a_base + a_off1);
+        rb_tap_ok = (vmask >> t_cur) & 1u;
+        const int toff = p.dy[t_cur] * p.Wg + p.dx[t_cur];                      // uniform
+        const uint32_t voff = rb_tap_ok ? (uint32_t)(pix + toff) : 0u;
+        const float* cbase = p.xin + (size_t)(c0_cur + khalf) * plane;          // uniform
+        rb_cmask = 0;
 #pragma unroll
         for (int j = 0; j < BK / 2; j++) {
-            const int c = c0_cur + khalf + 2 * j;
-            const bool ok = tap_ok && (c < p.Cg);
-            const long long o = ok ? (long long)c * (long long)plane + off : 0ll;
-            rb[j] = p.xin[o];
-            rb_ok |= ok ? (1u << j) : 0u;
+            const bool cok = (c0_cur + khalf + 2 * j) < p.Cg;                   // uniform: false only in the padded last channel tile
+            const float* src = cok ? cbase + (size_t)(2 * j) * plane : p.xin;
+            rb[j] = src[voff];
+            rb_cmask |= cok ? (1u << j) : 0u;
         }
         c0_cur += BK;
         if (c0_cur == p.Cpad) { c0_cur = 0; t_cur++; }
     };
     auto store_tile = [&](int buf) {
+        *reinterpret_cast<f32x4*>(&As[buf][ka * LDA + mq]) = ra[0];
+        *reinterpret_cast<f32x4*>(&As[buf][(ka + 8) * LDA + mq]) = ra[1];
 #pragma unroll
-        for (int j = 0; j < 2; j++) *reinterpret_cast<f32x4*>(&As[buf][(ka + 8 * j) * LDA + mq]) = ra[j];
-#pragma unroll
-        for (int j = 0; j < BK / 2; j++) Bs[buf][(khalf + 2 * j) * LDB + n_loc] = ((rb_ok >> j) & 1u) ? rb[j] : 0.f;
+        for (int j = 0; j < BK / 2; j++)
+            Bs[buf][(khalf + 2 * j) * LDB + n_loc] = (rb_tap_ok && ((rb_cmask >> j) & 1u)) ? rb[j] : 0.f;
     };
 
     const int nkt = kt_end - kt_beg;
