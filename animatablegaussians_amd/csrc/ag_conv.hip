@@ -4,17 +4,21 @@
 // backward.  Every variant is one of two implicit GEMMs on v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32
 // accumulate; 157 TF peak = the fp32 vector rate, but it leaves the VALU free for the gather arithmetic):
 //
-//   gather-conv  Y[m][gy, gx] = sum_{c, t} At[(c, t)][m] * Xin[c][gy*sy + dy_t][gx*sx + dx_t]
+//   gather-conv  Y[m][gy, gx] = sum_{t, c} A[m][(t, c)] * Xin[c][gy*sy + dy_t][gx*sx + dx_t]
 //       forward conv (any stride/pad), input gradient of a stride-1 conv (taps mirrored), input gradient of a transposed
 //       conv (= stride-2 conv) and -- split into the 4 output-parity classes so no zero taps are multiplied -- the
-//       stride-2 transposed conv forward and the input gradient of a stride-2 conv.  At is the weight tensor re-packed
-//       K-major [K = C*taps][M] by a small kernel, so the A tile streams in with full 512-byte rows.
+//       stride-2 transposed conv forward and the input gradient of a stride-2 conv.
 //   wgrad        dW[m][(c, t)] = sum_{gy, gx} A[m][gy, gx] * Xin[c][gy*sy + dy_t][gx*sx + dx_t]      (split-K + atomics)
 //
-// Tile: 128 x 128 outputs per 256-thread workgroup (2 x 2 waves, each 64 x 64 = 2 x 2 MFMA blocks, 64 accumulator
-// VGPRs), BK = 16, operands staged through LDS K-major ([k][m], [k][n]) so an MFMA operand fetch is one conflict-free
-// ds_read_b32 per lane; global->register loads of tile k+1 are issued before the 32 MFMAs of tile k and written to
-// the other LDS buffer after them (one barrier per K step).
+// Tile engine (shared): BM x BN outputs per workgroup of 8 waves (2 x 4), each wave WMB x WNB blocks of 32 x 32
+// (128 x 128 = 2x1 blocks per wave, and 64 x 256 = 1x2 for the <= 64-row problems), BK = 16.  Eight waves rather than
+// four: the loader / address work per wave halves while the MFMA work per SIMD stays, and two waves of the same
+// workgroup share every SIMD, so the matrix pipe has a second issuer between barriers (PMC: with 4-wave workgroups the
+// pipe sat at 62 % with both co-resident workgroups marching in phase).  Both operands sit in LDS **k-contiguous** ([row][16 k + 4 pad]);
+// since the order of the k's inside a tile is free as long as A and B agree, MFMA step i takes k = 8*(lane>>5) + i,
+// so each lane's 8 operand values of a 32-row block are two ds_read_b128 (8 per wave and tile instead of 32 scalar
+// reads).  Global->register loads of tile k+1 are issued before the MFMAs of tile k and written to the other LDS buffer
+// after them (one LDS-only barrier per K step).
 #include "ag_common.h"
 #include "../../include/ag_conv.h"
 
@@ -23,13 +27,49 @@ namespace ag {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: HIP's float4 struct in arrays defeats SROA (scratch spills)
 
-constexpr int BM = 128, BN = 128, BK = 16;
-constexpr int LDA = BM + 4, LDB = BN + 4;   // +4 floats: keeps float4 stores 16-B aligned, shifts rows across banks
+constexpr int BK = 16;
+constexpr int LDK = BK + 4;     // row pitch in floats: 80 B keeps b128 accesses aligned and spreads 16 rows over all 64 banks
 constexpr int kMaxTaps = 16;
 
+// WVM x WVN waves per workgroup, each owning WMB x WNB blocks of 32 x 32
+template <int WMB, int WNB, int WVM, int WVN>
+struct Tile {
+    static constexpr int BM = 32 * WMB * WVM, BN = 32 * WNB * WVN, NT = 64 * WVM * WVN;
+    static constexpr int lds_floats = 2 * (BM + BN) * LDK;
+};
+
+// 32 x 32 x 16 update of a wave's WMB x WNB blocks from the k-contiguous LDS tiles
+template <int WMB, int WNB>
+__device__ __forceinline__ void mma_tile(const float* __restrict__ As, const float* __restrict__ Bs, int wm, int wn, int lane,
+                                         f32x16 (&acc)[WMB][WNB])
+{
+    const int r = lane & 31, kh = lane >> 5;
+    f32x4 a[WMB][2], b[WNB][2];
+#pragma unroll
+    for (int i = 0; i < WMB; i++)
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+            a[i][h] = *reinterpret_cast<const f32x4*>(As + ((wm * WMB + i) * 32 + r) * LDK + kh * 8 + 4 * h);
+#pragma unroll
+    for (int j = 0; j < WNB; j++)
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+            b[j][h] = *reinterpret_cast<const f32x4*>(Bs + ((wn * WNB + j) * 32 + r) * LDK + kh * 8 + 4 * h);
+#pragma unroll
+    for (int kk = 0; kk < 8; kk++)
+#pragma unroll
+        for (int i = 0; i < WMB; i++)
+#pragma unroll
+            for (int j = 0; j < WNB; j++)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][kk >> 2][kk & 3], b[j][kk >> 2][kk & 3], acc[i][j], 0, 0, 0);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// gather-conv
+// ------------------------------------------------------------------------------------------------------------------
 struct GatherProblem {
     const float* xin;      // [Cg][Hg][Wg]
-    const float* At;       // [Kpad][Mpad], K index = tap * Cpad + channel
+    const float* At;       // tile-blocked packed weights [Mpad / BM][Kpad / 16][BM][16], K index = tap * Cpad + channel
     float* yout;           // [M][OHf][OWf]
     const float* out_scale;
     const float* bias;
@@ -43,42 +83,29 @@ struct GatherProblem {
     int dy[kMaxTaps], dx[kMaxTaps];
 };
 
-__device__ __forceinline__ void mma_tile(const float* __restrict__ As, const float* __restrict__ Bs, int wm, int wn, int lane,
-                                         f32x16 (&acc)[2][2])
-{
-    const int r = lane & 31, kh = lane >> 5;
-#pragma unroll
-    for (int kk = 0; kk < BK / 2; kk++) {
-        const float a0 = As[(2 * kk + kh) * LDA + wm * 64 + r];
-        const float a1 = As[(2 * kk + kh) * LDA + wm * 64 + 32 + r];
-        const float b0 = Bs[(2 * kk + kh) * LDB + wn * 64 + r];
-        const float b1 = Bs[(2 * kk + kh) * LDB + wn * 64 + 32 + r];
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// gather-conv
-// ------------------------------------------------------------------------------------------------------------------
 // K is ordered tap-major (k = tap * Cpad + channel), so the 16 rows of a K tile are 16 consecutive channels of ONE tap:
 // the tap (and with it the input offset and the padding test) is a wave-uniform scalar per tile, each thread keeps the
-// 16-bit in-bounds mask of its output pixel over the taps, and the 8 gathers of a tile are unconditional loads from
-// `pixel + tap offset + channel * plane` (address and value selected, no branches) -- all in flight under the MFMAs.
-__global__ void __launch_bounds__(256) gather_conv_kernel(GatherProblem p)
+// 16-bit in-bounds mask of its output pixel over the taps, and the gathers of a tile are unconditional loads
+// `global_load_dword v, v_off, s[base]` (uniform 64-bit channel base, 32-bit per-thread pixel offset) -- all in flight
+// under the MFMAs; padding is applied when the tile is written to LDS.
+template <int WMB, int WNB, int WVM, int WVN>
+__global__ void __launch_bounds__(64 * WVM * WVN) gather_conv_kernel(GatherProblem p)
 {
-    __shared__ __attribute__((aligned(16))) float As[2][BK * LDA];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB];
+    using T = Tile<WMB, WNB, WVM, WVN>;
+    constexpr int BM = T::BM, BN = T::BN, NT = T::NT;
+    constexpr int G = NT / BN, KG = BK / G;           // B loader: G thread groups, each KG consecutive k's of a pixel
+    constexpr int AF = BM * 4;                        // A loader: float4's in a tile (one per thread for the first AF threads)
+    static_assert(AF <= NT && KG % 4 == 0 && BN >= 64, "loader shapes");
+    __shared__ __attribute__((aligned(16))) float smem[T::lds_floats];
+    float* const As0 = smem;
+    float* const Bs0 = smem + 2 * BM * LDK;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WVN, wn = wave % WVN;
     const int N = p.gh * p.gw;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
 
-    // B loader: this thread owns output column n_loc for the whole kernel and rows khalf, khalf+2, ... of each K tile
-    const int n_loc = tid & (BN - 1), khalf = wave >> 1;
+    const int n_loc = tid % BN, g = (wave * 64) / BN;   // g is wave-uniform (BN >= 64)
     const int n = n0 + n_loc;
     const bool n_ok = n < N;
     const int gy = n_ok ? n / p.gw : 0, gx = n_ok ? n - (n / p.gw) * p.gw : 0;
@@ -89,45 +116,39 @@ __global__ void __launch_bounds__(256) gather_conv_kernel(GatherProblem p)
         const int iy = iy0 + p.dy[t], ix = ix0 + p.dx[t];
         if (n_ok && iy >= 0 && iy < p.Hg && ix >= 0 && ix < p.Wg) vmask |= 1u << t;
     }
-    // Address split that keeps the per-tile VALU work near zero: the channel (and the A row block) advance through a
-    // wave-uniform 64-bit base (SALU), the pixel / tap part is a 32-bit per-thread element offset, so every gather is
-    // `global_load_dword v, v_off, s[base]`.
-    const int pix = iy0 * p.Wg + ix0;                         // may be "negative-reaching" only for taps masked out by vmask
-    // A loader: rows ka, ka + 8 ; columns [mq, mq + 4)
-    const int ka = tid >> 5, mq = (tid & 31) * 4;
-    const uint32_t a_off0 = (uint32_t)(ka * p.Mpad + m0 + mq), a_off1 = a_off0 + 8u * (uint32_t)p.Mpad;
+    const int pix = iy0 * p.Wg + ix0;
 
-    f32x16 acc[2][2];
+    f32x16 acc[WMB][WNB];
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < WMB; i++)
 #pragma unroll
-        for (int j = 0; j < 2; j++)
+        for (int j = 0; j < WNB; j++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
     const int nkt_all = p.Kpad / BK, ctiles = p.Cpad / BK;
     const int kt_beg = blockIdx.z * p.kt_per_split, kt_end = min(nkt_all, kt_beg + p.kt_per_split);
     int t_cur = kt_beg / ctiles, c0_cur = (kt_beg - t_cur * ctiles) * BK;   // wave-uniform (tap, first channel) of the next tile to load
+    const float* a_tiles = p.At + (size_t)blockIdx.y * nkt_all * (BM * BK);
 
-    f32x4 ra[2];
-    float rb[BK / 2];
+    f32x4 ra;
+    float rb[KG];
+    const bool a_thread = tid < AF;
     bool rb_tap_ok = false; // rb[] are real samples for this thread's pixel (else spatial padding -> 0) and
-    uint32_t rb_cmask = 0;  // bit j: row j is a real channel (else channel padding -> 0, wave-uniform).  Both are applied when
-                            // the tile is written to LDS so that nothing consumes the loads before the MFMAs of the current
-                            // tile have been issued
+    uint32_t rb_cmask = 0;  // bit j: row j is a real channel (else channel padding -> 0, wave-uniform); both applied at the LDS write
     auto load_tile = [&](int kt) {
-        const float* a_base = p.At + (size_t)kt * BK * p.Mpad;                  // uniform
-        ra[0] = *reinterpret_cast<const f32x4*>(a_base + a_off0);
-        ra[1] = *reinterpret_cast<const f32x4*>(a_base + a_off1);
+        const float* a_base = a_tiles + (size_t)kt * (BM * BK);                 // uniform; the tile is one contiguous BM*64-byte run
+        if (a_thread) ra = *reinterpret_cast<const f32x4*>(a_base + tid * 4);
         rb_tap_ok = (vmask >> t_cur) & 1u;
         const int toff = p.dy[t_cur] * p.Wg + p.dx[t_cur];                      // uniform
         const uint32_t voff = rb_tap_ok ? (uint32_t)(pix + toff) : 0u;
-        const float* cbase = p.xin + (size_t)(c0_cur + khalf) * plane;          // uniform
+        const int cfirst = c0_cur + g * KG;
+        const float* cbase = p.xin + (size_t)cfirst * plane;                    // uniform
         rb_cmask = 0;
 #pragma unroll
-        for (int j = 0; j < BK / 2; j++) {
-            const bool cok = (c0_cur + khalf + 2 * j) < p.Cg;                   // uniform: false only in the padded last channel tile
-            const float* src = cok ? cbase + (size_t)(2 * j) * plane : p.xin;
+        for (int j = 0; j < KG; j++) {
+            const bool cok = (cfirst + j) < p.Cg;                               // uniform: false only in the padded last channel tile
+            const float* src = cok ? cbase + (size_t)j * plane : p.xin;
             rb[j] = src[voff];
             rb_cmask |= cok ? (1u << j) : 0u;
         }
@@ -135,63 +156,69 @@ __global__ void __launch_bounds__(256) gather_conv_kernel(GatherProblem p)
         if (c0_cur == p.Cpad) { c0_cur = 0; t_cur++; }
     };
     auto store_tile = [&](int buf) {
-        *reinterpret_cast<f32x4*>(&As[buf][ka * LDA + mq]) = ra[0];
-        *reinterpret_cast<f32x4*>(&As[buf][(ka + 8) * LDA + mq]) = ra[1];
+        float* As = As0 + buf * BM * LDK;
+        float* Bs = Bs0 + buf * BN * LDK;
+        if (a_thread) *reinterpret_cast<f32x4*>(As + (tid >> 2) * LDK + (tid & 3) * 4) = ra;   // float4 #tid of the [BM][16] tile
 #pragma unroll
-        for (int j = 0; j < BK / 2; j++)
-            Bs[buf][(khalf + 2 * j) * LDB + n_loc] = (rb_tap_ok && ((rb_cmask >> j) & 1u)) ? rb[j] : 0.f;
+        for (int q = 0; q < KG / 4; q++) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] = (rb_tap_ok && ((rb_cmask >> (4 * q + e)) & 1u)) ? rb[4 * q + e] : 0.f;
+            *reinterpret_cast<f32x4*>(Bs + n_loc * LDK + g * KG + 4 * q) = v;
+        }
     };
 
     const int nkt = kt_end - kt_beg;
     load_tile(kt_beg);
     store_tile(0);
-    __syncthreads();
+    lds_barrier();
     for (int kt = 0; kt < nkt; kt++) {
         const bool more = kt + 1 < nkt;
         if (more) load_tile(kt_beg + kt + 1);
-        mma_tile(As[kt & 1], Bs[kt & 1], wm, wn, lane, acc);
+        mma_tile<WMB, WNB>(As0 + (kt & 1) * BM * LDK, Bs0 + (kt & 1) * BN * LDK, wm, wn, lane, acc);
         if (more) store_tile((kt + 1) & 1);
-        __syncthreads();
+        lds_barrier();
     }
+    // (the gather kernel above and the wgrad kernel below share this loop shape)
 
     // epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
     const int col = lane & 31, rbase = 4 * (lane >> 5);
     if (gridDim.z > 1) {
         float* part = p.partial + (size_t)blockIdx.z * p.Mpad * N;
 #pragma unroll
-        for (int i = 0; i < 2; i++)
+        for (int i = 0; i < WMB; i++)
 #pragma unroll
-            for (int j = 0; j < 2; j++) {
-                const int nn = n0 + wn * 64 + j * 32 + col;
+            for (int j = 0; j < WNB; j++) {
+                const int nn = n0 + (wn * WNB + j) * 32 + col;
                 if (nn >= N) continue;
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
-                    const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + rbase;
+                    const int m = m0 + (wm * WMB + i) * 32 + (r & 3) + 8 * (r >> 2) + rbase;
                     part[(size_t)m * N + nn] = acc[i][j][r];
                 }
             }
         return;
     }
-    int nn[2];
-    size_t opix[2];
+    int nn[WNB];
+    size_t opix[WNB];
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
-        nn[j] = n0 + wn * 64 + j * 32 + col;
+    for (int j = 0; j < WNB; j++) {
+        nn[j] = n0 + (wn * WNB + j) * 32 + col;
         const int q = min(nn[j], N - 1);
         const int oy = q / p.gw, ox = q - oy * p.gw;
         opix[j] = (size_t)(p.y0 + oy * p.ys) * p.OWf + (p.x0 + ox * p.xs);
     }
     const bool has_scale = p.out_scale != nullptr, has_bias = p.bias != nullptr;
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < WMB; i++)
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + rbase;
+            const int m = m0 + (wm * WMB + i) * 32 + (r & 3) + 8 * (r >> 2) + rbase;
             if (m >= p.M) continue;
             const float sc = has_scale ? p.out_scale[m] : 1.f, bi = has_bias ? p.bias[m] : 0.f;
             float* row = p.yout + (size_t)m * p.OHf * p.OWf;
 #pragma unroll
-            for (int j = 0; j < 2; j++)
+            for (int j = 0; j < WNB; j++)
                 if (nn[j] < N) row[opix[j]] = acc[i][j][r] * sc + bi;
         }
 }
@@ -213,11 +240,12 @@ __global__ void __launch_bounds__(256) reduce_splits_kernel(GatherProblem p, int
     }
 }
 
-// weight re-pack: At[(c, t)][m] = w[c * stride_c + m * stride_m + tapoff[t]], zero padded to [Kpad][Mpad]
+// weight re-pack into the tile-blocked image: At[m / BM][kk / 16][m % BM][kk % 16] = w[c * stride_c + m * stride_m + tapoff[t]]
+// with kk = t * Cpad + c, zero padded
 struct PackProblem {
     const float* w;
     float* At;
-    int C, Cpad, M, Mpad, ntaps, Kpad;
+    int C, Cpad, M, Mpad, BM, ntaps, Kpad;
     long long stride_c, stride_m;
     int tapoff[kMaxTaps];
 };
@@ -225,8 +253,15 @@ struct PackProblem {
 __global__ void __launch_bounds__(256) pack_weights_kernel(PackProblem p)
 {
     const long long total = (long long)p.Kpad * p.Mpad;
+    const int nkt = p.Kpad / BK;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int kk = (int)(i / p.Mpad), m = (int)(i - (long long)kk * p.Mpad);
+        // destination-major enumeration (coalesced writes): i = ((mt * nkt + kt) * BM + ml) * 16 + kl
+        const int kl = (int)(i & 15);
+        long long q = i >> 4;
+        const int ml = (int)(q % p.BM);
+        q /= p.BM;
+        const int kt = (int)(q % nkt), mt = (int)(q / nkt);
+        const int m = mt * p.BM + ml, kk = kt * BK + kl;
         const int t = kk / p.Cpad, c = kk - t * p.Cpad;
         float v = 0.f;
         if (c < p.C && m < p.M) v = p.w[c * p.stride_c + m * p.stride_m + p.tapoff[t]];
@@ -246,38 +281,47 @@ struct WgradProblem {
     int dy[kMaxTaps], dx[kMaxTaps];
 };
 
-__global__ void __launch_bounds__(256) wgrad_kernel(WgradProblem p)
+template <int WMB, int WNB, int WVM, int WVN>
+__global__ void __launch_bounds__(64 * WVM * WVN) wgrad_kernel(WgradProblem p)
 {
-    __shared__ __attribute__((aligned(16))) float As[2][BK * LDA];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    using T = Tile<WMB, WNB, WVM, WVN>;
+    constexpr int BM = T::BM, BN = T::BN, NT = T::NT;
+    constexpr int BC = BN / (NT / 16);                 // B loader: columns per thread
+    static_assert(BM * 4 <= NT, "A loader: one row quarter per thread");
+    __shared__ __attribute__((aligned(16))) float smem[T::lds_floats];
+    float* const As0 = smem;
+    float* const Bs0 = smem + 2 * BM * LDK;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WVN, wn = wave % WVN;
     const int Kp = p.gh * p.gw, Nw = p.Cg * p.ntaps;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     const int kbeg = blockIdx.z * p.ksplit_len, kend = min(Kp, kbeg + p.ksplit_len);
     if (kbeg >= kend) return;
 
-    // A loader: row am (and am + 64), 4 consecutive pixels aq..aq+3   (A is pixel-contiguous)
+    // A loader: row am, 4 consecutive pixels aq..aq+3 (A is pixel-contiguous) -> one b128 LDS write
     const int am = tid >> 2, aq = (tid & 3) * 4;
-    // B loader: pixel row bk = tid & 15 of the tile, columns bn, bn + 16, ... (8 per thread); lanes run along pixels
+    const bool a_thread = am < BM;
+    // B loader: pixel bk = tid & 15 of the tile, columns bn, bn + NT/16, ...; lanes run along pixels
+    constexpr int BSTEP = NT / 16;
     const int bk = tid & 15, bn = tid >> 4;
     const size_t plane = (size_t)p.Hg * p.Wg;
 
-    f32x16 acc[2][2];
+    f32x16 acc[WMB][WNB];
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < WMB; i++)
 #pragma unroll
-        for (int j = 0; j < 2; j++)
+        for (int j = 0; j < WNB; j++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-    float ra[2][4];
-    float rb[8];
-    // per-thread column descriptors (channel, tap offsets) are fixed for the whole kernel
-    int col_c[8], col_dy[8], col_dx[8];
+    float ra[4];
+    float rb[BC];
+    // per-thread column descriptors (channel plane offset, tap offsets) are fixed for the whole kernel
+    int col_c[BC], col_dy[BC], col_dx[BC];
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const int nn = n0 + bn + 16 * j;
+    for (int j = 0; j < BC; j++) {
+        const int nn = n0 + bn + BSTEP * j;
         const int c = nn / p.ntaps, t = nn - c * p.ntaps;
         col_c[j] = (nn < Nw) ? c : -1;
         col_dy[j] = p.dy[t];
@@ -285,13 +329,12 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgradProblem p)
     }
 
     auto load_tile = [&](int k0) {
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const int m = m0 + am + 64 * h;
+        {
+            const int m = m0 + am;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const int k = k0 + aq + q;
-                ra[h][q] = (m < p.Mw && k < kend) ? p.a[(size_t)m * Kp + k] : 0.f;
+                ra[q] = (a_thread && m < p.Mw && k < kend) ? p.a[(size_t)m * Kp + k] : 0.f;
             }
         }
         const int k = k0 + bk;
@@ -299,43 +342,45 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgradProblem p)
         const int gy = k_ok ? k / p.gw : 0, gx = k_ok ? k - (k / p.gw) * p.gw : 0;
         const int iy0 = gy * p.sy, ix0 = gx * p.sx;
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
+        for (int j = 0; j < BC; j++) {
             const int iy = iy0 + col_dy[j], ix = ix0 + col_dx[j];
             const bool ok = k_ok && (col_c[j] >= 0) && (iy >= 0) && (iy < p.Hg) && (ix >= 0) && (ix < p.Wg);
             rb[j] = ok ? p.xin[(size_t)col_c[j] * plane + (size_t)iy * p.Wg + ix] : 0.f;
         }
     };
     auto store_tile = [&](int buf) {
+        float* As = As0 + buf * BM * LDK;
+        float* Bs = Bs0 + buf * BN * LDK;
+        if (a_thread) {
+            f32x4 v = { ra[0], ra[1], ra[2], ra[3] };
+            *reinterpret_cast<f32x4*>(As + am * LDK + aq) = v;
+        }
 #pragma unroll
-        for (int h = 0; h < 2; h++)
-#pragma unroll
-            for (int q = 0; q < 4; q++) As[buf][(aq + q) * LDA + am + 64 * h] = ra[h][q];
-#pragma unroll
-        for (int j = 0; j < 8; j++) Bs[buf][bk * LDB + bn + 16 * j] = rb[j];
+        for (int j = 0; j < BC; j++) Bs[(bn + BSTEP * j) * LDK + bk] = rb[j];
     };
 
     const int nkt = (kend - kbeg + BK - 1) / BK;
     load_tile(kbeg);
     store_tile(0);
-    __syncthreads();
+    lds_barrier();
     for (int kt = 0; kt < nkt; kt++) {
         const bool more = kt + 1 < nkt;
         if (more) load_tile(kbeg + (kt + 1) * BK);
-        mma_tile(As[kt & 1], Bs[kt & 1], wm, wn, lane, acc);
+        mma_tile<WMB, WNB>(As0 + (kt & 1) * BM * LDK, Bs0 + (kt & 1) * BN * LDK, wm, wn, lane, acc);
         if (more) store_tile((kt + 1) & 1);
-        __syncthreads();
+        lds_barrier();
     }
 
     const int col = lane & 31, rbase = 4 * (lane >> 5);
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < WMB; i++)
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const int nn = n0 + wn * 64 + j * 32 + col;
+        for (int j = 0; j < WNB; j++) {
+            const int nn = n0 + (wn * WNB + j) * 32 + col;
             if (nn >= Nw) continue;
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + rbase;
+                const int m = m0 + (wm * WMB + i) * 32 + (r & 3) + 8 * (r >> 2) + rbase;
                 if (m < p.Mw) atomicAdd(p.c + (size_t)m * Nw + nn, acc[i][j][r]);   // 32 lanes = 128 contiguous bytes
             }
         }
@@ -379,11 +424,15 @@ static void out_size(const AgConvDesc* d, int& OH, int& OW)
 // One gather-conv launch = one tap subset.  `taps` lists (ky, kx) of the subset.
 struct TapSet { int n; int ky[kMaxTaps], kx[kMaxTaps]; };
 
-static int launch_pack(const float* w, float* At, int C, int Cpad, int M, int Mpad, int Kpad, long long stride_c, long long stride_m,
-                       const TapSet& ts, int k, hipStream_t s)
+// Tile height: 64 rows when that wastes fewer padded rows than 128 (the 64-channel layers at 512^2, the 12-channel ToRGB)
+static int pick_bm(int M) { return round_up(M, 64) < round_up(M, 128) ? 64 : 128; }
+static int bn_of(int bm) { return bm == 64 ? 256 : 128; }
+
+static int launch_pack(const float* w, float* At, int C, int Cpad, int M, int Mpad, int bm, int Kpad, long long stride_c,
+                       long long stride_m, const TapSet& ts, int k, hipStream_t s)
 {
     PackProblem pp;
-    pp.w = w; pp.At = At; pp.C = C; pp.Cpad = Cpad; pp.M = M; pp.Mpad = Mpad; pp.ntaps = ts.n; pp.Kpad = Kpad;
+    pp.w = w; pp.At = At; pp.C = C; pp.Cpad = Cpad; pp.M = M; pp.Mpad = Mpad; pp.BM = bm; pp.ntaps = ts.n; pp.Kpad = Kpad;
     pp.stride_c = stride_c; pp.stride_m = stride_m;
     for (int t = 0; t < ts.n; t++) pp.tapoff[t] = ts.ky[t] * k + ts.kx[t];
     const long long total = (long long)Kpad * Mpad;
@@ -397,9 +446,10 @@ static int launch_pack(const float* w, float* At, int C, int Cpad, int M, int Mp
 // 8^2 .. 64^2 have 4 .. 128 tiles for 256 CUs) and the K loop (up to 576 tiles) becomes the critical path; slices of K go
 // to blockIdx.z until ~3 workgroups per CU exist, each keeping >= 4 K tiles, partial sums capped at kMaxPartialBytes.
 constexpr size_t kMaxPartialBytes = size_t(96) << 20;
-static int choose_splits(int Mpad, int N, int Kpad)
+static int choose_splits(int Mpad, int bm, int N, int Kpad)
 {
-    const long long tiles = (long long)((N + BN - 1) / BN) * (Mpad / BM);
+    const int BN = bn_of(bm);
+    const long long tiles = (long long)((N + BN - 1) / BN) * (Mpad / bm);
     const int nkt = Kpad / BK;
     if (tiles >= 512 || nkt < 8) return 1;
     long long s = (768 + tiles - 1) / tiles;
@@ -409,17 +459,19 @@ static int choose_splits(int Mpad, int N, int Kpad)
     return s < 2 ? 1 : (int)s;
 }
 
-static int launch_gather(GatherProblem& gp, float* partial, hipStream_t s)
+static int launch_gather(GatherProblem& gp, int bm, float* partial, hipStream_t s)
 {
     const int N = gp.gh * gp.gw;
     if (N <= 0) return AG_OK;
     const int nkt = gp.Kpad / BK;
-    int splits = choose_splits(gp.Mpad, N, gp.Kpad);
+    int splits = choose_splits(gp.Mpad, bm, N, gp.Kpad);
     gp.kt_per_split = (nkt + splits - 1) / splits;
     splits = (nkt + gp.kt_per_split - 1) / gp.kt_per_split;
     gp.partial = splits > 1 ? partial : nullptr;
-    dim3 grid((N + BN - 1) / BN, gp.Mpad / BM, splits);
-    hipLaunchKernelGGL(gather_conv_kernel, grid, dim3(256), 0, s, gp);
+    const int BN = bn_of(bm);
+    dim3 grid((N + BN - 1) / BN, gp.Mpad / bm, splits);
+    if (bm == 64) hipLaunchKernelGGL((gather_conv_kernel<1, 2, 2, 4>), grid, dim3(512), 0, s, gp);
+    else          hipLaunchKernelGGL((gather_conv_kernel<2, 1, 2, 4>), grid, dim3(512), 0, s, gp);
     int rc = check_hip(hipGetLastError(), "gather_conv_kernel");
     if (rc || splits == 1) return rc;
     const long long total = (long long)gp.M * N;
@@ -450,7 +502,7 @@ static size_t packed_bytes(const AgConvDesc* d)
 {
     const int Cmax = d->Cin > d->Cout ? d->Cin : d->Cout;
     const size_t kk = (size_t)round_up(Cmax, BK) * (d->k * d->k + 4);   // all tap subsets together (+ degenerate classes)
-    return align_up(kk * (size_t)round_up(Cmax, BM) * sizeof(float), 256);
+    return align_up(kk * (size_t)round_up(Cmax, 128) * sizeof(float), 256);
 }
 
 size_t ag_conv_workspace_bytes(const AgConvDesc* d)
@@ -485,7 +537,7 @@ static int run_gather_family(const AgConvDesc* d, bool backward_input, const flo
     const long long s_co = conv ? (long long)d->Cin * k2 : k2, s_ci = conv ? k2 : (long long)d->Cout * k2;
     stride_c = backward_input ? s_co : s_ci;
     stride_m = backward_input ? s_ci : s_co;
-    gp.Cg = Cg; gp.Hg = Hg; gp.Wg = Wg; gp.M = M; gp.Mpad = round_up(M, BM); gp.OHf = OHf; gp.OWf = OWf;
+    gp.Cg = Cg; gp.Hg = Hg; gp.Wg = Wg; gp.M = M; const int bm = pick_bm(M); gp.Mpad = round_up(M, bm); gp.OHf = OHf; gp.OWf = OWf;
 
     // "gather" cases: forward conv, input gradient of a transposed conv (a stride-2 conv over dy), input gradient of a
     // stride-1 conv (taps mirrored).  "scatter" cases (stride 2): transposed conv forward, input gradient of a stride-2 conv.
@@ -506,9 +558,9 @@ static int run_gather_family(const AgConvDesc* d, bool backward_input, const flo
             for (int t = 0; t < k2; t++) { gp.dy[t] = ts.ky[t]; gp.dx[t] = ts.kx[t]; }
         }
         gp.At = At;
-        int rc = launch_pack(w, At, Cg, gp.Cpad, M, gp.Mpad, gp.Kpad, stride_c, stride_m, ts, k, s);
+        int rc = launch_pack(w, At, Cg, gp.Cpad, M, gp.Mpad, bm, gp.Kpad, stride_c, stride_m, ts, k, s);
         if (rc) return rc;
-        return launch_gather(gp, partial, s);
+        return launch_gather(gp, bm, partial, s);
     }
     // scatter with stride 2: output coordinate o = 2*i + ky - poff  (poff = padding for the conv gradient, 0 for convT).
     // Class (qy, qx) = parity of the output coordinate; it receives only taps with ky = (o + poff) mod 2, from
@@ -540,9 +592,9 @@ static int run_gather_family(const AgConvDesc* d, bool backward_input, const flo
             for (int t = 0; t < ts.n; t++) { gp.dy[t] = (qy + poff - ts.ky[t]) / 2; gp.dx[t] = (qx + poff - ts.kx[t]) / 2; }
             // floor division for negative odd numerators never happens: numerators are even by construction
             gp.At = At + at_off;
-            int rc = launch_pack(w, At + at_off, gp.Cg, gp.Cpad, M, gp.Mpad, gp.Kpad, stride_c, stride_m, ts, k, s);
+            int rc = launch_pack(w, At + at_off, gp.Cg, gp.Cpad, M, gp.Mpad, bm, gp.Kpad, stride_c, stride_m, ts, k, s);
             if (rc) return rc;
-            if ((rc = launch_gather(gp, partial, s))) return rc;
+            if ((rc = launch_gather(gp, bm, partial, s))) return rc;
             at_off += (size_t)gp.Kpad * gp.Mpad;
         }
     return AG_OK;
@@ -589,7 +641,8 @@ int ag_conv_backward_weight(const AgConvDesc* d, const float* x, const float* dy
     }
     wp.c = dw; wp.ntaps = k2;
     const int Kp = wp.gh * wp.gw, Nw = wp.Cg * k2;
-    const int tiles = ((Nw + BN - 1) / BN) * ((wp.Mw + BM - 1) / BM);
+    const int bm = pick_bm(wp.Mw), BN = bn_of(bm);
+    const int tiles = ((Nw + BN - 1) / BN) * ((wp.Mw + bm - 1) / bm);
     int splits = (2048 + tiles - 1) / tiles;                 // aim at ~8 workgroups per CU
     const int max_splits = (Kp + 4 * BK - 1) / (4 * BK);     // at least 4 K tiles per split
     if (splits > max_splits) splits = max_splits;
@@ -597,8 +650,9 @@ int ag_conv_backward_weight(const AgConvDesc* d, const float* x, const float* dy
     wp.ksplit_len = round_up((Kp + splits - 1) / splits, BK);
     splits = (Kp + wp.ksplit_len - 1) / wp.ksplit_len;
     if ((rc = check_hip(hipMemsetAsync(dw, 0, (size_t)wp.Mw * Nw * sizeof(float), s), "memset dw"))) return rc;
-    dim3 grid((Nw + BN - 1) / BN, (wp.Mw + BM - 1) / BM, splits);
-    hipLaunchKernelGGL(wgrad_kernel, grid, dim3(256), 0, s, wp);
+    dim3 grid((Nw + BN - 1) / BN, (wp.Mw + bm - 1) / bm, splits);
+    if (bm == 64) hipLaunchKernelGGL((wgrad_kernel<1, 2, 2, 4>), grid, dim3(512), 0, s, wp);
+    else          hipLaunchKernelGGL((wgrad_kernel<2, 1, 2, 4>), grid, dim3(512), 0, s, wp);
     return check_hip(hipGetLastError(), "wgrad_kernel");
 }
 
