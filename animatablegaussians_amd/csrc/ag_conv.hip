@@ -38,30 +38,51 @@ struct Tile {
     static constexpr int lds_floats = 2 * (BM + BN) * LDK;
 };
 
-// 32 x 32 x 16 update of a wave's WMB x WNB blocks from the k-contiguous LDS tiles
+// Operand registers of one K tile for a wave: 8 k-values (two b128) per 32-row block
 template <int WMB, int WNB>
-__device__ __forceinline__ void mma_tile(const float* __restrict__ As, const float* __restrict__ Bs, int wm, int wn, int lane,
-                                         f32x16 (&acc)[WMB][WNB])
+struct Operands {
+    f32x4 a[WMB][2], b[WNB][2];
+};
+
+template <int WMB, int WNB>
+__device__ __forceinline__ void read_operands(const float* __restrict__ As, const float* __restrict__ Bs, int wm, int wn, int lane,
+                                              Operands<WMB, WNB>& o)
 {
     const int r = lane & 31, kh = lane >> 5;
-    f32x4 a[WMB][2], b[WNB][2];
 #pragma unroll
     for (int i = 0; i < WMB; i++)
 #pragma unroll
         for (int h = 0; h < 2; h++)
-            a[i][h] = *reinterpret_cast<const f32x4*>(As + ((wm * WMB + i) * 32 + r) * LDK + kh * 8 + 4 * h);
+            o.a[i][h] = *reinterpret_cast<const f32x4*>(As + ((wm * WMB + i) * 32 + r) * LDK + kh * 8 + 4 * h);
 #pragma unroll
     for (int j = 0; j < WNB; j++)
 #pragma unroll
         for (int h = 0; h < 2; h++)
-            b[j][h] = *reinterpret_cast<const f32x4*>(Bs + ((wn * WNB + j) * 32 + r) * LDK + kh * 8 + 4 * h);
+            o.b[j][h] = *reinterpret_cast<const f32x4*>(Bs + ((wn * WNB + j) * 32 + r) * LDK + kh * 8 + 4 * h);
+}
+
+// half a K tile (4 MFMA k-steps) on every block of the wave
+template <int WMB, int WNB>
+__device__ __forceinline__ void mma_half(const Operands<WMB, WNB>& o, int h, f32x16 (&acc)[WMB][WNB])
+{
 #pragma unroll
-    for (int kk = 0; kk < 8; kk++)
+    for (int e = 0; e < 4; e++)
 #pragma unroll
         for (int i = 0; i < WMB; i++)
 #pragma unroll
             for (int j = 0; j < WNB; j++)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][kk >> 2][kk & 3], b[j][kk >> 2][kk & 3], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a[i][h][e], o.b[j][h][e], acc[i][j], 0, 0, 0);
+}
+
+// 32 x 32 x 16 update of a wave's WMB x WNB blocks from the k-contiguous LDS tiles (un-pipelined form, used by wgrad)
+template <int WMB, int WNB>
+__device__ __forceinline__ void mma_tile(const float* __restrict__ As, const float* __restrict__ Bs, int wm, int wn, int lane,
+                                         f32x16 (&acc)[WMB][WNB])
+{
+    Operands<WMB, WNB> o;
+    read_operands<WMB, WNB>(As, Bs, wm, wn, lane, o);
+    mma_half<WMB, WNB>(o, 0, acc);
+    mma_half<WMB, WNB>(o, 1, acc);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -69,7 +90,7 @@ __device__ __forceinline__ void mma_tile(const float* __restrict__ As, const flo
 // ------------------------------------------------------------------------------------------------------------------
 struct GatherProblem {
     const float* xin;      // [Cg][Hg][Wg]
-    const float* At;       // tile-blocked packed weights [Mpad / BM][Kpad / 16][BM][16], K index = tap * Cpad + channel
+    const float* At;       // tile-blocked packed weights [Mpad / BM][Kpad / 16][BM][16], K tile = (channel block, tap)
     float* yout;           // [M][OHf][OWf]
     const float* out_scale;
     const float* bias;
@@ -83,9 +104,10 @@ struct GatherProblem {
     int dy[kMaxTaps], dx[kMaxTaps];
 };
 
-// K is ordered tap-major (k = tap * Cpad + channel), so the 16 rows of a K tile are 16 consecutive channels of ONE tap:
+// K is ordered (channel block of 16, tap, channel in block), so the 16 rows of a K tile are 16 consecutive channels of ONE tap:
 // the tap (and with it the input offset and the padding test) is a wave-uniform scalar per tile, each thread keeps the
-// 16-bit in-bounds mask of its output pixel over the taps, and the gathers of a tile are unconditional loads
+// 16-bit in-bounds mask of its output pixel over the taps (consecutive tiles walk the taps of one channel block, so the
+// shifted re-reads of the same input lines stay in L1/L2), and the gathers of a tile are unconditional loads
 // `global_load_dword v, v_off, s[base]` (uniform 64-bit channel base, 32-bit per-thread pixel offset) -- all in flight
 // under the MFMAs; padding is applied when the tile is written to LDS.
 template <int WMB, int WNB, int WVM, int WVN>
@@ -128,56 +150,100 @@ __global__ void __launch_bounds__(64 * WVM * WVN) gather_conv_kernel(GatherProbl
 
     const int nkt_all = p.Kpad / BK, ctiles = p.Cpad / BK;
     const int kt_beg = blockIdx.z * p.kt_per_split, kt_end = min(nkt_all, kt_beg + p.kt_per_split);
-    int t_cur = kt_beg / ctiles, c0_cur = (kt_beg - t_cur * ctiles) * BK;   // wave-uniform (tap, first channel) of the next tile to load
+    // K tile kt = (channel block kt / ntaps, tap kt % ntaps)
+    int c0_cur = (kt_beg / p.ntaps) * BK, t_cur = kt_beg % p.ntaps;           // wave-uniform (first channel, tap) of the next tile to load
+    (void)ctiles;
     const float* a_tiles = p.At + (size_t)blockIdx.y * nkt_all * (BM * BK);
 
-    f32x4 ra;
-    float rb[KG];
+    // Three-stage software pipeline.  While the MFMAs of tile k run from operand registers, tile k+1 moves
+    // registers -> LDS -> operand registers (one barrier, placed in the middle of the MFMA phase so that the LDS write
+    // burst and the operand read burst of all waves are covered by matrix work), and the global loads of tile k+2 are in
+    // flight.  Two sets of staging registers (S) and of operand registers (O) alternate by tile parity.
+    struct Stage {
+        f32x4 ra;
+        float rb[KG];
+        bool tap_ok;        // rb[] are real samples for this thread's pixel (else spatial padding -> 0)
+        uint32_t cmask;     // bit j: row j is a real channel (else channel padding -> 0, wave-uniform); both applied at the LDS write
+    };
+    Stage S[2];
+    Operands<WMB, WNB> O[2];
     const bool a_thread = tid < AF;
-    bool rb_tap_ok = false; // rb[] are real samples for this thread's pixel (else spatial padding -> 0) and
-    uint32_t rb_cmask = 0;  // bit j: row j is a real channel (else channel padding -> 0, wave-uniform); both applied at the LDS write
-    auto load_tile = [&](int kt) {
+    const int a_f4 = min(tid, AF - 1);
+    auto gload = [&](int kt, Stage& st) {
         const float* a_base = a_tiles + (size_t)kt * (BM * BK);                 // uniform; the tile is one contiguous BM*64-byte run
-        if (a_thread) ra = *reinterpret_cast<const f32x4*>(a_base + tid * 4);
-        rb_tap_ok = (vmask >> t_cur) & 1u;
+        st.ra = *reinterpret_cast<const f32x4*>(a_base + a_f4 * 4);            // unconditional (threads past the tile re-read its last float4)
+        st.tap_ok = (vmask >> t_cur) & 1u;
         const int toff = p.dy[t_cur] * p.Wg + p.dx[t_cur];                      // uniform
-        const uint32_t voff = rb_tap_ok ? (uint32_t)(pix + toff) : 0u;
+        const uint32_t voff = st.tap_ok ? (uint32_t)(pix + toff) : 0u;
         const int cfirst = c0_cur + g * KG;
         const float* cbase = p.xin + (size_t)cfirst * plane;                    // uniform
-        rb_cmask = 0;
+        st.cmask = 0;
 #pragma unroll
         for (int j = 0; j < KG; j++) {
             const bool cok = (cfirst + j) < p.Cg;                               // uniform: false only in the padded last channel tile
             const float* src = cok ? cbase + (size_t)j * plane : p.xin;
-            rb[j] = src[voff];
-            rb_cmask |= cok ? (1u << j) : 0u;
+            st.rb[j] = src[voff];
+            st.cmask |= cok ? (1u << j) : 0u;
         }
-        c0_cur += BK;
-        if (c0_cur == p.Cpad) { c0_cur = 0; t_cur++; }
+        t_cur++;
+        if (t_cur == p.ntaps) { t_cur = 0; c0_cur += BK; }
     };
-    auto store_tile = [&](int buf) {
+    auto lstore = [&](int buf, const Stage& st) {
         float* As = As0 + buf * BM * LDK;
         float* Bs = Bs0 + buf * BN * LDK;
-        if (a_thread) *reinterpret_cast<f32x4*>(As + (tid >> 2) * LDK + (tid & 3) * 4) = ra;   // float4 #tid of the [BM][16] tile
+        if (a_thread) *reinterpret_cast<f32x4*>(As + (tid >> 2) * LDK + (tid & 3) * 4) = st.ra;   // float4 #tid of the [BM][16] tile
 #pragma unroll
         for (int q = 0; q < KG / 4; q++) {
             f32x4 v;
 #pragma unroll
-            for (int e = 0; e < 4; e++) v[e] = (rb_tap_ok && ((rb_cmask >> (4 * q + e)) & 1u)) ? rb[4 * q + e] : 0.f;
+            for (int e = 0; e < 4; e++) v[e] = (st.tap_ok && ((st.cmask >> (4 * q + e)) & 1u)) ? st.rb[4 * q + e] : 0.f;
             *reinterpret_cast<f32x4*>(Bs + n_loc * LDK + g * KG + 4 * q) = v;
         }
     };
+    auto lread = [&](int buf, Operands<WMB, WNB>& o) {
+        read_operands<WMB, WNB>(As0 + buf * BM * LDK, Bs0 + buf * BN * LDK, wm, wn, lane, o);
+    };
 
     const int nkt = kt_end - kt_beg;
-    load_tile(kt_beg);
-    store_tile(0);
+    gload(kt_beg, S[0]);
+    if (nkt > 1) gload(kt_beg + 1, S[1]);
+    lstore(0, S[0]);
     lds_barrier();
-    for (int kt = 0; kt < nkt; kt++) {
-        const bool more = kt + 1 < nkt;
-        if (more) load_tile(kt_beg + kt + 1);
-        mma_tile<WMB, WNB>(As0 + (kt & 1) * BM * LDK, Bs0 + (kt & 1) * BN * LDK, wm, wn, lane, acc);
-        if (more) store_tile((kt + 1) & 1);
+    lread(0, O[0]);
+    // Steady-state step for tile kt (kt + 2 < nkt): branch-free, so the compiler's vmcnt bookkeeping stays exact and the
+    // wait before the LDS write covers only the loads issued one step earlier.
+    auto step_full = [&](int kt, Stage& s_same, Stage& s_next, Operands<WMB, WNB>& o_cur, Operands<WMB, WNB>& o_next) {
+        gload(kt_beg + kt + 2, s_same);                          // s_same held tile kt, already written to LDS
+        mma_half<WMB, WNB>(o_cur, 0, acc);
+        lstore((kt + 1) & 1, s_next);
         lds_barrier();
+        lread((kt + 1) & 1, o_next);
+        mma_half<WMB, WNB>(o_cur, 1, acc);
+    };
+    auto step_tail = [&](int kt, Stage& s_next, Operands<WMB, WNB>& o_cur, Operands<WMB, WNB>& o_next, bool has_next) {
+        mma_half<WMB, WNB>(o_cur, 0, acc);
+        if (has_next) {
+            lstore((kt + 1) & 1, s_next);
+            lds_barrier();
+            lread((kt + 1) & 1, o_next);
+        }
+        mma_half<WMB, WNB>(o_cur, 1, acc);
+    };
+    int kt = 0;
+    for (; kt + 3 < nkt; kt += 2) {
+        step_full(kt, S[0], S[1], O[0], O[1]);
+        step_full(kt + 1, S[1], S[0], O[1], O[0]);
+    }
+    const int rem = nkt - kt;                                    // 1, 2 or 3 tiles left, kt even
+    if (rem == 3) {
+        step_full(kt, S[0], S[1], O[0], O[1]);
+        step_tail(kt + 1, S[0], O[1], O[0], true);
+        step_tail(kt + 2, S[1], O[0], O[1], false);
+    } else if (rem == 2) {
+        step_tail(kt, S[1], O[0], O[1], true);
+        step_tail(kt + 1, S[0], O[1], O[0], false);
+    } else {
+        step_tail(kt, S[1], O[0], O[1], false);
     }
     // (the gather kernel above and the wgrad kernel below share this loop shape)
 
@@ -240,8 +306,8 @@ __global__ void __launch_bounds__(256) reduce_splits_kernel(GatherProblem p, int
     }
 }
 
-// weight re-pack into the tile-blocked image: At[m / BM][kk / 16][m % BM][kk % 16] = w[c * stride_c + m * stride_m + tapoff[t]]
-// with kk = t * Cpad + c, zero padded
+// weight re-pack into the tile-blocked image: At[m / BM][kt][m % BM][kl] = w[c * stride_c + m * stride_m + tapoff[t]]
+// with K tile kt = (c / 16) * ntaps + t and kl = c % 16, zero padded
 struct PackProblem {
     const float* w;
     float* At;
@@ -261,8 +327,8 @@ __global__ void __launch_bounds__(256) pack_weights_kernel(PackProblem p)
         const int ml = (int)(q % p.BM);
         q /= p.BM;
         const int kt = (int)(q % nkt), mt = (int)(q / nkt);
-        const int m = mt * p.BM + ml, kk = kt * BK + kl;
-        const int t = kk / p.Cpad, c = kk - t * p.Cpad;
+        const int m = mt * p.BM + ml;
+        const int cb = kt / p.ntaps, t = kt - cb * p.ntaps, c = cb * BK + kl;   // K tile = (channel block, tap)
         float v = 0.f;
         if (c < p.C && m < p.M) v = p.w[c * p.stride_c + m * p.stride_m + p.tapoff[t]];
         p.At[i] = v;
@@ -384,6 +450,28 @@ __global__ void __launch_bounds__(64 * WVM * WVN) wgrad_kernel(WgradProblem p)
                 if (m < p.Mw) atomicAdd(p.c + (size_t)m * Nw + nn, acc[i][j][r]);   // 32 lanes = 128 contiguous bytes
             }
         }
+}
+
+// Matrix-pipe calibration: every wave issues `iters` x 4 independent v_mfma_f32_32x32x2_f32 back to back, no memory.
+// Used by profiles/mfma_peak.py to measure the attainable fp32 MFMA rate of the box the convolutions are priced against.
+__global__ void __launch_bounds__(256) mfma_rate_kernel(int iters, float* out)
+{
+    f32x16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[i][r] = 0.f;
+    float a = 1.0f + threadIdx.x * 1e-6f, b = 0.5f;
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+    }
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) v += acc[i][r];
+    if (v == 12345.678f) out[0] = v;     // keep the chain alive
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -643,7 +731,7 @@ int ag_conv_backward_weight(const AgConvDesc* d, const float* x, const float* dy
     const int Kp = wp.gh * wp.gw, Nw = wp.Cg * k2;
     const int bm = pick_bm(wp.Mw), BN = bn_of(bm);
     const int tiles = ((Nw + BN - 1) / BN) * ((wp.Mw + bm - 1) / bm);
-    int splits = (2048 + tiles - 1) / tiles;                 // aim at ~8 workgroups per CU
+    int splits = (1536 + tiles - 1) / tiles;                 // ~6 workgroups per CU in flight or queued (measured flat from 768 to 2048)
     const int max_splits = (Kp + 4 * BK - 1) / (4 * BK);     // at least 4 K tiles per split
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
@@ -654,6 +742,12 @@ int ag_conv_backward_weight(const AgConvDesc* d, const float* x, const float* dy
     if (bm == 64) hipLaunchKernelGGL((wgrad_kernel<1, 2, 2, 4>), grid, dim3(512), 0, s, wp);
     else          hipLaunchKernelGGL((wgrad_kernel<2, 1, 2, 4>), grid, dim3(512), 0, s, wp);
     return check_hip(hipGetLastError(), "wgrad_kernel");
+}
+
+int ag_debug_mfma_rate(int blocks, int iters, float* out, void* stream)
+{
+    hipLaunchKernelGGL(mfma_rate_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), iters, out);
+    return check_hip(hipGetLastError(), "mfma_rate_kernel");
 }
 
 }  // extern "C"

@@ -57,6 +57,10 @@ int ag_conv_backward_input(const AgConvDesc* d, const float* dy, const float* w,
 int ag_conv_backward_weight(const AgConvDesc* d, const float* x, const float* dy, float* dw, void* workspace,
                             size_t workspace_bytes, void* stream);
 
+/* Calibration: `blocks` x 4 waves each issue iters x 4 independent v_mfma_f32_32x32x2_f32 (8192 FLOP each per wave) with
+ * no memory traffic; time it to get the attainable fp32 MFMA rate of the device (profiles/mfma_peak.py). */
+int ag_debug_mfma_rate(int blocks, int iters, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
