@@ -274,3 +274,38 @@ class AvatarNet(nn.Module):
         if not self.training:
             ret.update({'cano_tex_map': self._canvas(color_map), 'posed_gaussians': g})
         return ret
+
+    def render_views(self, items, views, bg_color=(0., 0., 0.)):
+        """Render V cameras of ONE pose (multi-view training step / free-view synthesis of a frame).
+
+        ``items`` carries the pose (``smpl_pos_map``, ``cano2live_jnt_mats``); ``views`` is a list of dicts with ``extr``,
+        ``intr``, ``img_w``, ``img_h``.  Everything that does not depend on the camera is evaluated once: the position and
+        the other networks, the encoder and decoder stages 0..4 of the colour network (77 % of its FLOPs), the assembly
+        of positions / opacities / scales / rotations and the LBS.  Per view: the view-direction features, stage 5 of the
+        colour decoders, the colour gather and the rasterizer.  Each returned dict equals what ``render`` returns for
+        ``{**items, **view}`` (in training mode up to the view-direction jitter's random draw); under autograd the
+        shared part is back-propagated once with the gradients of all views summed."""
+        dev = self.core.xyz.device
+        bg = torch.as_tensor(np.asarray(bg_color), dtype=torch.float32).to(dev)
+        pose_map = items['smpl_pos_map'][:3]
+        x = pose_map[None].contiguous()
+        position_map, _ = self.position_net([self.position_style], x, randomize_noise=False)
+        other_map, _ = self.other_net([self.other_style], x, randomize_noise=False)
+        feats = [self.get_viewdir_feat({**items, **v}) if self.with_viewdirs else (None, None) for v in views]
+        color_style = torch.rand_like(self.color_style) if self.random_style and self.training else self.color_style
+        color_maps = self.color_net.forward_views([color_style], x, feats, randomize_noise=False)
+        rets = []
+        live = None
+        for v, color_map in zip(views, color_maps):
+            g = self.core.assemble(position_map, other_map, color_map)
+            offset = g['positions'] - self.core.xyz
+            if live is None:                                   # camera-independent: skin once
+                live = ops.lbs_transform(g['positions'], g['rotations'], self.core.lbs, items['cano2live_jnt_mats'])
+            g['positions'], g['rotations'] = live
+            r = render3(g, bg, v['extr'], v['intr'], v['img_w'], v['img_h'])
+            ret = {'rgb_map': r['render'].permute(1, 2, 0), 'mask_map': r['mask'].permute(1, 2, 0), 'offset': offset,
+                   'pos_map': self._canvas(position_map)}
+            if not self.training:
+                ret.update({'cano_tex_map': self._canvas(color_map), 'posed_gaussians': g})
+            rets.append(ret)
+        return rets

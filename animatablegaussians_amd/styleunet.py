@@ -236,10 +236,10 @@ class DualStyleUNet(torch.nn.Module):
             levels.append(out)
         return levels
 
-    def decode(self, branch, levels, w_latent, noise, view_feature=None):
-        """One decoder (branch 1 = front map, 2 = back map)  (:869-905)."""
-        skip = out = None
-        for n, _, _ in self.dec:
+    VIEW_STAGE = 4      # the view-direction feature is added to the stage-4 activations (i == 8 at :881-883)
+
+    def _decode_stages(self, branch, levels, w_latent, noise, out, skip, stages):
+        for n in stages:
             if n == 0:
                 out = self._conv_layer(levels[-1], f"comb_convs.{self.n_comb - 1}")
             elif n < self.n_comb:
@@ -247,11 +247,51 @@ class DualStyleUNet(torch.nn.Module):
             out = self._styled_conv(out, f"convs{branch}.{2 * n}", w_latent, noise[2 * n], True)
             out = self._styled_conv(out, f"convs{branch}.{2 * n + 1}", w_latent, noise[2 * n + 1], False)
             skip = self._to_rgb(out, f"to_rgbs{branch}.{n}", w_latent, skip)
-            if view_feature is not None and n == 4:
-                if view_feature.shape[-2:] != out.shape[-2:]:
-                    view_feature = F.interpolate(view_feature, out.shape[-2:], mode="bilinear")
-                out = out + view_feature
+        return out, skip
+
+    def decode_shared(self, branch, levels, w_latent, noise):
+        """View-independent part of one decoder: stages 0 .. VIEW_STAGE  (77 % of the decoder's FLOPs)."""
+        return self._decode_stages(branch, levels, w_latent, noise, None, None, range(0, min(self.VIEW_STAGE + 1, len(self.dec))))
+
+    def decode_view(self, branch, levels, w_latent, noise, out, skip, view_feature=None):
+        """View-dependent tail of one decoder: add the view feature, run the remaining stages, inverse wavelet."""
+        if view_feature is not None and len(self.dec) > self.VIEW_STAGE:
+            if view_feature.shape[-2:] != out.shape[-2:]:
+                view_feature = F.interpolate(view_feature, out.shape[-2:], mode="bilinear")
+            out = out + view_feature
+        out, skip = self._decode_stages(branch, levels, w_latent, noise, out, skip, range(self.VIEW_STAGE + 1, len(self.dec)))
         return self._haar_merge(skip)
+
+    def decode(self, branch, levels, w_latent, noise, view_feature=None):
+        """One decoder (branch 1 = front map, 2 = back map)  (:869-905)."""
+        out, skip = self.decode_shared(branch, levels, w_latent, noise)
+        return self.decode_view(branch, levels, w_latent, noise, out, skip, view_feature)
+
+    def _latent_and_noise(self, styles, input_is_latent, noise, randomize_noise):
+        w_latent = styles[0] if input_is_latent else self.get_latent(styles[0])
+        if w_latent.dim() == 3:
+            w_latent = w_latent[:, 0]
+        if noise is None:
+            noise = [None] * self.num_layers if randomize_noise else \
+                [getattr(self, self._attr(f"noises.noise_{i}")) for i in range(self.num_layers)]
+        return w_latent, noise
+
+    def forward_views(self, styles, condition_img, view_features, input_is_latent=False, noise=None, randomize_noise=True):
+        """Several evaluations that differ only in ``(view_feature1, view_feature2)`` -- the colour network seen from V
+        cameras of the same pose.  Encoder and decoder stages 0..4 are computed once (and, under autograd, back-propagated
+        once with the summed gradient); only stage 5 runs per view.  Returns a list of V image tensors, each equal to
+        ``forward(..., view_feature1=f1, view_feature2=f2)[0]``."""
+        if randomize_noise and noise is None:
+            raise RuntimeError("forward_views shares activations between views: use fixed noise (randomize_noise=False)")
+        w_latent, noise = self._latent_and_noise(styles, input_is_latent, noise, randomize_noise)
+        levels = self.encode(condition_img)
+        shared = [self.decode_shared(b, levels, w_latent, noise) for b in (1, 2)]
+        images = []
+        for f1, f2 in view_features:
+            parts = [self.decode_view(b, levels, w_latent, noise, shared[b - 1][0], shared[b - 1][1], f)
+                     for b, f in ((1, f1), (2, f2))]
+            images.append(torch.cat(parts, 1))
+        return images
 
     def forward(self, styles, condition_img, cond=None, return_latents=False, inject_index=None, truncation=1,
                 truncation_latent=None, input_is_latent=False, noise=None, randomize_noise=True, view_feature1=None,
@@ -263,12 +303,7 @@ class DualStyleUNet(torch.nn.Module):
             raise RuntimeError("DualStyleUNet (MI355X path): batch 1")
         if not condition_img.is_cuda:
             raise RuntimeError("DualStyleUNet (MI355X path) runs on the GPU only")
-        w_latent = styles[0] if input_is_latent else self.get_latent(styles[0])
-        if w_latent.dim() == 3:
-            w_latent = w_latent[:, 0]
-        if noise is None:
-            noise = [None] * self.num_layers if randomize_noise else \
-                [getattr(self, self._attr(f"noises.noise_{i}")) for i in range(self.num_layers)]
+        w_latent, noise = self._latent_and_noise(styles, input_is_latent, noise, randomize_noise)
         levels = self.encode(condition_img)
         image1 = self.decode(1, levels, w_latent, noise, view_feature1)
         image2 = self.decode(2, levels, w_latent, noise, view_feature2)

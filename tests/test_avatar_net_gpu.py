@@ -107,6 +107,47 @@ def test_render_composes_the_verified_pieces_and_trains(net):
     net.zero_grad(set_to_none=True)
 
 
+def test_render_views_shares_the_pose_dependent_work_without_changing_results(net):
+    """render_views == render per view (eval: bit-identical images; training: summed gradients agree)."""
+    import torch
+    from animatablegaussians_amd import synth
+    base = _items(net)
+    net.get_pose_map(base)
+    cams = synth.free_view_cameras(3, img=1024)
+    views = [{'extr': torch.from_numpy(np.ascontiguousarray(c["extr"])).float().cuda(),
+              'intr': torch.from_numpy(np.ascontiguousarray(c["intr"])).float().cuda(), 'img_w': 1024, 'img_h': 1024} for c in cams]
+    pose_items = {k: base[k] for k in ('smpl_pos_map', 'cano2live_jnt_mats', 'cano2live_jnt_mats_woRoot')}
+    net.eval()
+    with torch.no_grad():
+        multi = net.render_views(pose_items, views, bg_color=(0.2, 0.1, 0.0))
+        for v, m in zip(views, multi):
+            single = net.render({**pose_items, **v}, bg_color=(0.2, 0.1, 0.0))
+            for key in ('rgb_map', 'mask_map', 'offset', 'pos_map', 'cano_tex_map'):
+                assert torch.equal(single[key], m[key]), key
+    # gradients: sum over views of separate backward passes vs one shared backward.  eval mode keeps the view-direction
+    # jitter off so both sides see the same features; autograd does not care about the mode.
+    probe = [("position_net", "convs1.0.conv.weight"), ("color_net", "convs1.2.activate.bias"),
+             ("color_net", "convs2.10.conv.weight"), ("other_net", "to_rgbs1.5.bias"), ("color_net", "conv_in.1.weight")]
+    target = torch.rand(1024, 1024, 3, generator=torch.Generator().manual_seed(5)).cuda()
+
+    def loss_of(r):
+        return (r['rgb_map'] - target).abs().mean() + 0.005 * torch.linalg.norm(r['offset'], dim=-1).mean()
+
+    net.zero_grad(set_to_none=True)
+    for v in views:
+        loss_of(net.render({**pose_items, **v})).backward()
+    want = {k: getattr(net, k[0])._p(k[1]).grad.clone() for k in probe}
+    want_vd = net.viewdir_net__0__weight.grad.clone()
+    net.zero_grad(set_to_none=True)
+    sum(loss_of(r) for r in net.render_views(pose_items, views)).backward()
+    for k in probe:
+        got = getattr(net, k[0])._p(k[1]).grad
+        scale = float(want[k].abs().max())
+        assert float((got - want[k]).abs().max()) <= 2e-3 * scale + 1e-12, (k, float((got - want[k]).abs().max()), scale)
+    assert float((net.viewdir_net__0__weight.grad - want_vd).abs().max()) <= 2e-3 * float(want_vd.abs().max())
+    net.zero_grad(set_to_none=True)
+
+
 def test_reference_state_dict_roundtrip(net):
     import torch
     sd = {}
