@@ -79,8 +79,12 @@ static int validate_forward(const AgRasterForwardArgs* a, bool need_bin, int R)
         return AG_ERR_INVALID_ARGUMENT;
     }
     if (!a->colors_precomp) {
-        set_error("spherical-harmonics colours are not implemented yet: pass colors_precomp");
-        return AG_ERR_UNSUPPORTED;
+        if (!a->shs || !a->campos) { set_error("need colors_precomp, or shs together with campos"); return AG_ERR_INVALID_ARGUMENT; }
+        if (a->sh_degree < 0 || a->sh_degree > 3 || a->sh_coeffs < (a->sh_degree + 1) * (a->sh_degree + 1)) {
+            set_error("SH degree %d needs 0 <= degree <= 3 and at least %d coefficients per Gaussian (got %d)", a->sh_degree,
+                      (a->sh_degree + 1) * (a->sh_degree + 1), a->sh_coeffs);
+            return AG_ERR_INVALID_ARGUMENT;
+        }
     }
     const bool sr = a->scales && a->rotations;
     if (!sr && !a->cov3D_precomp) { set_error("need scales+rotations or cov3D_precomp"); return AG_ERR_INVALID_ARGUMENT; }
@@ -163,7 +167,13 @@ int ag_raster_backward(const AgRasterBackwardArgs* a, void* stream)
     if (!a) { set_error("null args"); return AG_ERR_INVALID_ARGUMENT; }
     if (a->P < 0 || a->W <= 0 || a->H <= 0 || a->num_rendered < 0) { set_error("bad sizes"); return AG_ERR_INVALID_ARGUMENT; }
     if (a->P == 0) return AG_OK;   // all outputs are empty
-    if (!a->colors_precomp) { set_error("spherical-harmonics colours are not implemented yet"); return AG_ERR_UNSUPPORTED; }
+    if (!a->colors_precomp) {
+        if (!a->shs || !a->campos || !a->dL_dsh) { set_error("SH backward needs shs, campos and dL_dsh"); return AG_ERR_INVALID_ARGUMENT; }
+        if (a->sh_degree < 0 || a->sh_degree > 3 || a->sh_coeffs < (a->sh_degree + 1) * (a->sh_degree + 1)) {
+            set_error("bad SH degree / coefficient count");
+            return AG_ERR_INVALID_ARGUMENT;
+        }
+    }
     if (!a->means3D || !a->radii || !a->bg || !a->viewmatrix || !a->projmatrix || !a->alphas || !a->dL_dout_color ||
         !a->dL_dout_depth || !a->dL_dout_alpha || !a->geom_buffer || !a->image_buffer) {
         set_error("null input to backward");

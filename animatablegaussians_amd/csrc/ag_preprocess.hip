@@ -10,6 +10,7 @@
 // restates the reference's expression order (GLM column-major mat3 products, left-to-right sums).
 // HBM-bound streaming kernel: 44 B in, 48 B record + 24 B cov3D + 8 B out per Gaussian.
 #include "ag_common.h"
+#include "ag_sh.h"
 
 namespace ag {
 
@@ -72,7 +73,11 @@ struct PreParams {
     const float* __restrict__ scales;
     const float* __restrict__ rotations;
     const float* __restrict__ opacities;
-    const float* __restrict__ colors;
+    const float* __restrict__ colors;       // precomputed colours, or NULL -> spherical harmonics below
+    const float* __restrict__ shs;          // [P][sh_coeffs][3]
+    const float* __restrict__ campos;
+    uint8_t* __restrict__ clamped;          // [P][3], written on the SH path (the backward zeroes clamped channels' gradients)
+    int sh_degree, sh_coeffs;
     const float* __restrict__ cov3D_precomp;
     const float* __restrict__ view;
     const float* __restrict__ proj;
@@ -177,7 +182,15 @@ __global__ void __launch_bounds__(256) preprocess_kernel(PreParams p)
                 const float op = p.opacities[idx];
                 GaussRec g;
                 g.x = px; g.y = py; g.ca = ca; g.cb = cb; g.cc = cc; g.op = op;
-                g.r = p.colors[3 * idx + 0]; g.g = p.colors[3 * idx + 1]; g.b = p.colors[3 * idx + 2];
+                if (p.colors) {
+                    g.r = p.colors[3 * idx + 0]; g.g = p.colors[3 * idx + 1]; g.b = p.colors[3 * idx + 2];
+                } else {                                    // forward.cu:238-245: after the culls, only for Gaussians that are drawn
+                    float rgb[3];
+                    uint8_t cl[3];
+                    sh_colour(p.sh_degree, sh_direction(ox, oy, oz, p.campos), p.shs + (size_t)idx * p.sh_coeffs * 3, rgb, cl);
+                    g.r = rgb[0]; g.g = rgb[1]; g.b = rgb[2];
+                    p.clamped[3 * idx + 0] = cl[0]; p.clamped[3 * idx + 1] = cl[1]; p.clamped[3 * idx + 2] = cl[2];
+                }
                 g.depth = vz;
                 // Wave-level cull radius for the blend kernels.  power <= -0.5*d^2/lambda_max(cov2D) and
                 // alpha = op*exp(power) < 1/255  <=>  power < -ln(255*op); lambda1 >= lambda_max (0.1 floor above).
@@ -235,6 +248,7 @@ int launch_preprocess(const AgRasterForwardArgs& a, hipStream_t s)
     p.scale_modifier = a.scale_modifier;
     p.means3D = a.means3D; p.scales = a.scales; p.rotations = a.rotations; p.opacities = a.opacities;
     p.colors = a.colors_precomp; p.cov3D_precomp = a.cov3D_precomp;
+    p.shs = a.shs; p.campos = a.campos; p.sh_degree = a.sh_degree; p.sh_coeffs = a.sh_coeffs;
     p.view = a.viewmatrix; p.proj = a.projmatrix;
     p.radii = a.radii;
     char* gb = aligned_base(a.geom_buffer);
@@ -244,6 +258,7 @@ int launch_preprocess(const AgRasterForwardArgs& a, hipStream_t s)
     p.rec = reinterpret_cast<GaussRec*>(gb + gl.rec);
     p.cov3Ds = reinterpret_cast<float*>(gb + gl.cov3d);
     p.tiles_touched = reinterpret_cast<uint32_t*>(gb + gl.tiles_touched);
+    p.clamped = reinterpret_cast<uint8_t*>(gb + gl.clamped);
     p.tile_count = reinterpret_cast<uint32_t*>(ib + il.tile_count);
     const size_t T = (size_t)p.gx * p.gy;
     if (check_hip(hipMemsetAsync(p.tile_count, 0, T * sizeof(uint32_t), s), "memset tile_count")) return AG_ERR_HIP;

@@ -11,6 +11,7 @@
 // (:168-176), denom2inv = 1/(denom^2 + 1e-7) (:203), p_w = 1/(w + 1e-7) (:376), the depth gradient enters through
 // view-matrix row 2 (:391-403), the quaternion gradient is w.r.t. the RAW (un-normalised) quaternion (:340).
 #include "ag_common.h"
+#include "ag_sh.h"
 
 namespace ag {
 
@@ -57,6 +58,11 @@ struct PreBwdParams {
     const float* __restrict__ view;
     const float* __restrict__ proj;
     const float* __restrict__ accum;
+    const float* __restrict__ shs;          // NULL on the colors_precomp path
+    const float* __restrict__ campos;
+    const uint8_t* __restrict__ clamped;
+    int sh_degree, sh_coeffs;
+    float* __restrict__ dL_dsh;             // [P][sh_coeffs][3], every element written
     float* __restrict__ dL_dmeans2D;
     float* __restrict__ dL_dcolors;
     float* __restrict__ dL_dopacity;
@@ -169,6 +175,16 @@ __global__ void __launch_bounds__(256) preprocess_backward_kernel(PreBwdParams p
         g_mean[1] += (V[6] - V[7] * mul3) * g_depth;
         g_mean[2] += (V[10] - V[11] * mul3) * g_depth;
 
+        // ---- spherical-harmonics colours (backward.cu:406-407 -> :20-139), after the projection and depth terms ----
+        if (p.shs) {
+            const float gc[3] = { g_col[0] * (p.clamped[3 * idx + 0] ? 0.f : 1.f), g_col[1] * (p.clamped[3 * idx + 1] ? 0.f : 1.f),
+                                  g_col[2] * (p.clamped[3 * idx + 2] ? 0.f : 1.f) };
+            float gm[3];
+            sh_backward(p.sh_degree, sh_direction(mx, my, mz, p.campos), p.shs + (size_t)idx * p.sh_coeffs * 3, gc,
+                        p.dL_dsh + (size_t)idx * p.sh_coeffs * 3, gm);
+            g_mean[0] += gm[0]; g_mean[1] += gm[1]; g_mean[2] += gm[2];
+        }
+
         // ---- cov3D -> scale / raw quaternion (backward.cu:278-341) ----
         if (p.scales) {
             const float r = p.rotations[4 * idx + 0], x = p.rotations[4 * idx + 1];
@@ -205,6 +221,11 @@ __global__ void __launch_bounds__(256) preprocess_backward_kernel(PreBwdParams p
         }
     }
 
+    if (p.shs) {    // coefficients the active degree does not use, and every coefficient of a culled Gaussian: zero
+        const int first = (p.radii[idx] > 0) ? 3 * (p.sh_degree + 1) * (p.sh_degree + 1) : 0;
+        float* row = p.dL_dsh + (size_t)idx * p.sh_coeffs * 3;
+        for (int i = first; i < 3 * p.sh_coeffs; i++) row[i] = 0.f;
+    }
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         p.dL_dmeans2D[3 * idx + k] = g_m2[k];
@@ -232,6 +253,8 @@ int launch_preprocess_backward(const AgRasterBackwardArgs& a, hipStream_t s)
     p.cov3Ds = a.cov3D_precomp ? a.cov3D_precomp : reinterpret_cast<const float*>(gb + gl.cov3d);
     p.view = a.viewmatrix; p.proj = a.projmatrix;
     p.accum = reinterpret_cast<const float*>(aligned_base(a.accum_buffer));
+    p.shs = a.colors_precomp ? nullptr : a.shs; p.campos = a.campos; p.sh_degree = a.sh_degree; p.sh_coeffs = a.sh_coeffs;
+    p.clamped = reinterpret_cast<const uint8_t*>(gb + gl.clamped); p.dL_dsh = a.dL_dsh;
     p.dL_dmeans2D = a.dL_dmeans2D; p.dL_dcolors = a.dL_dcolors; p.dL_dopacity = a.dL_dopacity;
     p.dL_dmeans3D = a.dL_dmeans3D; p.dL_dcov3D = a.dL_dcov3D; p.dL_dscales = a.dL_dscales;
     p.dL_drotations = a.dL_drotations;

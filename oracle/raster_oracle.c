@@ -707,3 +707,135 @@ void ago_preprocess_backward(int P, int W, int H, const float* means3D, const in
                                    dL_dscale + 3 * idx, dL_drot + 4 * idx);
     }
 }
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Spherical-harmonics colours (forward.cu:20-71, backward.cu:20-139; constants auxiliary.h:22-39).  Never executed by
+ * AnimatableGaussians (sh_degree = 0, shs = None) -- restated for the API surface of the rasterizer.
+ *
+ * colour = clamp0( sum_i coef_i(dir) * sh_i + 0.5 ), dir = (mean - campos) / |mean - campos|, accumulated in index
+ * order exactly as the reference's left-to-right vec3 expressions do; coef_i is also d colour / d sh_i.
+ * ---------------------------------------------------------------------------------------------------------------- */
+static const float kSH0 = 0.28209479177387814f;
+static const float kSH1 = 0.4886025119029199f;
+static const float kSH2[5] = { 1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f, -1.0925484305920792f,
+                               0.5462742152960396f };
+static const float kSH3[7] = { -0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
+                               -0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f };
+
+static int sh_count(int deg) { return (deg + 1) * (deg + 1); }
+
+/* basis coefficients for a unit direction; returns how many are valid */
+static int sh_coefficients(int deg, float x, float y, float z, float c[16])
+{
+    c[0] = kSH0;
+    if (deg > 0) {
+        c[1] = -(kSH1 * y);
+        c[2] = kSH1 * z;
+        c[3] = -(kSH1 * x);
+    }
+    if (deg > 1) {
+        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+        c[4] = kSH2[0] * xy;
+        c[5] = kSH2[1] * yz;
+        c[6] = kSH2[2] * (2.0f * zz - xx - yy);
+        c[7] = kSH2[3] * xz;
+        c[8] = kSH2[4] * (xx - yy);
+        if (deg > 2) {
+            c[9] = kSH3[0] * y * (3.0f * xx - yy);
+            c[10] = kSH3[1] * xy * z;
+            c[11] = kSH3[2] * y * (4.0f * zz - xx - yy);
+            c[12] = kSH3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy);
+            c[13] = kSH3[4] * x * (4.0f * zz - xx - yy);
+            c[14] = kSH3[5] * z * (xx - yy);
+            c[15] = kSH3[6] * x * (xx - 3.0f * yy);
+        }
+    }
+    return sh_count(deg);
+}
+
+static void sh_direction(const float* mean, const float* campos, float dir_orig[3], float dir[3])
+{
+    for (int k = 0; k < 3; k++) dir_orig[k] = mean[k] - campos[k];
+    const float len = sqrtf(dir_orig[0] * dir_orig[0] + dir_orig[1] * dir_orig[1] + dir_orig[2] * dir_orig[2]);
+    for (int k = 0; k < 3; k++) dir[k] = dir_orig[k] / len;
+}
+
+/* rgb [P,3], clamped [P,3] (0/1); only Gaussians with radii > 0 are evaluated (forward.cu:238-245 runs after the culls) */
+void ago_sh_forward(int P, int deg, int M, const float* means3D, const float* campos, const float* shs, const int* radii,
+                    float* rgb, uint8_t* clamped)
+{
+    for (int idx = 0; idx < P; idx++) {
+        for (int k = 0; k < 3; k++) { rgb[3 * idx + k] = 0.f; clamped[3 * idx + k] = 0; }
+        if (!(radii[idx] > 0)) continue;
+        float d0[3], d[3], c[16];
+        sh_direction(means3D + 3 * idx, campos, d0, d);
+        const int n = sh_coefficients(deg, d[0], d[1], d[2], c);
+        const float* sh = shs + (size_t)idx * M * 3;
+        for (int ch = 0; ch < 3; ch++) {
+            float r = c[0] * sh[ch];
+            /* degree blocks are separate statements in the reference: the degree-1 terms are folded one by one into the
+               running value, the degree-2 and degree-3 sums start from the running value as well -> plain sequential sum */
+            for (int i = 1; i < n; i++) r = r + c[i] * sh[3 * i + ch];
+            r += 0.5f;
+            clamped[3 * idx + ch] = r < 0;
+            rgb[3 * idx + ch] = r > 0.0f ? r : 0.0f;
+        }
+    }
+}
+
+/* dL_dsh [P,M,3] (written), dL_dmeans3D [P,3] (+=) */
+void ago_sh_backward(int P, int deg, int M, const float* means3D, const float* campos, const float* shs,
+                     const uint8_t* clamped, const int* radii, const float* dL_dcolor, float* dL_dmeans3D, float* dL_dsh)
+{
+    for (size_t i = 0; i < (size_t)P * M * 3; i++) dL_dsh[i] = 0.f;
+    for (int idx = 0; idx < P; idx++) {
+        if (!(radii[idx] > 0)) continue;
+        float d0[3], d[3], c[16];
+        sh_direction(means3D + 3 * idx, campos, d0, d);
+        const int n = sh_coefficients(deg, d[0], d[1], d[2], c);
+        const float x = d[0], y = d[1], z = d[2];
+        const float* sh = shs + (size_t)idx * M * 3;
+        float g[3];
+        for (int ch = 0; ch < 3; ch++) g[ch] = dL_dcolor[3 * idx + ch] * (clamped[3 * idx + ch] ? 0.f : 1.f);
+        for (int i = 0; i < n; i++)
+            for (int ch = 0; ch < 3; ch++) dL_dsh[((size_t)idx * M + i) * 3 + ch] = c[i] * g[ch];
+
+        /* d colour / d direction, per channel, in the reference's association */
+        float ddx[3] = { 0, 0, 0 }, ddy[3] = { 0, 0, 0 }, ddz[3] = { 0, 0, 0 };
+#define SH(i) sh[3 * (i) + ch]
+        if (deg > 0)
+            for (int ch = 0; ch < 3; ch++) { ddx[ch] = -kSH1 * SH(3); ddy[ch] = -kSH1 * SH(1); ddz[ch] = kSH1 * SH(2); }
+        if (deg > 1)
+            for (int ch = 0; ch < 3; ch++) {
+                ddx[ch] += kSH2[0] * y * SH(4) + kSH2[2] * 2.f * -x * SH(6) + kSH2[3] * z * SH(7) + kSH2[4] * 2.f * x * SH(8);
+                ddy[ch] += kSH2[0] * x * SH(4) + kSH2[1] * z * SH(5) + kSH2[2] * 2.f * -y * SH(6) + kSH2[4] * 2.f * -y * SH(8);
+                ddz[ch] += kSH2[1] * y * SH(5) + kSH2[2] * 2.f * 2.f * z * SH(6) + kSH2[3] * x * SH(7);
+            }
+        if (deg > 2) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            for (int ch = 0; ch < 3; ch++) {
+                ddx[ch] += (kSH3[0] * SH(9) * 3.f * 2.f * xy + kSH3[1] * SH(10) * yz + kSH3[2] * SH(11) * -2.f * xy +
+                            kSH3[3] * SH(12) * -3.f * 2.f * xz + kSH3[4] * SH(13) * (-3.f * xx + 4.f * zz - yy) +
+                            kSH3[5] * SH(14) * 2.f * xz + kSH3[6] * SH(15) * 3.f * (xx - yy));
+                ddy[ch] += (kSH3[0] * SH(9) * 3.f * (xx - yy) + kSH3[1] * SH(10) * xz +
+                            kSH3[2] * SH(11) * (-3.f * yy + 4.f * zz - xx) + kSH3[3] * SH(12) * -3.f * 2.f * yz +
+                            kSH3[4] * SH(13) * -2.f * xy + kSH3[5] * SH(14) * -2.f * yz + kSH3[6] * SH(15) * -3.f * 2.f * xy);
+                ddz[ch] += (kSH3[1] * SH(10) * xy + kSH3[2] * SH(11) * 4.f * 2.f * yz +
+                            kSH3[3] * SH(12) * 3.f * (2.f * zz - xx - yy) + kSH3[4] * SH(13) * 4.f * 2.f * xz +
+                            kSH3[5] * SH(14) * (xx - yy));
+            }
+        }
+#undef SH
+        /* glm::dot(a, b) = a.x*b.x + a.y*b.y + a.z*b.z */
+        const float gdir[3] = { ddx[0] * g[0] + ddx[1] * g[1] + ddx[2] * g[2], ddy[0] * g[0] + ddy[1] * g[1] + ddy[2] * g[2],
+                                ddz[0] * g[0] + ddz[1] * g[1] + ddz[2] * g[2] };
+        /* through the normalisation (auxiliary.h:107-117) */
+        const float s2 = d0[0] * d0[0] + d0[1] * d0[1] + d0[2] * d0[2];
+        const float inv = 1.0f / sqrtf(s2 * s2 * s2);
+        const float gm[3] = {
+            ((+s2 - d0[0] * d0[0]) * gdir[0] - d0[1] * d0[0] * gdir[1] - d0[2] * d0[0] * gdir[2]) * inv,
+            (-d0[0] * d0[1] * gdir[0] + (s2 - d0[1] * d0[1]) * gdir[1] - d0[2] * d0[1] * gdir[2]) * inv,
+            (-d0[0] * d0[2] * gdir[0] - d0[1] * d0[2] * gdir[1] + (s2 - d0[2] * d0[2]) * gdir[2]) * inv };
+        for (int k = 0; k < 3; k++) dL_dmeans3D[3 * idx + k] += gm[k];
+    }
+}

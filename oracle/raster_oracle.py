@@ -51,10 +51,13 @@ def _f32(a):
 
 
 def forward(means3D, colors, opacities, scales, rotations, bg, viewmatrix, projmatrix, tanfovx, tanfovy,
-            img_w, img_h, scale_modifier: float = 1.0, cov3D_precomp=None, want_fragile: bool = True) -> Dict[str, np.ndarray]:
-    """Full forward; returns every intermediate state the parity tests compare."""
+            img_w, img_h, scale_modifier: float = 1.0, cov3D_precomp=None, want_fragile: bool = True,
+            shs=None, sh_degree: int = 0, campos=None) -> Dict[str, np.ndarray]:
+    """Full forward; returns every intermediate state the parity tests compare.  With ``colors=None`` the colours come
+    from the spherical harmonics ``shs`` [P, M, 3] at ``sh_degree`` seen from ``campos`` (state keys ``rgb``, ``clamped``)."""
     L = lib()
-    means3D, colors, opacities = _f32(means3D), _f32(colors), _f32(opacities)
+    means3D, opacities = _f32(means3D), _f32(opacities)
+    colors = None if colors is None else _f32(colors)
     bg, viewmatrix, projmatrix = _f32(bg), _f32(viewmatrix), _f32(projmatrix)
     scales = None if scales is None else _f32(scales)
     rotations = None if rotations is None else _f32(rotations)
@@ -86,6 +89,13 @@ def forward(means3D, colors, opacities, scales, rotations, bg, viewmatrix, projm
     if P == 0:
         # rasterize_points.cu:68-83: the native call is skipped entirely, outputs stay all-zero
         return st
+    if colors is None:
+        shs, campos = _f32(shs), _f32(campos)
+        st["rgb"] = np.zeros((P, 3), np.float32)
+        st["clamped"] = np.zeros((P, 3), np.uint8)
+        L.ago_sh_forward(c_i(P), c_i(sh_degree), c_i(shs.shape[1]), _p(means3D), _p(campos), _p(shs), _p(st["radii"]),
+                         _p(st["rgb"]), _p(st["clamped"]))
+        colors = st["rgb"]
     L.ago_bin(c_i(P), c_i(W), c_i(H), c_i(R), _p(st["means2D"]), _p(st["depths"]), _p(st["point_offsets"]),
               _p(st["radii"]), _p(st["keys_unsorted"]), _p(st["vals_unsorted"]), _p(st["keys_sorted"]),
               _p(st["point_list"]), _p(st["ranges"]))
@@ -142,13 +152,29 @@ def backward_preprocess(st: Dict[str, np.ndarray], acc: Dict[str, np.ndarray], m
     return g
 
 
+def backward_sh(st: Dict[str, np.ndarray], g: Dict[str, np.ndarray], means3D, shs, sh_degree: int, campos) -> None:
+    """SH part of the preprocess backward (``backward.cu:20-139``, called at ``:406-407``): writes ``g['dL_dsh']`` and adds
+    the view-direction term to ``g['dL_dmeans3D']`` (after the projection and depth terms, as the reference orders them)."""
+    L = lib()
+    means3D, shs, campos = _f32(means3D), _f32(shs), _f32(campos)
+    P, M = int(shs.shape[0]), int(shs.shape[1])
+    g["dL_dsh"] = np.zeros((P, M, 3), np.float32)
+    if P:
+        L.ago_sh_backward(c_i(P), c_i(sh_degree), c_i(M), _p(means3D), _p(campos), _p(shs), _p(st["clamped"]),
+                          _p(st["radii"]), _p(_f32(g["dL_dcolors"])), _p(g["dL_dmeans3D"]), _p(g["dL_dsh"]))
+
+
 def backward(st: Dict[str, np.ndarray], means3D, colors, scales, rotations, bg, viewmatrix, projmatrix,
              tanfovx, tanfovy, dL_dcolor, dL_ddepth, dL_dalpha, scale_modifier: float = 1.0,
-             cov3D_precomp=None, f32_accum: bool = False) -> Dict[str, np.ndarray]:
+             cov3D_precomp=None, f32_accum: bool = False, shs=None, sh_degree: int = 0, campos=None) -> Dict[str, np.ndarray]:
     """Backward given the forward state ``st`` (what the reference keeps in geom/binning/img buffers)."""
+    if colors is None:
+        colors = st["rgb"]
     g = backward_blend(st, colors, bg, dL_dcolor, dL_ddepth, dL_dalpha, f32_accum)
     g.update(backward_preprocess(st, g, means3D, scales, rotations, viewmatrix, projmatrix, tanfovx, tanfovy,
                                  scale_modifier, cov3D_precomp))
+    if shs is not None:
+        backward_sh(st, g, means3D, shs, sh_degree, campos)
     return g
 
 

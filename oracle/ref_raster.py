@@ -51,21 +51,31 @@ class RefRasterizer:
             pass
 
     def forward(self, means3D, colors, opacities, scales, rotations, bg, viewmatrix, projmatrix, campos, tanfovx, tanfovy,
-                img_w, img_h, scale_modifier=1.0, cov3D_precomp=None) -> Dict[str, np.ndarray]:
+                img_w, img_h, scale_modifier=1.0, cov3D_precomp=None, shs=None, sh_degree=0) -> Dict[str, np.ndarray]:
         L = lib()
         self.inp = dict(means3D=_f32(means3D), colors=_f32(colors), opacities=_f32(opacities), scales=_f32(scales),
                         rotations=_f32(rotations), bg=_f32(bg), view=_f32(viewmatrix), proj=_f32(projmatrix),
-                        campos=_f32(campos), cov3D_precomp=_f32(cov3D_precomp))
+                        campos=_f32(campos), cov3D_precomp=_f32(cov3D_precomp), shs=_f32(shs))
+        self.sh_degree = int(sh_degree)
         i = self.inp
         P, W, H = int(i["means3D"].shape[0]), int(img_w), int(img_h)
         T = ((W + 15) // 16) * ((H + 15) // 16)
         self.tan = (float(tanfovx), float(tanfovy), float(scale_modifier))
         st = {"color": np.zeros((3, H, W), np.float32), "depth": np.zeros((1, H, W), np.float32),
               "alpha": np.zeros((1, H, W), np.float32), "radii": np.zeros(P, np.int32)}
-        R = L.ref_forward(self.h, c_i(P), c_i(W), c_i(H), _p(i["bg"]), _p(i["means3D"]), _p(i["colors"]),
-                          _p(i["opacities"]), _p(i["scales"]), c_f(scale_modifier), _p(i["rotations"]),
-                          _p(i["cov3D_precomp"]), _p(i["view"]), _p(i["proj"]), _p(i["campos"]), c_f(tanfovx),
-                          c_f(tanfovy), _p(st["color"]), _p(st["depth"]), _p(st["alpha"]), _p(st["radii"]))
+        if i["shs"] is None:
+            R = L.ref_forward(self.h, c_i(P), c_i(W), c_i(H), _p(i["bg"]), _p(i["means3D"]), _p(i["colors"]),
+                              _p(i["opacities"]), _p(i["scales"]), c_f(scale_modifier), _p(i["rotations"]),
+                              _p(i["cov3D_precomp"]), _p(i["view"]), _p(i["proj"]), _p(i["campos"]), c_f(tanfovx),
+                              c_f(tanfovy), _p(st["color"]), _p(st["depth"]), _p(st["alpha"]), _p(st["radii"]))
+        else:
+            R = L.ref_forward_sh(self.h, c_i(P), c_i(self.sh_degree), c_i(i["shs"].shape[1]), c_i(W), c_i(H), _p(i["bg"]),
+                                 _p(i["means3D"]), _p(i["shs"]), _p(i["opacities"]), _p(i["scales"]), c_f(scale_modifier),
+                                 _p(i["rotations"]), _p(i["cov3D_precomp"]), _p(i["view"]), _p(i["proj"]), _p(i["campos"]),
+                                 c_f(tanfovx), c_f(tanfovy), _p(st["color"]), _p(st["depth"]), _p(st["alpha"]), _p(st["radii"]))
+            st["rgb"] = np.zeros((P, 3), np.float32)
+            st["clamped"] = np.zeros((P, 3), np.uint8)
+            L.ref_get_colors(self.h, _p(st["rgb"]), _p(st["clamped"]))
         st["num_rendered"] = R
         st.update(depths=np.zeros(P, np.float32), means2D=np.zeros((P, 2), np.float32), cov3D=np.zeros((P, 6), np.float32),
                   conic_opacity=np.zeros((P, 4), np.float32), tiles_touched=np.zeros(P, np.uint32),
@@ -89,11 +99,21 @@ class RefRasterizer:
              "dL_drotations": np.zeros((P, 4), np.float32)}
         al = _f32(st["alpha"] if alphas is None else alphas)
         a, b, c = _f32(dL_dcolor), _f32(dL_ddepth), _f32(dL_dalpha)
-        L.ref_backward(self.h, _p(i["bg"]), _p(i["means3D"]), _p(i["colors"]), _p(al), _p(i["scales"]), c_f(self.tan[2]),
-                       _p(i["rotations"]), _p(i["cov3D_precomp"]), _p(i["view"]), _p(i["proj"]), _p(i["campos"]),
-                       c_f(self.tan[0]), c_f(self.tan[1]), _p(st["radii"]), _p(a), _p(b), _p(c), _p(g["dL_dmeans2D"]),
-                       _p(g["dL_dconic"]), _p(g["dL_dopacity"]), _p(g["dL_dcolors"]), _p(g["dL_ddepths"]),
-                       _p(g["dL_dmeans3D"]), _p(g["dL_dcov3D"]), _p(g["dL_dscales"]), _p(g["dL_drotations"]))
+        if i["shs"] is None:
+            L.ref_backward(self.h, _p(i["bg"]), _p(i["means3D"]), _p(i["colors"]), _p(al), _p(i["scales"]), c_f(self.tan[2]),
+                           _p(i["rotations"]), _p(i["cov3D_precomp"]), _p(i["view"]), _p(i["proj"]), _p(i["campos"]),
+                           c_f(self.tan[0]), c_f(self.tan[1]), _p(st["radii"]), _p(a), _p(b), _p(c), _p(g["dL_dmeans2D"]),
+                           _p(g["dL_dconic"]), _p(g["dL_dopacity"]), _p(g["dL_dcolors"]), _p(g["dL_ddepths"]),
+                           _p(g["dL_dmeans3D"]), _p(g["dL_dcov3D"]), _p(g["dL_dscales"]), _p(g["dL_drotations"]))
+        else:
+            M = int(i["shs"].shape[1])
+            g["dL_dsh"] = np.zeros((P, M, 3), np.float32)
+            L.ref_backward_sh(self.h, c_i(self.sh_degree), c_i(M), _p(i["bg"]), _p(i["means3D"]), _p(i["shs"]), _p(al),
+                              _p(i["scales"]), c_f(self.tan[2]), _p(i["rotations"]), _p(i["cov3D_precomp"]), _p(i["view"]),
+                              _p(i["proj"]), _p(i["campos"]), c_f(self.tan[0]), c_f(self.tan[1]), _p(st["radii"]), _p(a),
+                              _p(b), _p(c), _p(g["dL_dmeans2D"]), _p(g["dL_dconic"]), _p(g["dL_dopacity"]),
+                              _p(g["dL_dcolors"]), _p(g["dL_ddepths"]), _p(g["dL_dmeans3D"]), _p(g["dL_dcov3D"]),
+                              _p(g["dL_dsh"]), _p(g["dL_dscales"]), _p(g["dL_drotations"]))
         return g
 
 

@@ -269,3 +269,54 @@ def test_argument_contract_errors():
         r(inp["means3D"], m2, inp["opacities"], colors_precomp=inp["colors"], scales=inp["scales"], rotations=None)
     with pytest.raises(RuntimeError, match="means3D must have dimensions"):
         r(inp["means3D"][:, :2], m2, inp["opacities"], colors_precomp=inp["colors"], scales=inp["scales"], rotations=inp["rotations"])
+
+
+@pytest.mark.parametrize("deg", [0, 1, 2, 3])
+def test_sh_colour_path_matches_reference_golden(deg):
+    """shs= path of GaussianRasterizer (forward.cu:20-71, backward.cu:20-139) against the fixture the reference's own code
+    produced (tests/golden/make_golden_sh.py): per-Gaussian colours are bit-identical (same fp32 operation order, no FMA
+    contraction in the preprocess kernels), images within 1e-4, gradients within the blend-backward tolerances."""
+    import os
+    import torch
+    from animatablegaussians_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "raster_sh_p600_96x80.npz"))
+    dev = "cuda:0"
+    t = lambda k: torch.from_numpy(np.ascontiguousarray(gold[k])).to(dev)  # noqa: E731
+    W, H = (int(v) for v in gold["in_img_wh"])
+    tanx, tany = (float(v) for v in gold["cam_tanfov"])
+    rs = GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=tanx, tanfovy=tany, bg=t("in_bg"), scale_modifier=1.0,
+                                       viewmatrix=t("cam_viewmatrix"), projmatrix=t("cam_projmatrix"), sh_degree=deg,
+                                       campos=t("cam_campos"), prefiltered=False, debug=False)
+    leaves = {k: t("in_" + k).requires_grad_(True) for k in ("means3D", "shs", "opacities", "scales", "rotations")}
+    m2 = torch.zeros_like(leaves["means3D"], requires_grad=True)
+    color, radii, depth, alpha = GaussianRasterizer(rs)(leaves["means3D"], m2, leaves["opacities"], shs=leaves["shs"],
+                                                        scales=leaves["scales"], rotations=leaves["rotations"])
+    assert np.array_equal(radii.cpu().numpy(), gold[f"d{deg}_st_radii"])
+    for got, key in ((color, "color"), (depth, "depth"), (alpha, "alpha")):
+        assert np.abs(got.detach().cpu().numpy() - gold[f"d{deg}_st_{key}"]).max() <= 1e-4, key
+    # backward on the reference's alpha (the reference's backward restarts from 1 - alpha_out, see DESIGN.md)
+    torch.autograd.backward([color, depth, alpha], [t("in_dL_dcolor"), t("in_dL_ddepth"), t("in_dL_dalpha")])
+    ref_sh = gold[f"d{deg}_g_dL_dsh"]
+    got_sh = leaves["shs"].grad.cpu().numpy()
+    n = (deg + 1) ** 2
+    assert not got_sh[:, n:, :].any() and not got_sh[gold[f"d{deg}_st_radii"] <= 0].any()
+    h.assert_rows_close(got_sh.reshape(len(got_sh), -1), ref_sh.reshape(len(ref_sh), -1), "dL_dsh", rtol=2e-3, row_rtol=2e-4)
+    h.assert_rows_close(leaves["means3D"].grad.cpu().numpy(), gold[f"d{deg}_g_dL_dmeans3D"], "dL_dmeans3D", rtol=2e-3, row_rtol=2e-4)
+    # clamped channels get exactly zero gradient: rows whose three channels are all clamped have dL_dsh == 0
+    all_clamped = gold[f"d{deg}_st_clamped"].all(axis=1) & (gold[f"d{deg}_st_radii"] > 0)
+    assert all_clamped.any() and not got_sh[all_clamped].any()
+
+
+def test_sh_argument_errors():
+    import torch
+    from animatablegaussians_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+    from animatablegaussians_amd._lib import AgNativeError
+    dev = "cuda:0"
+    z = lambda *s: torch.zeros(*s, device=dev)  # noqa: E731
+    rs = GaussianRasterizationSettings(image_height=32, image_width=32, tanfovx=0.5, tanfovy=0.5, bg=z(3), scale_modifier=1.0,
+                                       viewmatrix=torch.eye(4, device=dev), projmatrix=torch.eye(4, device=dev), sh_degree=2,
+                                       campos=z(3), prefiltered=False, debug=False)
+    m = torch.rand(10, 3, device=dev) + 1.0
+    with pytest.raises(AgNativeError):      # degree 2 needs 9 coefficients, 4 given
+        GaussianRasterizer(rs)(m, torch.zeros_like(m), torch.rand(10, 1, device=dev), shs=z(10, 4, 3),
+                               scales=torch.rand(10, 3, device=dev), rotations=torch.rand(10, 4, device=dev))
