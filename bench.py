@@ -168,6 +168,19 @@ def main() -> None:
     value = args.gpus * args.steps / elapsed
     ms_per_step = 1e3 * elapsed / args.steps
 
+    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the committed summary of
+    # the separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes over the same workload is reported (calibrated on
+    # a 256 MiB copy: FETCH_SIZE x2.0 on gfx950, WRITE_SIZE x1.0 -- profiles/traffic_probe.py, traffic_summarize.py).
+    traffic, traffic_src = None, None
+    tpath = os.path.join(ROOT, "profiles", "r01e_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            with open(tpath) as f:
+                traffic = json.load(f)["kernels"]["ag::blend_backward_kernel"]["hbm_bytes"]
+            traffic_src = "profiles/r01e_traffic.json (rocprofv3 PMC passes, bytes per launch)"
+        except Exception:
+            traffic = None
+
     out = {
         "metric": "rendered views/sec (fwd+bwd) @1024^2, ~250k Gaussians",
         "value": round(value, 2), "unit": "views/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
@@ -181,7 +194,7 @@ def main() -> None:
         },
         "roofline": {
             "kernel": "blend_backward_kernel", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": int(alg_dom), "avg_launch_us": round(dom_us, 2), "launches_timed": n_dom,
             "whole_step_algorithmic_GBps": round(alg_step / (ms_per_step * 1e-3) / 1e9, 2),
             "note": "VALU/LDS/atomic-bound kernel reported against HBM as SURVEY.md 8(d) prescribes",

@@ -1,0 +1,47 @@
+"""python profiles/traffic_summarize.py <fetch_dir> <write_dir> out.json
+Per-kernel HBM bytes per launch from two rocprofv3 PMC passes over profiles/traffic_probe.py."""
+import collections
+import csv
+import glob
+import json
+import sys
+
+
+def load(d, counter):
+    f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] == counter:
+            acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    return acc
+
+
+fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
+KB = 1024.0
+cal_bytes = 256 * 1024 * 1024
+
+
+def find(acc, frag):
+    return [(k, v) for k, v in acc.items() if frag in k]
+
+
+# calibration: the clone kernel (a vectorised elementwise copy) with exactly 256 MiB read and written per launch
+cal_f = [v for k, vs in fetch.items() if "direct_copy" in k or "copy" in k.lower() for v in vs if v * KB > 0.2 * cal_bytes]
+cal_w = [v for k, vs in write.items() if "direct_copy" in k or "copy" in k.lower() for v in vs if v * KB > 0.2 * cal_bytes]
+fcorr = cal_bytes / (sum(cal_f) / len(cal_f) * KB) if cal_f else None
+wcorr = cal_bytes / (sum(cal_w) / len(cal_w) * KB) if cal_w else None
+out = {"calibration": {"bytes_each_way": cal_bytes, "fetch_correction": fcorr, "write_correction": wcorr,
+                       "note": "correction = known bytes / (counter * 1024) on a 256 MiB coalesced copy"}, "kernels": {}}
+for name in sorted(set(fetch) | set(write)):
+    if not name.startswith("ag::") and "ag::" not in name:
+        continue
+    f = fetch.get(name, [])
+    w = write.get(name, [])
+    fr = sum(f) / len(f) * KB if f else 0.0
+    wr = sum(w) / len(w) * KB if w else 0.0
+    short = name.split("(")[0].replace("void ", "")
+    out["kernels"][short] = {"launches": max(len(f), len(w)), "fetch_raw_bytes": round(fr), "write_raw_bytes": round(wr),
+                             "fetch_bytes": round(fr * (fcorr or 1.0)), "write_bytes": round(wr * (wcorr or 1.0)),
+                             "hbm_bytes": round(fr * (fcorr or 1.0) + wr * (wcorr or 1.0))}
+json.dump(out, open(sys.argv[3], "w"), indent=1)
+print(json.dumps(out, indent=1))
