@@ -58,8 +58,15 @@ def main() -> None:
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # one rank per GPU over RCCL ("nccl"); AG_DIST_BACKEND=gloo lets the N > 1 control flow be exercised on a box with
+        # fewer GPUs than ranks (ranks then share devices) -- a functional check only, never a measurement
+        backend = os.environ.get("AG_DIST_BACKEND", "nccl")
+        local_rank = local_rank % torch.cuda.device_count()
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
