@@ -52,6 +52,98 @@ __global__ void __launch_bounds__(256) fused_bias_act_kernel(float* __restrict__
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// StyledConv tail in one pass (dual_styleunet.py:598-604): y = lrelu(x + nw * noise[pix] + bias[c], slope) * scale
+// and its backward with the two reductions folded in: gx = gy * (y > 0 ? 1 : slope) * scale,
+// gbias[c] += sum_pix gx, gnw += sum_{c,pix} gx * noise[pix].  One workgroup owns a run of pixels of ONE channel, so
+// the bias is a scalar and both sums are a workgroup reduction + one atomic each.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int kNbaChunk = 4096;   // pixels per workgroup (16 per thread)
+
+__global__ void __launch_bounds__(256) noise_bias_act_forward_kernel(float* __restrict__ y, const float* __restrict__ x,
+                                                                    const float* __restrict__ noise, const float* __restrict__ nw,
+                                                                    const float* __restrict__ bias, int C, int HW, int chunks,
+                                                                    float slope, float scale)
+{
+    const int c = blockIdx.x / chunks, p0 = (blockIdx.x - c * chunks) * kNbaChunk;
+    const float b = bias ? bias[c] : 0.f, w = noise ? nw[0] : 0.f;
+    const float* xr = x + (size_t)c * HW;
+    float* yr = y + (size_t)c * HW;
+    const int pend = min(HW, p0 + kNbaChunk);
+    if ((HW & 3) == 0) {
+        for (int p = p0 + threadIdx.x * 4; p < pend; p += 1024) {
+            const float4 v = *reinterpret_cast<const float4*>(xr + p);
+            float4 n = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (noise) n = *reinterpret_cast<const float4*>(noise + p);
+            float4 o;
+            float t;
+            t = v.x + w * n.x + b; o.x = (t > 0.f ? t : t * slope) * scale;
+            t = v.y + w * n.y + b; o.y = (t > 0.f ? t : t * slope) * scale;
+            t = v.z + w * n.z + b; o.z = (t > 0.f ? t : t * slope) * scale;
+            t = v.w + w * n.w + b; o.w = (t > 0.f ? t : t * slope) * scale;
+            *reinterpret_cast<float4*>(yr + p) = o;
+        }
+    } else {
+        for (int p = p0 + threadIdx.x; p < pend; p += 256) {
+            const float t = xr[p] + (noise ? w * noise[p] : 0.f) + b;
+            yr[p] = (t > 0.f ? t : t * slope) * scale;
+        }
+    }
+}
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__global__ void __launch_bounds__(256) noise_bias_act_backward_kernel(float* __restrict__ gx, const float* __restrict__ gy,
+                                                                     const float* __restrict__ y, const float* __restrict__ noise,
+                                                                     float* __restrict__ gbias, float* __restrict__ gnw, int C,
+                                                                     int HW, int chunks, float slope, float scale)
+{
+    __shared__ float s_red[2][4];
+    const int c = blockIdx.x / chunks, p0 = (blockIdx.x - c * chunks) * kNbaChunk;
+    const float* gyr = gy + (size_t)c * HW;
+    const float* yr = y + (size_t)c * HW;
+    float* gxr = gx + (size_t)c * HW;
+    const int pend = min(HW, p0 + kNbaChunk);
+    float sb = 0.f, sn = 0.f;
+    if ((HW & 3) == 0) {
+        for (int p = p0 + threadIdx.x * 4; p < pend; p += 1024) {
+            const float4 g = *reinterpret_cast<const float4*>(gyr + p);
+            const float4 o = *reinterpret_cast<const float4*>(yr + p);
+            float4 n = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (noise) n = *reinterpret_cast<const float4*>(noise + p);
+            float4 r;
+            r.x = g.x * (o.x > 0.f ? 1.f : slope) * scale;
+            r.y = g.y * (o.y > 0.f ? 1.f : slope) * scale;
+            r.z = g.z * (o.z > 0.f ? 1.f : slope) * scale;
+            r.w = g.w * (o.w > 0.f ? 1.f : slope) * scale;
+            *reinterpret_cast<float4*>(gxr + p) = r;
+            sb += (r.x + r.y) + (r.z + r.w);
+            sn += (r.x * n.x + r.y * n.y) + (r.z * n.z + r.w * n.w);
+        }
+    } else {
+        for (int p = p0 + threadIdx.x; p < pend; p += 256) {
+            const float r = gyr[p] * (yr[p] > 0.f ? 1.f : slope) * scale;
+            gxr[p] = r;
+            sb += r;
+            if (noise) sn += r * noise[p];
+        }
+    }
+    sb = wave_sum(sb);
+    sn = wave_sum(sn);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s_red[0][wave] = sb; s_red[1][wave] = sn; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (gbias) atomicAdd(gbias + c, (s_red[0][0] + s_red[0][1]) + (s_red[0][2] + s_red[0][3]));
+        if (gnw) atomicAdd(gnw, (s_red[1][0] + s_red[1][1]) + (s_red[1][2] + s_red[1][3]));
+    }
+}
+
 __device__ __forceinline__ int floor_div(int a, int b)
 {
     int c = a / b;
@@ -121,6 +213,37 @@ int ag_fused_bias_act(float* out, const float* x, const float* bias, const float
     hipLaunchKernelGGL(fused_bias_act_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), out, x, bias,
                        ref, mode, alpha, scale, (long long)size_x, (long long)step_b, (int)size_b, vec_ok);
     return check_hip(hipGetLastError(), "fused_bias_act_kernel");
+}
+
+int ag_noise_bias_act_forward(float* y, const float* x, const float* noise, const float* noise_weight, const float* bias,
+                              int32_t C, int32_t HW, float slope, float scale, void* stream)
+{
+    if (C < 0 || HW < 0 || ((C > 0 && HW > 0) && (!y || !x)) || (noise && !noise_weight)) {
+        set_error("bad noise_bias_act arguments");
+        return AG_ERR_INVALID_ARGUMENT;
+    }
+    if (C == 0 || HW == 0) return AG_OK;
+    const int chunks = (HW + kNbaChunk - 1) / kNbaChunk;
+    hipLaunchKernelGGL(noise_bias_act_forward_kernel, dim3(C * chunks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), y, x,
+                       noise, noise_weight, bias, C, HW, chunks, slope, scale);
+    return check_hip(hipGetLastError(), "noise_bias_act_forward_kernel");
+}
+
+int ag_noise_bias_act_backward(float* gx, const float* gy, const float* y, const float* noise, float* gbias, float* gnoise_weight,
+                               int32_t C, int32_t HW, float slope, float scale, void* stream)
+{
+    if (C < 0 || HW < 0 || ((C > 0 && HW > 0) && (!gx || !gy || !y)) || (gnoise_weight && !noise)) {
+        set_error("bad noise_bias_act_backward arguments");
+        return AG_ERR_INVALID_ARGUMENT;
+    }
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (gbias && check_hip(hipMemsetAsync(gbias, 0, (size_t)C * sizeof(float), s), "memset gbias")) return AG_ERR_HIP;
+    if (gnoise_weight && check_hip(hipMemsetAsync(gnoise_weight, 0, sizeof(float), s), "memset gnw")) return AG_ERR_HIP;
+    if (C == 0 || HW == 0) return AG_OK;
+    const int chunks = (HW + kNbaChunk - 1) / kNbaChunk;
+    hipLaunchKernelGGL(noise_bias_act_backward_kernel, dim3(C * chunks), dim3(256), 0, s, gx, gy, y, noise, gbias, gnoise_weight, C,
+                       HW, chunks, slope, scale);
+    return check_hip(hipGetLastError(), "noise_bias_act_backward_kernel");
 }
 
 int ag_upfirdn2d(float* out, const float* input, const float* kernel, int32_t major, int32_t in_h, int32_t in_w,

@@ -24,7 +24,7 @@ import torch
 import torch.nn.functional as F
 
 from . import conv as agc
-from .styleunet_ops import fused_leaky_relu, upfirdn2d_nchw
+from .styleunet_ops import fused_leaky_relu, noise_bias_act, upfirdn2d_nchw
 
 _SQRT2 = 2 ** 0.5
 
@@ -169,7 +169,7 @@ class DualStyleUNet(torch.nn.Module):
             x = agc.conv2d(x, w, stride=2, padding=0)
         else:
             x = agc.conv2d(x, w, stride=1, padding=k // 2)
-        return fused_leaky_relu(x, self._p(f"{prefix}.{base + 1}.bias"))
+        return noise_bias_act(x, None, None, self._p(f"{prefix}.{base + 1}.bias"))
 
     def _modulated_weight(self, prefix, w_latent, demodulate):
         w = self._p(f"{prefix}.weight")                                  # [1, Cout, Cin, k, k]
@@ -191,8 +191,8 @@ class DualStyleUNet(torch.nn.Module):
             x = agc.conv2d(x, weight, stride=1, padding=1)
         if noise is None:
             noise = torch.randn(1, 1, x.shape[2], x.shape[3], device=x.device, dtype=x.dtype)
-        x = x + self._p(f"{prefix}.noise.weight") * noise                # NoiseInjection (:301-311)
-        return fused_leaky_relu(x, self._p(f"{prefix}.activate.bias"))
+        # NoiseInjection (:301-311) + FusedLeakyReLU (:596) in one pass
+        return noise_bias_act(x, noise, self._p(f"{prefix}.noise.weight"), self._p(f"{prefix}.activate.bias"))
 
     def _haar_split(self, x):                                             # HaarTransform (:387-403)
         return torch.cat([upfirdn2d_nchw(x, getattr(self, "_dwt_" + n), down=2) for n in ("ll", "lh", "hl", "hh")], 1)

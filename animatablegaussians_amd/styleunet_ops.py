@@ -158,3 +158,46 @@ def upfirdn2d_nchw(input, kernel, up=1, down=1, pad=(0, 0)):
     if len(pad) == 2:
         pad = (pad[0], pad[1], pad[0], pad[1])
     return _UpFirDn2d.apply(input, kernel, up, down, pad)
+
+
+class _NoiseBiasAct(torch.autograd.Function):
+    """StyledConv tail ``lrelu(x + w * noise + bias) * sqrt(2)`` in one kernel each way (include/ag_styleunet.h)."""
+
+    @staticmethod
+    def forward(ctx, x, noise, noise_weight, bias, slope, scale):
+        if x.dim() != 4 or x.shape[0] != 1 or not x.is_cuda or x.dtype != torch.float32:
+            raise RuntimeError("noise_bias_act: float32 GPU tensor [1, C, H, W]")
+        x = x.contiguous()
+        C, HW = int(x.shape[1]), int(x.shape[2] * x.shape[3])
+        if noise is not None:
+            noise = noise.contiguous()
+            if noise.numel() != HW:
+                raise RuntimeError("noise must be [1, 1, H, W]")
+        y = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().ag_noise_bias_act_forward(_p(y), _p(x), _p(noise), _p(noise_weight), _p(bias), C, HW,
+                                                            float(slope), float(scale), _stream(x.device)),
+                       "ag_noise_bias_act_forward")
+        ctx.save_for_backward(y, noise)
+        ctx.cfg = (C, HW, float(slope), float(scale), noise_weight is not None and noise is not None, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        y, noise = ctx.saved_tensors
+        C, HW, slope, scale, has_nw, has_bias = ctx.cfg
+        gy = gy.contiguous()
+        gx = torch.empty_like(y)
+        gb = torch.empty(C, dtype=torch.float32, device=y.device) if has_bias else None
+        gw = torch.empty(1, dtype=torch.float32, device=y.device) if has_nw else None
+        with torch.cuda.device(y.device):
+            _lib.check(_lib.lib().ag_noise_bias_act_backward(_p(gx), _p(gy), _p(y), _p(noise) if has_nw else None, _p(gb), _p(gw),
+                                                             C, HW, slope, scale, _stream(y.device)),
+                       "ag_noise_bias_act_backward")
+        return gx, None, gw, gb, None, None
+
+
+def noise_bias_act(x, noise, noise_weight, bias, negative_slope=0.2, scale=2 ** 0.5):
+    """``fused_leaky_relu(x + noise_weight * noise, bias)`` (NoiseInjection + FusedLeakyReLU) without the intermediate
+    tensors; ``noise`` / ``bias`` may be None.  No gradient flows to ``noise`` (a fixed buffer or a fresh random draw)."""
+    return _NoiseBiasAct.apply(x, noise, noise_weight if noise is not None else None, bias, float(negative_slope), float(scale))

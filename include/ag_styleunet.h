@@ -39,6 +39,25 @@ int ag_upfirdn2d(float* out, const float* input, const float* kernel, int32_t ma
                  int32_t kernel_h, int32_t kernel_w, int32_t up_x, int32_t up_y, int32_t down_x, int32_t down_y,
                  int32_t pad_x0, int32_t pad_x1, int32_t pad_y0, int32_t pad_y1, void* stream);
 
+/*
+ * The tail of StyledConv / ConvLayer in one pass (network/styleunet/dual_styleunet.py:303-313,598-604 = NoiseInjection
+ * followed by FusedLeakyReLU; :367-369 without noise), batch 1:
+ *   y[c][p] = lrelu(x[c][p] + noise_weight[0] * noise[p] + bias[c], slope) * scale        x, y [C][HW], noise [HW]
+ * noise == NULL: no noise term; bias == NULL: no bias.  Same arithmetic as `image + weight * noise` followed by
+ * fused_bias_act(act 3, grad 0).
+ */
+int ag_noise_bias_act_forward(float* y, const float* x, const float* noise, const float* noise_weight, const float* bias,
+                              int32_t C, int32_t HW, float slope, float scale, void* stream);
+
+/*
+ * Backward of the above from the saved OUTPUT y (the sign of y selects the slope, fused_bias_act_kernel.cu:41):
+ *   gx = gy * (y > 0 ? 1 : slope) * scale;  gbias[c] = sum_p gx[c][p];  gnoise_weight[0] = sum_{c,p} gx[c][p] * noise[p]
+ * gbias / gnoise_weight may be NULL (not needed); they are overwritten (zeroed, then accumulated with float atomics, one per
+ * workgroup).
+ */
+int ag_noise_bias_act_backward(float* gx, const float* gy, const float* y, const float* noise, float* gbias, float* gnoise_weight,
+                               int32_t C, int32_t HW, float slope, float scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -103,3 +103,39 @@ def test_hip_ops_at_styleunet_sizes_vs_oracle():
     np.testing.assert_allclose(got.cpu().numpy()[..., 0], want.numpy(), rtol=1e-5, atol=1e-6)
     with pytest.raises(RuntimeError):
         ops.upfirdn2d(torch.zeros(1, 2, 2, 1, device="cuda"), torch.zeros(4, 4, device="cuda"), 1, 1, 1, 1, 0, 0, 0, 0)   # empty output
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,with_noise,with_bias", [((1, 5, 33, 31), True, True), ((1, 8, 64, 64), True, True),
+                                                         ((1, 3, 16, 20), False, True), ((1, 4, 72, 72), True, False)])
+def test_noise_bias_act_matches_the_unfused_oracle(shape, with_noise, with_bias):
+    """StyledConv tail (NoiseInjection + FusedLeakyReLU, dual_styleunet.py:303-313,598-604) fused into one kernel each way,
+    vs `x + w * noise` followed by the fused_bias_act oracle on CPU with autograd.  Odd pixel counts take the scalar path."""
+    import torch
+    from animatablegaussians_amd.styleunet_ops import noise_bias_act
+    from oracle import styleunet_oracle as so
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(*shape, generator=g)
+    noise = torch.randn(1, 1, shape[2], shape[3], generator=g) if with_noise else None
+    nw = torch.randn(1, generator=g)
+    b = torch.randn(shape[1], generator=g) if with_bias else None
+    gy = torch.randn(*shape, generator=g)
+    xc = x.clone().requires_grad_(True)
+    nwc = nw.clone().requires_grad_(True)
+    bc = b.clone().requires_grad_(True) if with_bias else None
+    pre = xc + nwc * noise if with_noise else xc
+    yc = so.fused_bias_act(pre, bc, None, 3, 0, 0.2, 2 ** 0.5)
+    yc.backward(gy)
+    xg = x.cuda().requires_grad_(True)
+    nwg = nw.cuda().requires_grad_(True)
+    bg = b.cuda().requires_grad_(True) if with_bias else None
+    yg = noise_bias_act(xg, noise.cuda() if with_noise else None, nwg, bg)
+    yg.backward(gy.cuda())
+    np.testing.assert_allclose(yg.detach().cpu().numpy(), yc.detach().numpy(), rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), xc.grad.numpy(), rtol=1e-6, atol=1e-6)
+    if with_bias:
+        np.testing.assert_allclose(bg.grad.cpu().numpy(), bc.grad.numpy(), rtol=1e-4, atol=1e-4)
+    if with_noise:
+        np.testing.assert_allclose(nwg.grad.cpu().numpy(), nwc.grad.numpy(), rtol=1e-4, atol=2e-3)
+    else:
+        assert nwg.grad is None
