@@ -352,7 +352,8 @@ __global__ void __launch_bounds__(64 * WVM * WVN) wgrad_kernel(WgradProblem p)
 {
     using T = Tile<WMB, WNB, WVM, WVN>;
     constexpr int BM = T::BM, BN = T::BN, NT = T::NT;
-    constexpr int BC = BN / (NT / 16);                 // B loader: columns per thread
+    constexpr int BSTEP = NT / 16;                     // B loader: columns covered per pass
+    constexpr int BC = BN / BSTEP;                     // columns per thread
     static_assert(BM * 4 <= NT, "A loader: one row quarter per thread");
     __shared__ __attribute__((aligned(16))) float smem[T::lds_floats];
     float* const As0 = smem;
@@ -365,13 +366,27 @@ __global__ void __launch_bounds__(64 * WVM * WVN) wgrad_kernel(WgradProblem p)
     const int kbeg = blockIdx.z * p.ksplit_len, kend = min(Kp, kbeg + p.ksplit_len);
     if (kbeg >= kend) return;
 
-    // A loader: row am, 4 consecutive pixels aq..aq+3 (A is pixel-contiguous) -> one b128 LDS write
+    // A loader: row am, 4 consecutive pixels aq..aq+3 (A is pixel-contiguous) -> one dwordx4 load, one b128 LDS write
     const int am = tid >> 2, aq = (tid & 3) * 4;
-    const bool a_thread = am < BM;
-    // B loader: pixel bk = tid & 15 of the tile, columns bn, bn + NT/16, ...; lanes run along pixels
-    constexpr int BSTEP = NT / 16;
+    const bool a_thread = am < BM && (m0 + am) < p.Mw;
+    const float* a_row = p.a + (size_t)min(m0 + am, p.Mw - 1) * Kp;
+    const bool a_vec = (Kp & 3) == 0;                  // rows 16-byte aligned, every 4-group entirely inside or outside [kbeg, kend)
+    // B loader: pixel bk of the tile (lanes run along pixels), columns bn, bn + BSTEP, ...; a column = (channel, tap) is fixed per
+    // thread for the whole kernel: its plane + tap offset and its tap displacement live in registers
     const int bk = tid & 15, bn = tid >> 4;
-    const size_t plane = (size_t)p.Hg * p.Wg;
+    const int plane = p.Hg * p.Wg;
+    int col_off[BC], col_dy[BC], col_dx[BC];
+#pragma unroll
+    for (int j = 0; j < BC; j++) {
+        const int nn = n0 + bn + BSTEP * j;
+        const int c = min(nn / p.ntaps, p.Cg - 1), t = nn % p.ntaps;
+        col_dy[j] = (nn < Nw) ? p.dy[t] : (1 << 28);               // out-of-range columns fail the bounds test below
+        col_dx[j] = p.dx[t];
+        col_off[j] = c * plane + p.dy[t] * p.Wg + p.dx[t];
+    }
+    // this thread's pixel of the NEXT tile to load, tracked incrementally (no division in the loop)
+    int kpix = kbeg + bk;
+    int gy = kpix / p.gw, gx = kpix - gy * p.gw;
 
     f32x16 acc[WMB][WNB];
 #pragma unroll
@@ -381,60 +396,91 @@ __global__ void __launch_bounds__(64 * WVM * WVN) wgrad_kernel(WgradProblem p)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-    float ra[4];
-    float rb[BC];
-    // per-thread column descriptors (channel plane offset, tap offsets) are fixed for the whole kernel
-    int col_c[BC], col_dy[BC], col_dx[BC];
+    struct Stage {
+        f32x4 ra;
+        float rb[BC];
+        uint32_t ok;        // bit j: rb[j] is a real sample; bit 31: ra is real
+    };
+    Stage S[2];
+    Operands<WMB, WNB> O[2];
+    auto gload = [&](int k0, Stage& st) {
+        const int ka = k0 + aq;
+        const bool a_ok = a_thread && ka < kend;
+        if (a_vec) {
+            st.ra = *reinterpret_cast<const f32x4*>(a_row + (a_ok ? ka : 0));
+        } else {
 #pragma unroll
-    for (int j = 0; j < BC; j++) {
-        const int nn = n0 + bn + BSTEP * j;
-        const int c = nn / p.ntaps, t = nn - c * p.ntaps;
-        col_c[j] = (nn < Nw) ? c : -1;
-        col_dy[j] = p.dy[t];
-        col_dx[j] = p.dx[t];
-    }
-
-    auto load_tile = [&](int k0) {
-        {
-            const int m = m0 + am;
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int k = k0 + aq + q;
-                ra[q] = (a_thread && m < p.Mw && k < kend) ? p.a[(size_t)m * Kp + k] : 0.f;
-            }
+            for (int q = 0; q < 4; q++) st.ra[q] = (a_ok && ka + q < kend) ? a_row[ka + q] : 0.f;
         }
-        const int k = k0 + bk;
-        const bool k_ok = k < kend;
-        const int gy = k_ok ? k / p.gw : 0, gx = k_ok ? k - (k / p.gw) * p.gw : 0;
+        uint32_t ok = a_ok ? 0x80000000u : 0u;
+        const bool k_ok = kpix < kend;
         const int iy0 = gy * p.sy, ix0 = gx * p.sx;
+        const int pixoff = iy0 * p.Wg + ix0;
 #pragma unroll
         for (int j = 0; j < BC; j++) {
-            const int iy = iy0 + col_dy[j], ix = ix0 + col_dx[j];
-            const bool ok = k_ok && (col_c[j] >= 0) && (iy >= 0) && (iy < p.Hg) && (ix >= 0) && (ix < p.Wg);
-            rb[j] = ok ? p.xin[(size_t)col_c[j] * plane + (size_t)iy * p.Wg + ix] : 0.f;
+            const bool in = k_ok && (unsigned)(iy0 + col_dy[j]) < (unsigned)p.Hg && (unsigned)(ix0 + col_dx[j]) < (unsigned)p.Wg;
+            st.rb[j] = p.xin[in ? col_off[j] + pixoff : 0];
+            ok |= in ? (1u << j) : 0u;
         }
+        st.ok = ok;
+        kpix += BK;
+        gx += BK;
+        while (gx >= p.gw) { gx -= p.gw; gy++; }
     };
-    auto store_tile = [&](int buf) {
+    auto lstore = [&](int buf, const Stage& st) {
         float* As = As0 + buf * BM * LDK;
         float* Bs = Bs0 + buf * BN * LDK;
-        if (a_thread) {
-            f32x4 v = { ra[0], ra[1], ra[2], ra[3] };
+        if (am < BM) {
+            f32x4 v = st.ra;
+            if (!(st.ok >> 31)) v = f32x4{ 0.f, 0.f, 0.f, 0.f };
             *reinterpret_cast<f32x4*>(As + am * LDK + aq) = v;
         }
 #pragma unroll
-        for (int j = 0; j < BC; j++) Bs[(bn + BSTEP * j) * LDK + bk] = rb[j];
+        for (int j = 0; j < BC; j++) Bs[(bn + BSTEP * j) * LDK + bk] = ((st.ok >> j) & 1u) ? st.rb[j] : 0.f;
+    };
+    auto lread = [&](int buf, Operands<WMB, WNB>& o) {
+        read_operands<WMB, WNB>(As0 + buf * BM * LDK, Bs0 + buf * BN * LDK, wm, wn, lane, o);
     };
 
+    // same three-stage pipeline as gather_conv_kernel
     const int nkt = (kend - kbeg + BK - 1) / BK;
-    load_tile(kbeg);
-    store_tile(0);
+    gload(kbeg, S[0]);
+    if (nkt > 1) gload(kbeg + BK, S[1]);
+    lstore(0, S[0]);
     lds_barrier();
-    for (int kt = 0; kt < nkt; kt++) {
-        const bool more = kt + 1 < nkt;
-        if (more) load_tile(kbeg + (kt + 1) * BK);
-        mma_tile<WMB, WNB>(As0 + (kt & 1) * BM * LDK, Bs0 + (kt & 1) * BN * LDK, wm, wn, lane, acc);
-        if (more) store_tile((kt + 1) & 1);
+    lread(0, O[0]);
+    auto step_full = [&](int kt, Stage& s_same, Stage& s_next, Operands<WMB, WNB>& o_cur, Operands<WMB, WNB>& o_next) {
+        gload(kbeg + (kt + 2) * BK, s_same);
+        mma_half<WMB, WNB>(o_cur, 0, acc);
+        lstore((kt + 1) & 1, s_next);
         lds_barrier();
+        lread((kt + 1) & 1, o_next);
+        mma_half<WMB, WNB>(o_cur, 1, acc);
+    };
+    auto step_tail = [&](int kt, Stage& s_next, Operands<WMB, WNB>& o_cur, Operands<WMB, WNB>& o_next, bool has_next) {
+        mma_half<WMB, WNB>(o_cur, 0, acc);
+        if (has_next) {
+            lstore((kt + 1) & 1, s_next);
+            lds_barrier();
+            lread((kt + 1) & 1, o_next);
+        }
+        mma_half<WMB, WNB>(o_cur, 1, acc);
+    };
+    int kt = 0;
+    for (; kt + 3 < nkt; kt += 2) {
+        step_full(kt, S[0], S[1], O[0], O[1]);
+        step_full(kt + 1, S[1], S[0], O[1], O[0]);
+    }
+    const int rem = nkt - kt;
+    if (rem == 3) {
+        step_full(kt, S[0], S[1], O[0], O[1]);
+        step_tail(kt + 1, S[0], O[1], O[0], true);
+        step_tail(kt + 2, S[1], O[0], O[1], false);
+    } else if (rem == 2) {
+        step_tail(kt, S[1], O[0], O[1], true);
+        step_tail(kt + 1, S[0], O[1], O[0], false);
+    } else {
+        step_tail(kt, S[1], O[0], O[1], false);
     }
 
     const int col = lane & 31, rbase = 4 * (lane >> 5);
