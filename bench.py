@@ -107,8 +107,11 @@ def main() -> None:
         if world > 1:
             # exchange step of view sharding: sum the per-Gaussian attribute gradients over the views of this step
             comm_stream.wait_stream(torch.cuda.current_stream(dev))
+            grads = [means3D.grad, scales.grad, rotations.grad, opacities.grad, colors.grad]
             with torch.cuda.stream(comm_stream):
-                torch.cat([means3D.grad, scales.grad, rotations.grad, opacities.grad, colors.grad], dim=1, out=grad_pack)
+                for g in grads:
+                    g.record_stream(comm_stream)      # their memory is released below while the side stream still reads it
+                torch.cat(grads, dim=1, out=grad_pack)
                 dist.all_reduce(grad_pack)
         for leaf in leaves:
             leaf.grad = None
