@@ -95,6 +95,10 @@ SYMBOLS = [
                                                ctypes.c_float, c_vp]),
     ("ag_noise_bias_act_backward", ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_int32, ctypes.c_int32,
                                                 ctypes.c_float, ctypes.c_float, c_vp]),
+    ("ag_modulate_weight_forward", ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, ctypes.c_float, ctypes.c_int32, ctypes.c_int32,
+                                                ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_vp]),
+    ("ag_modulate_weight_backward", ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_float, ctypes.c_int32,
+                                                 ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_vp]),
     ("ag_debug_mfma_rate", ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_vp, c_vp]),
     # include/ag_avatar.h
     ("ag_gather_activate_forward", ctypes.c_int, [ctypes.POINTER(AgGatherArgs), c_vp]),

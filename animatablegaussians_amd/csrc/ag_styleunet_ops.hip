@@ -144,6 +144,83 @@ __global__ void __launch_bounds__(256) noise_bias_act_backward_kernel(float* __r
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Weight modulation + demodulation of ModulatedConv2d's fused branch (dual_styleunet.py:254-259), one workgroup per
+// output channel:  w'[co][ci][k] = (scale * W[co][ci][k]) * style[ci];  d[co] = rsqrt(sum w'^2 + 1e-8);  out = w' * d.
+// `transposed` writes out[ci][co][k] (the layout conv_transpose2d takes, :268-272).
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum_256(float v, float* s_red)
+{
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const float r = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+    __syncthreads();
+    return r;
+}
+
+__global__ void __launch_bounds__(256) modulate_weight_forward_kernel(float* __restrict__ out, float* __restrict__ dcoef,
+                                                                     const float* __restrict__ W, const float* __restrict__ style,
+                                                                     float scale, int demod, int Co, int Ci, int K2, int transposed)
+{
+    __shared__ float s_red[4];
+    const int co = blockIdx.x, n = Ci * K2;
+    const float* w = W + (size_t)co * n;
+    float q = 0.f;
+    if (demod) {
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const float v = (scale * w[i]) * style[i / K2];
+            q += v * v;
+        }
+        q = block_sum_256(q, s_red);
+    }
+    const float d = demod ? rsqrtf(q + 1e-8f) : 1.0f;
+    if (threadIdx.x == 0 && dcoef) dcoef[co] = d;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int ci = i / K2, k = i - ci * K2;
+        const float v = (scale * w[i]) * style[ci];
+        const size_t o = transposed ? ((size_t)ci * Co + co) * K2 + k : (size_t)co * n + i;
+        out[o] = demod ? v * d : v;
+    }
+}
+
+// g = dL/dout.  dL/dw' = g * d - d^3 * (sum g w') * w'   (g when there is no demodulation);
+// dW = dL/dw' * scale * style[ci];  dstyle[ci] += sum_{co, k} dL/dw' * scale * W     (float atomics over co)
+__global__ void __launch_bounds__(256) modulate_weight_backward_kernel(float* __restrict__ dW, float* __restrict__ dstyle,
+                                                                      const float* __restrict__ g, const float* __restrict__ W,
+                                                                      const float* __restrict__ style, const float* __restrict__ dcoef,
+                                                                      float scale, int demod, int Co, int Ci, int K2, int transposed)
+{
+    __shared__ float s_red[4];
+    const int co = blockIdx.x, n = Ci * K2;
+    const float* w = W + (size_t)co * n;
+    float gw = 0.f;
+    const float d = demod ? dcoef[co] : 1.0f;
+    if (demod) {
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const int ci = i / K2, k = i - ci * K2;
+            const size_t o = transposed ? ((size_t)ci * Co + co) * K2 + k : (size_t)co * n + i;
+            gw += g[o] * ((scale * w[i]) * style[ci]);
+        }
+        gw = block_sum_256(gw, s_red);
+    }
+    const float c3 = d * d * d * gw;
+    // one thread per input channel keeps the K2 taps of that channel together: a single atomic per (co, ci)
+    for (int ci = threadIdx.x; ci < Ci; ci += 256) {
+        const float sc = scale * style[ci];
+        float ds = 0.f;
+        for (int k = 0; k < K2; k++) {
+            const int i = ci * K2 + k;
+            const size_t o = transposed ? ((size_t)ci * Co + co) * K2 + k : (size_t)co * n + i;
+            const float sw = scale * w[i];
+            const float gp = demod ? g[o] * d - c3 * (sw * style[ci]) : g[o];
+            dW[(size_t)co * n + i] = gp * sc;
+            ds += gp * sw;
+        }
+        atomicAdd(dstyle + ci, ds);
+    }
+}
+
 __device__ __forceinline__ int floor_div(int a, int b)
 {
     int c = a / b;
@@ -244,6 +321,29 @@ int ag_noise_bias_act_backward(float* gx, const float* gy, const float* y, const
     hipLaunchKernelGGL(noise_bias_act_backward_kernel, dim3(C * chunks), dim3(256), 0, s, gx, gy, y, noise, gbias, gnoise_weight, C,
                        HW, chunks, slope, scale);
     return check_hip(hipGetLastError(), "noise_bias_act_backward_kernel");
+}
+
+int ag_modulate_weight_forward(float* out, float* dcoef, const float* W, const float* style, float scale, int32_t demodulate,
+                               int32_t Co, int32_t Ci, int32_t K2, int32_t transposed, void* stream)
+{
+    if (Co <= 0 || Ci <= 0 || K2 <= 0 || !out || !W || !style) { set_error("bad modulate_weight arguments"); return AG_ERR_INVALID_ARGUMENT; }
+    hipLaunchKernelGGL(modulate_weight_forward_kernel, dim3(Co), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), out, dcoef, W,
+                       style, scale, demodulate, Co, Ci, K2, transposed);
+    return check_hip(hipGetLastError(), "modulate_weight_forward_kernel");
+}
+
+int ag_modulate_weight_backward(float* dW, float* dstyle, const float* g, const float* W, const float* style, const float* dcoef,
+                                float scale, int32_t demodulate, int32_t Co, int32_t Ci, int32_t K2, int32_t transposed, void* stream)
+{
+    if (Co <= 0 || Ci <= 0 || K2 <= 0 || !dW || !dstyle || !g || !W || !style || (demodulate && !dcoef)) {
+        set_error("bad modulate_weight_backward arguments");
+        return AG_ERR_INVALID_ARGUMENT;
+    }
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (check_hip(hipMemsetAsync(dstyle, 0, (size_t)Ci * sizeof(float), s), "memset dstyle")) return AG_ERR_HIP;
+    hipLaunchKernelGGL(modulate_weight_backward_kernel, dim3(Co), dim3(256), 0, s, dW, dstyle, g, W, style, dcoef, scale, demodulate,
+                       Co, Ci, K2, transposed);
+    return check_hip(hipGetLastError(), "modulate_weight_backward_kernel");
 }
 
 int ag_upfirdn2d(float* out, const float* input, const float* kernel, int32_t major, int32_t in_h, int32_t in_w,

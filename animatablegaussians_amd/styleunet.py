@@ -24,7 +24,7 @@ import torch
 import torch.nn.functional as F
 
 from . import conv as agc
-from .styleunet_ops import fused_leaky_relu, noise_bias_act, upfirdn2d_nchw
+from .styleunet_ops import fused_leaky_relu, modulate_weight, noise_bias_act, upfirdn2d_nchw
 
 _SQRT2 = 2 ** 0.5
 
@@ -171,21 +171,18 @@ class DualStyleUNet(torch.nn.Module):
             x = agc.conv2d(x, w, stride=1, padding=k // 2)
         return noise_bias_act(x, None, None, self._p(f"{prefix}.{base + 1}.bias"))
 
-    def _modulated_weight(self, prefix, w_latent, demodulate):
+    def _modulated_weight(self, prefix, w_latent, demodulate, transposed=False):
         w = self._p(f"{prefix}.weight")                                  # [1, Cout, Cin, k, k]
         mw, mb = self._p(f"{prefix}.modulation.weight"), self._p(f"{prefix}.modulation.bias")
         style = F.linear(w_latent, mw * (1 / math.sqrt(mw.shape[1])), bias=mb * 1.0)    # EqualLinear, lr_mul 1 (:152-155)
         k = w.shape[-1]
-        weight = (1 / math.sqrt(w.shape[2] * k * k)) * w * style.view(1, 1, -1, 1, 1)  # (:254-255)
-        if demodulate:
-            demod = torch.rsqrt(weight.pow(2).sum([2, 3, 4]) + 1e-8)
-            weight = weight * demod.view(1, -1, 1, 1, 1)
-        return weight[0]                                                  # [Cout, Cin, k, k]
+        # (scale * W) * style, demodulated (:254-259), in one kernel; [Cout, Cin, k, k] or transposed for conv_transpose2d
+        return modulate_weight(w, style, 1 / math.sqrt(w.shape[2] * k * k), demodulate, transposed)
 
     def _styled_conv(self, x, prefix, w_latent, noise, upsample):
-        weight = self._modulated_weight(f"{prefix}.conv", w_latent, True)
+        weight = self._modulated_weight(f"{prefix}.conv", w_latent, True, transposed=upsample)
         if upsample:
-            x = agc.conv_transpose2d(x, weight.transpose(0, 1).contiguous(), stride=2, padding=0)
+            x = agc.conv_transpose2d(x, weight, stride=2, padding=0)
             x = upfirdn2d_nchw(x, self._k_blur_up, pad=(1, 1))           # p = (4 - 2) - (3 - 1) = 0 -> pad (1, 1) (:188-193)
         else:
             x = agc.conv2d(x, weight, stride=1, padding=1)

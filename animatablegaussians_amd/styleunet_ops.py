@@ -201,3 +201,43 @@ def noise_bias_act(x, noise, noise_weight, bias, negative_slope=0.2, scale=2 ** 
     """``fused_leaky_relu(x + noise_weight * noise, bias)`` (NoiseInjection + FusedLeakyReLU) without the intermediate
     tensors; ``noise`` / ``bias`` may be None.  No gradient flows to ``noise`` (a fixed buffer or a fresh random draw)."""
     return _NoiseBiasAct.apply(x, noise, noise_weight if noise is not None else None, bias, float(negative_slope), float(scale))
+
+
+class _ModulateWeight(torch.autograd.Function):
+    """``(scale * W) * style`` with optional demodulation (ModulatedConv2d, fused branch) in one kernel each way."""
+
+    @staticmethod
+    def forward(ctx, weight, style, scale, demodulate, transposed):
+        w = weight.contiguous()
+        st = style.contiguous()
+        Co, Ci, K2 = int(w.shape[-4]), int(w.shape[-3]), int(w.shape[-2] * w.shape[-1])
+        k = int(w.shape[-1])
+        if st.numel() != Ci or not w.is_cuda or w.dtype != torch.float32:
+            raise RuntimeError("modulate_weight: weight [.., Co, Ci, k, k] float32 on the GPU, style with Ci entries")
+        out = torch.empty((Ci, Co, k, k) if transposed else (Co, Ci, k, k), dtype=torch.float32, device=w.device)
+        dcoef = torch.empty(Co, dtype=torch.float32, device=w.device) if demodulate else None
+        with torch.cuda.device(w.device):
+            _lib.check(_lib.lib().ag_modulate_weight_forward(_p(out), _p(dcoef), _p(w), _p(st), float(scale), int(demodulate), Co, Ci,
+                                                             K2, int(transposed), _stream(w.device)), "ag_modulate_weight_forward")
+        ctx.save_for_backward(w, st, dcoef)
+        ctx.cfg = (float(scale), bool(demodulate), bool(transposed), Co, Ci, K2, weight.shape, style.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        w, st, dcoef = ctx.saved_tensors
+        scale, demodulate, transposed, Co, Ci, K2, wshape, sshape = ctx.cfg
+        g = g.contiguous()
+        dW = torch.empty_like(w)
+        ds = torch.empty(Ci, dtype=torch.float32, device=w.device)
+        with torch.cuda.device(w.device):
+            _lib.check(_lib.lib().ag_modulate_weight_backward(_p(dW), _p(ds), _p(g), _p(w), _p(st), _p(dcoef), scale, int(demodulate),
+                                                              Co, Ci, K2, int(transposed), _stream(w.device)),
+                       "ag_modulate_weight_backward")
+        return dW.view(wshape), ds.view(sshape), None, None, None
+
+
+def modulate_weight(weight, style, scale, demodulate=True, transposed=False):
+    """weight [1, Co, Ci, k, k] or [Co, Ci, k, k], style [1, Ci] -> modulated (and demodulated) conv weight [Co, Ci, k, k]
+    (``transposed``: [Ci, Co, k, k] for conv_transpose2d)."""
+    return _ModulateWeight.apply(weight, style, float(scale), bool(demodulate), bool(transposed))

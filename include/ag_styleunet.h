@@ -58,6 +58,19 @@ int ag_noise_bias_act_forward(float* y, const float* x, const float* noise, cons
 int ag_noise_bias_act_backward(float* gx, const float* gy, const float* y, const float* noise, float* gbias, float* gnoise_weight,
                                int32_t C, int32_t HW, float slope, float scale, void* stream);
 
+/*
+ * Weight modulation + demodulation of ModulatedConv2d's fused branch (network/styleunet/dual_styleunet.py:254-259):
+ *   w'[co][ci][k] = (scale * W[co][ci][k]) * style[ci];  dcoef[co] = rsqrt(sum_{ci,k} w'^2 + 1e-8)  (1 when !demodulate)
+ *   out = w' * dcoef[co],  laid out [Co][Ci][K2], or [Ci][Co][K2] when `transposed` (what conv_transpose2d takes, :268-272).
+ * W [Co][Ci][K2], style [Ci]; dcoef [Co] may be NULL when not needed for a backward.
+ */
+int ag_modulate_weight_forward(float* out, float* dcoef, const float* W, const float* style, float scale, int32_t demodulate,
+                               int32_t Co, int32_t Ci, int32_t K2, int32_t transposed, void* stream);
+
+/* Backward: g = dL/dout (same layout as out).  dW [Co][Ci][K2] and dstyle [Ci] are overwritten. */
+int ag_modulate_weight_backward(float* dW, float* dstyle, const float* g, const float* W, const float* style, const float* dcoef,
+                                float scale, int32_t demodulate, int32_t Co, int32_t Ci, int32_t K2, int32_t transposed, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -139,3 +139,32 @@ def test_noise_bias_act_matches_the_unfused_oracle(shape, with_noise, with_bias)
         np.testing.assert_allclose(nwg.grad.cpu().numpy(), nwc.grad.numpy(), rtol=1e-4, atol=2e-3)
     else:
         assert nwg.grad is None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("co,ci,k,demod,transposed", [(48, 40, 3, True, False), (12, 64, 1, False, False),
+                                                       (40, 33, 3, True, True), (300, 20, 3, True, False)])
+def test_modulate_weight_matches_the_reference_formulation(co, ci, k, demod, transposed):
+    """ModulatedConv2d's fused weight path (dual_styleunet.py:254-259, :268-272 for the transposed layout) in one kernel each
+    way vs the same torch expressions on CPU with autograd (fp32; the demodulation sum order differs)."""
+    import math
+    import torch
+    from animatablegaussians_amd.styleunet_ops import modulate_weight
+    g = torch.Generator().manual_seed(co * 7 + ci)
+    W = torch.randn(1, co, ci, k, k, generator=g)
+    style = torch.randn(1, ci, generator=g) + 1.0
+    scale = 1 / math.sqrt(ci * k * k)
+    Wc, sc = W.clone().requires_grad_(True), style.clone().requires_grad_(True)
+    w = scale * Wc * sc.view(1, 1, ci, 1, 1)
+    if demod:
+        w = w * torch.rsqrt(w.pow(2).sum([2, 3, 4]) + 1e-8).view(1, co, 1, 1, 1)
+    ref = w[0].transpose(0, 1) if transposed else w[0]
+    up = torch.randn(ref.shape, generator=g)
+    (ref * up).sum().backward()
+    Wg, sg = W.cuda().requires_grad_(True), style.cuda().requires_grad_(True)
+    out = modulate_weight(Wg, sg, scale, demod, transposed)
+    assert out.shape == ref.shape and out.is_contiguous()
+    (out * up.cuda()).sum().backward()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(Wg.grad.cpu().numpy(), Wc.grad.numpy(), rtol=1e-4, atol=2e-5 * float(Wc.grad.abs().max()))
+    np.testing.assert_allclose(sg.grad.cpu().numpy(), sc.grad.numpy(), rtol=1e-4, atol=2e-5 * float(sc.grad.abs().max()))
