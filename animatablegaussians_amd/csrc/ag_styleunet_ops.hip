@@ -221,6 +221,51 @@ __global__ void __launch_bounds__(256) modulate_weight_backward_kernel(float* __
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// 2x2 block transforms: the Haar analysis / synthesis of the wavelet skip path (dual_styleunet.py:374-425) as ONE pass
+// instead of 4 upfirdn2d calls + 3 additions / a concatenation.
+//   split: y[b][c][i][j] = sum_p M[b][p] * x[c][2i + p/2][2j + p%2]          x [C][2h][2w] -> y [4][C][h][w]
+//   merge: x[c][2i + p/2][2j + p%2] = sum_b M[p][b] * y[b][c][i][j]          y [4][C][h][w] -> x [C][2h][2w]
+// ------------------------------------------------------------------------------------------------------------------
+struct Block2x2 { float m[16]; };
+
+__global__ void __launch_bounds__(256) block2x2_split_kernel(float* __restrict__ y, const float* __restrict__ x, Block2x2 M, int C,
+                                                            int h, int w)
+{
+    const long long total = (long long)C * h * w;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int jx = (int)(i % w);
+        const long long r = i / w;
+        const int iy = (int)(r % h), c = (int)(r / h);
+        const float* src = x + ((size_t)c * 2 * h + 2 * iy) * (2 * w) + 2 * jx;
+        const float2 t = *reinterpret_cast<const float2*>(src), b = *reinterpret_cast<const float2*>(src + 2 * w);
+        const float v[4] = { t.x, t.y, b.x, b.y };
+#pragma unroll
+        for (int band = 0; band < 4; band++)
+            y[(size_t)band * total + i] = M.m[4 * band + 0] * v[0] + M.m[4 * band + 1] * v[1] + M.m[4 * band + 2] * v[2] + M.m[4 * band + 3] * v[3];
+    }
+}
+
+__global__ void __launch_bounds__(256) block2x2_merge_kernel(float* __restrict__ x, const float* __restrict__ y, Block2x2 M, int C,
+                                                            int h, int w)
+{
+    const long long total = (long long)C * h * w;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int jx = (int)(i % w);
+        const long long r = i / w;
+        const int iy = (int)(r % h), c = (int)(r / h);
+        float v[4];
+#pragma unroll
+        for (int band = 0; band < 4; band++) v[band] = y[(size_t)band * total + i];
+        float o[4];
+#pragma unroll
+        for (int p = 0; p < 4; p++) o[p] = M.m[4 * p + 0] * v[0] + M.m[4 * p + 1] * v[1] + M.m[4 * p + 2] * v[2] + M.m[4 * p + 3] * v[3];
+        float* dst = x + ((size_t)c * 2 * h + 2 * iy) * (2 * w) + 2 * jx;
+        *reinterpret_cast<float2*>(dst) = make_float2(o[0], o[1]);
+        *reinterpret_cast<float2*>(dst + 2 * w) = make_float2(o[2], o[3]);
+    }
+}
+
 __device__ __forceinline__ int floor_div(int a, int b)
 {
     int c = a / b;
@@ -344,6 +389,23 @@ int ag_modulate_weight_backward(float* dW, float* dstyle, const float* g, const 
     hipLaunchKernelGGL(modulate_weight_backward_kernel, dim3(Co), dim3(256), 0, s, dW, dstyle, g, W, style, dcoef, scale, demodulate,
                        Co, Ci, K2, transposed);
     return check_hip(hipGetLastError(), "modulate_weight_backward_kernel");
+}
+
+int ag_block2x2_transform(float* out, const float* in, const float* matrix16, int32_t merge, int32_t C, int32_t h, int32_t w,
+                          void* stream)
+{
+    if (C < 0 || h < 0 || w < 0 || !matrix16) { set_error("bad block2x2 arguments"); return AG_ERR_INVALID_ARGUMENT; }
+    const long long total = (long long)C * h * w;
+    if (total == 0) return AG_OK;
+    if (!out || !in) { set_error("null pointer"); return AG_ERR_INVALID_ARGUMENT; }
+    Block2x2 M;
+    for (int i = 0; i < 16; i++) M.m[i] = matrix16[i];       // host pointer: 16 coefficients passed by value to the kernel
+    long long blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (merge) hipLaunchKernelGGL(block2x2_merge_kernel, dim3((int)blocks), dim3(256), 0, s, out, in, M, C, h, w);
+    else       hipLaunchKernelGGL(block2x2_split_kernel, dim3((int)blocks), dim3(256), 0, s, out, in, M, C, h, w);
+    return check_hip(hipGetLastError(), "block2x2 kernel");
 }
 
 int ag_upfirdn2d(float* out, const float* input, const float* kernel, int32_t major, int32_t in_h, int32_t in_w,

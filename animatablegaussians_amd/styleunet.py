@@ -24,7 +24,7 @@ import torch
 import torch.nn.functional as F
 
 from . import conv as agc
-from .styleunet_ops import fused_leaky_relu, modulate_weight, noise_bias_act, upfirdn2d_nchw
+from .styleunet_ops import fused_leaky_relu, haar_merge, haar_split, modulate_weight, noise_bias_act, upfirdn2d_nchw
 
 _SQRT2 = 2 ** 0.5
 
@@ -191,20 +191,15 @@ class DualStyleUNet(torch.nn.Module):
         # NoiseInjection (:301-311) + FusedLeakyReLU (:596) in one pass
         return noise_bias_act(x, noise, self._p(f"{prefix}.noise.weight"), self._p(f"{prefix}.activate.bias"))
 
-    def _haar_split(self, x):                                             # HaarTransform (:387-403)
-        return torch.cat([upfirdn2d_nchw(x, getattr(self, "_dwt_" + n), down=2) for n in ("ll", "lh", "hl", "hh")], 1)
+    def _haar_split(self, x):                                             # HaarTransform (:387-403), one kernel
+        return haar_split(x)
 
-    def _haar_merge(self, x):                                             # InverseHaarTransform (:406-425)
-        parts = x.chunk(4, 1)
-        out = None
-        for part, n in zip(parts, ("ll", "lh", "hl", "hh")):
-            y = upfirdn2d_nchw(part, getattr(self, "_iwt_" + n), up=2, pad=(1, 0, 1, 0))
-            out = y if out is None else out + y
-        return out
+    def _haar_merge(self, x):                                             # InverseHaarTransform (:406-425), one kernel
+        return haar_merge(x)
 
     def _to_rgb(self, x, prefix, w_latent, skip):
         weight = self._modulated_weight(f"{prefix}.conv", w_latent, False)
-        out = agc.conv2d(x, weight, stride=1, padding=0) + self._p(f"{prefix}.bias")
+        out = agc.conv2d(x, weight, bias=self._p(f"{prefix}.bias").reshape(-1), stride=1, padding=0)   # bias in the conv epilogue
         if skip is not None:
             s = self._haar_merge(skip)
             s = upfirdn2d_nchw(s, self._k_blur_up, up=2, pad=(2, 1))     # Upsample (:32-50)

@@ -241,3 +241,59 @@ def modulate_weight(weight, style, scale, demodulate=True, transposed=False):
     """weight [1, Co, Ci, k, k] or [Co, Ci, k, k], style [1, Ci] -> modulated (and demodulated) conv weight [Co, Ci, k, k]
     (``transposed``: [Ci, Co, k, k] for conv_transpose2d)."""
     return _ModulateWeight.apply(weight, style, float(scale), bool(demodulate), bool(transposed))
+
+
+# Haar analysis matrix A[band][p], p = 2*dy + dx over a 2x2 input block, bands (ll, lh, hl, hh) in the order HaarTransform
+# concatenates them.  From upfirdn2d(x, k_b, down=2) = correlation with the FLIPPED kernel: out[i][j] = sum k_b[1-dy][1-dx] *
+# x[2i+dy][2j+dx], with the kernels of get_haar_wavelet (dual_styleunet.py:374-384): ll = +.5 everywhere,
+# lh = [[-.5,-.5],[.5,.5]], hl = [[-.5,.5],[-.5,.5]], hh = [[.5,-.5],[-.5,.5]].
+_HAAR_ANALYSIS = (0.5, 0.5, 0.5, 0.5,
+                  0.5, 0.5, -0.5, -0.5,
+                  0.5, -0.5, 0.5, -0.5,
+                  0.5, -0.5, -0.5, 0.5)
+# Synthesis B[p][band]: upfirdn2d(y_b, k'_b, up=2, pad=(1,0,1,0)) puts k'_b[dy][dx] * y_b[i][j] at (2i+dy, 2j+dx), with
+# k' = (ll, -lh, -hl, hh) (InverseHaarTransform, :406-425).  The Haar basis is orthonormal: B = A^T.
+_HAAR_SYNTHESIS = tuple(_HAAR_ANALYSIS[4 * b + p] for p in range(4) for b in range(4))
+
+
+def _transpose4(m):
+    return tuple(m[4 * c + r] for r in range(4) for c in range(4))
+
+
+class _Block2x2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, matrix, merge):
+        if x.dim() != 4 or x.shape[0] != 1 or not x.is_cuda or x.dtype != torch.float32:
+            raise RuntimeError("block2x2: float32 GPU tensor [1, C, H, W]")
+        x = x.contiguous()
+        if merge:
+            C, h, w = int(x.shape[1]) // 4, int(x.shape[2]), int(x.shape[3])
+            if x.shape[1] % 4:
+                raise RuntimeError("merge expects 4*C channels")
+            out = torch.empty((1, C, 2 * h, 2 * w), dtype=torch.float32, device=x.device)
+        else:
+            C, h, w = int(x.shape[1]), int(x.shape[2]) // 2, int(x.shape[3]) // 2
+            if x.shape[2] % 2 or x.shape[3] % 2:
+                raise RuntimeError("split expects even height and width")
+            out = torch.empty((1, 4 * C, h, w), dtype=torch.float32, device=x.device)
+        m = (ctypes.c_float * 16)(*matrix)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().ag_block2x2_transform(_p(out), _p(x), ctypes.cast(m, ctypes.c_void_p), int(merge), C, h, w,
+                                                        _stream(x.device)), "ag_block2x2_transform")
+        ctx.cfg = (matrix, merge)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        matrix, merge = ctx.cfg
+        return _Block2x2.apply(g, _transpose4(matrix), not merge), None, None
+
+
+def haar_split(x):
+    """HaarTransform (dual_styleunet.py:387-403): [1, C, 2h, 2w] -> [1, 4C, h, w] = cat(ll, lh, hl, hh)."""
+    return _Block2x2.apply(x, _HAAR_ANALYSIS, False)
+
+
+def haar_merge(y):
+    """InverseHaarTransform (dual_styleunet.py:406-425): [1, 4C, h, w] -> [1, C, 2h, 2w]."""
+    return _Block2x2.apply(y, _HAAR_SYNTHESIS, True)

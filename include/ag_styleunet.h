@@ -71,6 +71,16 @@ int ag_modulate_weight_forward(float* out, float* dcoef, const float* W, const f
 int ag_modulate_weight_backward(float* dW, float* dstyle, const float* g, const float* W, const float* style, const float* dcoef,
                                 float scale, int32_t demodulate, int32_t Co, int32_t Ci, int32_t K2, int32_t transposed, void* stream);
 
+/*
+ * 2x2 block transform = HaarTransform / InverseHaarTransform of the wavelet skip path (dual_styleunet.py:374-425: four
+ * upfirdn2d calls with 2x2 kernels, down = 2 resp. up = 2, plus a concatenation resp. three additions) in one pass.
+ *   merge == 0 (split): in [C][2h][2w] -> out [4][C][h][w],  out[b][c][i][j] = sum_p matrix16[4b + p] * in[c][2i + p/2][2j + p%2]
+ *   merge != 0        : in [4][C][h][w] -> out [C][2h][2w],  out[c][2i + p/2][2j + p%2] = sum_b matrix16[4p + b] * in[b][c][i][j]
+ * matrix16 is a HOST pointer to the 16 coefficients.  The adjoint of a split with M is a merge with M^T and vice versa.
+ */
+int ag_block2x2_transform(float* out, const float* in, const float* matrix16, int32_t merge, int32_t C, int32_t h, int32_t w,
+                          void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -168,3 +168,41 @@ def test_modulate_weight_matches_the_reference_formulation(co, ci, k, demod, tra
     np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=2e-5, atol=1e-6)
     np.testing.assert_allclose(Wg.grad.cpu().numpy(), Wc.grad.numpy(), rtol=1e-4, atol=2e-5 * float(Wc.grad.abs().max()))
     np.testing.assert_allclose(sg.grad.cpu().numpy(), sc.grad.numpy(), rtol=1e-4, atol=2e-5 * float(sc.grad.abs().max()))
+
+
+@pytest.mark.gpu
+def test_haar_split_merge_match_the_upfirdn_formulation():
+    """HaarTransform / InverseHaarTransform as one 2x2-block kernel each vs the reference's formulation (four upfirdn2d calls
+    with the kernels of get_haar_wavelet, dual_styleunet.py:374-425) on the CPU oracle, forward and backward."""
+    import torch
+    from animatablegaussians_amd.styleunet_ops import haar_merge, haar_split
+    from oracle import styleunet_oracle as so
+    a = 1 / (2 ** 0.5)
+    lo, hi = torch.tensor([[a, a]]), torch.tensor([[-a, a]])
+    k = {"ll": lo.T * lo, "lh": hi.T * lo, "hl": lo.T * hi, "hh": hi.T * hi}
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(1, 3, 20, 28, generator=g)
+    xc = x.clone().requires_grad_(True)
+    ref = torch.cat([so.upfirdn2d(xc[0], k[n], 1, 1, 2, 2, 0, 0, 0, 0)[None] for n in ("ll", "lh", "hl", "hh")], 1)
+    up = torch.randn(ref.shape, generator=g)
+    (ref * up).sum().backward()
+    xg = x.cuda().requires_grad_(True)
+    got = haar_split(xg)
+    (got * up.cuda()).sum().backward()
+    np.testing.assert_allclose(got.detach().cpu().numpy(), ref.detach().numpy(), rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), xc.grad.numpy(), rtol=1e-6, atol=1e-6)
+
+    y = torch.randn(1, 12, 10, 14, generator=g)
+    yc = y.clone().requires_grad_(True)
+    sign = {"ll": 1.0, "lh": -1.0, "hl": -1.0, "hh": 1.0}
+    parts = yc.chunk(4, 1)
+    ref2 = sum(so.upfirdn2d(p_[0], sign[n] * k[n], 2, 2, 1, 1, 1, 0, 1, 0)[None] for p_, n in zip(parts, ("ll", "lh", "hl", "hh")))
+    up2 = torch.randn(ref2.shape, generator=g)
+    (ref2 * up2).sum().backward()
+    yg = y.cuda().requires_grad_(True)
+    got2 = haar_merge(yg)
+    (got2 * up2.cuda()).sum().backward()
+    np.testing.assert_allclose(got2.detach().cpu().numpy(), ref2.detach().numpy(), rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(yg.grad.cpu().numpy(), yc.grad.numpy(), rtol=1e-6, atol=1e-6)
+    # perfect reconstruction
+    np.testing.assert_allclose(haar_merge(haar_split(xg.detach())).cpu().numpy(), x.numpy(), rtol=1e-6, atol=1e-6)
