@@ -13,7 +13,8 @@ import os
 import torch  # noqa: F401  (loads the HIP runtime the library must share)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libag_hip.so")
+# AG_LIB_PATH selects another build of the same library (same-box A/B measurements of kernel variants); default: in-tree
+LIB_PATH = os.environ.get("AG_LIB_PATH") or os.path.join(_HERE, "lib", "libag_hip.so")
 
 c_i32 = ctypes.c_int32
 c_f = ctypes.c_float
