@@ -85,6 +85,32 @@ def _knn3_log_scale(points: np.ndarray) -> np.ndarray:
     return np.log(np.sqrt(dist2)).astype(np.float32)
 
 
+class _Graphed:
+    """A no-grad callable captured once in a hipGraph and replayed: ``fn(*tensors) -> tuple of tensors`` with static
+    shapes.  Inputs are copied into the capture's static buffers; the returned tensors are the capture's static outputs
+    (valid until the next call).  The ~1000 kernel launches of a StyleUNet forward become one graph launch."""
+
+    def __init__(self, fn, example_inputs):
+        self.static_in = [t.clone() if t is not None else None for t in example_inputs]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(2):                      # warm-up outside the capture (allocator, lazy module state)
+                fn(*self.static_in)
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self.graph):
+            out = fn(*self.static_in)
+        self.static_out = out if isinstance(out, (tuple, list)) else (out,)
+
+    def __call__(self, *inputs):
+        for dst, src in zip(self.static_in, inputs):
+            if dst is not None and dst is not src:
+                dst.copy_(src)
+        self.graph.replay()
+        return self.static_out
+
+
 class AvatarNet(nn.Module):
     """Re-host of the reference's ``network.avatar.AvatarNet`` (``network/avatar.py:16-239``) on this package's kernels:
     three ``DualStyleUNet`` (position / other / colour), the view-direction encoder, the fused per-Gaussian assembly,
@@ -254,9 +280,36 @@ class AvatarNet(nn.Module):
             feats.append(weight * h)
         return feats[0], feats[1]
 
+    def enable_graphs(self, on: bool = True):
+        """Eval-mode option: run the three networks from captured hipGraphs (one launch per network instead of ~1000).
+        Results are bit-identical to eager.  In steady state the eager path is already GPU-bound (35.6 vs 35.5 ms per view,
+        bench_avatar.py --infer [--graphs]); the capture pays when the host is the bottleneck (a cold or busy CPU:
+        15.3 -> 12.4 ms per network in profiles/graph_probe.py).  Captures lazily on the next eval
+        call with gradients disabled; the captures hold parameter ADDRESSES, so call ``enable_graphs(False)`` before moving
+        the module or swapping parameter tensors (in-place updates such as ``load_reference_state_dict`` are fine)."""
+        self._use_graphs = bool(on)
+        self._graphs = {}
+
+    def _graphs_active(self):
+        return getattr(self, "_use_graphs", False) and not self.training and not torch.is_grad_enabled()
+
+    def _graphed(self, key, fn, inputs):
+        g = self._graphs.get(key)
+        if g is None:
+            g = self._graphs[key] = _Graphed(fn, inputs)
+        return g(*inputs)
+
     def get_maps(self, pose_map, front_viewdirs=None, back_viewdirs=None):
         """The three StyleUNet evaluations of ``get_positions`` / ``get_others`` / ``get_colors``  (:93-124), raw maps."""
         x = pose_map[None].contiguous()
+        if self._graphs_active():
+            (position_map,) = self._graphed("position", lambda p: self.position_net([self.position_style], p, randomize_noise=False)[0], [x])
+            (other_map,) = self._graphed("other", lambda p: self.other_net([self.other_style], p, randomize_noise=False)[0], [x])
+            (color_map,) = self._graphed(
+                ("color", front_viewdirs is not None),
+                lambda p, f, b: self.color_net([self.color_style], p, randomize_noise=False, view_feature1=f, view_feature2=b)[0],
+                [x, front_viewdirs, back_viewdirs])
+            return position_map, other_map, color_map
         position_map, _ = self.position_net([self.position_style], x, randomize_noise=False)
         other_map, _ = self.other_net([self.other_style], x, randomize_noise=False)
         color_style = torch.rand_like(self.color_style) if self.random_style and self.training else self.color_style
@@ -305,11 +358,35 @@ class AvatarNet(nn.Module):
         bg = torch.as_tensor(np.asarray(bg_color), dtype=torch.float32).to(dev)
         pose_map = items['smpl_pos_map'][:3]
         x = pose_map[None].contiguous()
-        position_map, _ = self.position_net([self.position_style], x, randomize_noise=False)
-        other_map, _ = self.other_net([self.other_style], x, randomize_noise=False)
         feats = [self.get_viewdir_feat({**items, **v}) if self.with_viewdirs else (None, None) for v in views]
-        color_style = torch.rand_like(self.color_style) if self.random_style and self.training else self.color_style
-        color_maps = self.color_net.forward_views([color_style], x, feats, randomize_noise=False)
+        if self._graphs_active():
+            (position_map,) = self._graphed("position", lambda p: self.position_net([self.position_style], p, randomize_noise=False)[0], [x])
+            (other_map,) = self._graphed("other", lambda p: self.other_net([self.other_style], p, randomize_noise=False)[0], [x])
+            cn = self.color_net
+
+            def shared_fn(p):
+                w_latent, noise = cn._latent_and_noise([self.color_style], False, None, False)
+                levels = cn.encode(p)
+                (o1, s1), (o2, s2) = (cn.decode_shared(b, levels, w_latent, noise) for b in (1, 2))
+                return o1, s1, o2, s2, levels[0], w_latent
+
+            o1, s1, o2, s2, level0, w_latent = self._graphed("color_shared", shared_fn, [x])
+
+            def view_fn(f, b):        # closes over the static outputs of the shared capture
+                noise = [getattr(cn, cn._attr(f"noises.noise_{i}")) for i in range(cn.num_layers)]
+                lv = [level0] * (len(cn.enc) + 1)     # the view-dependent stages only read the finest level, levels[0]
+                parts = [cn.decode_view(br, lv, w_latent, noise, o, sk, vf) for br, o, sk, vf in ((1, o1, s1, f), (2, o2, s2, b))]
+                return torch.cat(parts, 1)
+
+            color_maps = []
+            for f, b in feats:
+                (cm,) = self._graphed(("color_view", f is not None), view_fn, [f, b])
+                color_maps.append(cm.clone())     # the capture's output buffer is reused by the next view
+        else:
+            position_map, _ = self.position_net([self.position_style], x, randomize_noise=False)
+            other_map, _ = self.other_net([self.other_style], x, randomize_noise=False)
+            color_style = torch.rand_like(self.color_style) if self.random_style and self.training else self.color_style
+            color_maps = self.color_net.forward_views([color_style], x, feats, randomize_noise=False)
         rets = []
         live = None
         for v, color_map in zip(views, color_maps):

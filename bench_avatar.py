@@ -45,6 +45,7 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-viewdirs", action="store_true")
     ap.add_argument("--infer", action="store_true", help="eval-mode render only (animation / free-view synthesis)")
+    ap.add_argument("--graphs", action="store_true", help="with --infer: run the networks from captured hipGraphs")
     ap.add_argument("--views", type=int, default=1, help="cameras of the same pose per step (multi-view step: "
                     "pose-dependent work shared through AvatarNet.render_views)")
     args = ap.parse_args()
@@ -98,11 +99,12 @@ def main() -> None:
 
     if args.infer:
         net.eval()
+        net.enable_graphs(args.graphs)
         sync = opt = None
     else:
         net.train()
         sync = BucketedGradSync(list(net.parameters()))
-        opt = torch.optim.Adam(net.parameters(), lr=5e-4, foreach=True)
+        opt = torch.optim.Adam(net.parameters(), lr=5e-4, fused=True)      # one pass over the 224 M parameters
 
     V = args.views
 
@@ -156,7 +158,7 @@ def main() -> None:
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"SURVEY 8d config 3: {V} view(s) of one pose per step, whole render path"
                                    + (" (eval)" if args.infer else " + loss + backward + Adam"),
-                       "gaussians": int(net.lbs.shape[0]), "parameters": int(n_params), "with_viewdirs": bool(net.with_viewdirs), "views_per_step": V,
+                       "gaussians": int(net.lbs.shape[0]), "parameters": int(n_params), "with_viewdirs": bool(net.with_viewdirs), "views_per_step": V, "hip_graphs": bool(args.infer and args.graphs),
                        "parallelism": "1 process" if world == 1 else f"view-sharded x{world}, bucketed RCCL all-reduce of {n_params * 4 >> 20} MB grads"},
             "roofline": {"kernel": "gather_conv_kernel + wgrad_kernel (all StyleUNet convolutions of the step)", "bound": "mfma",
                          "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TF, 4),

@@ -148,6 +148,37 @@ def test_render_views_shares_the_pose_dependent_work_without_changing_results(ne
     net.zero_grad(set_to_none=True)
 
 
+def test_graph_captured_networks_reproduce_eager_results(net):
+    """enable_graphs(): the hipGraph replays of the three networks (and of the shared / per-view colour decoder parts)
+    give bit-identical renders, also after the parameters are updated in place."""
+    import torch
+    from animatablegaussians_amd import synth
+    base = _items(net)
+    net.get_pose_map(base)
+    cams = synth.free_view_cameras(2, img=1024)
+    views = [{'extr': torch.from_numpy(np.ascontiguousarray(c["extr"])).float().cuda(),
+              'intr': torch.from_numpy(np.ascontiguousarray(c["intr"])).float().cuda(), 'img_w': 1024, 'img_h': 1024} for c in cams]
+    net.eval()
+    try:
+        with torch.no_grad():
+            eager1 = net.render(base)['rgb_map'].clone()
+            eagerv = [r['rgb_map'].clone() for r in net.render_views(base, views)]
+            net.enable_graphs(True)
+            for _ in range(2):                      # first call captures, second replays
+                assert torch.equal(net.render(base)['rgb_map'], eager1)
+                got = net.render_views(base, views)
+                assert all(torch.equal(g['rgb_map'], e) for g, e in zip(got, eagerv))
+            # in-place parameter update: the captures see it
+            p = net.color_net._p("to_rgbs1.5.bias")
+            p.add_(0.05)
+            changed = net.render(base)['rgb_map']
+            net.enable_graphs(False)
+            assert torch.equal(net.render(base)['rgb_map'], changed) and not torch.equal(changed, eager1)
+            p.sub_(0.05)
+    finally:
+        net.enable_graphs(False)
+
+
 def test_reference_state_dict_roundtrip(net):
     import torch
     sd = {}
