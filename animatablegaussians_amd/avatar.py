@@ -280,6 +280,30 @@ class AvatarNet(nn.Module):
             feats.append(weight * h)
         return feats[0], feats[1]
 
+    def _concurrently(self, fns):
+        """Run independent sub-networks on their own HIP streams (the first on the current one) and join: their small
+        layers interleave on the CUs.  Autograd replays each node on its recording stream, so the backward overlaps too."""
+        import os
+        cur = torch.cuda.current_stream()
+        if os.environ.get("AG_SINGLE_STREAM") == "1" or len(fns) == 1 or torch.cuda.is_current_stream_capturing():
+            return [f() for f in fns]
+        pool = getattr(self, "_net_streams", None)
+        if pool is None or len(pool) < len(fns) - 1 or pool[0].device != cur.device:
+            pool = self._net_streams = [torch.cuda.Stream(cur.device) for _ in range(len(fns) - 1)]
+        outs = [None] * len(fns)
+        for i, f in enumerate(fns[1:]):
+            pool[i].wait_stream(cur)
+            with torch.cuda.stream(pool[i]):
+                outs[i + 1] = f()
+        outs[0] = fns[0]()
+        for i in range(len(fns) - 1):
+            cur.wait_stream(pool[i])
+            o = outs[i + 1]
+            for t in (o if isinstance(o, (tuple, list)) else (o,)):
+                if isinstance(t, torch.Tensor):
+                    t.record_stream(cur)
+        return outs
+
     def enable_graphs(self, on: bool = True):
         """Eval-mode option: run the three networks from captured hipGraphs (one launch per network instead of ~1000).
         Results are bit-identical to eager.  In steady state the eager path is already GPU-bound (35.6 vs 35.5 ms per view,
@@ -310,11 +334,12 @@ class AvatarNet(nn.Module):
                 lambda p, f, b: self.color_net([self.color_style], p, randomize_noise=False, view_feature1=f, view_feature2=b)[0],
                 [x, front_viewdirs, back_viewdirs])
             return position_map, other_map, color_map
-        position_map, _ = self.position_net([self.position_style], x, randomize_noise=False)
-        other_map, _ = self.other_net([self.other_style], x, randomize_noise=False)
         color_style = torch.rand_like(self.color_style) if self.random_style and self.training else self.color_style
-        color_map, _ = self.color_net([color_style], x, randomize_noise=False, view_feature1=front_viewdirs,
-                                      view_feature2=back_viewdirs)
+        position_map, other_map, color_map = self._concurrently([
+            lambda: self.position_net([self.position_style], x, randomize_noise=False)[0],
+            lambda: self.other_net([self.other_style], x, randomize_noise=False)[0],
+            lambda: self.color_net([color_style], x, randomize_noise=False, view_feature1=front_viewdirs,
+                                   view_feature2=back_viewdirs)[0]])
         return position_map, other_map, color_map
 
     @staticmethod
@@ -383,10 +408,11 @@ class AvatarNet(nn.Module):
                 (cm,) = self._graphed(("color_view", f is not None), view_fn, [f, b])
                 color_maps.append(cm.clone())     # the capture's output buffer is reused by the next view
         else:
-            position_map, _ = self.position_net([self.position_style], x, randomize_noise=False)
-            other_map, _ = self.other_net([self.other_style], x, randomize_noise=False)
             color_style = torch.rand_like(self.color_style) if self.random_style and self.training else self.color_style
-            color_maps = self.color_net.forward_views([color_style], x, feats, randomize_noise=False)
+            position_map, other_map, color_maps = self._concurrently([
+                lambda: self.position_net([self.position_style], x, randomize_noise=False)[0],
+                lambda: self.other_net([self.other_style], x, randomize_noise=False)[0],
+                lambda: self.color_net.forward_views([color_style], x, feats, randomize_noise=False)])
         rets = []
         live = None
         for v, color_map in zip(views, color_maps):

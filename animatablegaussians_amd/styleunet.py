@@ -259,6 +259,27 @@ class DualStyleUNet(torch.nn.Module):
         out, skip = self.decode_shared(branch, levels, w_latent, noise)
         return self.decode_view(branch, levels, w_latent, noise, out, skip, view_feature)
 
+    # The two decoders are independent given the encoder levels: branch 2 runs on a side HIP stream so that its small
+    # layers (a few workgroups each at 16^2 .. 64^2) fill the CUs branch 1 leaves idle, forward and -- because autograd replays
+    # every node on the stream it was recorded on -- backward.  AG_SINGLE_STREAM=1 disables it (A/B measurements, captures).
+    def _two_branches(self, fn):
+        import os
+        cur = torch.cuda.current_stream()
+        if os.environ.get("AG_SINGLE_STREAM") == "1" or torch.cuda.is_current_stream_capturing():
+            return [fn(1), fn(2)]
+        if getattr(self, "_side_stream", None) is None or self._side_stream.device != cur.device:
+            self._side_stream = torch.cuda.Stream(cur.device)
+        side = self._side_stream
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            r2 = fn(2)
+        r1 = fn(1)
+        cur.wait_stream(side)
+        for t in (r2 if isinstance(r2, (tuple, list)) else (r2,)):
+            if isinstance(t, torch.Tensor):
+                t.record_stream(cur)          # allocated on the side stream, consumed (and later freed) on the main one
+        return [r1, r2]
+
     def _latent_and_noise(self, styles, input_is_latent, noise, randomize_noise):
         w_latent = styles[0] if input_is_latent else self.get_latent(styles[0])
         if w_latent.dim() == 3:
@@ -277,11 +298,11 @@ class DualStyleUNet(torch.nn.Module):
             raise RuntimeError("forward_views shares activations between views: use fixed noise (randomize_noise=False)")
         w_latent, noise = self._latent_and_noise(styles, input_is_latent, noise, randomize_noise)
         levels = self.encode(condition_img)
-        shared = [self.decode_shared(b, levels, w_latent, noise) for b in (1, 2)]
+        shared = self._two_branches(lambda b: self.decode_shared(b, levels, w_latent, noise))
         images = []
         for f1, f2 in view_features:
-            parts = [self.decode_view(b, levels, w_latent, noise, shared[b - 1][0], shared[b - 1][1], f)
-                     for b, f in ((1, f1), (2, f2))]
+            parts = self._two_branches(lambda b: self.decode_view(b, levels, w_latent, noise, shared[b - 1][0], shared[b - 1][1],
+                                                                  f1 if b == 1 else f2))
             images.append(torch.cat(parts, 1))
         return images
 
@@ -297,8 +318,7 @@ class DualStyleUNet(torch.nn.Module):
             raise RuntimeError("DualStyleUNet (MI355X path) runs on the GPU only")
         w_latent, noise = self._latent_and_noise(styles, input_is_latent, noise, randomize_noise)
         levels = self.encode(condition_img)
-        image1 = self.decode(1, levels, w_latent, noise, view_feature1)
-        image2 = self.decode(2, levels, w_latent, noise, view_feature2)
+        image1, image2 = self._two_branches(lambda b: self.decode(b, levels, w_latent, noise, view_feature1 if b == 1 else view_feature2))
         images = torch.cat([image1, image2], 1)
         if return_latents:
             return images, w_latent.unsqueeze(1).repeat(1, self.n_latent, 1)
