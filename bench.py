@@ -9,7 +9,9 @@ Workload = BASELINE.json configs[1] ("avatarrex_zzr: 512^2 front/back maps (~250
 reference's 1024x2048 front|back canvas) seen from 8 free-view cameras (f = 1100, 2.5 m).  One step = one view
 through the public operator surface (GaussianRasterizer forward, torch.autograd backward with resident random
 upstream gradients): preprocess -> tile counts/scan -> scatter -> per-tile sort -> blend, then blend backward ->
-preprocess backward.  All inputs are resident in HBM before the timed region.
+preprocess backward.  All inputs are resident in HBM before the timed region.  Consecutive views alternate between two HIP
+streams (--streams), as a multi-view trainer would issue them: views are independent, and the one host synchronisation per
+view (the reference's num_rendered read-back) then overlaps the other view's kernels.
 
 Multi-GPU: views are sharded over ranks (weak scaling: every rank renders K views of the same Gaussians).  The
 exchange step of view-sharded rendering is the sum over views of the per-Gaussian attribute gradients (14 floats per
@@ -43,6 +45,9 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle timing (profiling runs)")
     ap.add_argument("--breakdown", action="store_true", help="add a per-kernel HIP-event breakdown pass")
+    ap.add_argument("--streams", type=int, default=2, help="render consecutive views round-robin on this many HIP streams: "
+                    "the host-side plan sync (the reference's num_rendered read-back) of one view overlaps the kernels of the "
+                    "previous one.  Measured 1: 2460, 2: 2875, 3: 2350, 4: 2675 views/s on one box; kernel durations unchanged")
     args = ap.parse_args()
 
     import numpy as np
@@ -98,7 +103,17 @@ def main() -> None:
     grad_pack = torch.zeros((P, 14), device=dev) if world > 1 else None
     R_seen = []
 
+    streams = [torch.cuda.Stream(dev) for _ in range(args.streams)] if args.streams > 1 else None
+
     def step(i: int):
+        if streams is None:
+            return step_on(i)
+        st = streams[i % len(streams)]
+        st.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(st):
+            step_on(i)
+
+    def step_on(i: int):
         r = rasterizers[(i * world + rank) % len(rasterizers)]     # this rank's view of the step
         means2D = torch.zeros_like(means3D, requires_grad=True)
         color, radii, depth, alpha = r(means3D=means3D, means2D=means2D, opacities=opacities, shs=None,
@@ -117,6 +132,9 @@ def main() -> None:
             leaf.grad = None
 
     def sync_all():
+        if streams is not None:
+            for st in streams:
+                torch.cuda.current_stream(dev).wait_stream(st)
         if world > 1:
             torch.cuda.current_stream(dev).wait_stream(comm_stream)
             dist.barrier()
@@ -199,7 +217,7 @@ def main() -> None:
         "config": {
             "workload": "BASELINE configs[1]: avatar front|back map, 1 view @1024x1024 per step, rasterizer fwd+bwd "
                         "through GaussianRasterizer + autograd",
-            "gaussians": P, "instances_per_view": int(R_mean), "tiles": T_tiles, "views": len(settings),
+            "gaussians": P, "instances_per_view": int(R_mean), "tiles": T_tiles, "views": len(settings), "streams": args.streams,
             "parallelism": "1 process" if world == 1 else f"view-sharded x{world}, RCCL all-reduce of per-Gaussian grads (14 f32 each)",
         },
         "roofline": {
