@@ -116,7 +116,10 @@ __device__ __forceinline__ float wave_reduce16_transposed(float (&v)[16], int la
 #ifndef BWD_WAVES_PER_SIMD
 #define BWD_WAVES_PER_SIMD 4
 #endif
-constexpr int kSub = 64;                 // compacted entries blended between two flushes of the per-wave partial sums
+// Compacted entries blended between two flushes of the per-wave partial sums.  Every flush costs two workgroup barriers and
+// PMC shows the waves of this kernel parked on barriers / waitcnt 60 % of their lifetime, so fewer, larger flushes win even
+// though the 42 KiB of partial slabs leave room for only 2 workgroups per CU: 64 -> 128 entries measured 189 -> 172 us.
+constexpr int kSub = 128;
 constexpr int kPartStride = kSub + 4;
 
 __global__ void __launch_bounds__(kBlendThreads, BWD_WAVES_PER_SIMD) blend_backward_kernel(BlendBwdParams p)
@@ -406,7 +409,7 @@ int launch_blend_backward(const AgRasterBackwardArgs& a, hipStream_t s)
     if (check_hip(hipMemsetAsync(p.accum, 0, (size_t)a.P * kAccumFloats * sizeof(float), s), "memset accum")) return AG_ERR_HIP;
     if (a.num_rendered <= 0) return AG_OK;
     const long long items = (long long)p.T * kRegionsPerTile;
-    const int grid = (int)(items < 768 ? items : 768);   // 3 workgroups of 8 waves per CU (46 KiB of LDS each)
+    const int grid = (int)(items < 512 ? items : 512);   // 2 resident workgroups of 8 waves per CU (69 KiB of LDS each)
     { ProfScope ps(AG_K_BLEND_BACKWARD, s); hipLaunchKernelGGL(blend_backward_kernel, dim3(grid), dim3(kBlendThreads), 0, s, p); }
     return check_hip(hipGetLastError(), "blend_backward_kernel");
 }
