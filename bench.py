@@ -175,7 +175,7 @@ def main() -> None:
     if args.breakdown and rank == 0:
         _lib.prof_enable(range(_lib.AG_K_COUNT))
         for i in range(min(args.steps, 64)):
-            step(i)
+            step_on(i)            # one stream: per-kernel times without the overlap of the pipelined timed region
         sync_all() if world == 1 else torch.cuda.synchronize(dev)
         bd = _lib.prof_collect()
         _lib.prof_enable([])
