@@ -280,9 +280,10 @@ class AvatarNet(nn.Module):
             feats.append(weight * h)
         return feats[0], feats[1]
 
-    def _concurrently(self, fns):
+    def _concurrently(self, fns, shared=()):
         """Run independent sub-networks on their own HIP streams (the first on the current one) and join: their small
-        layers interleave on the CUs.  Autograd replays each node on its recording stream, so the backward overlaps too."""
+        layers interleave on the CUs.  Autograd replays each node on its recording stream, so the backward overlaps too.
+        ``shared``: tensors of the current stream the side streams read (registered with them for the allocator)."""
         import os
         cur = torch.cuda.current_stream()
         if os.environ.get("AG_SINGLE_STREAM") == "1" or len(fns) == 1 or torch.cuda.is_current_stream_capturing():
@@ -293,6 +294,9 @@ class AvatarNet(nn.Module):
         outs = [None] * len(fns)
         for i, f in enumerate(fns[1:]):
             pool[i].wait_stream(cur)
+            for t in shared:
+                if isinstance(t, torch.Tensor) and t.is_cuda:
+                    t.record_stream(pool[i])
             with torch.cuda.stream(pool[i]):
                 outs[i + 1] = f()
         outs[0] = fns[0]()
@@ -339,7 +343,7 @@ class AvatarNet(nn.Module):
             lambda: self.position_net([self.position_style], x, randomize_noise=False)[0],
             lambda: self.other_net([self.other_style], x, randomize_noise=False)[0],
             lambda: self.color_net([color_style], x, randomize_noise=False, view_feature1=front_viewdirs,
-                                   view_feature2=back_viewdirs)[0]])
+                                   view_feature2=back_viewdirs)[0]], shared=[x, color_style, front_viewdirs, back_viewdirs])
         return position_map, other_map, color_map
 
     @staticmethod
@@ -412,7 +416,8 @@ class AvatarNet(nn.Module):
             position_map, other_map, color_maps = self._concurrently([
                 lambda: self.position_net([self.position_style], x, randomize_noise=False)[0],
                 lambda: self.other_net([self.other_style], x, randomize_noise=False)[0],
-                lambda: self.color_net.forward_views([color_style], x, feats, randomize_noise=False)])
+                lambda: self.color_net.forward_views([color_style], x, feats, randomize_noise=False)],
+                shared=[x, color_style] + [t for fb in feats for t in fb])
         rets = []
         live = None
         for v, color_map in zip(views, color_maps):

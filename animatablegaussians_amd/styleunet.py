@@ -262,7 +262,10 @@ class DualStyleUNet(torch.nn.Module):
     # The two decoders are independent given the encoder levels: branch 2 runs on a side HIP stream so that its small
     # layers (a few workgroups each at 16^2 .. 64^2) fill the CUs branch 1 leaves idle, forward and -- because autograd replays
     # every node on the stream it was recorded on -- backward.  AG_SINGLE_STREAM=1 disables it (A/B measurements, captures).
-    def _two_branches(self, fn):
+    def _two_branches(self, fn, shared=()):
+        """``shared``: tensors allocated on the current stream that branch 2 reads on the side stream (encoder levels, latent,
+        shared decoder state): they are registered with the side stream so the caching allocator does not hand their memory
+        out again while side-stream kernels -- forward now, backward later -- may still be reading it."""
         import os
         cur = torch.cuda.current_stream()
         if os.environ.get("AG_SINGLE_STREAM") == "1" or torch.cuda.is_current_stream_capturing():
@@ -271,6 +274,9 @@ class DualStyleUNet(torch.nn.Module):
             self._side_stream = torch.cuda.Stream(cur.device)
         side = self._side_stream
         side.wait_stream(cur)
+        for t in shared:
+            if isinstance(t, torch.Tensor) and t.is_cuda:
+                t.record_stream(side)
         with torch.cuda.stream(side):
             r2 = fn(2)
         r1 = fn(1)
@@ -298,11 +304,11 @@ class DualStyleUNet(torch.nn.Module):
             raise RuntimeError("forward_views shares activations between views: use fixed noise (randomize_noise=False)")
         w_latent, noise = self._latent_and_noise(styles, input_is_latent, noise, randomize_noise)
         levels = self.encode(condition_img)
-        shared = self._two_branches(lambda b: self.decode_shared(b, levels, w_latent, noise))
+        shared = self._two_branches(lambda b: self.decode_shared(b, levels, w_latent, noise), shared=[*levels, w_latent])
         images = []
         for f1, f2 in view_features:
             parts = self._two_branches(lambda b: self.decode_view(b, levels, w_latent, noise, shared[b - 1][0], shared[b - 1][1],
-                                                                  f1 if b == 1 else f2))
+                                                                  f1 if b == 1 else f2), shared=[f2])
             images.append(torch.cat(parts, 1))
         return images
 
@@ -318,7 +324,8 @@ class DualStyleUNet(torch.nn.Module):
             raise RuntimeError("DualStyleUNet (MI355X path) runs on the GPU only")
         w_latent, noise = self._latent_and_noise(styles, input_is_latent, noise, randomize_noise)
         levels = self.encode(condition_img)
-        image1, image2 = self._two_branches(lambda b: self.decode(b, levels, w_latent, noise, view_feature1 if b == 1 else view_feature2))
+        image1, image2 = self._two_branches(lambda b: self.decode(b, levels, w_latent, noise, view_feature1 if b == 1 else view_feature2),
+                                            shared=[*levels, w_latent, view_feature2])
         images = torch.cat([image1, image2], 1)
         if return_latents:
             return images, w_latent.unsqueeze(1).repeat(1, self.n_latent, 1)
