@@ -272,6 +272,11 @@ class DualStyleUNet(torch.nn.Module):
             return [fn(1), fn(2)]
         if getattr(self, "_side_stream", None) is None or self._side_stream.device != cur.device:
             self._side_stream = torch.cuda.Stream(cur.device)
+            # gradients of branch-2 parameters are produced on the side stream and accumulated on the parameters' own
+            # (default) stream; autograd synchronises the two, the mismatch is intended
+            quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+            if quiet is not None:
+                quiet(False)
         side = self._side_stream
         side.wait_stream(cur)
         for t in shared:
