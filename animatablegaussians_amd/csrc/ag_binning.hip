@@ -10,7 +10,8 @@
 //   1. count instances per tile (atomics in the preprocess kernel),
 //   2. exclusive-scan the T tile counts in ONE workgroup -> ranges[tile] directly (no identifyTileRanges pass),
 //   3. scatter (depth_bits<<32 | index) keys into each tile's segment in arbitrary order (atomic cursor),
-//   4. sort every segment independently in LDS (bitonic network on 64-bit keys, one workgroup per tile).
+//   4. sort every segment independently in LDS: sort-8 network per thread + merge-path rounds on the 64-bit keys, persistent
+//      workgroups over the non-empty tiles in two size classes (<= 2048 and <= 8192 entries; a global bitonic network beyond).
 // The sorted point_list and ranges are bit-identical to the reference's for every input, and the data moved is
 // 8 B + 4 B per instance once, instead of 6+ radix passes over 12 B pairs.
 #include "ag_common.h"
@@ -23,14 +24,13 @@ namespace ag {
 __global__ void __launch_bounds__(1024) tile_scan_kernel(int T, const uint32_t* __restrict__ tile_count,
                                                         uint32_t* __restrict__ cursor, uint2* __restrict__ ranges,
                                                         uint32_t* __restrict__ num_rendered,
-                                                        uint4* __restrict__ tile_order, uint32_t* __restrict__ queue)
+                                                        uint4* __restrict__ tile_order)
 {
     __shared__ uint32_t wave_sums[16];
     __shared__ uint32_t carry_s;
     __shared__ uint32_t cls_hist[34], cls_off[34];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) carry_s = 0;
-    if (tid < 2 * kQueues) queue[tid] = 0;
     if (tid < 34) cls_hist[tid] = 0;
     __syncthreads();
     for (int base = 0; base < T; base += 1024) {
@@ -84,8 +84,7 @@ int launch_tile_scan(const AgRasterForwardArgs& a, hipStream_t s)
                        reinterpret_cast<uint32_t*>(ib + il.cursor),
                        reinterpret_cast<uint2*>(ib + il.ranges),
                        reinterpret_cast<uint32_t*>(ib + il.num_rendered),
-                       reinterpret_cast<uint4*>(ib + il.tile_order),
-                       reinterpret_cast<uint32_t*>(ib + il.queue)); }
+                       reinterpret_cast<uint4*>(ib + il.tile_order)); }
     return check_hip(hipGetLastError(), "tile_scan_kernel");
 }
 

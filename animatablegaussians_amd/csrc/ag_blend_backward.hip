@@ -14,9 +14,10 @@
 //                                                                      exclusive scan of affine maps (A, B[5]) for the
 //                                                                      colour / depth / alpha "accum_rec" of :541-565
 // after which the ten gradient terms of all 16 entries are independent.  The terms of the wave's 4 pixels are summed
-// with two register-exchange stages (v_permlane32_swap, v_permlane16_swap: 10 -> 5 -> 3 registers), added into a
-// per-chunk LDS accumulator [10][512] with ds_add_f32 (8 waves share it), and flushed once per chunk with one global
-// atomic per (region, splat, component) into the splat's 64-byte accumulator line.  The reference issues the same ten
+// with two register-exchange stages (v_permlane32_swap, v_permlane16_swap: 10 -> 5 -> 3 registers) and stored (plain
+// ds_write, no LDS atomics) into that wave's partial slab [10][kSub]; every kSub compacted entries the 8 slabs are summed
+// and flushed with one global atomic per (region, splat, component), laid out so that 16 adjacent lanes hit the 16 slots
+// of ONE 64-byte accumulator line (the atomic units work per line request: 409 -> 183 us).  The reference issues ten
 // atomics per (pixel, splat).
 #include <cstdlib>
 #include "ag_common.h"

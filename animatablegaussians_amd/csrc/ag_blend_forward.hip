@@ -12,7 +12,8 @@
 // an avatar only 300-650 of 4096 tiles are non-empty and side views put 6000 entries in one tile, so that serial chain
 // -- not throughput -- sets the kernel time.  This kernel breaks the chain in two places:
 //   * PIXELS: a tile is split into 8 regions of 8x4 pixels, each owned by one 8-wave workgroup; persistent workgroups
-//     pull (tile, region) items from a global queue ordered longest-list-first (tile_scan_kernel).
+//     take (tile, region) items from the longest-list-first order of tile_scan_kernel by a STATIC rule (ItemIter in
+//     ag_common.h: all regions of a tile on one XCD; a global work queue was measured first and cost 100+ us per frame).
 //   * LIST ENTRIES: inside a wave, each 16-lane DPP row is ONE pixel and its 16 lanes are 16 CONSECUTIVE list entries.
 //     The transmittance is a prefix product: T_before(e) = T * prod_{i<e} (1 - alpha_i) over the contributing entries,
 //     computed with a 4-step DPP row scan; the reference's early stop is "the first entry with T_before*(1-alpha) <
@@ -36,7 +37,6 @@ struct BlendFwdParams {
     const GaussRec* __restrict__ rec;
     const uint4* __restrict__ tile_order;
     const uint32_t* __restrict__ counts;   // [0] instances, [1] non-empty tiles
-    uint32_t* __restrict__ queue;
     const float* __restrict__ bg;
     float* __restrict__ out_color;
     float* __restrict__ out_depth;
@@ -87,7 +87,7 @@ __global__ void __launch_bounds__(kBlendThreads) blend_forward_kernel(BlendFwdPa
     const int row = lane >> 4, e = lane & 15;
     const uint32_t n_active = p.counts[1];
 
-    // Empty tiles (the tail of the work order) only need their background: static share, no queue traffic.
+    // Empty tiles (the tail of the work order) only need their background: static share.
     for (uint32_t t = n_active + blockIdx.x; t < (uint32_t)p.T; t += gridDim.x) {
         const int tile = (int)p.tile_order[t].x;
         const int px = (tile % p.gx) * kTileX + (tid & 15), py = (tile / p.gx) * kTileY + (tid >> 4);
@@ -272,7 +272,6 @@ int launch_blend_forward(const AgRasterForwardArgs& a, int R, hipStream_t s)
         p.point_list = nullptr;  // every range is (0,0): never dereferenced
     }
     p.tile_order = reinterpret_cast<const uint4*>(ib + il.tile_order);
-    p.queue = reinterpret_cast<uint32_t*>(ib + il.queue);
     p.counts = reinterpret_cast<const uint32_t*>(ib + il.num_rendered);
     p.bg = a.bg;
     p.out_color = a.out_color; p.out_depth = a.out_depth; p.out_alpha = a.out_alpha;

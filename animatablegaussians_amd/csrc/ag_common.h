@@ -35,7 +35,7 @@ enum AccumSlot { A_M2X = 0, A_M2Y, A_CONX, A_CONY, A_CONW, A_OPAC, A_COLR, A_COL
 constexpr int kRegW = 8, kRegH = 4, kRegionsPerTile = (kTileX / kRegW) * (kTileY / kRegH);
 constexpr int kBlendThreads = 512;
 constexpr int kChunk = 512;   // tile-list entries culled cooperatively per pass (one per thread)
-constexpr int kQueues = 8;    // one work-queue head per XCD: a single L2 atomic word saturates near 88 pops/us
+constexpr int kQueues = 8;    // XCDs: the static work assignment keeps all regions of a tile on one of them
 
 // Work distribution of the persistent blend kernels: STATIC.  (A global work queue was measured first: returning
 // atomics on a few hot words sustain only ~5-10 pops/us on this part, 100+ us per frame for ~5000 items.)
@@ -82,7 +82,7 @@ struct GeomLayout {
 };
 
 struct ImageLayout {
-    size_t ranges, tile_count, cursor, n_contrib, num_rendered, tile_order, queue, total;
+    size_t ranges, tile_count, cursor, n_contrib, num_rendered, tile_order, total;
     __host__ __device__ ImageLayout(size_t W, size_t H)
     {
         const size_t T = ((W + kTileX - 1) / kTileX) * ((H + kTileY - 1) / kTileY);
@@ -93,7 +93,6 @@ struct ImageLayout {
         n_contrib = o;     o = align_up(o + W * H * sizeof(uint32_t), 256);
         num_rendered = o;  o = align_up(o + 16, 256);
         tile_order = o;    o = align_up(o + T * 4 * sizeof(uint32_t), 256);   // uint4 {tile, begin, end, 0}, longest list first
-        queue = o;         o = align_up(o + 64, 256);                     // work-queue heads: [0..7] forward, [8..15] backward (one per XCD)
         total = o + 256;
     }
 };

@@ -41,8 +41,8 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle timing (profiling runs)")
     ap.add_argument("--breakdown", action="store_true", help="add a per-kernel HIP-event breakdown pass")
     ap.add_argument("--streams", type=int, default=2, help="render consecutive views round-robin on this many HIP streams: "
@@ -103,6 +103,19 @@ def main() -> None:
     grad_pack = torch.zeros((P, 14), device=dev) if world > 1 else None
     R_seen = []
 
+    # A training loop calls backward() on a scalar loss; this benchmark injects resident upstream gradients for the three
+    # images instead, and torch.autograd.backward spends ~0.3 ms of pure Python per call validating such (tensor, gradient)
+    # pairs (symbolic-shape checks in _make_grads) -- more than the GPU needs for the whole view.  The engine entry point that
+    # backward() itself ends in is called directly; shapes and dtypes are ours and fixed.
+    try:
+        from torch.autograd.graph import _engine_run_backward
+
+        def run_backward(outs, grads):
+            _engine_run_backward(outs, grads, False, False, (), allow_unreachable=True, accumulate_grad=True)
+    except ImportError:                                        # pragma: no cover
+        def run_backward(outs, grads):
+            torch.autograd.backward(list(outs), list(grads))
+
     streams = [torch.cuda.Stream(dev) for _ in range(args.streams)] if args.streams > 1 else None
 
     def step(i: int):
@@ -118,7 +131,7 @@ def main() -> None:
         means2D = torch.zeros_like(means3D, requires_grad=True)
         color, radii, depth, alpha = r(means3D=means3D, means2D=means2D, opacities=opacities, shs=None,
                                        colors_precomp=colors, scales=scales, rotations=rotations, cov3D_precomp=None)
-        torch.autograd.backward([color, depth, alpha], [g_color, g_depth, g_alpha])
+        run_backward((color, depth, alpha), (g_color, g_depth, g_alpha))
         if world > 1:
             # exchange step of view sharding: sum the per-Gaussian attribute gradients over the views of this step
             comm_stream.wait_stream(torch.cuda.current_stream(dev))
