@@ -12,12 +12,15 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import helpers as h  # noqa: E402
 from animatablegaussians_amd import _lib, synth  # noqa: E402
 
-av = synth.avatar_map_gaussians()
-cams = synth.free_view_cameras()
+# python profiles/per_view.py [S]   S = canvas height (1024: configs[1], 268 k Gaussians @1024^2; 2048: configs[4], 1.07 M @2048^2)
+S = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+IMG = S
+av = synth.avatar_map_gaussians(S)
+cams = synth.free_view_cameras(8, img=IMG, focal=1100.0 * S / 1024)
 print("view      R  tiles  mean_len  max_len | pre  scan  scat  sort   fwd   bwd  prebwd (us)")
 for vi, camd in enumerate(cams):
     scene = dict(av, **camd)
-    scene.update(synth.upstream_grads(1024, 1024, 11))
+    scene.update(synth.upstream_grads(IMG, IMG, 11))
     cam = h.cam_of(scene)
     for _ in range(2):
         fw = h.gpu_native_forward(scene, cam)
@@ -42,7 +45,7 @@ for vi, camd in enumerate(cams):
 # item = (tile rank by list length, region); workgroup b of G takes XCD x = b % 8, items of tile ranks x, x+8, ... dealt
 # round-robin inside the XCD (ag_common.h ItemIter).  Actual work of an item ~ walk length = max n_contrib of its 32 pixels.
 G = 512
-for vi in (0, 2):
+for vi in ((0, 2) if S == 1024 else ()):
     scene = dict(av, **cams[vi])
     fw = h.gpu_native_forward(scene, h.cam_of(scene))
     rng = fw["ranges"].astype(np.int64)
