@@ -101,6 +101,11 @@ SYMBOLS = [
     ("ag_modulate_weight_backward", ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_float, ctypes.c_int32,
                                                  ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_vp]),
     ("ag_block2x2_transform", ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_vp]),
+    # include/ag_lpips.h
+    ("ag_maxpool2x2_forward", ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_vp]),
+    ("ag_maxpool2x2_backward", ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_vp]),
+    ("ag_lpips_level_forward", ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, ctypes.c_int32, ctypes.c_int32, c_vp]),
+    ("ag_lpips_level_backward", ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_int32, ctypes.c_int32, c_vp]),
     ("ag_debug_mfma_rate", ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_vp, c_vp]),
     # include/ag_avatar.h
     ("ag_gather_activate_forward", ctypes.c_int, [ctypes.POINTER(AgGatherArgs), c_vp]),

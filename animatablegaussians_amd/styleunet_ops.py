@@ -188,10 +188,11 @@ class _NoiseBiasAct(torch.autograd.Function):
         C, HW, slope, scale, has_nw, has_bias = ctx.cfg
         gy = gy.contiguous()
         gx = torch.empty_like(y)
-        gb = torch.empty(C, dtype=torch.float32, device=y.device) if has_bias else None
-        gw = torch.empty(1, dtype=torch.float32, device=y.device) if has_nw else None
+        # frozen parameters (the VGG trunk of LPIPS): no reduction, no buffer
+        gb = torch.empty(C, dtype=torch.float32, device=y.device) if has_bias and ctx.needs_input_grad[3] else None
+        gw = torch.empty(1, dtype=torch.float32, device=y.device) if has_nw and ctx.needs_input_grad[2] else None
         with torch.cuda.device(y.device):
-            _lib.check(_lib.lib().ag_noise_bias_act_backward(_p(gx), _p(gy), _p(y), _p(noise) if has_nw else None, _p(gb), _p(gw),
+            _lib.check(_lib.lib().ag_noise_bias_act_backward(_p(gx), _p(gy), _p(y), _p(noise) if gw is not None else None, _p(gb), _p(gw),
                                                              C, HW, slope, scale, _stream(y.device)),
                        "ag_noise_bias_act_backward")
         return gx, None, gw, gb, None, None

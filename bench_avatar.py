@@ -45,6 +45,8 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-viewdirs", action="store_true")
     ap.add_argument("--infer", action="store_true", help="eval-mode render only (animation / free-view synthesis)")
+    ap.add_argument("--lpips", action="store_true", help="add the reference's full loss tail: boundary compositing, L1, mask loss, "
+                    "512^2 crop and LPIPS-VGG16 (weight 0.1) -- SURVEY.md 8f-1")
     ap.add_argument("--graphs", action="store_true", help="with --infer: run the networks from captured hipGraphs")
     ap.add_argument("--views", type=int, default=1, help="cameras of the same pose per step (multi-view step: "
                     "pose-dependent work shared through AvatarNet.render_views)")
@@ -107,8 +109,19 @@ def main() -> None:
         opt = torch.optim.Adam(net.parameters(), lr=5e-4, fused=True)      # one pass over the 224 M parameters
 
     V = args.views
+    lp = None
+    if args.lpips and not args.infer:
+        from animatablegaussians_amd import losses, synth as _synth
+        from animatablegaussians_amd.lpips import LPIPS
+        lp = LPIPS(net='vgg').to(dev)
+        m = torch.from_numpy(_synth.body_mask(H).copy()).to(dev)
+        gt_items = {'color_img': target, 'mask_img': m, 'boundary_mask_img': torch.zeros_like(m)}
+        bg_dev = torch.zeros(3, device=dev)
+        weights = {'l1': 1.0, 'mask': 0.1, 'lpips': 0.1, 'offset': 0.005}
 
     def loss_of(out):
+        if lp is not None:
+            return losses.training_loss(out, gt_items, bg_dev, weights, lpips=lp, patch_size=512)[0]
         return (out['rgb_map'] - target).abs().mean() + 0.005 * torch.linalg.norm(out['offset'], dim=-1).mean()
 
     def step(i: int):
@@ -158,7 +171,7 @@ def main() -> None:
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"SURVEY 8d config 3: {V} view(s) of one pose per step, whole render path"
                                    + (" (eval)" if args.infer else " + loss + backward + Adam"),
-                       "gaussians": int(net.lbs.shape[0]), "parameters": int(n_params), "with_viewdirs": bool(net.with_viewdirs), "views_per_step": V, "hip_graphs": bool(args.infer and args.graphs),
+                       "gaussians": int(net.lbs.shape[0]), "parameters": int(n_params), "with_viewdirs": bool(net.with_viewdirs), "views_per_step": V, "lpips_loss_tail": lp is not None, "hip_graphs": bool(args.infer and args.graphs),
                        "parallelism": "1 process" if world == 1 else f"view-sharded x{world}, bucketed RCCL all-reduce of {n_params * 4 >> 20} MB grads"},
             "roofline": {"kernel": "gather_conv_kernel + wgrad_kernel (all StyleUNet convolutions of the step)", "bound": "mfma",
                          "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TF, 4),
