@@ -75,6 +75,11 @@ class AgConvDesc(ctypes.Structure):
     _fields_ = [(n, c_i32) for n in ("kind", "Cin", "Cout", "H", "W", "k", "stride", "padding")]
 
 
+class AgSmplxModel(ctypes.Structure):
+    _fields_ = [("V", c_i32), ("J", c_i32), ("NB", c_i32), ("reserved", c_i32)] + [(n, c_vp) for n in (
+        "v_template", "shapedirs", "posedirs", "J_regressor", "parents", "lbs_weights")]
+
+
 # every symbol include/*.h declares: (name, restype, argtypes)
 SYMBOLS = [
     ("ag_abi_version", ctypes.c_int, []),
@@ -107,6 +112,12 @@ SYMBOLS = [
     ("ag_lpips_level_forward", ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, ctypes.c_int32, ctypes.c_int32, c_vp]),
     ("ag_lpips_level_backward", ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_int32, ctypes.c_int32, c_vp]),
     ("ag_debug_mfma_rate", ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_vp, c_vp]),
+    # include/ag_smplx.h
+    ("ag_smplx_workspace_floats", c_sz, [ctypes.POINTER(AgSmplxModel), c_i32]),
+    ("ag_smplx_forward", ctypes.c_int, [ctypes.POINTER(AgSmplxModel), c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    ("ag_smplx_shape", ctypes.c_int, [ctypes.POINTER(AgSmplxModel), c_i32, c_vp, c_vp, c_vp]),
+    ("ag_mat4_mul_inverse", ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
+    ("ag_smplx_keypoints", ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
     # include/ag_avatar.h
     ("ag_gather_activate_forward", ctypes.c_int, [ctypes.POINTER(AgGatherArgs), c_vp]),
     ("ag_gather_activate_backward", ctypes.c_int, [ctypes.POINTER(AgGatherArgs), c_vp, c_vp, c_vp, c_vp]),

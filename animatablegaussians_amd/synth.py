@@ -156,3 +156,63 @@ def pose_map(S: int = 512, seed: int = SEED):
         chans.append(0.5 * np.sin(a[0] * xx + a[1]) * np.cos(a[2] * yy + a[3]) + 0.1 * xx * (c - 1))
     m = (np.abs(xx) < 0.8) & (np.abs(yy) < 0.9)
     return torch.from_numpy((np.stack(chans) * m[None]).astype(np.float32))[None]
+
+
+# SMPL-X kinematic tree (55 joints: pelvis, 21 body, jaw, 2 eyes, 15 + 15 finger joints) as the model files' kintree_table[0]
+# holds it; any tree with parents[j] < j exercises the same code.
+SMPLX_PARENTS = (-1, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19, 15, 15, 15,
+                 20, 25, 26, 20, 28, 29, 20, 31, 32, 20, 34, 35, 20, 37, 38,
+                 21, 40, 41, 21, 43, 44, 21, 46, 47, 21, 49, 50, 21, 52, 53)
+
+
+def smplx_model_arrays(seed: int = SEED, V: int = 10475, shape_dims: int = 400, n_faces: int = 20908) -> Dict[str, np.ndarray]:
+    """A synthetic body model with the ARRAY NAMES, SHAPES AND DTYPES of `SMPLX_NEUTRAL.npz` (the licensed model files are
+    not redistributable and not in this image): what smplx/body_models.py:237-260,604-625,995-1073 read from the file.
+    Random but body-sized: vertices in a 0.6 x 1.7 x 0.3 m box, 1-cm shape / 2-mm pose-corrective bases, each joint a convex
+    combination of 32 vertices, 4 skinning weights per vertex."""
+    rng = np.random.default_rng(seed)
+    J = len(SMPLX_PARENTS)
+    m: Dict[str, np.ndarray] = {}
+    m['v_template'] = ((rng.random((V, 3)) - 0.5) * np.array([0.6, 1.7, 0.3])).astype(np.float64)
+    m['shapedirs'] = (rng.standard_normal((V, 3, shape_dims)) * 0.01).astype(np.float64)
+    m['posedirs'] = (rng.standard_normal((V, 3, 9 * (J - 1))) * 0.002).astype(np.float64)
+    Jr = np.zeros((J, V))
+    for j in range(J):
+        idx = rng.choice(V, 32, replace=False)
+        w = rng.random(32)
+        Jr[j, idx] = w / w.sum()
+    m['J_regressor'] = Jr
+    kin = np.zeros((2, J), np.int64)
+    kin[0] = SMPLX_PARENTS
+    kin[0, 0] = 2 ** 32 - 1                      # the files store the root's parent as uint32(-1); smplx overwrites it
+    kin[1] = np.arange(J)
+    m['kintree_table'] = kin
+    W = np.zeros((V, J))
+    for k, idx in enumerate(rng.integers(0, J, (4, V))):
+        W[np.arange(V), idx] += rng.random(V) + (1.0 if k == 0 else 0.0)
+    m['weights'] = W / W.sum(1, keepdims=True)
+    m['f'] = rng.integers(0, V, (n_faces, 3)).astype(np.uint32)
+    m['hands_componentsl'] = rng.standard_normal((45, 45)) * 0.3
+    m['hands_componentsr'] = rng.standard_normal((45, 45)) * 0.3
+    m['hands_meanl'] = rng.standard_normal(45) * 0.2
+    m['hands_meanr'] = rng.standard_normal(45) * 0.2
+    m['lmk_faces_idx'] = rng.integers(0, n_faces, 51).astype(np.int64)
+    b = rng.random((51, 3))
+    m['lmk_bary_coords'] = b / b.sum(1, keepdims=True)
+    return m
+
+
+def smplx_pose_params(seed: int = SEED, n: int = 1) -> Dict[str, np.ndarray]:
+    """`n` frames of the parameter arrays a dataset's smpl_params.npz holds (dataset_mv_rgb.py:44-45)."""
+    rng = np.random.default_rng(seed + 17)
+    f32 = np.float32
+    return {
+        'betas': (rng.standard_normal((1, 10)) * 0.8).astype(f32),
+        'global_orient': (rng.standard_normal((n, 3)) * 0.6).astype(f32),
+        'transl': (rng.standard_normal((n, 3)) * 0.5).astype(f32),
+        'body_pose': (rng.standard_normal((n, 63)) * 0.35).astype(f32),
+        'jaw_pose': (rng.standard_normal((n, 3)) * 0.1).astype(f32),
+        'expression': (rng.standard_normal((n, 10)) * 0.7).astype(f32),
+        'left_hand_pose': (rng.standard_normal((n, 45)) * 0.3).astype(f32),
+        'right_hand_pose': (rng.standard_normal((n, 45)) * 0.3).astype(f32),
+    }
