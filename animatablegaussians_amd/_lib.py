@@ -77,7 +77,7 @@ class AgConvDesc(ctypes.Structure):
 
 class AgSmplxModel(ctypes.Structure):
     _fields_ = [("V", c_i32), ("J", c_i32), ("NB", c_i32), ("reserved", c_i32)] + [(n, c_vp) for n in (
-        "v_template", "shapedirs", "posedirs", "J_regressor", "parents", "lbs_weights")]
+        "v_template", "shapedirs", "posedirs", "J_regressor", "parents", "lbs_weights", "joint_template", "joint_dirs")]
 
 
 # every symbol include/*.h declares: (name, restype, argtypes)
@@ -115,6 +115,7 @@ SYMBOLS = [
     # include/ag_smplx.h
     ("ag_smplx_workspace_floats", c_sz, [ctypes.POINTER(AgSmplxModel), c_i32]),
     ("ag_smplx_forward", ctypes.c_int, [ctypes.POINTER(AgSmplxModel), c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    ("ag_smplx_prepare", ctypes.c_int, [ctypes.POINTER(AgSmplxModel), c_vp, c_vp, c_vp]),
     ("ag_smplx_shape", ctypes.c_int, [ctypes.POINTER(AgSmplxModel), c_i32, c_vp, c_vp, c_vp]),
     ("ag_mat4_mul_inverse", ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
     ("ag_smplx_keypoints", ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),

@@ -2,10 +2,12 @@
 // stage follows.  All of it is HBM / latency bound and tiny next to the render path -- the point of having it on the
 // device is that `cano2live_jnt_mats` is produced where it is consumed (no CPU data-loader stage, no upload) and that the
 // three model evaluations a data item needs (live, canonical, live without root) read the 61-MB pose-corrective basis
-// once.  Four launches:
+// once.  Three launches per call:
 //   shape_kernel   v_shaped = v_template + shapedirs . components           thread per (pose, coordinate)
-//   joints_kernel  rest joints = J_regressor . v_shaped                       workgroup per (joint, pose), fixed-order tree sum
-//   chain_kernel   Rodrigues, pose features, kinematic chain, A               one wave per pose, level-synchronous over the tree
+//   chain_kernel   rest joints, Rodrigues, pose features, kinematic chain, A  one wave per pose, level-synchronous over the tree
+//                  (rest joints = J_regressor . v_shaped is linear in the components: J_regressor . v_template and
+//                  J_regressor . shapedirs are folded once per model by ag_smplx_prepare -> 60 FMAs per joint instead of a
+//                  10475-long reduction per joint and pose)
 //   skin_kernel    pose_offsets = features . posedirs (the 61 MB stream), v_posed, T = W . A, vertices
 //                  workgroup = 32 vertices x 8 slices of the 486 features; lanes along coordinates (256-B segments)
 #include "ag_common.h"
@@ -35,19 +37,21 @@ __global__ void __launch_bounds__(256) smplx_shape_kernel(float* __restrict__ v_
     v_shaped[(size_t)b * n_coord + i] = v_template[i] + acc;
 }
 
-__global__ void __launch_bounds__(256) smplx_joints_kernel(float* __restrict__ joints_rest, const float* __restrict__ J_regressor,
-                                                          const float* __restrict__ v_shaped, int V, int J)
+// out[(j * 3 + c) * out_stride + b] = sum_v J_regressor[j][v] * src[(3 v + c) * src_stride + b]   (once per model: folds
+// the regressor into v_template (stride 1, one column) and into every column of shapedirs (stride NB, NB columns))
+__global__ void __launch_bounds__(256) smplx_joints_kernel(float* __restrict__ out, const float* __restrict__ J_regressor,
+                                                          const float* __restrict__ src, int V, int src_stride, int out_stride)
 {
     __shared__ float s_part[4][3];
     const int j = blockIdx.x, b = blockIdx.y;
     const float* reg = J_regressor + (size_t)j * V;
-    const float* vs = v_shaped + (size_t)b * V * 3;
+    const float* vs = src + b;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
     for (int v = threadIdx.x; v < V; v += 256) {
         const float w = reg[v];
-        a0 = fmaf(w, vs[3 * v + 0], a0);
-        a1 = fmaf(w, vs[3 * v + 1], a1);
-        a2 = fmaf(w, vs[3 * v + 2], a2);
+        a0 = fmaf(w, vs[(size_t)(3 * v + 0) * src_stride], a0);
+        a1 = fmaf(w, vs[(size_t)(3 * v + 1) * src_stride], a1);
+        a2 = fmaf(w, vs[(size_t)(3 * v + 2) * src_stride], a2);
     }
     for (int o = 32; o > 0; o >>= 1) {
         a0 += __shfl_xor(a0, o);
@@ -59,7 +63,7 @@ __global__ void __launch_bounds__(256) smplx_joints_kernel(float* __restrict__ j
     __syncthreads();
     if (threadIdx.x < 3) {
         const int c = threadIdx.x;
-        joints_rest[((size_t)b * J + j) * 3 + c] = (s_part[0][c] + s_part[1][c]) + (s_part[2][c] + s_part[3][c]);
+        out[(size_t)(j * 3 + c) * out_stride + b] = (s_part[0][c] + s_part[1][c]) + (s_part[2][c] + s_part[3][c]);
     }
 }
 
@@ -83,11 +87,14 @@ __device__ __forceinline__ void rodrigues(const float* rv, float* R)
         }
 }
 
-__global__ void __launch_bounds__(64) smplx_chain_kernel(float* __restrict__ A_out, float* __restrict__ joints_out,
-                                                        float* __restrict__ pose_feature, const float* __restrict__ full_pose,
-                                                        const float* __restrict__ joints_rest, const int* __restrict__ parents, int J)
+__global__ void __launch_bounds__(64) smplx_chain_kernel(float* __restrict__ A_out, float* __restrict__ A_skin,
+                                                        float* __restrict__ joints_out, float* __restrict__ pose_feature,
+                                                        const float* __restrict__ full_pose, const float* __restrict__ comps,
+                                                        const float* __restrict__ joint_template, const float* __restrict__ joint_dirs,
+                                                        const int* __restrict__ parents, const float* __restrict__ transl, int J, int NB)
 {
     __shared__ Affine s_glob[kMaxJoints];
+    __shared__ float s_rest[kMaxJoints][3];
     __shared__ int s_maxdepth;
     const int b = blockIdx.x, j = threadIdx.x;
     const bool on = j < J;
@@ -98,10 +105,20 @@ __global__ void __launch_bounds__(64) smplx_chain_kernel(float* __restrict__ A_o
     float rest[3] = {0.f, 0.f, 0.f};
     int parent = -1, depth = 0;
     if (on) {
+        // lbs.py:208-212 with the regressor folded: J_regressor . (v_template + dirs . comps) = joint_template + joint_dirs . comps
+        for (int c = 0; c < 3; ++c) {
+            const float* d = joint_dirs + (size_t)(3 * j + c) * NB;
+            float acc = 0.f;
+            for (int l = 0; l < NB; ++l) acc = fmaf(d[l], comps[(size_t)b * NB + l], acc);
+            rest[c] = joint_template[3 * j + c] + acc;
+            s_rest[j][c] = rest[c];
+        }
+    }
+    __syncthreads();
+    if (on) {
         rodrigues(full_pose + ((size_t)b * J + j) * 3, loc.r);
         parent = parents[j];
-        for (int c = 0; c < 3; ++c) rest[c] = joints_rest[((size_t)b * J + j) * 3 + c];
-        for (int c = 0; c < 3; ++c) loc.t[c] = parent >= 0 ? rest[c] - joints_rest[((size_t)b * J + parent) * 3 + c] : rest[c];
+        for (int c = 0; c < 3; ++c) loc.t[c] = parent >= 0 ? rest[c] - s_rest[parent][c] : rest[c];
         if (j >= 1) {
             float* pf = pose_feature + (size_t)b * 9 * (J - 1) + 9 * (j - 1);
             for (int k = 0; k < 9; ++k) pf[k] = loc.r[k] - ((k == 0 || k == 4 || k == 8) ? 1.f : 0.f);
@@ -129,14 +146,16 @@ __global__ void __launch_bounds__(64) smplx_chain_kernel(float* __restrict__ A_o
     if (!on) return;
     const Affine g = s_glob[j];
     float* Aj = A_out + ((size_t)b * J + j) * 16;
+    float* As = A_skin + ((size_t)b * J + j) * 12;
     for (int r = 0; r < 3; ++r) {
         // lbs.py:402-403: rel = T - pad(T @ [J; 0]) -> translation column minus R . J_rest
         const float rj = fmaf(g.r[3 * r + 2], rest[2], fmaf(g.r[3 * r + 1], rest[1], g.r[3 * r] * rest[0]));
-        Aj[4 * r + 0] = g.r[3 * r + 0];
-        Aj[4 * r + 1] = g.r[3 * r + 1];
-        Aj[4 * r + 2] = g.r[3 * r + 2];
-        Aj[4 * r + 3] = g.t[r] - rj;
-        joints_out[((size_t)b * J + j) * 3 + r] = g.t[r];
+        const float tr = transl ? transl[3 * b + r] : 0.f;
+        for (int c = 0; c < 3; ++c) Aj[4 * r + c] = As[4 * r + c] = g.r[3 * r + c];
+        As[4 * r + 3] = g.t[r] - rj;                     // what the skinning uses (lbs.py:241)
+        // body_models.py:1272-1275: joints += transl; A[:, :, :3, 3] += transl -- AFTER the skinning used the un-translated A
+        Aj[4 * r + 3] = transl ? (g.t[r] - rj) + tr : g.t[r] - rj;
+        joints_out[((size_t)b * J + j) * 3 + r] = transl ? g.t[r] + tr : g.t[r];
     }
     Aj[12] = 0.f; Aj[13] = 0.f; Aj[14] = 0.f; Aj[15] = 1.f;
 }
@@ -156,10 +175,7 @@ __global__ void __launch_bounds__(kSkinThreads) smplx_skin_kernel(float* __restr
     const int tid = threadIdx.x;
     const int n_coord = 3 * V;
     for (int i = tid; i < NBATCH * P; i += kSkinThreads) s_feat[i] = pose_feature[i];
-    for (int i = tid; i < NBATCH * J * 12; i += kSkinThreads) {
-        const int bj = i / 12, e = i % 12;
-        s_A[i] = A[(size_t)bj * 16 + e];                    // the three affine rows are the first 12 of the 16 floats
-    }
+    for (int i = tid; i < NBATCH * J * 12; i += kSkinThreads) s_A[i] = A[i];     // the un-translated affine rows (chain_kernel)
     __syncthreads();
 
     const int cx = tid % kSkinCoords, slice = tid / kSkinCoords;
@@ -215,18 +231,6 @@ __global__ void __launch_bounds__(kSkinThreads) smplx_skin_kernel(float* __restr
         if (transl) out += transl[3 * wb + c];
         vertices[(size_t)wb * n_coord + coord] = out;
     }
-}
-
-// body_models.py:1272-1275: joints += transl; A[:, :, :3, 3] += transl (after the skinning used the un-translated A)
-__global__ void __launch_bounds__(64) smplx_add_transl_kernel(float* __restrict__ A, float* __restrict__ joints,
-                                                             const float* __restrict__ transl, int J, int total)
-{
-    const int i = blockIdx.x * 64 + threadIdx.x;   // (b, j, r)
-    if (i >= total) return;
-    const int r = i % 3, bj = i / 3, b = bj / J;
-    const float t = transl[3 * b + r];
-    A[(size_t)bj * 16 + 4 * r + 3] += t;
-    joints[i] += t;
 }
 
 __global__ void __launch_bounds__(64) smplx_keypoints_kernel(float* __restrict__ out, const float* __restrict__ vertices,
@@ -288,6 +292,11 @@ static bool model_ok(const AgSmplxModel* m)
            m->J_regressor && m->parents && m->lbs_weights && (m->NB == 0 || m->shapedirs);
 }
 
+static bool folded_ok(const AgSmplxModel* m)
+{
+    return m->joint_template && (m->NB == 0 || m->joint_dirs);
+}
+
 template <int NBATCH>
 static void launch_skin(const AgSmplxModel* m, float* vertices, const float* feat, const float* v_shaped, const float* A,
                         const float* transl, hipStream_t s)
@@ -309,13 +318,14 @@ extern "C" {
 size_t ag_smplx_workspace_floats(const AgSmplxModel* m, int32_t B)
 {
     if (!m || B <= 0) return 0;
-    return (size_t)B * ((size_t)3 * m->V + (size_t)3 * m->J + (size_t)9 * (m->J - 1));
+    return (size_t)B * ((size_t)3 * m->V + (size_t)12 * m->J + (size_t)9 * (m->J - 1));
 }
 
 int ag_smplx_forward(const AgSmplxModel* m, int32_t B, const float* shape_components, const float* full_pose, const float* transl,
                      float* vertices, float* joints, float* A, float* workspace, size_t workspace_floats, void* stream)
 {
     if (!model_ok(m)) { set_error("smplx: bad model (need 0 < J <= 64, non-null arrays)"); return AG_ERR_INVALID_ARGUMENT; }
+    if (!folded_ok(m)) { set_error("smplx: joint_template / joint_dirs missing -- run ag_smplx_prepare once per model"); return AG_ERR_INVALID_ARGUMENT; }
     if (B < 0) { set_error("smplx: B < 0"); return AG_ERR_INVALID_ARGUMENT; }
     if (B == 0) return AG_OK;
     if (!full_pose || !vertices || !joints || !A || !workspace || (m->NB > 0 && !shape_components)) {
@@ -326,20 +336,19 @@ int ag_smplx_forward(const AgSmplxModel* m, int32_t B, const float* shape_compon
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int n_coord = 3 * m->V, P = 9 * (m->J - 1);
     float* v_shaped = workspace;
-    float* joints_rest = v_shaped + (size_t)B * n_coord;
-    float* feat = joints_rest + (size_t)B * 3 * m->J;
+    float* A_skin = v_shaped + (size_t)B * n_coord;
+    float* feat = A_skin + (size_t)B * 12 * m->J;
 
     hipLaunchKernelGGL(smplx_shape_kernel, dim3((n_coord + 255) / 256, B), dim3(256), sizeof(float) * (m->NB > 0 ? m->NB : 1), s, v_shaped,
                        m->v_template, m->shapedirs, shape_components, n_coord, m->NB);
-    hipLaunchKernelGGL(smplx_joints_kernel, dim3(m->J, B), dim3(256), 0, s, joints_rest, m->J_regressor, v_shaped, m->V, m->J);
-    // A is produced WITHOUT transl first (the skinning uses it that way, body_models.py:1233-1275), transl is added after
-    hipLaunchKernelGGL(smplx_chain_kernel, dim3(B), dim3(64), 0, s, A, joints, feat, full_pose, joints_rest, m->parents, m->J);
+    hipLaunchKernelGGL(smplx_chain_kernel, dim3(B), dim3(64), 0, s, A, A_skin, joints, feat, full_pose, shape_components, m->joint_template,
+                       m->joint_dirs, m->parents, transl, m->J, m->NB);
     for (int b0 = 0; b0 < B; b0 += 4) {
         const int nb = B - b0 < 4 ? B - b0 : 4;
         float* vo = vertices + (size_t)b0 * n_coord;
         const float* f = feat + (size_t)b0 * P;
         const float* vs = v_shaped + (size_t)b0 * n_coord;
-        const float* Ab = A + (size_t)b0 * m->J * 16;
+        const float* Ab = A_skin + (size_t)b0 * m->J * 12;
         const float* tb = transl ? transl + (size_t)3 * b0 : nullptr;
         switch (nb) {
             case 1: launch_skin<1>(m, vo, f, vs, Ab, tb, s); break;
@@ -348,11 +357,18 @@ int ag_smplx_forward(const AgSmplxModel* m, int32_t B, const float* shape_compon
             default: launch_skin<4>(m, vo, f, vs, Ab, tb, s); break;
         }
     }
-    if (transl) {
-        const int total = B * m->J * 3;
-        hipLaunchKernelGGL(smplx_add_transl_kernel, dim3((total + 63) / 64), dim3(64), 0, s, A, joints, transl, m->J, total);
-    }
     return check_hip(hipGetLastError(), "ag_smplx_forward");
+}
+
+int ag_smplx_prepare(const AgSmplxModel* m, float* joint_template, float* joint_dirs, void* stream)
+{
+    if (!model_ok(m)) { set_error("smplx_prepare: bad model"); return AG_ERR_INVALID_ARGUMENT; }
+    if (!joint_template || (m->NB > 0 && !joint_dirs)) { set_error("null pointer"); return AG_ERR_INVALID_ARGUMENT; }
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(smplx_joints_kernel, dim3(m->J, 1), dim3(256), 0, s, joint_template, m->J_regressor, m->v_template, m->V, 1, 1);
+    if (m->NB > 0)
+        hipLaunchKernelGGL(smplx_joints_kernel, dim3(m->J, m->NB), dim3(256), 0, s, joint_dirs, m->J_regressor, m->shapedirs, m->V, m->NB, m->NB);
+    return check_hip(hipGetLastError(), "smplx_joints_kernel");
 }
 
 int ag_smplx_shape(const AgSmplxModel* m, int32_t B, const float* shape_components, float* v_shaped, void* stream)

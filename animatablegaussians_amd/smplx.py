@@ -154,6 +154,7 @@ class SMPLX(nn.Module):
         reg('left_hand_mean', f32(zeros45 if flat_hand_mean else data['hands_meanl']))
         reg('right_hand_mean', f32(zeros45 if flat_hand_mean else data['hands_meanr']))
         reg('pose_mean', torch.cat([torch.zeros(3 + 3 * self.NUM_BODY_JOINTS + 9), self.left_hand_mean.cpu(), self.right_hand_mean.cpu()]))
+        self._pose_mean_host = self.pose_mean.cpu().clone()
         # device-side forms the kernels read
         reg('_dirs', torch.cat([self.shapedirs, self.expr_dirs], -1).contiguous())     # [V, 3, NB]  (body_models.py:1233)
         reg('_parents32', self.parents.to(torch.int32))
@@ -188,7 +189,13 @@ class SMPLX(nn.Module):
                 if not t.is_cuda or not t.is_contiguous():
                     raise _lib.AgNativeError(f"SMPLX.{name} must be a contiguous GPU tensor (there is no CPU path)")
                 setattr(m, name, t.data_ptr())
-            self._desc = (self.posedirs.data_ptr(), m)
+            dev = self.v_template.device
+            jt = torch.empty((m.J, 3), dtype=torch.float32, device=dev)
+            jd = torch.empty((m.J, 3, max(m.NB, 1)), dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):          # once per model: the joint regressor folded through the shape basis
+                _lib.check(_lib.lib().ag_smplx_prepare(ctypes.byref(m), _p(jt), _p(jd), _stream(dev)), "ag_smplx_prepare")
+            m.joint_template, m.joint_dirs = jt.data_ptr(), jd.data_ptr()
+            self._desc = (self.posedirs.data_ptr(), m, jt, jd)
         return self._desc[1]
 
     def lbs(self, shape_components: torch.Tensor, full_pose: torch.Tensor, transl: Optional[torch.Tensor]):
@@ -260,27 +267,39 @@ class SMPLX(nn.Module):
 
     def data_item(self, smpl_data, pose_idx: int, cano_global_orient, cano_transl, cano_body_pose) -> dict:
         """dataset/dataset_mv_rgb.py:118-143,155-171 for one frame: the live, canonical and live-without-root evaluations as ONE
-        batch of three, then both `cano2live` matrix sets.  `smpl_data`: dict of tensors/arrays as in smpl_params.npz."""
+        batch of three, then both `cano2live` matrix sets.  `smpl_data`: the tensors / arrays of smpl_params.npz (host memory,
+        as the reference's dataset holds them): the three parameter rows are assembled on the host and uploaded in one copy."""
         dev = self.v_template.device
-        t = lambda x: torch.as_tensor(x).to(dev, torch.float32)
-        row = lambda k: t(smpl_data[k][pose_idx]).reshape(1, -1)
-        z = lambda n: torch.zeros((1, n), dtype=torch.float32, device=dev)
-        betas = t(smpl_data['betas'][0]).reshape(1, -1)
-        out = self.forward(
-            betas=betas.expand(3, -1),
-            global_orient=torch.cat([row('global_orient'), t(cano_global_orient).reshape(1, 3), z(3)]),
-            transl=torch.cat([row('transl'), t(cano_transl).reshape(1, 3), z(3)]),
-            body_pose=torch.cat([row('body_pose'), t(cano_body_pose).reshape(1, -1), row('body_pose')]),
-            jaw_pose=row('jaw_pose').expand(3, -1), expression=row('expression').expand(3, -1),
-            left_hand_pose=torch.cat([row('left_hand_pose'), z(45), z(45)]),
-            right_hand_pose=torch.cat([row('right_hand_pose'), z(45), z(45)]))
-        A = out.A
+        h = lambda x: torch.as_tensor(x).detach().to('cpu', torch.float32).reshape(-1)
+        row = lambda k: h(smpl_data[k][pose_idx])
+        nb, ne = self._num_betas, self._num_expression_coeffs
+        n_pose = 3 * (self.NUM_JOINTS + 1)
+        o1, o2 = 3 * (nb + ne), 3 * (nb + ne + n_pose)
+        buf = torch.zeros((o2 + 9,), dtype=torch.float32)             # three contiguous blocks: components | poses | transl
+        comps, pose, tr = buf[:o1].view(3, nb + ne), buf[o1:o2].view(3, n_pose), buf[o2:].view(3, 3)
+        comps[:, :nb] = h(smpl_data['betas'][0])[:nb]
+        comps[:, nb:] = row('expression')[:ne]
+        # full_pose = global_orient | body 63 | jaw | leye | reye | left hand 45 | right hand 45  (body_models.py:1203-1210)
+        pose[0, 0:3], pose[1, 0:3] = row('global_orient'), h(cano_global_orient)
+        pose[0, 3:66] = pose[2, 3:66] = row('body_pose')
+        pose[1, 3:66] = h(cano_body_pose)
+        pose[:, 66:69] = row('jaw_pose')
+        pose[0, 75:120], pose[0, 120:165] = row('left_hand_pose'), row('right_hand_pose')
+        pose += self._pose_mean_host
+        tr[0], tr[1] = row('transl'), h(cano_transl)
+        d = buf.to(dev, non_blocking=True)
+        verts, joints, A = self.lbs(d[:o1].view(3, nb + ne), d[o1:o2].view(3, n_pose), d[o2:].view(3, 3))
+        K = self._kp_idx.shape[0]
+        extra = torch.empty((2, K, 3), dtype=torch.float32, device=dev)      # the dataset reads joints of live and canonical only
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().ag_smplx_keypoints(_p(extra), _p(verts), _p(self._kp_idx), _p(self._kp_w), 2, verts.shape[1], K,
+                                                     _stream(dev)), "ag_smplx_keypoints")
         c2l = mat4_mul_inverse(torch.stack([A[0], A[2]]), A[1])
-        v = out.vertices
+        v = verts
         return {
-            'joints': out.joints[0, :22], 'kin_parent': self.parents[:22].to(torch.long),
-            'live_smpl_v': v[0], 'cano_smpl_v': v[1], 'live_smpl_v_woRoot': v[2], 'cano_jnts': out.joints[1],
+            'joints': joints[0, :22], 'kin_parent': self.parents[:22].to(torch.long),
+            'live_smpl_v': v[0], 'cano_smpl_v': v[1], 'live_smpl_v_woRoot': v[2], 'cano_jnts': torch.cat([joints[1], extra[1]], 0),
             'cano2live_jnt_mats': c2l[0], 'cano2live_jnt_mats_woRoot': c2l[1],
             'live_bounds': torch.stack([v[0].min(0)[0] - 0.15, v[0].max(0)[0] + 0.15], 0),
-            'global_orient': row('global_orient')[0], 'transl': row('transl')[0],
+            'global_orient': d[o1:o1 + 3], 'transl': d[o2:o2 + 3],
         }

@@ -4,18 +4,18 @@
  * the producer of `cano2live_jnt_mats` (what AvatarNet.transform_cano2live skins the Gaussians with)
  * is the dataset-side SMPL-X forward -- three `smpl_model.forward` calls per item (live, canonical, live without root:
  * dataset/dataset_mv_rgb.py:118-143) followed by `live.A @ inv(cano.A)` (:170-171).  The reference runs it on the CPU in
- * the data loader (smplx/body_models.py:1114-1290 -> smplx/lbs.py:152-246); here the B poses go through four launches
+ * the data loader (smplx/body_models.py:1114-1290 -> smplx/lbs.py:152-246); here the B poses go through three launches
  * that read the 61-MB pose-corrective basis ONCE for all of them.
  *
  * Replaces, stage by stage (smplx/lbs.py):
  *   :208  v_shaped = v_template + blend_shapes(betas ++ expression, shapedirs ++ expr_dirs)      (ag_smplx_forward, kernel 1)
- *   :212  J = vertices2joints(J_regressor, v_shaped)                                              (kernel 2)
- *   :218  rot_mats = batch_rodrigues(pose)  (:299-330, incl. its `+ 1e-8` inside the norm)        (kernel 3)
- *   :221  pose_feature = (rot_mats[1:] - I).view(-1)                                              (kernel 3)
- *   :235  J_transformed, A = batch_rigid_transform(rot_mats, J, parents)  (:347-405)              (kernel 3)
- *   :223  pose_offsets = pose_feature @ posedirs;  :233 v_posed = pose_offsets + v_shaped         (kernel 4)
- *   :239-248  T = W @ A;  verts = (T @ [v_posed, 1])[:3]                                          (kernel 4)
- *   body_models.py:1272-1275  `+ transl` on vertices, joints and A[:, :3, 3] AFTER the skinning   (kernel 4 + a tail launch)
+ *   :212  J = vertices2joints(J_regressor, v_shaped)           (kernel 2, through the per-model fold of ag_smplx_prepare)
+ *   :218  rot_mats = batch_rodrigues(pose)  (:299-330, incl. its `+ 1e-8` inside the norm)        (kernel 2)
+ *   :221  pose_feature = (rot_mats[1:] - I).view(-1)                                              (kernel 2)
+ *   :235  J_transformed, A = batch_rigid_transform(rot_mats, J, parents)  (:347-405)              (kernel 2)
+ *   :223  pose_offsets = pose_feature @ posedirs;  :233 v_posed = pose_offsets + v_shaped         (kernel 3)
+ *   :239-248  T = W @ A;  verts = (T @ [v_posed, 1])[:3]                                          (kernel 3)
+ *   body_models.py:1272-1275  `+ transl` on vertices, joints and A[:, :3, 3] AFTER the skinning   (kernels 2, 3)
  * Device pointers, contiguous row-major; 0 on success (codes in ag_raster.h).
  */
 #ifndef AG_SMPLX_H
@@ -40,9 +40,17 @@ typedef struct AgSmplxModel {
     const float* J_regressor;  /* [J][V] dense */
     const int32_t* parents;    /* [J], parents[0] = -1, parents[j] < j */
     const float* lbs_weights;  /* [V][J] */
+    const float* joint_template; /* [J][3]      = J_regressor . v_template   } written once per model by ag_smplx_prepare */
+    const float* joint_dirs;     /* [J][3][NB]  = J_regressor . shapedirs    } (device memory owned by the caller)        */
 } AgSmplxModel;
 
-/* Floats of workspace ag_smplx_forward needs for B poses (v_shaped, rest joints, pose features). */
+/* Folds the joint regressor through the (linear) shape model: lbs.py:208-212 computes J_regressor . (v_template + shapedirs . c)
+ * per call, a 10475-long reduction per joint; J_regressor . v_template + (J_regressor . shapedirs) . c is the same sum
+ * re-associated (difference ~1e-7 of the joint positions).  joint_template [J][3], joint_dirs [J][3][NB]: device outputs;
+ * the model's own joint_template / joint_dirs fields are not read by this call. */
+int ag_smplx_prepare(const AgSmplxModel* m, float* joint_template, float* joint_dirs, void* stream);
+
+/* Floats of workspace ag_smplx_forward needs for B poses (v_shaped, un-translated joint matrices, pose features). */
 size_t ag_smplx_workspace_floats(const AgSmplxModel* m, int32_t B);
 
 /*
