@@ -410,7 +410,7 @@ int launch_blend_backward(const AgRasterBackwardArgs& a, hipStream_t s)
     if (check_hip(hipMemsetAsync(p.accum, 0, (size_t)a.P * kAccumFloats * sizeof(float), s), "memset accum")) return AG_ERR_HIP;
     if (a.num_rendered <= 0) return AG_OK;
     const long long items = (long long)p.T * kRegionsPerTile;
-    const int grid = (int)(items < 512 ? items : 512);   // 2 resident workgroups of 8 waves per CU (69 KiB of LDS each)
+    const int grid = (int)(items < kBlendGrid ? items : kBlendGrid);   // 2 resident workgroups of 8 waves per CU (69 KiB of LDS each), 4x oversubscribed
     { ProfScope ps(AG_K_BLEND_BACKWARD, s); hipLaunchKernelGGL(blend_backward_kernel, dim3(grid), dim3(kBlendThreads), 0, s, p); }
     return check_hip(hipGetLastError(), "blend_backward_kernel");
 }

@@ -276,9 +276,11 @@ int launch_blend_forward(const AgRasterForwardArgs& a, int R, hipStream_t s)
     p.bg = a.bg;
     p.out_color = a.out_color; p.out_depth = a.out_depth; p.out_alpha = a.out_alpha;
     p.n_contrib = reinterpret_cast<uint32_t*>(ib + il.n_contrib);
-    // persistent grid: 4 workgroups of 8 waves per CU fill the 32 wave slots of each of the 256 CUs
+    // 2048 workgroups, of which 1024 (4 per CU) are resident: each takes 2-3 items of the longest-first order by the static
+    // rule, and the hardware dispatcher starts the second half wherever a slot frees up first -- load balancing without
+    // atomics (see kBlendGrid in ag_common.h for the measurements).
     const long long items = (long long)p.T * kRegionsPerTile;
-    const int grid = (int)(items < 1024 ? items : 1024);
+    const int grid = (int)(items < kBlendGrid ? items : kBlendGrid);
     { ProfScope ps(AG_K_BLEND_FORWARD, s); hipLaunchKernelGGL(blend_forward_kernel, dim3(grid), dim3(kBlendThreads), 0, s, p); }
     return check_hip(hipGetLastError(), "blend_forward_kernel");
 }

@@ -43,6 +43,18 @@ constexpr int kQueues = 8;    // XCDs: the static work assignment keeps all regi
 // placement, used for speed only) and is the (b / 8)-th workgroup of that XCD.  XCD x owns tile ranks x, x+8, x+16, ...
 // and ALL regions of those tiles, so the workgroups that gather one tile's list share an L2; inside the XCD the
 // (tile, region) items are dealt round-robin, which with the longest-first order is the usual LPT balance.
+//
+// Balance: the cost of an item depends on how many of the tile's entries survive the region's cull and on where its pixels
+// saturate, which no length-based order predicts -- with exactly as many workgroups as resident slots (512 in the backward)
+// their end times spread over 82-154 us of a 154-us kernel (busy fraction 0.63-0.76, profiles/bwd_wg_times.py).  A software
+// queue costs more than it gains (32 counters, tickets drawn two items ahead: backward 166 -> 146 us but forward 67 -> 75 us
+// and the whole step 10 % SLOWER: device-scope returning atomics take microseconds under the flush traffic).  The hardware
+// dispatcher does it for free: with kBlendGrid = 2048 workgroups each takes 2-3 items by the same static rule and late
+// workgroups start on whichever CU frees a slot first: forward 67 -> 59 us, backward 166 -> 152 us, step +14-20 %.
+// (4096-8192 workgroups: same kernel times, but two concurrent streams then starve each other; 32768: dispatch of empty
+// workgroups costs more than it saves.)
+constexpr int kBlendGrid = 2048;
+
 struct ItemIter {
     uint32_t i, stride, x, n_active;
     __device__ __forceinline__ ItemIter(uint32_t block, uint32_t grid, uint32_t n_active_)

@@ -244,7 +244,7 @@ def main() -> None:
     if breakdown is not None:
         out["kernels_us"] = breakdown
 
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:            # reported at N = 1 only (it costs ~25 s of host time)
         out["cpu_baseline"] = cpu_baseline(av, cams_np, up, W, H)
     print(json.dumps(out), flush=True)
     if world > 1:
