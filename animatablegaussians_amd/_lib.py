@@ -91,6 +91,7 @@ SYMBOLS = [
     ("ag_raster_describe_scratch", ctypes.c_int, [c_i32, c_i32, c_i32, c_i32, ctypes.POINTER(AgRasterScratchLayout)]),
     ("ag_raster_forward_plan", ctypes.c_int, [ctypes.POINTER(AgRasterForwardArgs), c_vp, ctypes.POINTER(c_i32)]),
     ("ag_raster_forward_render", ctypes.c_int, [ctypes.POINTER(AgRasterForwardArgs), c_i32, c_vp]),
+    ("ag_raster_forward_optimistic", ctypes.c_int, [ctypes.POINTER(AgRasterForwardArgs), c_i32, c_vp, ctypes.POINTER(c_i32)]),
     ("ag_raster_backward", ctypes.c_int, [ctypes.POINTER(AgRasterBackwardArgs), c_vp]),
     ("ag_raster_mark_visible", ctypes.c_int, [c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
     ("ag_prof_kernel_name", ctypes.c_char_p, [c_i32]),
@@ -134,6 +135,8 @@ SYMBOLS = [
     ("ag_conv_backward_input", ctypes.c_int, [ctypes.POINTER(AgConvDesc), c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     ("ag_conv_backward_weight", ctypes.c_int, [ctypes.POINTER(AgConvDesc), c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
 ]
+
+AG_ERR_SCRATCH_TOO_SMALL = -2      # include/ag_raster.h
 
 _lib = None
 

@@ -69,6 +69,13 @@ static int32_t* pinned_word()
     return w;
 }
 
+static hipEvent_t plan_event()
+{
+    static thread_local hipEvent_t ev = nullptr;
+    if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) ev = nullptr;
+    return ev;
+}
+
 static int validate_forward(const AgRasterForwardArgs* a, bool need_bin, int R)
 {
     if (!a) { set_error("null args"); return AG_ERR_INVALID_ARGUMENT; }
@@ -143,6 +150,36 @@ int ag_raster_forward_plan(const AgRasterForwardArgs* a, void* stream, int32_t* 
     if ((rc = check_hip(hipMemcpyAsync(w, ib + il.num_rendered, sizeof(int32_t), hipMemcpyDeviceToHost, s), "read num_rendered"))) return rc;
     if ((rc = check_hip(hipStreamSynchronize(s), "sync after plan"))) return rc;
     *num_rendered_host = *w;
+    return AG_OK;
+}
+
+int ag_raster_forward_optimistic(const AgRasterForwardArgs* a, int32_t capacity, void* stream, int32_t* num_rendered_host)
+{
+    if (!num_rendered_host) { set_error("null num_rendered_host"); return AG_ERR_INVALID_ARGUMENT; }
+    *num_rendered_host = 0;
+    if (capacity <= 0) { set_error("capacity must be positive"); return AG_ERR_INVALID_ARGUMENT; }
+    int rc = validate_forward(a, true, capacity);
+    if (rc) return rc;
+    if (a->P == 0) return ag_raster_forward_render(a, 0, stream);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    int32_t* w = pinned_word();
+    hipEvent_t ev = plan_event();
+    if (!w || !ev) { set_error("hipHostMalloc / hipEventCreate failed"); return AG_ERR_HIP; }
+    if ((rc = launch_preprocess(*a, s))) return rc;
+    if ((rc = launch_tile_scan(*a, s, (uint32_t)capacity))) return rc;
+    ImageLayout il((size_t)a->W, (size_t)a->H);
+    const char* ib = aligned_base(a->image_buffer);
+    if ((rc = check_hip(hipMemcpyAsync(w, ib + il.num_rendered, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, s), "read num_rendered"))) return rc;
+    if ((rc = check_hip(hipEventRecord(ev, s), "record plan event"))) return rc;
+    // everything else is enqueued BEFORE the host learns the count: the GPU never waits for the host round trip
+    if ((rc = launch_bin_sort(*a, capacity, s))) return rc;
+    if ((rc = launch_blend_forward(*a, capacity, s))) return rc;
+    if ((rc = check_hip(hipEventSynchronize(ev), "wait for the instance count"))) return rc;
+    *num_rendered_host = w[0];
+    if (w[2]) {
+        set_error("optimistic forward: %d instances exceed the capacity of %d; redo with ag_raster_forward_plan + _render", w[0], capacity);
+        return AG_ERR_SCRATCH_TOO_SMALL;
+    }
     return AG_OK;
 }
 

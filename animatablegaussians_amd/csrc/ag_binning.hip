@@ -24,7 +24,7 @@ namespace ag {
 __global__ void __launch_bounds__(1024) tile_scan_kernel(int T, const uint32_t* __restrict__ tile_count,
                                                         uint32_t* __restrict__ cursor, uint2* __restrict__ ranges,
                                                         uint32_t* __restrict__ num_rendered,
-                                                        uint4* __restrict__ tile_order)
+                                                        uint4* __restrict__ tile_order, uint32_t capacity)
 {
     __shared__ uint32_t wave_sums[16];
     __shared__ uint32_t carry_s;
@@ -59,7 +59,15 @@ __global__ void __launch_bounds__(1024) tile_scan_kernel(int T, const uint32_t* 
         if (tid == 1023) carry_s = incl;
         __syncthreads();
     }
-    if (tid == 0) { num_rendered[0] = carry_s; num_rendered[1] = (uint32_t)T - cls_hist[0]; }   // instances, non-empty tiles
+    // instances, non-empty tiles, overflow flag.  `capacity` = instances the binning buffer was sized for when the later stages
+    // were enqueued before this count was known (ag_raster_forward_optimistic): on overflow they must not touch it -- the
+    // scatter returns on the flag, and with zero active tiles the sort and blend kernels have nothing to walk.
+    if (tid == 0) {
+        const bool over = carry_s > capacity;
+        num_rendered[0] = carry_s;
+        num_rendered[1] = over ? 0u : (uint32_t)T - cls_hist[0];
+        num_rendered[2] = over ? 1u : 0u;
+    }
     // Work order for the persistent blend kernels: tiles by descending size class (longest-processing-time first),
     // empty tiles last.  Order inside a class is arbitrary.
     if (tid == 0) {
@@ -74,7 +82,7 @@ __global__ void __launch_bounds__(1024) tile_scan_kernel(int T, const uint32_t* 
     }
 }
 
-int launch_tile_scan(const AgRasterForwardArgs& a, hipStream_t s)
+int launch_tile_scan(const AgRasterForwardArgs& a, hipStream_t s, uint32_t capacity)
 {
     const int gx = (a.W + kTileX - 1) / kTileX, gy = (a.H + kTileY - 1) / kTileY;
     char* ib = aligned_base(a.image_buffer);
@@ -84,7 +92,7 @@ int launch_tile_scan(const AgRasterForwardArgs& a, hipStream_t s)
                        reinterpret_cast<uint32_t*>(ib + il.cursor),
                        reinterpret_cast<uint2*>(ib + il.ranges),
                        reinterpret_cast<uint32_t*>(ib + il.num_rendered),
-                       reinterpret_cast<uint4*>(ib + il.tile_order)); }
+                       reinterpret_cast<uint4*>(ib + il.tile_order), capacity); }
     return check_hip(hipGetLastError(), "tile_scan_kernel");
 }
 
@@ -109,8 +117,9 @@ constexpr int kWinBins = 2048;   // same workgroup tile window as the preprocess
 
 __global__ void __launch_bounds__(256) scatter_kernel(int P, int gx, int gy, const int* __restrict__ radii,
                                                      const GaussRec* __restrict__ rec, uint32_t* __restrict__ cursor,
-                                                     uint64_t* __restrict__ keys)
+                                                     uint64_t* __restrict__ keys, const uint32_t* __restrict__ counts)
 {
+    if (counts[2]) return;   // more instances than the binning buffer holds (optimistic forward): the caller redoes the frame
     // Slots are handed out per (workgroup, tile): instances are counted in an LDS histogram over the workgroup's
     // tile window, one global atomic per touched tile reserves the workgroup's block of the tile segment, and the
     // rank inside the block comes from a second pass of LDS atomics.  Order inside a segment is arbitrary (the sort
@@ -302,7 +311,8 @@ int launch_bin_sort(const AgRasterForwardArgs& a, int R, hipStream_t s)
     uint64_t* keys = reinterpret_cast<uint64_t*>(bb + bl.keys);
     uint32_t* point_list = reinterpret_cast<uint32_t*>(bb + bl.point_list);
     { ProfScope ps(AG_K_SCATTER, s); hipLaunchKernelGGL(scatter_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, a.P, gx, gy, a.radii,
-                       reinterpret_cast<const GaussRec*>(gb + gl.rec), reinterpret_cast<uint32_t*>(ib + il.cursor), keys); }
+                       reinterpret_cast<const GaussRec*>(gb + gl.rec), reinterpret_cast<uint32_t*>(ib + il.cursor), keys,
+                       reinterpret_cast<const uint32_t*>(ib + il.num_rendered)); }
     if (check_hip(hipGetLastError(), "scatter_kernel")) return AG_ERR_HIP;
     static bool attr_set = false;
     constexpr size_t kSmallLds = 2ull * kSortSmallCap * sizeof(uint64_t), kLargeLds = 2ull * kSortLargeCap * sizeof(uint64_t);

@@ -114,16 +114,18 @@ __device__ __forceinline__ float wave_reduce16_transposed(float (&v)[16], int la
     return x;
 }
 
-#ifndef BWD_WAVES_PER_SIMD
-#define BWD_WAVES_PER_SIMD 4
-#endif
-// Compacted entries blended between two flushes of the per-wave partial sums.  Every flush costs two workgroup barriers and
-// PMC shows the waves of this kernel parked on barriers / waitcnt 60 % of their lifetime, so fewer, larger flushes win even
-// though the 42 KiB of partial slabs leave room for only 2 workgroups per CU: 64 -> 128 entries measured 189 -> 172 us.
-constexpr int kSub = 128;
+// Occupancy: 6 waves per SIMD (80 VGPRs, 4 of them spilled) and 48 KiB of LDS = 3 resident workgroups per CU.  Every item
+// starts with three dependent global round trips (n_contrib -> list indices -> records) and every flush ends in two workgroup
+// barriers; PMC shows the waves parked on barriers / waitcnt 60 % of their lifetime, and a third workgroup fills those holes.
+constexpr int kBwdWavesPerSimd = 6;
+// Compacted entries blended between two flushes of the per-wave partial sums.  With only two workgroups per CU resident
+// (512-workgroup grid) 64 -> 128 entries per flush measured 189 -> 172 us; with the 2048-workgroup grid the 21 KiB this
+// saves buy the third resident workgroup instead: 154 -> 135 us (same-box A/B).  (One shared slab filled with LDS float
+// atomics would need 5 KiB only, but measured 240-300 us.)
+constexpr int kSub = 64;
 constexpr int kPartStride = kSub + 4;
 
-__global__ void __launch_bounds__(kBlendThreads, BWD_WAVES_PER_SIMD) blend_backward_kernel(BlendBwdParams p)
+__global__ void __launch_bounds__(kBlendThreads, kBwdWavesPerSimd) blend_backward_kernel(BlendBwdParams p)
 {
     constexpr int NW = kBlendThreads / 64;
     __shared__ float4 s_rec[kChunk * 3];
@@ -410,7 +412,7 @@ int launch_blend_backward(const AgRasterBackwardArgs& a, hipStream_t s)
     if (check_hip(hipMemsetAsync(p.accum, 0, (size_t)a.P * kAccumFloats * sizeof(float), s), "memset accum")) return AG_ERR_HIP;
     if (a.num_rendered <= 0) return AG_OK;
     const long long items = (long long)p.T * kRegionsPerTile;
-    const int grid = (int)(items < kBlendGrid ? items : kBlendGrid);   // 2 resident workgroups of 8 waves per CU (69 KiB of LDS each), 4x oversubscribed
+    const int grid = (int)(items < kBlendGrid ? items : kBlendGrid);   // 3 resident workgroups of 8 waves per CU (48 KiB of LDS each), 2.7x oversubscribed
     { ProfScope ps(AG_K_BLEND_BACKWARD, s); hipLaunchKernelGGL(blend_backward_kernel, dim3(grid), dim3(kBlendThreads), 0, s, p); }
     return check_hip(hipGetLastError(), "blend_backward_kernel");
 }

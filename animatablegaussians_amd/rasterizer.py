@@ -35,6 +35,8 @@ def _ptr(t: Optional[torch.Tensor]):
 
 
 def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
+    if t.dtype is torch.float32 and t.is_cuda and t.is_contiguous():      # the usual case, checked first: this runs ~25x per view
+        return t
     if t.numel() == 0:
         return t
     if not t.is_cuda:
@@ -48,12 +50,52 @@ def _stream_ptr(device) -> ctypes.c_void_p:
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
+class _on_device:
+    """``torch.cuda.device(dev)`` only when ``dev`` is not already current (the context manager costs ~5 us per use)."""
+    __slots__ = ("ctx",)
+
+    def __init__(self, dev):
+        self.ctx = None if torch.cuda.current_device() == dev.index else torch.cuda.device(dev)
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            return self.ctx.__exit__(*exc)
+        return False
+
+
+_bytes_cache = {}
+
+
+def _scratch_bytes(kind: str, *dims) -> int:
+    """Scratch sizes from the library, memoised (pure functions of their arguments)."""
+    k = (kind,) + dims
+    v = _bytes_cache.get(k)
+    if v is None:
+        v = _bytes_cache[k] = int(getattr(_lib.lib(), "ag_raster_" + kind + "_bytes")(*dims))
+    return v
+
+
+# Instance capacity the next optimistic forward sizes its binning buffer for, per (P, W, H, device): 1.25 x the largest
+# count seen so far.  The first frame of a configuration (and any frame that outgrows the capacity) takes the two-stage path.
+_capacity = {}
+
+
 def native_rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                                viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree,
-                               campos, prefiltered, debug):
+                               campos, prefiltered, debug, *, _optimistic=False):
     """``_C.rasterize_gaussians`` (``rasterize_points.cu:35-119``).
 
     Returns ``(num_rendered, color, depth, alpha, radii, geomBuffer, binningBuffer, imgBuffer)``.
+
+    ``_optimistic`` (the autograd node's path): all forward stages are enqueued before the host reads the instance count,
+    against a binning buffer sized from earlier frames (``ag_raster_forward_optimistic``), so the GPU does not idle over the
+    host round trip the reference has between its scan and its sort (``rasterizer_impl.cu:282``).  The first element of the
+    result is then a pair ``(num_rendered, layout_R)``: the scratch is laid out for ``layout_R`` instances and THAT is what the
+    backward takes as ``R``.
     """
     if means3D.dim() != 2 or means3D.size(1) != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")
@@ -67,7 +109,7 @@ def native_rasterize_gaussians(background, means3D, colors, opacity, scales, rot
         # the reference skips the native call and returns its zero-filled outputs and empty buffers
         z = lambda c: torch.zeros((c, H, W), **f_opts)  # noqa: E731
         e = lambda: torch.empty((0,), **byte)           # noqa: E731
-        return 0, z(NUM_CHANNELS), z(1), z(1), radii, e(), e(), e()
+        return ((0, 0) if _optimistic else 0), z(NUM_CHANNELS), z(1), z(1), radii, e(), e(), e()
 
     out_color = torch.empty((NUM_CHANNELS, H, W), **f_opts)
     out_depth = torch.empty((1, H, W), **f_opts)
@@ -84,8 +126,8 @@ def native_rasterize_gaussians(background, means3D, colors, opacity, scales, rot
     projmatrix = _f32c(projmatrix, "projmatrix")
     campos = _f32c(campos, "campos")
 
-    geom = torch.empty((L.ag_raster_geom_bytes(P),), **byte)
-    img = torch.empty((L.ag_raster_image_bytes(W, H),), **byte)
+    geom = torch.empty((_scratch_bytes("geom", P),), **byte)
+    img = torch.empty((_scratch_bytes("image", W, H),), **byte)
 
     a = _lib.AgRasterForwardArgs()
     a.P, a.W, a.H = P, W, H
@@ -102,16 +144,35 @@ def native_rasterize_gaussians(background, means3D, colors, opacity, scales, rot
     a.image_buffer = _ptr(img); a.image_bytes = img.numel()
     a.binning_buffer = None; a.binning_bytes = 0
 
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         stream = _stream_ptr(dev)
         R = ctypes.c_int32(0)
-        _lib.check(L.ag_raster_forward_plan(ctypes.byref(a), stream, ctypes.byref(R)), "ag_raster_forward_plan")
+        key = (P, W, H, dev.index)
+        cap = _capacity.get(key) if _optimistic else None
+        layout_R = None
+        if cap is not None:
+            binning = torch.empty((_scratch_bytes("binning", cap),), **byte)
+            a.binning_buffer = _ptr(binning); a.binning_bytes = binning.numel()
+            rc = L.ag_raster_forward_optimistic(ctypes.byref(a), cap, stream, ctypes.byref(R))
+            if rc == 0:
+                layout_R = cap
+            elif rc != _lib.AG_ERR_SCRATCH_TOO_SMALL:
+                _lib.check(rc, "ag_raster_forward_optimistic")
+        if layout_R is None:                                  # first frame of this configuration, or more instances than planned for
+            _lib.check(L.ag_raster_forward_plan(ctypes.byref(a), stream, ctypes.byref(R)), "ag_raster_forward_plan")
+            layout_R = int(R.value)
+            binning = torch.empty((L.ag_raster_binning_bytes(layout_R),), **byte)
+            a.binning_buffer = _ptr(binning); a.binning_bytes = binning.numel()
+            _lib.check(L.ag_raster_forward_render(ctypes.byref(a), layout_R, stream), "ag_raster_forward_render")
         num_rendered = int(R.value)
-        binning = torch.empty((L.ag_raster_binning_bytes(num_rendered),), **byte)
-        a.binning_buffer = _ptr(binning); a.binning_bytes = binning.numel()
-        _lib.check(L.ag_raster_forward_render(ctypes.byref(a), num_rendered, stream), "ag_raster_forward_render")
+        if _optimistic:
+            want = num_rendered + num_rendered // 4 + 1024
+            if want > _capacity.get(key, 0):
+                _capacity[key] = want
         if debug:
             torch.cuda.synchronize(dev)
+    if _optimistic:
+        return (num_rendered, layout_R), out_color, out_depth, out_alpha, radii, geom, binning, img
     return num_rendered, out_color, out_depth, out_alpha, radii, geom, binning, img
 
 
@@ -142,7 +203,7 @@ def native_rasterize_gaussians_backward(background, means3D, radii, colors, scal
     if P == 0:
         return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations
 
-    accum = _accum_buffer if _accum_buffer is not None else torch.empty((L.ag_raster_accum_bytes(P),), dtype=torch.uint8, device=dev)
+    accum = _accum_buffer if _accum_buffer is not None else torch.empty((_scratch_bytes("accum", P),), dtype=torch.uint8, device=dev)
     keep = [_f32c(t, n) for t, n in ((background, "bg"), (means3D, "means3D"), (colors, "colors_precomp"),
                                      (scales, "scales"), (rotations, "rotations"), (cov3D_precomp, "cov3D_precomp"),
                                      (viewmatrix, "viewmatrix"), (projmatrix, "projmatrix"), (campos, "campos"),
@@ -165,7 +226,7 @@ def native_rasterize_gaussians_backward(background, means3D, radii, colors, scal
     b.dL_dmeans3D = _ptr(dL_dmeans3D); b.dL_dcov3D = _ptr(dL_dcov3D); b.dL_dsh = _ptr(dL_dsh)
     b.dL_dscales = _ptr(dL_dscales); b.dL_drotations = _ptr(dL_drotations)
     b.accum_buffer = _ptr(accum); b.accum_bytes = accum.numel()
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         _lib.check(L.ag_raster_backward(ctypes.byref(b), _stream_ptr(dev)), "ag_raster_backward")
         if debug:
             torch.cuda.synchronize(dev)
@@ -193,12 +254,12 @@ class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
         rs = raster_settings
-        num_rendered, color, depth, alpha, radii, geom, binning, img = native_rasterize_gaussians(
+        (num_rendered, layout_R), color, depth, alpha, radii, geom, binning, img = native_rasterize_gaussians(
             rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
             rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh, rs.sh_degree,
-            rs.campos, rs.prefiltered, rs.debug)
+            rs.campos, rs.prefiltered, rs.debug, _optimistic=True)
         ctx.raster_settings = rs
-        ctx.num_rendered = num_rendered
+        ctx.num_rendered = layout_R          # what the scratch buffers are laid out for (>= the true count)
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning,
                               img, alpha)
         ctx.mark_non_differentiable(radii)

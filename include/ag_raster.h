@@ -77,7 +77,7 @@ typedef struct AgRasterForwardArgs {
 typedef struct AgRasterBackwardArgs {
     int32_t P, W, H;
     int32_t sh_degree, sh_coeffs;
-    int32_t num_rendered;        /* R returned by the forward */
+    int32_t num_rendered;        /* R returned by the forward (the capacity, after ag_raster_forward_optimistic) */
     float tan_fovx, tan_fovy;
     float scale_modifier;
     const float* bg;
@@ -150,6 +150,18 @@ int ag_raster_forward_plan(const AgRasterForwardArgs* args, void* stream, int32_
  * identical to the reference's stable (tile|depth) sort), blends.  Asynchronous on `stream`.
  */
 int ag_raster_forward_render(const AgRasterForwardArgs* args, int32_t num_rendered, void* stream);
+
+/*
+ * Forward in one call without a GPU-side bubble: like _plan + _render, but stage 2 is enqueued before the host has read the
+ * instance count, against a binning buffer the caller sized for `capacity` instances (ag_raster_binning_bytes(capacity);
+ * typically 1.25 x the count of the previous frame of the same scene).  The call still blocks until the count is known
+ * (the reference's semantics: rasterize_gaussians returns it) -- but only the host waits, the stream keeps running.
+ * Returns AG_ERR_SCRATCH_TOO_SMALL when the frame has more instances than `capacity`: *num_rendered_host then holds the true
+ * count, the outputs are undefined and nothing was written to the binning buffer; redo the frame with ag_raster_forward_plan
+ * + ag_raster_forward_render.  A successful frame's scratch is laid out for `capacity`: pass THAT as
+ * AgRasterBackwardArgs.num_rendered.
+ */
+int ag_raster_forward_optimistic(const AgRasterForwardArgs* args, int32_t capacity, void* stream, int32_t* num_rendered_host);
 
 /* Backward (replaces CudaRasterizer::Rasterizer::backward, rasterizer_impl.cu:341-446).  Asynchronous. */
 int ag_raster_backward(const AgRasterBackwardArgs* args, void* stream);

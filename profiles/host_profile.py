@@ -15,3 +15,4 @@ bench.main()
 pr.disable()
 st = pstats.Stats(pr)
 st.sort_stats("cumulative").print_stats("bench.py|rasterizer.py|_lib.py|autograd|function.py", 30)
+st.sort_stats("tottime").print_stats(28)

@@ -380,3 +380,73 @@ def test_full_size_1m_gaussians_2048_properties():
         scale = np.abs(g1[k]).max()
         assert np.abs(g2[k] - 2.0 * g1[k]).max() <= 2e-4 * scale, k
     del torch
+
+
+def test_optimistic_forward_is_bit_identical_and_survives_overflow():
+    """The autograd node enqueues scatter / sort / blend before the host has read the instance count, against a binning buffer
+    sized from earlier frames (ag_raster_forward_optimistic).  Same images and gradients, bit for bit in the forward, as the
+    two-stage path; a frame that outgrows the planned capacity is redone through the two-stage path and raises the capacity."""
+    import torch
+    from animatablegaussians_amd import rasterizer as rz
+    from animatablegaussians_amd.rasterizer import GaussianRasterizer
+    sc = synth.random_gaussians(4000, seed=5, img=256, focal=275.0)
+    sc.update(synth.upstream_grads(256, 256, 3))
+    cam = h.cam_of(sc)
+    rs = h.gpu_settings(sc, cam)
+    key = (4000, 256, 256, rs.bg.device.index)
+
+    def run():
+        inp = h.gpu_inputs(sc, requires_grad=True)
+        m2d = torch.zeros_like(inp["means3D"], requires_grad=True)
+        color, radii, depth, alpha = GaussianRasterizer(rs)(means3D=inp["means3D"], means2D=m2d, opacities=inp["opacities"],
+                                                            colors_precomp=inp["colors"], scales=inp["scales"], rotations=inp["rotations"])
+        g = {k: torch.from_numpy(sc[k]).cuda() for k in ("dL_dcolor", "dL_ddepth", "dL_dalpha")}
+        torch.autograd.backward([color, depth, alpha], [g["dL_dcolor"], g["dL_ddepth"], g["dL_dalpha"]])
+        grads = [inp[k].grad.clone() for k in ("means3D", "opacities", "colors", "scales", "rotations")] + [m2d.grad.clone()]
+        return [color, depth, alpha, radii], grads
+
+    rz._capacity.pop(key, None)
+    out0, gr0 = run()                                   # first frame of the configuration: two-stage path, plans a capacity
+    cap = rz._capacity[key]
+    R = h.gpu_native_forward(sc, cam)["num_rendered"]
+    assert cap >= R + R // 4
+    out1, gr1 = run()                                   # optimistic, roomy buffer
+    rz._capacity[key] = R                               # optimistic, exactly full
+    out2, gr2 = run()
+    rz._capacity[key] = max(R // 3, 1)                  # too small: device-side guard, redo, capacity raised again
+    out3, gr3 = run()
+    assert rz._capacity[key] >= R + R // 4
+    for outs in (out1, out2, out3):
+        for a, b in zip(outs, out0):
+            assert torch.equal(a, b)
+    for grs in (gr1, gr2, gr3):
+        for a, b in zip(grs, gr0):                      # float atomics: order-dependent rounding only
+            assert float((a - b).abs().max()) <= 1e-5 * max(1.0, float(b.abs().max()))
+    # raw ABI: overflow is reported with the true count and leaves the binning buffer untouched
+    from animatablegaussians_amd import _lib
+    rz._capacity[key] = max(R // 3, 1)
+    sentinel_cap = max(R // 3, 1)
+    import ctypes
+    L = _lib.lib()
+    inp = h.gpu_inputs(sc)
+    P = 4000
+    geom = torch.empty((L.ag_raster_geom_bytes(P),), dtype=torch.uint8, device="cuda")
+    img = torch.empty((L.ag_raster_image_bytes(256, 256),), dtype=torch.uint8, device="cuda")
+    binning = torch.full((L.ag_raster_binning_bytes(sentinel_cap),), 0xAB, dtype=torch.uint8, device="cuda")
+    oc, od, oa = (torch.empty((c, 256, 256), device="cuda") for c in (3, 1, 1))
+    radii = torch.empty((P,), dtype=torch.int32, device="cuda")
+    a = _lib.AgRasterForwardArgs()
+    a.P, a.W, a.H, a.sh_degree, a.sh_coeffs, a.prefiltered = P, 256, 256, 0, 0, 0
+    a.tan_fovx, a.tan_fovy, a.scale_modifier = rs.tanfovx, rs.tanfovy, 1.0
+    for name, t in (("bg", rs.bg), ("means3D", inp["means3D"]), ("colors_precomp", inp["colors"]), ("opacities", inp["opacities"]),
+                    ("scales", inp["scales"]), ("rotations", inp["rotations"]), ("viewmatrix", rs.viewmatrix),
+                    ("projmatrix", rs.projmatrix), ("campos", rs.campos), ("out_color", oc), ("out_depth", od), ("out_alpha", oa),
+                    ("radii", radii), ("geom_buffer", geom), ("image_buffer", img), ("binning_buffer", binning)):
+        setattr(a, name, t.data_ptr())
+    a.geom_bytes, a.image_bytes, a.binning_bytes = geom.numel(), img.numel(), binning.numel()
+    Rh = ctypes.c_int32(0)
+    rc = L.ag_raster_forward_optimistic(ctypes.byref(a), sentinel_cap, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), ctypes.byref(Rh))
+    torch.cuda.synchronize()
+    assert rc == _lib.AG_ERR_SCRATCH_TOO_SMALL and Rh.value == R
+    assert bool((binning == 0xAB).all())
+    rz._capacity.pop(key, None)
