@@ -219,12 +219,12 @@ def main() -> None:
     # the separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes over the same workload is reported (calibrated on
     # a 256 MiB copy: FETCH_SIZE x2.0 on gfx950, WRITE_SIZE x1.0 -- profiles/traffic_probe.py, traffic_summarize.py).
     traffic, traffic_src = None, None
-    tpath = os.path.join(ROOT, "profiles", "r01e_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "r01l_traffic.json")
     if os.path.exists(tpath):
         try:
             with open(tpath) as f:
                 traffic = json.load(f)["kernels"]["ag::blend_backward_kernel"]["hbm_bytes"]
-            traffic_src = "profiles/r01e_traffic.json (rocprofv3 PMC passes, bytes per launch)"
+            traffic_src = "profiles/r01l_traffic.json (rocprofv3 PMC passes, bytes per launch)"
         except Exception:
             traffic = None
 
