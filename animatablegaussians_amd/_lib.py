@@ -71,6 +71,12 @@ class AgLbsArgs(ctypes.Structure):
         "lbs", "jnt_mats", "positions", "rotations", "out_positions", "out_rotations")]
 
 
+class AgHandFuseArgs(ctypes.Structure):
+    _fields_ = [("N", c_i32), ("reserved", c_i32)] + [(n, c_vp) for n in (
+        "xyz", "left_box", "right_box", "centre", "hand_positions", "hand_opacity", "hand_scales", "hand_rotations",
+        "positions", "opacity", "scales", "rotations")]
+
+
 class AgConvDesc(ctypes.Structure):
     _fields_ = [(n, c_i32) for n in ("kind", "Cin", "Cout", "H", "W", "k", "stride", "padding")]
 
@@ -125,6 +131,7 @@ SYMBOLS = [
     ("ag_gather_activate_backward", ctypes.c_int, [ctypes.POINTER(AgGatherArgs), c_vp, c_vp, c_vp, c_vp]),
     ("ag_lbs_forward", ctypes.c_int, [ctypes.POINTER(AgLbsArgs), c_vp]),
     ("ag_lbs_backward", ctypes.c_int, [ctypes.POINTER(AgLbsArgs), c_vp, c_vp, c_vp]),
+    ("ag_hand_fuse", ctypes.c_int, [ctypes.POINTER(AgHandFuseArgs), c_vp]),
     # include/ag_styleunet.h
     ("ag_fused_bias_act", ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_f, c_f, ctypes.c_int64, ctypes.c_int64, c_i32, c_vp]),
     ("ag_upfirdn2d", ctypes.c_int, [c_vp, c_vp, c_vp] + [c_i32] * 13 + [c_vp]),

@@ -130,6 +130,7 @@ class AvatarNet(nn.Module):
         from .styleunet import DualStyleUNet
         opt = dict(opt or {})
         self.opt = opt
+        self.hand_mask = self.hand_positions = self.hand_opacity = self.hand_scales = self.hand_rotations = self.hand_colors = None
         self.random_style = opt.get('random_style', False)
         self.with_viewdirs = opt.get('with_viewdirs', True) and cano_nml_map is not None
         self.max_sh_degree = 0
@@ -352,17 +353,34 @@ class AvatarNet(nn.Module):
         c = m.shape[1] // 2
         return torch.cat([m[:, :c], m[:, c:]], 3)[0].permute(1, 2, 0)
 
+    @torch.no_grad()
+    def generate_mean_hands(self, pose_map):
+        """network/avatar.py:52-77: the Gaussians of one fixed frame (``opt['test']['fix_hand_id']``; the reference reads its
+        position map from disk, here the caller passes it: ``[3 or 6, S, S]``) that ``render`` fades the hands into at test
+        time when ``opt['fix_hand']`` is set.  Also records ``hand_mask`` (Gaussians skinned mostly to wrist / finger joints)."""
+        am = self.core.lbs.argmax(1)
+        self.hand_mask = (am == 20) | (am == 21) | (am >= 25)
+        position_map, other_map, color_map = self.get_maps(pose_map[:3])
+        g = self.core.assemble(position_map, other_map, color_map)
+        self.hand_positions, self.hand_opacity, self.hand_scales = g['positions'], g['opacity'], g['scales']
+        self.hand_rotations, self.hand_colors = g['rotations'], g['colors']
+
     def render(self, items, bg_color=(0., 0., 0.), use_pca=False, use_vae=False):
         dev = self.core.xyz.device
         bg = torch.as_tensor(np.asarray(bg_color), dtype=torch.float32).to(dev)
         assert not (use_pca and use_vae), "Cannot use both PCA and VAE!"
         key = 'smpl_pos_map_pca' if use_pca else 'smpl_pos_map_vae' if use_vae else 'smpl_pos_map'
         pose_map = items[key][:3]
-        if (not self.training) and self.opt.get('fix_hand', False):
-            raise NotImplementedError("eval-time hand fusion (network/avatar.py:183-200) is outside the render hot path")
         front_vd, back_vd = self.get_viewdir_feat(items) if self.with_viewdirs else (None, None)
         position_map, other_map, color_map = self.get_maps(pose_map, front_vd, back_vd)
         g = self.core.assemble(position_map, other_map, color_map)
+        if (not self.training) and self.opt.get('fix_hand', False):                                                # :183-200
+            if self.hand_positions is None:
+                raise RuntimeError("fix_hand: call generate_mean_hands(pose_map) first (main_avatar.py:584)")
+            g['positions'], g['opacity'], g['scales'], g['rotations'] = ops.hand_fuse(
+                g['positions'], g['opacity'], g['scales'], g['rotations'], self.core.xyz, items['left_cano_mano_v'],
+                items['right_cano_mano_v'], items['cano_smpl_center'], self.hand_positions, self.hand_opacity, self.hand_scales,
+                self.hand_rotations)
         offset = g['positions'] - self.core.xyz                                                                   # :211
         g['positions'], g['rotations'] = ops.lbs_transform(g['positions'], g['rotations'], self.core.lbs,
                                                            items['cano2live_jnt_mats'])

@@ -124,3 +124,30 @@ class _LbsTransform(torch.autograd.Function):
 def lbs_transform(positions, rotations, lbs, jnt_mats):
     """-> (live positions [N,3], live rotations [N,4])."""
     return _LbsTransform.apply(positions, rotations, lbs, jnt_mats)
+
+
+def hand_fuse(positions, opacity, scales, rotations, xyz, left_mano_v, right_mano_v, centre, hand_positions, hand_opacity,
+              hand_scales, hand_rotations):
+    """Eval-time hand fusion, network/avatar.py:183-200 (no autograd: the reference runs it under ``torch.no_grad`` in test
+    mode).  Returns new (positions, opacity, scales, rotations); the inputs are left untouched."""
+    dev = xyz.device
+    outs = [_chk(t.detach(), n).clone() for t, n in ((positions, "positions"), (opacity, "opacity"), (scales, "scales"),
+                                                     (rotations, "rotations"))]
+    boxes = []
+    for v in (left_mano_v, right_mano_v):            # normalize_vert_bbox only needs the x extent of the hand vertices
+        vx = _chk(v.to(dev), "mano vertices")[:, 0]
+        boxes.append(torch.stack([vx.min(), vx.max()]))
+    a = _lib.AgHandFuseArgs()
+    a.N = int(xyz.shape[0])
+    keep = [_chk(xyz, "xyz"), boxes[0], boxes[1], _chk(torch.as_tensor(centre, dtype=torch.float32).to(dev).reshape(3), "centre"),
+            _chk(hand_positions, "hand_positions"), _chk(hand_opacity, "hand_opacity"), _chk(hand_scales, "hand_scales"),
+            _chk(hand_rotations, "hand_rotations")]
+    for name, t in zip(("xyz", "left_box", "right_box", "centre", "hand_positions", "hand_opacity", "hand_scales", "hand_rotations",
+                        "positions", "opacity", "scales", "rotations"), keep + outs):
+        if name in ("hand_positions", "hand_opacity", "hand_scales", "hand_rotations", "positions", "opacity", "scales", "rotations") \
+                and t.shape[0] != a.N:
+            raise RuntimeError(f"hand_fuse: {name} has {t.shape[0]} rows, expected {a.N}")
+        setattr(a, name, t.data_ptr())
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().ag_hand_fuse(ctypes.byref(a), _stream(dev)), "ag_hand_fuse")
+    return tuple(outs)

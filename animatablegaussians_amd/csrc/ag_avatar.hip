@@ -270,7 +270,45 @@ __global__ void __launch_bounds__(256) lbs_backward_kernel(AgLbsArgs a, float* _
 
 using namespace ag;
 
+// Eval-time hand fusion (network/avatar.py:183-200): one thread per Gaussian, 11 attribute floats blended in place.
+__global__ void __launch_bounds__(256) hand_fuse_kernel(AgHandFuseArgs a)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.N) return;
+    const float x = a.xyz[3 * i + 0], y = a.xyz[3 * i + 1];
+    const float lmin = a.left_box[0], lmax = a.left_box[1], rmin = a.right_box[0], rmax = a.right_box[1];
+    // utils/geo_util.py:104-114 with per_axis: 2 (v - 0.5 (max + min)) / (max - min), first coordinate
+    const float nl = 2.0f * (x - 0.5f * (lmax + lmin)) / (lmax - lmin);
+    const float nr = 2.0f * (x - 0.5f * (rmax + rmin)) / (rmax - rmin);
+    float wl = 1.0f / (1.0f + __expf(-2.5f * (nl + 2.0f)));
+    float wr = 1.0f / (1.0f + __expf(2.5f * (nr - 2.0f)));
+    if (y < a.centre[1]) { wl = 0.f; wr = 0.f; }
+    const float s = fmaxf(wl + wr, 1.0f);
+    const float w = wl / s + wr / s;
+    const float u = 1.0f - w;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) a.positions[3 * i + c] = w * a.hand_positions[3 * i + c] + u * a.positions[3 * i + c];
+    a.opacity[i] = w * a.hand_opacity[i] + u * a.opacity[i];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) a.scales[3 * i + c] = w * a.hand_scales[3 * i + c] + u * a.scales[3 * i + c];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) a.rotations[4 * i + c] = w * a.hand_rotations[4 * i + c] + u * a.rotations[4 * i + c];
+}
+
 extern "C" {
+
+int ag_hand_fuse(const AgHandFuseArgs* a, void* stream)
+{
+    if (!a || a->N < 0) { set_error("bad hand-fuse sizes"); return AG_ERR_INVALID_ARGUMENT; }
+    if (a->N == 0) return AG_OK;
+    if (!a->xyz || !a->left_box || !a->right_box || !a->centre || !a->hand_positions || !a->hand_opacity || !a->hand_scales ||
+        !a->hand_rotations || !a->positions || !a->opacity || !a->scales || !a->rotations) {
+        set_error("null pointer in AgHandFuseArgs");
+        return AG_ERR_INVALID_ARGUMENT;
+    }
+    hipLaunchKernelGGL(hand_fuse_kernel, dim3((a->N + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), *a);
+    return check_hip(hipGetLastError(), "hand_fuse_kernel");
+}
 
 static int check_gather(const AgGatherArgs* a)
 {

@@ -70,6 +70,34 @@ int ag_lbs_forward(const AgLbsArgs* args, void* stream);
 int ag_lbs_backward(const AgLbsArgs* fwd_inputs_and_grads, float* dL_dpositions /*[N,3]*/, float* dL_drotations /*[N,4]*/,
                     void* stream);
 
+/*
+ * Eval-time hand fusion (network/avatar.py:183-200): inside the bounding boxes of the canonical MANO hands the
+ * predicted Gaussians are cross-faded into those of one fixed "mean hands" frame (AvatarNet.generate_mean_hands, :52-77).
+ * Per Gaussian, with n_l / n_r = first coordinate of utils/geo_util.py:104-114 normalize_vert_bbox(hand verts, attris = xyz,
+ * per_axis = True), i.e. 2 (x - centre_x) / extent_x of the left / right hand box:
+ *     wl = sigmoid( 2.5 (n_l + 2)),  wr = sigmoid(-2.5 (n_r - 2)),  both 0 where xyz.y < centre_y;
+ *     s = max(wl + wr, 1);  w = (wl + wr) / s;   attr = w * hand_attr + (1 - w) * attr      (positions, opacity, scales, rotations)
+ * In place on the four attribute arrays.  left_box / right_box: device pointers to {min_x, max_x} of the hand vertices.
+ */
+typedef struct AgHandFuseArgs {
+    int32_t N;
+    int32_t reserved;
+    const float* xyz;             /* [N,3] canonical positions (self.init_points) */
+    const float* left_box;        /* [2]: min and max x of items['left_cano_mano_v'] */
+    const float* right_box;       /* [2]: ... of items['right_cano_mano_v'] */
+    const float* centre;          /* [3]: items['cano_smpl_center'] (y is read) */
+    const float* hand_positions;  /* [N,3] */
+    const float* hand_opacity;    /* [N,1] */
+    const float* hand_scales;     /* [N,3] */
+    const float* hand_rotations;  /* [N,4] */
+    float* positions;             /* [N,3] in/out */
+    float* opacity;               /* [N,1] in/out */
+    float* scales;                /* [N,3] in/out */
+    float* rotations;             /* [N,4] in/out */
+} AgHandFuseArgs;
+
+int ag_hand_fuse(const AgHandFuseArgs* args, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -130,3 +130,22 @@ def get_viewdir_feat(cano_smpl_map, cano_nml_map, mask, lbs, jnt_mats, extr, w0,
         h = F.leaky_relu(F.conv2d(v, w0, b0, stride=2, padding=1), 0.2)
         outs.append(weight_viewdirs * F.conv2d(h, w2, b2, stride=2, padding=1))
     return outs[0], outs[1]
+
+
+def normalize_vert_bbox(verts, attris=None, dim=-1, per_axis=False):
+    """utils/geo_util.py:104-114."""
+    lo, hi = verts.min(dim=dim, keepdim=True)[0], verts.max(dim=dim, keepdim=True)[0]
+    v = (verts if attris is None else attris) - 0.5 * (hi + lo)
+    return 2 * v / (hi - lo) if per_axis else 2 * v / (hi - lo).max(dim=dim, keepdim=True)[0]
+
+
+def hand_fuse(g, cano_xyz, left_mano_v, right_mano_v, centre, hand):
+    """network/avatar.py:183-200 on dicts with positions / opacity / scales / rotations."""
+    wl = torch.sigmoid(2.5 * (normalize_vert_bbox(left_mano_v, attris=cano_xyz, dim=0, per_axis=True)[..., 0:1] + 2.0))
+    wr = torch.sigmoid(-2.5 * (normalize_vert_bbox(right_mano_v, attris=cano_xyz, dim=0, per_axis=True)[..., 0:1] - 2.0))
+    wl[cano_xyz[..., 1] < centre[1]] = 0.
+    wr[cano_xyz[..., 1] < centre[1]] = 0.
+    s = torch.maximum(wl + wr, torch.ones_like(wl))
+    wl, wr = wl / s, wr / s
+    w = wl + wr
+    return {k: w * hand[k] + (1.0 - w) * g[k] for k in ('positions', 'opacity', 'scales', 'rotations')}, w

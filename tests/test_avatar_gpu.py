@@ -183,3 +183,30 @@ def test_avatar_render_core_end_to_end():
         dd = np.abs(ga - gb)
         lim = 2e-3 * np.abs(gb) + 2e-4 * np.abs(gb).max()          # coarse: forward-rounding conditioning
         assert (dd > lim).mean() < 2e-3, f"dL/d{name}: {(dd > lim).mean():.2e} of elements off, max {dd.max():.3e}"
+
+
+def test_hand_fuse_matches_reference_blend():
+    """Eval-time hand fusion (network/avatar.py:183-200 + utils/geo_util.py:104-114) against the torch restatement: weights
+    rise across the hand boxes, vanish below the body centre, and the four attribute arrays are cross-faded in place."""
+    import torch
+    from animatablegaussians_amd import avatar_ops as ops
+    from oracle import avatar_oracle as ao
+    g = torch.Generator().manual_seed(4)
+    N = 20000
+    xyz = (torch.rand(N, 3, generator=g) - 0.5) * torch.tensor([1.8, 1.8, 0.4])
+    left = torch.tensor([0.72, 0.35, 0.0]) + (torch.rand(778, 3, generator=g) - 0.5) * torch.tensor([0.2, 0.1, 0.08])
+    right = torch.tensor([-0.72, 0.35, 0.0]) + (torch.rand(778, 3, generator=g) - 0.5) * torch.tensor([0.2, 0.1, 0.08])
+    centre = torch.tensor([0.0, 0.1, 0.0])
+    cur = {'positions': torch.randn(N, 3, generator=g), 'opacity': torch.rand(N, 1, generator=g),
+           'scales': torch.rand(N, 3, generator=g) * 0.01, 'rotations': torch.randn(N, 4, generator=g)}
+    hand = {k: torch.randn(v.shape, generator=g) for k, v in cur.items()}
+    ref, w = ao.hand_fuse({k: v.clone() for k, v in cur.items()}, xyz, left, right, centre, hand)
+    assert 0.02 < float((w > 0.5).float().mean()) < 0.5 and float(w[xyz[:, 1] < centre[1]].abs().max()) == 0.0
+    c = lambda t: t.cuda()  # noqa: E731
+    got = ops.hand_fuse(c(cur['positions']), c(cur['opacity']), c(cur['scales']), c(cur['rotations']), c(xyz), c(left), c(right),
+                        centre, c(hand['positions']), c(hand['opacity']), c(hand['scales']), c(hand['rotations']))
+    for k, t in zip(('positions', 'opacity', 'scales', 'rotations'), got):
+        np.testing.assert_allclose(t.cpu().numpy(), ref[k].numpy(), rtol=1e-5, atol=2e-6)
+    with pytest.raises(RuntimeError):
+        ops.hand_fuse(c(cur['positions'])[:5], c(cur['opacity']), c(cur['scales']), c(cur['rotations']), c(xyz), c(left), c(right),
+                      centre, c(hand['positions']), c(hand['opacity']), c(hand['scales']), c(hand['rotations']))

@@ -198,3 +198,47 @@ def test_reference_state_dict_roundtrip(net):
     for k in sd:
         sd[k] = sd[k] - 1.0
     net.load_reference_state_dict(sd)
+
+
+def test_fix_hand_fades_the_hands_into_the_mean_hands_frame(net):
+    """Test-time `fix_hand` (network/avatar.py:52-77,183-200): generate_mean_hands stores the Gaussians of one frame, render
+    cross-fades positions / opacity / scales / rotations into them inside the MANO boxes; opacity and scales (untouched by the
+    skinning) must equal the torch restatement of the blend."""
+    import torch
+    from oracle import avatar_oracle as ao
+    items = _items(net)
+    net.get_pose_map(items)
+    pose_b = items['smpl_pos_map']
+    pose_a = pose_b.flip(-1).contiguous()                              # "another frame"
+    xyz = net.init_points
+    lo, hi = xyz.min(0)[0], xyz.max(0)[0]
+    g = torch.Generator().manual_seed(8)
+    box = lambda cx: (torch.tensor([cx, float(hi[1]) - 0.2, 0.0]) + (torch.rand(778, 3, generator=g) - 0.5) * torch.tensor([0.2, 0.12, 0.1])).cuda()  # noqa: E731
+    items.update({'left_cano_mano_v': box(float(hi[0]) - 0.1), 'right_cano_mano_v': box(float(lo[0]) + 0.1),
+                  'cano_smpl_center': (0.5 * (lo + hi))})
+    net.eval()
+    old = net.opt.get('fix_hand', False)
+    try:
+        with torch.no_grad():
+            net.opt['fix_hand'] = False
+            plain = net.render(items)['posed_gaussians']
+            net.opt['fix_hand'] = True
+            with pytest.raises(RuntimeError):
+                net.hand_positions = None
+                net.render(items)
+            net.generate_mean_hands(pose_a)
+            assert net.hand_mask.dtype == torch.bool and net.hand_mask.shape == (xyz.shape[0],)
+            fused = net.render(items)['posed_gaussians']
+            fv, bv = net.get_viewdir_feat(items)
+            cur = net.core.assemble(*net.get_maps(pose_b[:3], fv, bv))
+        hand = {'positions': net.hand_positions, 'opacity': net.hand_opacity, 'scales': net.hand_scales, 'rotations': net.hand_rotations}
+        ref, w = ao.hand_fuse({k: cur[k].cpu() for k in hand}, xyz.cpu(), items['left_cano_mano_v'].cpu(), items['right_cano_mano_v'].cpu(),
+                              items['cano_smpl_center'].cpu(), {k: v.cpu() for k, v in hand.items()})
+        assert float((w > 0.5).float().mean()) > 0.005
+        for k in ('opacity', 'scales'):
+            np.testing.assert_allclose(fused[k].cpu().numpy(), ref[k].numpy(), rtol=1e-5, atol=1e-7)
+            far = (w[:, 0] == 0)
+            assert torch.equal(fused[k][far.cuda()], plain[k][far.cuda()])
+        assert not torch.equal(fused['opacity'], plain['opacity'])
+    finally:
+        net.opt['fix_hand'] = old
