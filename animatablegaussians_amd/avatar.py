@@ -14,6 +14,8 @@ from __future__ import annotations
 
 from typing import Dict, Optional
 
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -119,9 +121,9 @@ class AvatarNet(nn.Module):
     ``mask_map``, ``offset``, ``pos_map`` [+ ``cano_tex_map``, ``posed_gaussians`` in eval mode]).
 
     Differences, all deliberate: the per-subject assets are passed in as tensors (``cano_smpl_map`` [S, 2S, 3],
-    ``lbs`` [N, J], optional ``cano_nml_map``) instead of being read with OpenCV from ``config.opt`` -- the EXR loader
-    is SURVEY.md §8(f)-3; eval-time hand fusion (``:183-200``) is §8(f)-4 and raises.  ``load_reference_state_dict``
-    takes the reference's ``net.pt['avatar_net']`` dict key for key.
+    ``lbs`` [N, J], optional ``cano_nml_map``) or read by ``from_data_dir`` with the OpenCV-free EXR reader (``exr.py``)
+    instead of through ``config.opt``; ``generate_mean_hands`` takes the fixed frame's position map instead of a file id.
+    ``load_reference_state_dict`` takes the reference's ``net.pt['avatar_net']`` dict key for key.
     """
 
     def __init__(self, opt: Optional[dict] = None, *, cano_smpl_map: torch.Tensor, lbs: torch.Tensor,
@@ -169,6 +171,19 @@ class AvatarNet(nn.Module):
         self.to(dev)
 
     # ---- construction helpers -------------------------------------------------------------------------------------
+    @classmethod
+    def from_data_dir(cls, opt: Optional[dict], data_dir: str, device="cuda") -> "AvatarNet":
+        """The constructor's file reads of network/avatar.py:27-43: ``<data_dir>/smpl_pos_map/cano_smpl_pos_map.exr``,
+        ``init_pts_lbs.npy`` and (with view directions) ``cano_smpl_nml_map.exr``."""
+        from . import exr
+        d = os.path.join(data_dir, 'smpl_pos_map')
+        cano = torch.from_numpy(exr.imread(os.path.join(d, 'cano_smpl_pos_map.exr')))
+        lbs = torch.from_numpy(np.load(os.path.join(d, 'init_pts_lbs.npy'))).to(torch.float32)
+        nml = None
+        if (opt or {}).get('with_viewdirs', True):
+            nml = torch.from_numpy(exr.imread(os.path.join(d, 'cano_smpl_nml_map.exr')))
+        return cls(opt, cano_smpl_map=cano, lbs=lbs, cano_nml_map=nml, device=device)
+
     @classmethod
     def synthetic(cls, opt: Optional[dict] = None, S: int = 1024, J: int = 55, seed: int = 31359, device="cuda") -> "AvatarNet":
         """The synthetic subject of SURVEY.md 8d config 3 (``synth.avatar_map_gaussians`` canvas, 4-sparse LBS weights)."""

@@ -5,27 +5,18 @@
     model:
       module: avatar_module          # with animatablegaussians_amd/dropin on PYTHONPATH
 
-The per-subject assets are read exactly where the reference reads them (``network/avatar.py:27,31,43``) -- this is the
-one place that needs OpenCV's EXR reader and the reference's ``config`` module, both imported at call time.  NOT
-exercised by this repository's tests (no OpenCV, no dataset in the build image); everything behind it is."""
-import numpy as np
-import torch
-
+The per-subject assets are read exactly where the reference reads them (``network/avatar.py:27,31,43``), with the
+OpenCV-free EXR reader (``animatablegaussians_amd/exr.py``); the only reference dependency left is its global ``config``
+module (data directory and device), imported at call time."""
 from animatablegaussians_amd.avatar import AvatarNet as _AvatarNet
 
 
 class AvatarNet(_AvatarNet):
-    def __init__(self, opt):
-        import cv2 as cv            # noqa: F401  (reference dependency; EXR support must be enabled as the reference does)
+    def __new__(cls, opt):
         import config               # the reference's global config module
-        data_dir = config.opt['train']['data']['data_dir']
-        cano = cv.imread(data_dir + '/smpl_pos_map/cano_smpl_pos_map.exr', cv.IMREAD_UNCHANGED)
-        lbs = np.load(data_dir + '/smpl_pos_map/init_pts_lbs.npy')
-        nml = None
-        if opt.get('with_viewdirs', True):
-            nml = torch.from_numpy(cv.imread(data_dir + '/smpl_pos_map/cano_smpl_nml_map.exr', cv.IMREAD_UNCHANGED))
-        super().__init__(opt, cano_smpl_map=torch.from_numpy(cano), lbs=torch.from_numpy(lbs).float(), cano_nml_map=nml,
-                         device=config.device)
+        net = _AvatarNet.from_data_dir(opt, config.opt['train']['data']['data_dir'], device=config.device)
+        net.__class__ = cls
+        return net
 
-    def to(self, *args, **kwargs):   # main_avatar.py:48 calls .to(config.device); buffers are already there
-        return super().to(*args, **kwargs)
+    def __init__(self, opt):         # built in __new__ (main_avatar.py:48 then calls .to(config.device): a no-op)
+        pass
