@@ -268,16 +268,21 @@ __global__ void __launch_bounds__(kBlendThreads, kBwdWavesPerSimd) blend_backwar
                 // affine maps g_e(S) = A S + B, A = fac, B = alpha * c (0 when inactive); inclusive row scan
                 const float al = act ? alpha : 0.f;
                 float A = fac, Br = al * b.z, Bg = al * b.w, Bb = al * c.x, Bd = al * c.y, Ba = al;
-#define AG_SCAN_STEP(N)                                                                      \
-                {                                                                            \
-                    const float Ap = row_shr<N>(A, 1.0f);                                    \
-                    Br = fmaf(row_shr0<N>(Br), A, Br);                                       \
-                    Bg = fmaf(row_shr0<N>(Bg), A, Bg);                                       \
-                    Bb = fmaf(row_shr0<N>(Bb), A, Bb);                                       \
-                    Bd = fmaf(row_shr0<N>(Bd), A, Bd);                                       \
-                    Ba = fmaf(row_shr0<N>(Ba), A, Ba);                                       \
-                    A *= Ap;                                                                 \
-                }
+                // One scan step = six DPP-operand VOP2 instructions.  The compiler does not fold these row shifts into the FMAs
+                // (it emits a v_mov_b32_dpp per operand: 30 of the 168 VALU instructions of a step), so the step is spelled out:
+                //   B  <- B + row_shr(B) * A      v_fmac_f32_dpp with bound_ctrl: lanes shifted in from outside the row read 0
+                //   A  <- row_shr(A) * A          v_mul_f32_dpp WITHOUT bound_ctrl: those lanes are not written and keep A (x 1)
+                // s_nop 1: a DPP read needs two wait states after the VALU write of its source; inside the block the five
+                // accumulators alternate, so only the first read needs the explicit gap.  Measured 139 -> 128 us.
+#define AG_SCAN_STEP(N)                                                                                                        \
+                asm volatile("s_nop 1\n\t"                                                                                     \
+                             "v_fmac_f32_dpp %0, %0, %5 row_shr:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"             \
+                             "v_fmac_f32_dpp %1, %1, %5 row_shr:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"             \
+                             "v_fmac_f32_dpp %2, %2, %5 row_shr:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"             \
+                             "v_fmac_f32_dpp %3, %3, %5 row_shr:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"             \
+                             "v_fmac_f32_dpp %4, %4, %5 row_shr:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"             \
+                             "v_mul_f32_dpp %5, %5, %5 row_shr:" #N " row_mask:0xf bank_mask:0xf"                               \
+                             : "+v"(Br), "+v"(Bg), "+v"(Bb), "+v"(Bd), "+v"(Ba), "+v"(A));
                 AG_SCAN_STEP(1) AG_SCAN_STEP(2) AG_SCAN_STEP(4) AG_SCAN_STEP(8)
 #undef AG_SCAN_STEP
                 // A is now prod_{i<=e} fac_i: T in front of entry e; exclusive maps give the blend behind entry e

@@ -55,10 +55,18 @@ __device__ __forceinline__ float row_shr(float v, float fill)
 
 __device__ __forceinline__ float row_inclusive_product(float x)
 {
-    x *= row_shr<1>(x, 1.0f);
-    x *= row_shr<2>(x, 1.0f);
-    x *= row_shr<4>(x, 1.0f);
-    x *= row_shr<8>(x, 1.0f);
+    // x <- row_shr(x) * x with the shift as the DPP operand of the multiply: without bound_ctrl the lanes whose source falls
+    // outside the row are not written and keep x (x 1).  The compiler's own code for `x *= row_shr<N>(x, 1.0f)` is a
+    // v_mov_b32 of the fill, a v_mov_b32_dpp and the v_mul.  s_nop 1: two wait states between a VALU write and a DPP read.
+    asm volatile("s_nop 1\n\t"
+                 "v_mul_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_mul_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_mul_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_mul_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf"
+                 : "+v"(x));
     return x;
 }
 
