@@ -266,6 +266,12 @@ int ag_debug_wave_reduce16(const float* in, float* out, void* stream)
     return launch_debug_wave_reduce16(in, out, reinterpret_cast<hipStream_t>(stream));
 }
 
+int ag_debug_atomic_rate(float* accum, int32_t lines, int32_t blocks, int32_t iters, int32_t comps, void* stream)
+{
+    if (!accum || lines <= 0 || blocks <= 0 || iters < 0 || comps < 1 || comps > 16) { set_error("bad atomic-rate arguments"); return AG_ERR_INVALID_ARGUMENT; }
+    return launch_debug_atomic_rate(accum, lines, blocks, iters, comps, reinterpret_cast<hipStream_t>(stream));
+}
+
 int ag_raster_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,
                            uint8_t* present, void* stream)
 {

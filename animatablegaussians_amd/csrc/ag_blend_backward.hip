@@ -377,6 +377,26 @@ __global__ void __launch_bounds__(kBlendThreads, kBwdWavesPerSimd) blend_backwar
     }
 }
 
+// Calibration (profiles/atomic_rate.py): how many line-coalesced float atomics per second the memory side sustains -- the
+// ceiling of every design that flushes the backward's sums with less pre-reduction.  Each wave instruction adds to the first
+// `comps` slots of 4 pseudo-random 64-byte accumulator lines (16 adjacent lanes per line), exactly the flush's access shape.
+__global__ void __launch_bounds__(512) debug_atomic_rate_kernel(float* __restrict__ accum, uint32_t lines, int iters, int comps)
+{
+    const uint32_t lane = threadIdx.x & 63, wave_global = (blockIdx.x * 512 + threadIdx.x) >> 6;
+    uint32_t h = wave_global * 0x9E3779B9u + 12345u;
+    for (int i = 0; i < iters; i++) {
+        h = h * 1664525u + 1013904223u;
+        const uint32_t line = ((h >> 8) + (lane >> 4) * 977u) % lines;
+        if ((int)(lane & 15) < comps) atomicAdd(accum + (size_t)line * kAccumFloats + (lane & 15), 1.0f);
+    }
+}
+
+int launch_debug_atomic_rate(float* accum, int lines, int blocks, int iters, int comps, hipStream_t s)
+{
+    hipLaunchKernelGGL(debug_atomic_rate_kernel, dim3(blocks), dim3(512), 0, s, accum, (uint32_t)lines, iters, comps);
+    return check_hip(hipGetLastError(), "debug_atomic_rate_kernel");
+}
+
 __global__ void __launch_bounds__(64) debug_wave_reduce16_kernel(const float* __restrict__ in, float* __restrict__ out)
 {
     const int lane = threadIdx.x;

@@ -196,6 +196,13 @@ int ag_prof_collect(int32_t* launches /*[AG_K_COUNT]*/, float* total_ms /*[AG_K_
  */
 int ag_debug_wave_reduce16(const float* in, float* out, void* stream);
 
+/*
+ * Calibration hook (profiles/atomic_rate.py): `blocks` workgroups of 8 waves; every wave issues `iters` instructions, each adding
+ * 1.0f to the first `comps` (<= 16) floats of 4 pseudo-random 64-byte lines of accum [lines][16] -- the access shape of the blend
+ * backward's flush.  Measures the line-atomic rate of the memory side.
+ */
+int ag_debug_atomic_rate(float* accum, int32_t lines, int32_t blocks, int32_t iters, int32_t comps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
