@@ -19,44 +19,79 @@
 namespace ag {
 
 // ---------------------------------------------------------------------------------------------------------
-// 2. scan of tile counts (T = 4096 at 1024^2, 16384 at 2048^2): one 1024-thread workgroup
+// 2. scan of tile counts (T = 4096 at 1024^2, 16384 at 2048^2): one 1024-thread workgroup, four tiles per thread
 // ---------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024) tile_scan_kernel(int T, const uint32_t* __restrict__ tile_count,
                                                         uint32_t* __restrict__ cursor, uint2* __restrict__ ranges,
                                                         uint32_t* __restrict__ num_rendered,
                                                         uint4* __restrict__ tile_order, uint32_t capacity)
 {
-    __shared__ uint32_t wave_sums[16];
-    __shared__ uint32_t carry_s;
+    // Four consecutive tiles per thread and pass (one 16-byte load, one 16-byte cursor store, two 16-byte range stores): the
+    // kernel is one workgroup deep, so its time is the number of dependent global round trips -- 2 per 4096 tiles this way,
+    // 8 with one tile per thread.
+    // Empty tiles (3500 of 4096 for an avatar) take no LDS atomics -- same-address LDS atomics serialise lane by lane and were
+    // most of this kernel's time: their slot in tile_order is T - 1 - (empty tiles before them), known from the same scan.
+    __shared__ uint32_t wave_sums[16], wave_ne[16];
+    __shared__ uint32_t carry_s, carry_ne;
     __shared__ uint32_t cls_hist[34], cls_off[34];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) carry_s = 0;
+    if (tid == 0) { carry_s = 0; carry_ne = 0; }
     if (tid < 34) cls_hist[tid] = 0;
     __syncthreads();
-    for (int base = 0; base < T; base += 1024) {
-        const int t = base + tid;
-        const uint32_t c = (t < T) ? tile_count[t] : 0u;
-        // inclusive scan inside the wave
-        uint32_t v = c;
+    const uint4* count4 = reinterpret_cast<const uint4*>(tile_count);      // 256-byte aligned sub-array (ImageLayout)
+    for (int base = 0; base < T; base += 4096) {
+        const int t0 = base + 4 * tid;
+        uint32_t c[4] = {0u, 0u, 0u, 0u};
+        if (t0 + 3 < T) {
+            const uint4 v4 = count4[t0 >> 2];
+            c[0] = v4.x; c[1] = v4.y; c[2] = v4.z; c[3] = v4.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) if (t0 + k < T) c[k] = tile_count[t0 + k];
+        }
+        const uint32_t mine = c[0] + c[1] + c[2] + c[3];
+        const uint32_t ne_mine = (c[0] != 0u) + (c[1] != 0u) + (c[2] != 0u) + (c[3] != 0u);
+        uint32_t v = mine, vn = ne_mine;                     // inclusive scans of the thread totals inside the wave
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t n = __shfl_up(v, d, 64);
-            if (lane >= d) v += n;
+            const uint32_t n = __shfl_up(v, d, 64), nn = __shfl_up(vn, d, 64);
+            if (lane >= d) { v += n; vn += nn; }
         }
-        if (lane == 63) wave_sums[wave] = v;
+        if (lane == 63) { wave_sums[wave] = v; wave_ne[wave] = vn; }
         __syncthreads();
-        uint32_t woff = 0;
-        for (int w = 0; w < wave; w++) woff += wave_sums[w];
+        uint32_t woff = 0, woff_ne = 0;
+        for (int w = 0; w < wave; w++) { woff += wave_sums[w]; woff_ne += wave_ne[w]; }
         const uint32_t carry = carry_s;
-        const uint32_t incl = carry + woff + v;
-        if (t < T) {
-            const uint32_t start = incl - c;
-            cursor[t] = start;
-            ranges[t] = c ? make_uint2(start, incl) : make_uint2(0u, 0u);  // empty tiles keep the memset value
-            atomicAdd(&cls_hist[32 - __clz(c)], 1u);                       // size class = bit length of the count
+        uint32_t ne_before = carry_ne + woff_ne + vn - ne_mine;      // non-empty tiles before tile t0
+        uint32_t start[5];
+        start[0] = carry + woff + v - mine;
+#pragma unroll
+        for (int k = 0; k < 4; k++) start[k + 1] = start[k] + c[k];
+        if (t0 + 3 < T) {
+            reinterpret_cast<uint4*>(cursor)[t0 >> 2] = make_uint4(start[0], start[1], start[2], start[3]);
+            uint4* r4 = reinterpret_cast<uint4*>(ranges + t0);   // empty tiles keep (0, 0), the reference's memset value
+            r4[0] = make_uint4(c[0] ? start[0] : 0u, c[0] ? start[1] : 0u, c[1] ? start[1] : 0u, c[1] ? start[2] : 0u);
+            r4[1] = make_uint4(c[2] ? start[2] : 0u, c[2] ? start[3] : 0u, c[3] ? start[3] : 0u, c[3] ? start[4] : 0u);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (t0 + k < T) {
+                    cursor[t0 + k] = start[k];
+                    ranges[t0 + k] = c[k] ? make_uint2(start[k], start[k + 1]) : make_uint2(0u, 0u);
+                }
         }
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (t0 + k < T) {
+                if (c[k]) {
+                    atomicAdd(&cls_hist[32 - __clz(c[k])], 1u);              // size class = bit length of the count
+                    ne_before++;
+                } else {
+                    tile_order[(uint32_t)(T - 1) - ((uint32_t)(t0 + k) - ne_before)] = make_uint4((uint32_t)(t0 + k), 0u, 0u, 0u);
+                }
+            }
         __syncthreads();
-        if (tid == 1023) carry_s = incl;
+        if (tid == 1023) { carry_s = start[4]; carry_ne = ne_before; }
         __syncthreads();
     }
     // instances, non-empty tiles, overflow flag.  `capacity` = instances the binning buffer was sized for when the later stages
@@ -65,20 +100,33 @@ __global__ void __launch_bounds__(1024) tile_scan_kernel(int T, const uint32_t* 
     if (tid == 0) {
         const bool over = carry_s > capacity;
         num_rendered[0] = carry_s;
-        num_rendered[1] = over ? 0u : (uint32_t)T - cls_hist[0];
+        num_rendered[1] = over ? 0u : carry_ne;
         num_rendered[2] = over ? 1u : 0u;
     }
     // Work order for the persistent blend kernels: tiles by descending size class (longest-processing-time first),
     // empty tiles last.  Order inside a class is arbitrary.
     if (tid == 0) {
         uint32_t acc = 0;
-        for (int cls = 33; cls >= 0; cls--) { cls_off[cls] = acc; acc += cls_hist[cls]; }
+        for (int cls = 33; cls >= 1; cls--) { cls_off[cls] = acc; acc += cls_hist[cls]; }
     }
     __syncthreads();
-    for (int t = tid; t < T; t += 1024) {
-        const uint32_t cls = 32 - __clz(tile_count[t]);
-        const uint2 rg = ranges[t];   // written above by this workgroup (barriers in between)
-        tile_order[atomicAdd(&cls_off[cls], 1u)] = make_uint4((uint32_t)t, rg.x, rg.y, 0u);
+    for (int base = 0; base < T; base += 4096) {
+        const int t0 = base + 4 * tid;
+        if (t0 >= T) break;
+        uint32_t c[4] = {0u, 0u, 0u, 0u}, st[4] = {0u, 0u, 0u, 0u};
+        if (t0 + 3 < T) {      // written above by this workgroup (barriers in between): one round trip for both
+            const uint4 v4 = count4[t0 >> 2], s4 = reinterpret_cast<const uint4*>(cursor)[t0 >> 2];
+            c[0] = v4.x; c[1] = v4.y; c[2] = v4.z; c[3] = v4.w;
+            st[0] = s4.x; st[1] = s4.y; st[2] = s4.z; st[3] = s4.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) if (t0 + k < T) { c[k] = tile_count[t0 + k]; st[k] = cursor[t0 + k]; }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (t0 + k < T) {
+                if (c[k]) tile_order[atomicAdd(&cls_off[32 - __clz(c[k])], 1u)] = make_uint4((uint32_t)(t0 + k), st[k], st[k] + c[k], 0u);
+            }
     }
 }
 
