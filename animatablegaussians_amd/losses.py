@@ -15,12 +15,26 @@ def composite(image, gt_image, boundary_mask_img, bg_color):
     return image * keep[None] + fill, gt_image * keep[None] + fill
 
 
-def crop_image(gt_mask, patch_size, randomly, bg_color, *images):
+def mask_bbox(mask) -> tuple:
+    """(min_v, min_u, max_v, max_u) of the set pixels of a HOST mask (numpy array / CPU tensor), as ``crop_image`` derives them from
+    ``torch.argwhere`` (main_avatar.py:82-84).  The ground-truth mask is data: the loader has it on the host anyway, and a box
+    computed there (``items['mask_bbox']``) spares the training step the device read-back the reference pays in every iteration."""
+    import numpy as np
+    m = np.asarray(mask) > 0
+    vs, us = np.nonzero(m.any(1))[0], np.nonzero(m.any(0))[0]
+    return int(vs[0]), int(us[0]), int(vs[-1]), int(us[-1])
+
+
+def crop_image(gt_mask, patch_size, randomly, bg_color, *images, bbox=None):
     """Square crop around the mask's bounding box, padded with the background, then a random ``patch_size`` window or a
-    bilinear resize to ``patch_size`` (main_avatar.py:75-115).  One host synchronisation (the bounding box)."""
-    mask_uv = torch.argwhere(gt_mask > 0.)
-    min_v, min_u = (int(v) for v in mask_uv.min(0)[0])
-    max_v, max_u = (int(v) for v in mask_uv.max(0)[0])
+    bilinear resize to ``patch_size`` (main_avatar.py:75-115).  One host synchronisation (the bounding box) unless ``bbox`` =
+    ``mask_bbox(host mask)`` is passed."""
+    if bbox is None:
+        mask_uv = torch.argwhere(gt_mask > 0.)
+        min_v, min_u = (int(v) for v in mask_uv.min(0)[0])
+        max_v, max_u = (int(v) for v in mask_uv.max(0)[0])
+    else:
+        min_v, min_u, max_v, max_u = bbox
     len_v, len_u = max_v - min_v, max_u - min_u
     max_size = max(len_v, len_u)
     rnd = randomly and max_size > patch_size
@@ -52,7 +66,8 @@ def lpips_loss(lpips, image, gt_image):
 
 def training_loss(render_output, items, bg_color, loss_weight, lpips=None, patch_size=512, random_patch=False):
     """The scalar the reference back-propagates (main_avatar.py:196-245) from ``AvatarNet.render`` output and the dataset
-    item (``color_img`` [H, W, 3], ``mask_img`` [H, W] bool, ``boundary_mask_img`` [H, W] bool).  Returns (loss, parts)."""
+    item (``color_img`` [H, W, 3], ``mask_img`` [H, W] bool, ``boundary_mask_img`` [H, W] bool; optional ``mask_bbox`` from
+    ``mask_bbox`` on the host copy of the mask: no read-back in the step).  Returns (loss, parts)."""
     image = render_output['rgb_map'].permute(2, 0, 1)
     color = items['color_img'].clone()
     color[~items['mask_img']] = bg_color
@@ -68,7 +83,7 @@ def training_loss(render_output, items, bg_color, loss_weight, lpips=None, patch
         parts['mask_loss'] = torch.abs(render_output['mask_map'].squeeze(-1) * keep - mask_img * keep).mean()
         total = total + loss_weight['mask'] * parts['mask_loss']
     if loss_weight.get('lpips', 0.) > 0. and lpips is not None:
-        ci, cg = crop_image(mask_img, patch_size, random_patch, bg_color, image, gt_image)
+        ci, cg = crop_image(mask_img, patch_size, random_patch, bg_color, image, gt_image, bbox=items.get('mask_bbox'))
         parts['lpips_loss'] = lpips_loss(lpips, ci, cg)
         total = total + loss_weight['lpips'] * parts['lpips_loss']
     parts['offset_loss'] = torch.linalg.norm(render_output['offset'], dim=-1).mean()

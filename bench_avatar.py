@@ -115,7 +115,8 @@ def main() -> None:
         from animatablegaussians_amd.lpips import LPIPS
         lp = LPIPS(net='vgg').to(dev)
         m = torch.from_numpy(_synth.body_mask(H).copy()).to(dev)
-        gt_items = {'color_img': target, 'mask_img': m, 'boundary_mask_img': torch.zeros_like(m)}
+        gt_items = {'color_img': target, 'mask_img': m, 'boundary_mask_img': torch.zeros_like(m),
+                    'mask_bbox': losses.mask_bbox(_synth.body_mask(H))}      # from the host copy, as a data loader would
         bg_dev = torch.zeros(3, device=dev)
         weights = {'l1': 1.0, 'mask': 0.1, 'lpips': 0.1, 'offset': 0.005}
 

@@ -124,3 +124,22 @@ def test_training_loss_tail_runs_and_differentiates():
     for t in (rgb, mask_map, offset):
         assert t.grad is not None and torch.isfinite(t.grad).all() and float(t.grad.abs().max()) > 0
     assert not rgb.grad[boundary.cuda()].any()              # the boundary band is replaced by the background on both images
+    # the same step with the bounding box computed on the host copy of the mask (no device read-back): identical loss
+    assert losses.mask_bbox(mask.numpy()) == (30, 50, 129, 109)
+    total2, _ = losses.training_loss({'rgb_map': rgb, 'mask_map': mask_map, 'offset': offset}, {**items, 'mask_bbox': losses.mask_bbox(mask)},
+                                     bg, {'l1': 1.0, 'mask': 0.1, 'lpips': 0.1, 'offset': 0.005}, lpips=lp, patch_size=64)
+    assert torch.equal(total2, total)
+
+
+def test_crop_with_host_bbox_equals_crop_with_device_readback():
+    import torch
+    from animatablegaussians_amd import losses
+    g = torch.Generator().manual_seed(1)
+    mask = torch.zeros(90, 120)
+    mask[10:71, 33:60] = 1.0
+    mask[40, 80] = 1.0
+    img, gt = torch.rand(3, 90, 120, generator=g), torch.rand(3, 90, 120, generator=g)
+    bg = torch.tensor([0.2, 0.4, 0.6])
+    a = losses.crop_image(mask, 32, False, bg, img, gt)
+    b = losses.crop_image(mask, 32, False, bg, img, gt, bbox=losses.mask_bbox(mask.numpy()))
+    assert all(torch.equal(x, y) for x, y in zip(a, b)) and a[0].shape == (3, 32, 32)
