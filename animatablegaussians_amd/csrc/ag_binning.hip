@@ -186,9 +186,8 @@ __global__ void __launch_bounds__(256) scatter_kernel(int P, int gx, int gy, con
         const uint32_t dbits = __float_as_uint(rec[idx].depth);
         get_rect_i(px, py, rad, gx, gy, x0, y0, x1, y1);
         key = ((uint64_t)dbits << 32) | (uint32_t)idx;
-        atomicMin(&s_win[0], (int)x0); atomicMin(&s_win[1], (int)y0);
-        atomicMax(&s_win[2], (int)x1); atomicMax(&s_win[3], (int)y1);
     }
+    window_accumulate(s_win, x1 > x0 && y1 > y0, (int)x0, (int)y0, (int)x1, (int)y1);
     __syncthreads();
     const int wx0 = s_win[0], wy0 = s_win[1];
     const int bw = s_win[2] - wx0, bh = s_win[3] - wy0;

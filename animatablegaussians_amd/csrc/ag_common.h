@@ -78,6 +78,25 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// Bounding window of the tile rects of a workgroup's Gaussians, for the window histograms of the preprocess and scatter kernels.
+// One LDS atomic per wave and bound after a wave reduction: 256 threads hammering the same four LDS words directly serialise lane
+// by lane (1024 same-address atomics per workgroup).  Call from ALL lanes; lanes without a rect pass has = false.
+__device__ __forceinline__ void window_accumulate(int* s_win, bool has, int x0, int y0, int x1, int y1)
+{
+    int a = has ? x0 : 0x7fffffff, b = has ? y0 : 0x7fffffff, c = has ? x1 : 0, d = has ? y1 : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        a = min(a, __shfl_xor(a, o, 64));
+        b = min(b, __shfl_xor(b, o, 64));
+        c = max(c, __shfl_xor(c, o, 64));
+        d = max(d, __shfl_xor(d, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0 && c > 0) {
+        atomicMin(&s_win[0], a); atomicMin(&s_win[1], b);
+        atomicMax(&s_win[2], c); atomicMax(&s_win[3], d);
+    }
+}
+
 inline __host__ __device__ size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct GeomLayout {

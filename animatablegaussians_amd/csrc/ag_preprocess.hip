@@ -205,8 +205,6 @@ __global__ void __launch_bounds__(256) preprocess_kernel(PreParams p)
                 g.pad = 0.f;
                 p.rec[idx] = g;
                 rx0 = x0; ry0 = y0; rx1 = x1; ry1 = y1;
-                atomicMin(&s_win[0], (int)x0); atomicMin(&s_win[1], (int)y0);
-                atomicMax(&s_win[2], (int)x1); atomicMax(&s_win[3], (int)y1);
             }
         }
     }
@@ -214,6 +212,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(PreParams p)
         p.radii[idx] = my_radii;
         p.tiles_touched[idx] = touched;
     }
+    window_accumulate(s_win, touched != 0, (int)rx0, (int)ry0, (int)rx1, (int)ry1);
     __syncthreads();
     const int wx0 = s_win[0], wy0 = s_win[1];
     const int bw = s_win[2] - wx0, bh = s_win[3] - wy0;
