@@ -1,0 +1,36 @@
+"""bench.py's one-line JSON contract (driver-facing): keys, types, the roofline and cpu_baseline objects, and that the reported
+HIP-event duration of the dominant kernel is consistent with the step time.  Short run (the driver's defaults are 2000 / 200)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_json_line():
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "60", "--warmup", "20"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k, t in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
+                 ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict),
+                 ("roofline", dict), ("cpu_baseline", dict)):
+        assert isinstance(d[k], t), (k, d[k])
+    assert d["vs_baseline"] is None and d["n_gpus"] == 1 and d["steps"] == 60 and d["warmup"] == 20 and d["scaling"] == "weak"
+    assert d["unit"] == "views/s" and d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"]
+    assert abs(d["value"] * d["ms_per_step"] - 1000.0) < 5.0                       # value = steps / elapsed at N = 1
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["launches_timed"] == 60
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 and 0.01 < r["frac"] < 1.0
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e9) < 0.02 * r["achieved"]
+    assert r["traffic"] is None or r["traffic"] > 0.5 * r["algorithmic_bytes_per_launch"]
+    assert 20.0 < r["avg_launch_us"] < 1000.0 * d["ms_per_step"] * 2               # the kernel fits into (two overlapped) steps
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == "views/s" and c["cores"] >= 1 and c["value"] > 0 and isinstance(c["sample"], str)
+    assert d["value"] > 100 * c["value"]
