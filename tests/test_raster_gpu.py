@@ -450,3 +450,39 @@ def test_optimistic_forward_is_bit_identical_and_survives_overflow():
     assert rc == _lib.AG_ERR_SCRATCH_TOO_SMALL and Rh.value == R
     assert bool((binning == 0xAB).all())
     rz._capacity.pop(key, None)
+
+
+def test_optimistic_path_edge_cases_through_autograd():
+    """The autograd node's optimistic forward on the reference's edge cases: P == 0 (all-zero colour, no native call), a frame with
+    every Gaussian behind the near plane after a populated frame of the same shape (num_rendered 0 against a planned capacity:
+    colour == bg), and gradients that are exactly zero for culled Gaussians."""
+    import torch
+    from animatablegaussians_amd import rasterizer as rz
+    from animatablegaussians_amd.rasterizer import GaussianRasterizer
+    sc = synth.random_gaussians(300, seed=9, img=96, focal=100.0)
+    cam = h.cam_of(sc)
+    rs = h.gpu_settings(sc, cam)
+    key = (300, 96, 96, rs.bg.device.index)
+    rz._capacity.pop(key, None)
+
+    def run(scene):
+        inp = h.gpu_inputs(scene, requires_grad=True)
+        m2d = torch.zeros_like(inp["means3D"], requires_grad=True)
+        out = GaussianRasterizer(rs)(means3D=inp["means3D"], means2D=m2d, opacities=inp["opacities"], colors_precomp=inp["colors"],
+                                     scales=inp["scales"], rotations=inp["rotations"])
+        (out[0].sum() + out[2].sum() + out[3].sum()).backward()
+        return out, inp
+
+    run(sc)                                                     # plans a capacity for (300, 96, 96)
+    assert rz._capacity[key] > 0
+    behind = dict(sc, means3D=sc["means3D"] + np.array([0, 0, 10.0], np.float32))
+    (color, radii, depth, alpha), inp = run(behind)             # optimistic path, zero instances
+    assert not radii.any() and not alpha.any() and not depth.any()
+    assert torch.equal(color, rs.bg[:, None, None].expand_as(color))
+    for k in ("means3D", "opacities", "colors", "scales", "rotations"):
+        assert not inp[k].grad.any(), k
+    empty = {k: (v[:0] if isinstance(v, np.ndarray) and v.shape[:1] == (300,) else v) for k, v in sc.items()}
+    (color, radii, depth, alpha), _ = run(empty)                # P == 0
+    assert radii.numel() == 0 and not color.any() and not alpha.any()
+    rz._capacity.pop(key, None)
+    rz._capacity.pop((0, 96, 96, rs.bg.device.index), None)
