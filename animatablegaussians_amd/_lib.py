@@ -120,6 +120,7 @@ SYMBOLS = [
     ("ag_lpips_level_forward", ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, ctypes.c_int32, ctypes.c_int32, c_vp]),
     ("ag_lpips_level_backward", ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_int32, ctypes.c_int32, c_vp]),
     ("ag_debug_mfma_rate", ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_vp, c_vp]),
+    ("ag_debug_mfma_rate_bf16", ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_vp, c_vp]),
     # include/ag_smplx.h
     ("ag_smplx_workspace_floats", c_sz, [ctypes.POINTER(AgSmplxModel), c_i32]),
     ("ag_smplx_forward", ctypes.c_int, [ctypes.POINTER(AgSmplxModel), c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),

@@ -520,6 +520,31 @@ __global__ void __launch_bounds__(256) mfma_rate_kernel(int iters, float* out)
     if (v == 12345.678f) out[0] = v;     // keep the chain alive
 }
 
+// The same for v_mfma_f32_32x32x16_bf16 (fp32 accumulation): the rate a three-term bf16 split of the fp32 operands
+// (a_hi b_hi + a_hi b_lo + a_lo b_hi) would run on -- calibration only, nothing in the product uses it.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__global__ void __launch_bounds__(256) mfma_rate_bf16_kernel(int iters, float* out)
+{
+    f32x16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[i][r] = 0.f;
+    bf16x8 a, b;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { a[i] = (__bf16)(1.0f + (threadIdx.x & 7) * 0.125f); b[i] = (__bf16)0.5f; }
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i], 0, 0, 0);
+    }
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) v += acc[i][r];
+    if (v == 12345.678f) out[0] = v;
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------------------
@@ -788,6 +813,12 @@ int ag_conv_backward_weight(const AgConvDesc* d, const float* x, const float* dy
     if (bm == 64) hipLaunchKernelGGL((wgrad_kernel<1, 2, 2, 4>), grid, dim3(512), 0, s, wp);
     else          hipLaunchKernelGGL((wgrad_kernel<2, 1, 2, 4>), grid, dim3(512), 0, s, wp);
     return check_hip(hipGetLastError(), "wgrad_kernel");
+}
+
+int ag_debug_mfma_rate_bf16(int blocks, int iters, float* out, void* stream)
+{
+    hipLaunchKernelGGL(mfma_rate_bf16_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), iters, out);
+    return check_hip(hipGetLastError(), "mfma_rate_bf16_kernel");
 }
 
 int ag_debug_mfma_rate(int blocks, int iters, float* out, void* stream)

@@ -60,6 +60,8 @@ int ag_conv_backward_weight(const AgConvDesc* d, const float* x, const float* dy
 /* Calibration: `blocks` x 4 waves each issue iters x 4 independent v_mfma_f32_32x32x2_f32 (8192 FLOP each per wave) with
  * no memory traffic; time it to get the attainable fp32 MFMA rate of the device (profiles/mfma_peak.py). */
 int ag_debug_mfma_rate(int blocks, int iters, float* out, void* stream);
+/* Same for v_mfma_f32_32x32x16_bf16 (calibration of the bf16-split option; not used by the product). */
+int ag_debug_mfma_rate_bf16(int blocks, int iters, float* out, void* stream);
 
 #ifdef __cplusplus
 }
