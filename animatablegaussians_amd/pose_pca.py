@@ -48,3 +48,12 @@ class PosePCA:
         std = torch.sqrt(self.explained_variance_)
         low = torch.minimum(torch.maximum(low, -sigma_pca * std), sigma_pca * std)
         return self.inverse_transform(low).reshape(-1, 3)
+
+    def project_pose_map(self, smpl_pos_map: torch.Tensor, mask: torch.Tensor, sigma_pca: float = 2.) -> torch.Tensor:
+        """main_avatar.py:722-733 without the device -> host -> device round trip: the FRONT half (channels 0..2) of
+        ``items['smpl_pos_map']`` [6, S, S] is replaced at ``mask`` [S, S] (the dataset's ``pos_map_mask``) by its clamped PCA
+        reconstruction; the back half is passed through.  Returns ``items['smpl_pos_map_pca']`` [6, S, S]."""
+        out = smpl_pos_map.clone()
+        front = out[:3].permute(1, 2, 0)                       # [S, S, 3] view of the clone
+        front[mask] = self.transform_pca(front[mask], sigma_pca).to(out.dtype)
+        return out

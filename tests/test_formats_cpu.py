@@ -173,6 +173,18 @@ def test_pose_pca_matches_scikit_learn():
     got = ours.transform_pca(torch.from_numpy(x.reshape(-1, 3)), sigma_pca=2.)
     np.testing.assert_allclose(got.numpy(), want, rtol=1e-7, atol=1e-9)
     assert float(np.abs(want - x.reshape(-1, 3)).max()) > 0.1                # the clamp was active
+    # the test loop's use (main_avatar.py:722-733): front half of the pose map replaced at the mask, back half untouched
+    S = 32
+    mask = np.zeros((S, S), bool)
+    mask.reshape(-1)[rng.choice(S * S, P, replace=False)] = True
+    pos = rng.standard_normal((S, S, 6))
+    pos[..., :3][mask] = x.reshape(-1, 3)
+    live = pos.copy()
+    front, back = np.split(live, [3], 2)
+    front[mask] = want
+    ref_map = np.concatenate([front, back], 2).transpose(2, 0, 1)
+    got_map = ours.project_pose_map(torch.from_numpy(pos).permute(2, 0, 1), torch.from_numpy(mask), sigma_pca=2.)
+    np.testing.assert_allclose(got_map.numpy(), ref_map, rtol=1e-7, atol=1e-9)
 
 
 def test_checkpoint_files_use_the_reference_layout(tmp_path):
