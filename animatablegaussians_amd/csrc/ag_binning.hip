@@ -246,8 +246,19 @@ __device__ __forceinline__ void sort8(uint64_t (&v)[8])
     cswap(v[3], v[4]);
 }
 
+__device__ __forceinline__ void sort4(uint64_t (&v)[4])
+{
+    cswap(v[0], v[1]); cswap(v[2], v[3]);
+    cswap(v[0], v[2]); cswap(v[1], v[3]);
+    cswap(v[1], v[2]);
+}
+
+template <int K> __device__ __forceinline__ void sort_regs(uint64_t (&v)[K]);
+template <> __device__ __forceinline__ void sort_regs<8>(uint64_t (&v)[8]) { sort8(v); }
+template <> __device__ __forceinline__ void sort_regs<4>(uint64_t (&v)[4]) { sort4(v); }
+
 constexpr uint64_t kKeyInf = ~0ull;
-constexpr int kSortSmallCap = 2048;   // 256 threads x 8 keys
+constexpr int kSortSmallCap = 2048;   // 512 threads x 4 keys (half the sequential merge steps per round of 256 x 8)
 constexpr int kSortLargeCap = 8192;   // 1024 threads x 8 keys
 
 template <typename KeyPtr>
@@ -274,12 +285,12 @@ __device__ __forceinline__ void bitonic_sort_global(KeyPtr sk, uint32_t n, uint3
 
 // Workgroups walk the non-empty tiles in tile_scan_kernel's longest-first order with a grid stride, so only as many
 // workgroups are launched as can be resident (the 128 KiB class would otherwise queue 4096 one-per-CU launches).
-template <int NT, bool LARGE>
+template <int NT, bool LARGE, int KPT>
 __global__ void __launch_bounds__(NT) tile_sort_kernel(const uint4* __restrict__ tile_order, const uint32_t* __restrict__ counts,
                                                       uint64_t* __restrict__ keys, uint32_t* __restrict__ point_list)
 {
-    extern __shared__ __attribute__((aligned(16))) uint64_t sk[];   // two buffers of NT * 8 keys
-    constexpr uint32_t CAP = NT * 8;
+    extern __shared__ __attribute__((aligned(16))) uint64_t sk[];   // two buffers of NT * KPT keys
+    constexpr uint32_t CAP = NT * KPT;
     const uint32_t n_active = counts[1];
     const int tid = threadIdx.x;
     for (uint32_t rank = blockIdx.x; rank < n_active; rank += gridDim.x) {
@@ -301,20 +312,20 @@ __global__ void __launch_bounds__(NT) tile_sort_kernel(const uint4* __restrict__
     }
     uint64_t* bufA = sk;
     uint64_t* bufB = sk + CAP;
-    // 1. 8 keys per thread, sorted in registers; slots past n hold +inf and simply stay at the top
-    uint64_t v[8];
-    const uint32_t base = (uint32_t)tid * 8u;
+    // 1. KPT keys per thread, sorted in registers; slots past n hold +inf and simply stay at the top
+    uint64_t v[KPT];
+    const uint32_t base = (uint32_t)tid * (uint32_t)KPT;
 #pragma unroll
-    for (int i = 0; i < 8; i++) v[i] = (base + i < n) ? seg[base + i] : kKeyInf;
-    sort8(v);
+    for (int i = 0; i < KPT; i++) v[i] = (base + i < n) ? seg[base + i] : kKeyInf;
+    sort_regs<KPT>(v);
     if (base < n) {
 #pragma unroll
-        for (int i = 0; i < 8; i++) bufA[base + i] = v[i];
+        for (int i = 0; i < KPT; i++) bufA[base + i] = v[i];
     }
     __syncthreads();
-    // 2. merge rounds over the first n8 = ceil(n / 8) * 8 slots
-    const uint32_t n8 = (n + 7u) & ~7u;
-    for (uint32_t L = 8; L < n8; L <<= 1) {
+    // 2. merge rounds over the first n8 = ceil(n / KPT) * KPT slots
+    const uint32_t n8 = (n + (uint32_t)KPT - 1u) & ~((uint32_t)KPT - 1u);
+    for (uint32_t L = KPT; L < n8; L <<= 1) {
         if (base < n8) {
             const uint32_t ps = base & ~(2u * L - 1u);          // start of this thread's run pair
             const uint32_t o = base - ps;                        // first output index inside the merged pair
@@ -331,7 +342,7 @@ __global__ void __launch_bounds__(NT) tile_sort_kernel(const uint4* __restrict__
             uint32_t i = lo, j = o - lo;
             uint64_t xv = (i < lx) ? X[i] : kKeyInf, yv = (j < ly) ? Y[j] : kKeyInf;
 #pragma unroll
-            for (int r = 0; r < 8; r++) {
+            for (int r = 0; r < KPT; r++) {
                 const bool takex = xv <= yv;
                 bufB[base + r] = takex ? xv : yv;
                 if (takex) { i++; xv = (i < lx) ? X[i] : kKeyInf; }
@@ -364,7 +375,7 @@ int launch_bin_sort(const AgRasterForwardArgs& a, int R, hipStream_t s)
     static bool attr_set = false;
     constexpr size_t kSmallLds = 2ull * kSortSmallCap * sizeof(uint64_t), kLargeLds = 2ull * kSortLargeCap * sizeof(uint64_t);
     if (!attr_set) {
-        if (check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_sort_kernel<1024, true>),
+        if (check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_sort_kernel<1024, true, 8>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLargeLds), "sort LDS attr"))
             return AG_ERR_HIP;
         attr_set = true;
@@ -374,8 +385,8 @@ int launch_bin_sort(const AgRasterForwardArgs& a, int R, hipStream_t s)
         const uint4* order = reinterpret_cast<const uint4*>(ib + il.tile_order);
         const uint32_t* counts = reinterpret_cast<const uint32_t*>(ib + il.num_rendered);
         const int T = gx * gy;
-        hipLaunchKernelGGL((tile_sort_kernel<256, false>), dim3(T < 1280 ? T : 1280), dim3(256), kSmallLds, s, order, counts, keys, point_list);
-        hipLaunchKernelGGL((tile_sort_kernel<1024, true>), dim3(T < 256 ? T : 256), dim3(1024), kLargeLds, s, order, counts, keys, point_list);
+        hipLaunchKernelGGL((tile_sort_kernel<512, false, 4>), dim3(T < 1280 ? T : 1280), dim3(512), kSmallLds, s, order, counts, keys, point_list);
+        hipLaunchKernelGGL((tile_sort_kernel<1024, true, 8>), dim3(T < 256 ? T : 256), dim3(1024), kLargeLds, s, order, counts, keys, point_list);
     }
     return check_hip(hipGetLastError(), "tile_sort_kernel");
 }
