@@ -10,7 +10,7 @@
 //   1. count instances per tile (atomics in the preprocess kernel),
 //   2. exclusive-scan the T tile counts in ONE workgroup -> ranges[tile] directly (no identifyTileRanges pass),
 //   3. scatter (depth_bits<<32 | index) keys into each tile's segment in arbitrary order (atomic cursor),
-//   4. sort every segment independently in LDS: sort-8 network per thread + merge-path rounds on the 64-bit keys, persistent
+//   4. sort every segment independently in LDS: sort-4 / sort-8 network per thread + merge-path rounds on the 64-bit keys, persistent
 //      workgroups over the non-empty tiles in two size classes (<= 2048 and <= 8192 entries; a global bitonic network beyond).
 // The sorted point_list and ranges are bit-identical to the reference's for every input, and the data moved is
 // 8 B + 4 B per instance once, instead of 6+ radix passes over 12 B pairs.
