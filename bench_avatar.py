@@ -5,7 +5,7 @@
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench_avatar.py --gpus N ...)
 
 One step = one camera view of one pose, exactly what one iteration of the reference trainer does with the render path
-(main_avatar.py:186-262 minus LPIPS, which is outside the hot path -- SURVEY.md 8f-1):
+(main_avatar.py:186-262; the LPIPS loss tail of SURVEY.md 8f-1 is added with --lpips):
 
     get_pose_map (LBS of the canonical points, no grad)  ->  AvatarNet.render: 3 x DualStyleUNet (586 GFLOP each,
     MFMA fp32 convolutions) + view-direction encoder -> fused gather/activations -> LBS -> rasterizer @1024^2
@@ -13,7 +13,7 @@ One step = one camera view of one pose, exactly what one iteration of the refere
 
 `--views V` (config 3 proper: "training step, 4 views"): V cameras of the SAME pose per step through
 `AvatarNet.render_views` -- position / other networks, 77 % of the colour network, the assembly and the LBS are evaluated
-(and back-propagated) once per step instead of once per view; measured 21 views/s at V = 4 against 7.4 at V = 1.
+(and back-propagated) once per step instead of once per view; measured 34 views/s at V = 4 against 10.9 at V = 1.
 
 Synthetic subject (AvatarNet.synthetic: 268 348 Gaussians on the 1024x2048 front|back canvas, 4-sparse LBS weights,
 55 random rigid joint transforms), default-initialised networks (224 M parameters), 8 free-view cameras round-robin.
