@@ -32,6 +32,7 @@ class AvatarRenderCore(nn.Module):
         S2 = cano_mask.shape[1]
         assert cano_mask.shape[0] * 2 == S2, "canvas mask must be [S, 2S] (front | back)"
         self.max_sh_degree = max_sh_degree
+        self.map_side = int(cano_mask.shape[0])
         self.register_buffer("pix", ops.mask_to_pix(cano_mask), persistent=False)
         for name, t in (("xyz", xyz), ("opacity_raw", opacity_raw), ("scaling_raw", scaling_raw),
                         ("rotation_raw", rotation_raw), ("lbs", lbs)):
@@ -113,6 +114,43 @@ class _Graphed:
         return self.static_out
 
 
+class CanoGaussianModel:
+    """The read surface of the reference's canonical ``GaussianModel`` (``gaussians/gaussian_model.py:53-61,115-147``) that
+    ``AvatarNet`` and the trainer's pre-training pass use (``network/avatar.py:100,113-115``, ``main_avatar.py:134-153``):
+    ``get_xyz``, ``get_opacity``, ``get_scaling``, ``get_rotation``, their ``*_raw`` forms and the three activation callables.
+    A view over ``AvatarRenderCore``'s buffers -- as in the reference it is not an ``nn.Module`` and nothing in it is trained
+    (main_avatar.py:55-58 only collects ``avatar_net.parameters()``).  The activated getters run on the assembly kernel
+    (null network map) and are cached until a raw buffer is modified in place."""
+
+    def __init__(self, core: AvatarRenderCore, sh_degree: int = 0):
+        self._core = core
+        self.max_sh_degree = sh_degree
+        self.active_sh_degree = 0
+        self.spatial_lr_scale = 2.5                                 # network/avatar.py:32
+        self.opacity_activation = torch.sigmoid                     # gaussian_model.py:53-61
+        self.scaling_activation = torch.exp
+        self.scaling_inverse_activation = torch.log
+        self.rotation_activation = F.normalize
+        self.inverse_opacity_activation = lambda x: torch.log(x / (1 - x))
+        self._act = None
+
+    def _activated(self):
+        c = self._core
+        key = (c.opacity_raw.data_ptr(), c.opacity_raw._version, c.scaling_raw.data_ptr(), c.scaling_raw._version,
+               c.rotation_raw.data_ptr(), c.rotation_raw._version)
+        if self._act is None or self._act[0] != key:
+            self._act = (key, ops.canonical_activations(c.pix, c.map_side, c.opacity_raw, c.scaling_raw, c.rotation_raw))
+        return self._act[1]
+
+    get_xyz = property(lambda self: self._core.xyz)
+    get_opacity_raw = property(lambda self: self._core.opacity_raw)
+    get_scaling_raw = property(lambda self: self._core.scaling_raw)
+    get_rotation_raw = property(lambda self: self._core.rotation_raw)
+    get_opacity = property(lambda self: self._activated()[0])
+    get_scaling = property(lambda self: self._activated()[1])
+    get_rotation = property(lambda self: self._activated()[2])
+
+
 class AvatarNet(nn.Module):
     """Re-host of the reference's ``network.avatar.AvatarNet`` (``network/avatar.py:16-239``) on this package's kernels:
     three ``DualStyleUNet`` (position / other / colour), the view-direction encoder, the fused per-Gaussian assembly,
@@ -122,8 +160,9 @@ class AvatarNet(nn.Module):
 
     Differences, all deliberate: the per-subject assets are passed in as tensors (``cano_smpl_map`` [S, 2S, 3],
     ``lbs`` [N, J], optional ``cano_nml_map``) or read by ``from_data_dir`` with the OpenCV-free EXR reader (``exr.py``)
-    instead of through ``config.opt``; ``generate_mean_hands`` takes the fixed frame's position map instead of a file id.
-    ``load_reference_state_dict`` takes the reference's ``net.pt['avatar_net']`` dict key for key.
+    instead of through ``config.opt`` (``dropin/avatar_module.py`` is the ``config``-reading constructor the reference trainer
+    imports).  ``state_dict()`` / ``load_state_dict()`` / ``parameters()`` have the reference module's keys and order, so ``net.pt``
+    and ``optm.pt`` written by either implementation load in the other (main_avatar.py:777-813).
     """
 
     def __init__(self, opt: Optional[dict] = None, *, cano_smpl_map: torch.Tensor, lbs: torch.Tensor,
@@ -162,13 +201,11 @@ class AvatarNet(nn.Module):
         if self.with_viewdirs:
             nml = cano_nml_map.to(torch.float32)
             self.register_buffer("cano_nmls", nml[mask].to(dev), persistent=False)                                 # :45
-            # viewdir_net = Conv2d(1, 64, 4, 2, 1) + LeakyReLU(0.2) + Conv2d(64, 128, 4, 2, 1)  (:46-50); torch's default
-            # Conv2d initialisation (kaiming_uniform(a=sqrt 5) weights, uniform(+-1/sqrt(fan_in)) biases)
-            for idx, (cin, cout) in ((0, (1, 64)), (2, (64, 128))):
-                bound = 1 / np.sqrt(cin * 16)
-                self.register_parameter(f"viewdir_net__{idx}__weight", nn.Parameter((torch.rand(cout, cin, 4, 4) * 2 - 1) * bound))
-                self.register_parameter(f"viewdir_net__{idx}__bias", nn.Parameter((torch.rand(cout) * 2 - 1) * bound))
+            # :46-50.  The torch modules only HOLD the parameters (reference names, initialisation and registration order:
+            # ``viewdir_net.{0,2}.{weight,bias}`` after the three networks); get_viewdir_feat runs them on ag_conv.
+            self.viewdir_net = nn.Sequential(nn.Conv2d(1, 64, 4, 2, 1), nn.LeakyReLU(0.2, inplace=True), nn.Conv2d(64, 128, 4, 2, 1))
         self.to(dev)
+        self.cano_gaussian_model = CanoGaussianModel(self.core, self.max_sh_degree)
 
     # ---- construction helpers -------------------------------------------------------------------------------------
     @classmethod
@@ -211,18 +248,22 @@ class AvatarNet(nn.Module):
 
     @torch.no_grad()
     def load_reference_state_dict(self, sd, strict=True):
-        """``sd`` = the reference's ``AvatarNet.state_dict()`` (``net.pt['avatar_net']``, main_avatar.py:778-786)."""
+        """``sd`` = the reference's ``AvatarNet.state_dict()`` (``net.pt['avatar_net']``, main_avatar.py:778-786), with or without
+        its constant FIR / Haar buffers.  ``load_state_dict`` / ``state_dict`` themselves use the reference's exact keys."""
         per_net = {"color_net": {}, "position_net": {}, "other_net": {}}
+        vd = {}
         for key, value in sd.items():
             head, _, rest = key.partition(".")
             if head in per_net:
                 per_net[head][rest] = value
-            elif head == "viewdir_net" and self.with_viewdirs:
-                getattr(self, "viewdir_net__" + rest.replace(".", "__")).copy_(value)
-            elif strict and head != "viewdir_net":
+            elif head == "viewdir_net":
+                vd[rest] = value
+            elif strict:
                 raise RuntimeError(f"unexpected key in reference state_dict: {key}")
         for name, part in per_net.items():
             getattr(self, name).load_reference_state_dict(part, strict=strict)
+        if self.with_viewdirs:
+            self.viewdir_net.load_state_dict(vd, strict=strict)
 
     # ---- the reference's methods ----------------------------------------------------------------------------------
     @property
@@ -290,9 +331,10 @@ class AvatarNet(nn.Module):
         weight = self.opt.get('weight_viewdirs', 1.)
         feats = []
         for v in (front, back):
-            h = agc.conv2d(v, self.viewdir_net__0__weight, bias=self.viewdir_net__0__bias, stride=2, padding=1)
+            c0, c2 = self.viewdir_net[0], self.viewdir_net[2]
+            h = agc.conv2d(v, c0.weight, bias=c0.bias, stride=2, padding=1)
             h = fused_leaky_relu(h, None, 0.2, 1.0)
-            h = agc.conv2d(h, self.viewdir_net__2__weight, bias=self.viewdir_net__2__bias, stride=2, padding=1)
+            h = agc.conv2d(h, c2.weight, bias=c2.bias, stride=2, padding=1)
             feats.append(weight * h)
         return feats[0], feats[1]
 
@@ -368,11 +410,48 @@ class AvatarNet(nn.Module):
         c = m.shape[1] // 2
         return torch.cat([m[:, :c], m[:, c:]], 3)[0].permute(1, 2, 0)
 
+    # ---- the per-network accessors the trainer's pre-training pass calls one at a time (main_avatar.py:126-160) ----------------
+    def get_positions(self, pose_map, return_map=False):
+        """:93-104 -> positions [N,3] (= 0.05 * position_map[mask] + cano xyz) [, position_map [S, 2S, 3]]."""
+        position_map = self.position_net([self.position_style], pose_map[None].contiguous(), randomize_noise=False)[0]
+        positions = ops.gather_positions(position_map, self.core.pix, self.core.xyz)
+        return (positions, self._canvas(position_map)) if return_map else positions
+
+    def get_others(self, pose_map):
+        """:106-117 -> (opacity [N,1], scales [N,3], rotations [N,4])."""
+        other_map = self.other_net([self.other_style], pose_map[None].contiguous(), randomize_noise=False)[0]
+        return ops.gather_others(other_map, self.core.pix, self.core.opacity_raw, self.core.scaling_raw, self.core.rotation_raw)
+
+    def get_colors(self, pose_map, front_viewdirs=None, back_viewdirs=None):
+        """:119-124 -> (colors [N,3], color_map [S, 2S, 3])."""
+        color_style = torch.rand_like(self.color_style) if self.random_style and self.training else self.color_style
+        color_map = self.color_net([color_style], pose_map[None].contiguous(), randomize_noise=False, view_feature1=front_viewdirs,
+                                   view_feature2=back_viewdirs)[0]
+        return ops.gather_colors(color_map, self.core.pix), self._canvas(color_map)
+
+    def transform_cano2live(self, gaussian_vals, items):
+        """:84-91: skin ``positions`` and ``rotations`` of ``gaussian_vals`` (in place, as the reference) with the blended joint
+        matrices of ``items['cano2live_jnt_mats']``."""
+        gaussian_vals['positions'], gaussian_vals['rotations'] = ops.lbs_transform(
+            gaussian_vals['positions'], gaussian_vals['rotations'], self.core.lbs, items['cano2live_jnt_mats'])
+        return gaussian_vals
+
+    def _fix_hand_pose_map(self):
+        """The fixed frame's position map for ``generate_mean_hands()`` (the reference reads ``smpl_pos_map/%08d.exr %
+        config.opt['test']['fix_hand_id']``, :61-67); the stand-alone class has no global config: pass it in, or use the drop-in."""
+        raise RuntimeError("generate_mean_hands(): pass the fixed frame's pose map [3 or 6, S, S] (dropin/avatar_module.py reads "
+                           "it from config.opt like the reference)")
+
+    def _fix_hand_enabled(self):
+        return bool(self.opt.get('fix_hand', False))
+
     @torch.no_grad()
-    def generate_mean_hands(self, pose_map):
-        """network/avatar.py:52-77: the Gaussians of one fixed frame (``opt['test']['fix_hand_id']``; the reference reads its
-        position map from disk, here the caller passes it: ``[3 or 6, S, S]``) that ``render`` fades the hands into at test
-        time when ``opt['fix_hand']`` is set.  Also records ``hand_mask`` (Gaussians skinned mostly to wrist / finger joints)."""
+    def generate_mean_hands(self, pose_map=None):
+        """network/avatar.py:52-77: the Gaussians of one fixed frame (``opt['test']['fix_hand_id']``) that ``render`` fades the hands
+        into at test time when ``fix_hand`` is set.  Also records ``hand_mask`` (Gaussians skinned mostly to wrist / finger
+        joints)."""
+        if pose_map is None:
+            pose_map = self._fix_hand_pose_map()
         am = self.core.lbs.argmax(1)
         self.hand_mask = (am == 20) | (am == 21) | (am >= 25)
         position_map, other_map, color_map = self.get_maps(pose_map[:3])
@@ -389,7 +468,7 @@ class AvatarNet(nn.Module):
         front_vd, back_vd = self.get_viewdir_feat(items) if self.with_viewdirs else (None, None)
         position_map, other_map, color_map = self.get_maps(pose_map, front_vd, back_vd)
         g = self.core.assemble(position_map, other_map, color_map)
-        if (not self.training) and self.opt.get('fix_hand', False):                                                # :183-200
+        if (not self.training) and self._fix_hand_enabled():                                                       # :183-200
             if self.hand_positions is None:
                 raise RuntimeError("fix_hand: call generate_mean_hands(pose_map) first (main_avatar.py:584)")
             g['positions'], g['opacity'], g['scales'], g['rotations'] = ops.hand_fuse(
@@ -435,7 +514,7 @@ class AvatarNet(nn.Module):
             o1, s1, o2, s2, level0, w_latent = self._graphed("color_shared", shared_fn, [x])
 
             def view_fn(f, b):        # closes over the static outputs of the shared capture
-                noise = [getattr(cn, cn._attr(f"noises.noise_{i}")) for i in range(cn.num_layers)]
+                noise = [cn._p(f"noises.noise_{i}") for i in range(cn.num_layers)]
                 lv = [level0] * (len(cn.enc) + 1)     # the view-dependent stages only read the finest level, levels[0]
                 parts = [cn.decode_view(br, lv, w_latent, noise, o, sk, vf) for br, o, sk, vf in ((1, o1, s1, f), (2, o2, s2, b))]
                 return torch.cat(parts, 1)

@@ -85,6 +85,97 @@ def gather_activate(position_map, other_map, color_map, pix, xyz, opacity_raw, s
     return _GatherActivate.apply(position_map, other_map, color_map, pix, xyz, opacity_raw, scaling_raw, rotation_raw)
 
 
+class _GatherPart(torch.autograd.Function):
+    """One part of the assembly on its own -- what ``AvatarNet.get_positions`` / ``get_others`` / ``get_colors`` return for ONE
+    network output (network/avatar.py:93-124), the way the reference trainer's pre-training pass calls them
+    (main_avatar.py:126-160).  ``part`` in {'position', 'other', 'color'}; ``raws`` = the canonical parameters that part adds."""
+
+    _SHAPES = {"position": (6, (3,)), "other": (16, (1, 3, 4)), "color": (6, (3,))}
+
+    @staticmethod
+    def forward(ctx, part, net_map, pix, *raws):
+        L = _lib.lib()
+        ch, outs = _GatherPart._SHAPES[part]
+        net_map = _chk(net_map, part + "_map")
+        S = int(net_map.shape[-1])
+        if tuple(net_map.shape) != (1, ch, S, S):
+            raise RuntimeError(f"expected a {part} map of shape [1,{ch},S,S]")
+        raws = tuple(_chk(r, "canonical parameter") for r in raws)
+        N, dev = int(pix.numel()), net_map.device
+        out = [torch.empty((N, c), dtype=torch.float32, device=dev) for c in outs]
+        a = _lib.AgGatherArgs()
+        a.N, a.S, a.pix = N, S, _p(pix)
+        if part == "position":
+            a.position_map, a.xyz, a.positions = _p(net_map), _p(raws[0]), _p(out[0])
+        elif part == "other":
+            a.other_map = _p(net_map)
+            a.opacity_raw, a.scaling_raw, a.rotation_raw = (_p(r) for r in raws)
+            a.opacity, a.scales, a.rotations = (_p(t) for t in out)
+        else:
+            a.color_map, a.colors = _p(net_map), _p(out[0])
+        with torch.cuda.device(dev):
+            _lib.check(L.ag_gather_activate_forward(ctypes.byref(a), _stream(dev)), "ag_gather_activate_forward")
+        ctx.part = part
+        ctx.save_for_backward(net_map, pix, *raws)
+        return tuple(out)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        L = _lib.lib()
+        net_map, pix, *raws = ctx.saved_tensors
+        part, dev = ctx.part, net_map.device
+        N, S = int(pix.numel()), int(net_map.shape[-1])
+        outs = _GatherPart._SHAPES[part][1]
+        grads = [(_chk(g, "grad") if g is not None else torch.zeros((N, c), dtype=torch.float32, device=dev)) for g, c in zip(grads, outs)]
+        gm = torch.empty_like(net_map)
+        a = _lib.AgGatherArgs()
+        a.N, a.S, a.pix = N, S, _p(pix)
+        null = ctypes.c_void_p(None)
+        gp = go = gc = null
+        if part == "position":
+            a.positions, gp = _p(grads[0]), _p(gm)
+        elif part == "other":
+            a.other_map = _p(net_map)
+            a.opacity_raw, a.scaling_raw, a.rotation_raw = (_p(r) for r in raws)
+            a.opacity, a.scales, a.rotations = (_p(t) for t in grads)
+            go = _p(gm)
+        else:
+            a.colors, gc = _p(grads[0]), _p(gm)
+        with torch.cuda.device(dev):
+            _lib.check(L.ag_gather_activate_backward(ctypes.byref(a), gp, go, gc, _stream(dev)), "ag_gather_activate_backward")
+        return (None, gm, None) + (None,) * len(raws)
+
+
+def gather_positions(position_map, pix, xyz):
+    """``0.05 * position_map[mask] + xyz`` -> [N,3]  (network/avatar.py:93-104)."""
+    return _GatherPart.apply("position", position_map, pix, xyz)[0]
+
+
+def gather_others(other_map, pix, opacity_raw, scaling_raw, rotation_raw):
+    """-> (opacity [N,1], scales [N,3], rotations [N,4]) = sigmoid / exp / normalize of map + raw  (network/avatar.py:106-117)."""
+    return _GatherPart.apply("other", other_map, pix, opacity_raw, scaling_raw, rotation_raw)
+
+
+def gather_colors(color_map, pix):
+    """``color_map[mask]`` -> [N,3]  (network/avatar.py:119-124)."""
+    return _GatherPart.apply("color", color_map, pix)[0]
+
+
+@torch.no_grad()
+def canonical_activations(pix, S, opacity_raw, scaling_raw, rotation_raw):
+    """``GaussianModel.get_opacity / get_scaling / get_rotation`` (gaussians/gaussian_model.py:115-147): the activations of
+    the canonical parameters alone (the assembly kernel with a null network map)."""
+    N, dev = int(pix.numel()), opacity_raw.device
+    out = [torch.empty((N, c), dtype=torch.float32, device=dev) for c in (1, 3, 4)]
+    a = _lib.AgGatherArgs()
+    a.N, a.S, a.pix = N, int(S), _p(pix)
+    a.opacity_raw, a.scaling_raw, a.rotation_raw = (_p(_chk(r, "canonical parameter")) for r in (opacity_raw, scaling_raw, rotation_raw))
+    a.opacity, a.scales, a.rotations = (_p(t) for t in out)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().ag_gather_activate_forward(ctypes.byref(a), _stream(dev)), "ag_gather_activate_forward")
+    return tuple(out)
+
+
 class _LbsTransform(torch.autograd.Function):
     @staticmethod
     def forward(ctx, positions, rotations, lbs, jnt_mats):

@@ -24,6 +24,9 @@ __device__ __forceinline__ size_t map_offset(int pix, int S, int C, int c)
     return ((size_t)(back * C + c) * S + v) * S + (u - back * S);
 }
 
+// Each of the three parts (positions | opacity, scales, rotations | colours) is produced when its output pointer is set;
+// a null MAP pointer stands for an all-zero network output (the activations of the canonical parameters alone:
+// GaussianModel.get_opacity / get_scaling / get_rotation, gaussians/gaussian_model.py:115-147).  All wave-uniform.
 __global__ void __launch_bounds__(256) gather_forward_kernel(AgGatherArgs a)
 {
     const int n = blockIdx.x * 256 + threadIdx.x;
@@ -31,19 +34,27 @@ __global__ void __launch_bounds__(256) gather_forward_kernel(AgGatherArgs a)
     const int pix = a.pix[n];
     const size_t plane = (size_t)a.S * a.S;
     const size_t o3 = map_offset(pix, a.S, 3, 0), o8 = map_offset(pix, a.S, 8, 0);
+    if (a.positions) {
 #pragma unroll
-    for (int c = 0; c < 3; c++) {
-        a.positions[3 * n + c] = 0.05f * a.position_map[o3 + c * plane] + a.xyz[3 * n + c];
-        a.colors[3 * n + c] = a.color_map[o3 + c * plane];
+        for (int c = 0; c < 3; c++)
+            a.positions[3 * n + c] = 0.05f * (a.position_map ? a.position_map[o3 + c * plane] : 0.f) + a.xyz[3 * n + c];
     }
-    const float o = a.other_map[o8] + a.opacity_raw[n];
+    if (a.colors) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) a.colors[3 * n + c] = a.color_map ? a.color_map[o3 + c * plane] : 0.f;
+    }
+    if (!a.opacity) return;
+    float m[8];
+#pragma unroll
+    for (int c = 0; c < 8; c++) m[c] = a.other_map ? a.other_map[o8 + c * plane] : 0.f;
+    const float o = m[0] + a.opacity_raw[n];
     a.opacity[n] = 1.0f / (1.0f + expf(-o));
 #pragma unroll
-    for (int c = 0; c < 3; c++) a.scales[3 * n + c] = expf(a.other_map[o8 + (1 + c) * plane] + a.scaling_raw[3 * n + c]);
+    for (int c = 0; c < 3; c++) a.scales[3 * n + c] = expf(m[1 + c] + a.scaling_raw[3 * n + c]);
     float q[4], nn = 0.f;
 #pragma unroll
     for (int c = 0; c < 4; c++) {
-        q[c] = a.other_map[o8 + (4 + c) * plane] + a.rotation_raw[4 * n + c];
+        q[c] = m[4 + c] + a.rotation_raw[4 * n + c];
         nn += q[c] * q[c];
     }
     const float inv = 1.0f / fmaxf(sqrtf(nn), 1e-12f);   // F.normalize: x / max(||x||, eps)
@@ -51,6 +62,7 @@ __global__ void __launch_bounds__(256) gather_forward_kernel(AgGatherArgs a)
     for (int c = 0; c < 4; c++) a.rotations[4 * n + c] = q[c] * inv;
 }
 
+// A null gradient-map pointer skips that part (its upstream-gradient slots are then not read).
 __global__ void __launch_bounds__(256) gather_backward_kernel(AgGatherArgs a, float* __restrict__ g_pos_map,
                                                              float* __restrict__ g_other_map, float* __restrict__ g_col_map)
 {
@@ -59,11 +71,15 @@ __global__ void __launch_bounds__(256) gather_backward_kernel(AgGatherArgs a, fl
     const int pix = a.pix[n];
     const size_t plane = (size_t)a.S * a.S;
     const size_t o3 = map_offset(pix, a.S, 3, 0), o8 = map_offset(pix, a.S, 8, 0);
+    if (g_pos_map) {
 #pragma unroll
-    for (int c = 0; c < 3; c++) {
-        g_pos_map[o3 + c * plane] = 0.05f * a.positions[3 * n + c];
-        g_col_map[o3 + c * plane] = a.colors[3 * n + c];
+        for (int c = 0; c < 3; c++) g_pos_map[o3 + c * plane] = 0.05f * a.positions[3 * n + c];
     }
+    if (g_col_map) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) g_col_map[o3 + c * plane] = a.colors[3 * n + c];
+    }
+    if (!g_other_map) return;
     // sigmoid'
     const float o = a.other_map[o8] + a.opacity_raw[n];
     const float sg = 1.0f / (1.0f + expf(-o));
@@ -314,9 +330,10 @@ static int check_gather(const AgGatherArgs* a)
 {
     if (!a || a->N < 0 || a->S <= 0) { set_error("bad gather sizes"); return AG_ERR_INVALID_ARGUMENT; }
     if (a->N == 0) return AG_OK;
-    if (!a->pix || !a->position_map || !a->other_map || !a->color_map || !a->xyz || !a->opacity_raw || !a->scaling_raw ||
-        !a->rotation_raw || !a->positions || !a->opacity || !a->scales || !a->rotations || !a->colors) {
-        set_error("null pointer in AgGatherArgs");
+    const bool others_all = a->opacity && a->scales && a->rotations, others_none = !a->opacity && !a->scales && !a->rotations;
+    if (!a->pix || (a->positions && !a->xyz) || !(others_all || others_none) ||
+        (others_all && (!a->opacity_raw || !a->scaling_raw || !a->rotation_raw)) || (!a->positions && others_none && !a->colors)) {
+        set_error("AgGatherArgs: pix, at least one output part, and the canonical parameters of every requested part are required");
         return AG_ERR_INVALID_ARGUMENT;
     }
     return AG_OK;
@@ -332,14 +349,20 @@ int ag_gather_activate_forward(const AgGatherArgs* a, void* stream)
 
 int ag_gather_activate_backward(const AgGatherArgs* a, float* g_pos_map, float* g_other_map, float* g_col_map, void* stream)
 {
-    int rc = check_gather(a);
-    if (rc) return rc;
-    if (!g_pos_map || !g_other_map || !g_col_map) { set_error("null gradient map"); return AG_ERR_INVALID_ARGUMENT; }
+    if (!a || a->N < 0 || a->S <= 0) { set_error("bad gather sizes"); return AG_ERR_INVALID_ARGUMENT; }
+    if (!g_pos_map && !g_other_map && !g_col_map) { set_error("no gradient map requested"); return AG_ERR_INVALID_ARGUMENT; }
+    if (a->N > 0 && (!a->pix || (g_pos_map && !a->positions) || (g_col_map && !a->colors) ||
+                     (g_other_map && (!a->other_map || !a->opacity_raw || !a->scaling_raw || !a->rotation_raw || !a->opacity ||
+                                      !a->scales || !a->rotations)))) {
+        set_error("AgGatherArgs: a requested gradient map needs its upstream gradients (and, for the other map, the forward inputs)");
+        return AG_ERR_INVALID_ARGUMENT;
+    }
+    int rc;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const size_t plane = (size_t)a->S * a->S * sizeof(float);
-    if ((rc = check_hip(hipMemsetAsync(g_pos_map, 0, 6 * plane, s), "memset"))) return rc;
-    if ((rc = check_hip(hipMemsetAsync(g_other_map, 0, 16 * plane, s), "memset"))) return rc;
-    if ((rc = check_hip(hipMemsetAsync(g_col_map, 0, 6 * plane, s), "memset"))) return rc;
+    if (g_pos_map && (rc = check_hip(hipMemsetAsync(g_pos_map, 0, 6 * plane, s), "memset"))) return rc;
+    if (g_other_map && (rc = check_hip(hipMemsetAsync(g_other_map, 0, 16 * plane, s), "memset"))) return rc;
+    if (g_col_map && (rc = check_hip(hipMemsetAsync(g_col_map, 0, 6 * plane, s), "memset"))) return rc;
     if (a->N == 0) return AG_OK;
     hipLaunchKernelGGL(gather_backward_kernel, dim3((a->N + 255) / 256), dim3(256), 0, s, *a, g_pos_map, g_other_map, g_col_map);
     return check_hip(hipGetLastError(), "gather_backward_kernel");

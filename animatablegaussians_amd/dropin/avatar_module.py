@@ -20,3 +20,21 @@ class AvatarNet(_AvatarNet):
 
     def __init__(self, opt):         # built in __new__ (main_avatar.py:48 then calls .to(config.device): a no-op)
         pass
+
+    def _fix_hand_enabled(self):     # network/avatar.py:183
+        import config
+        return bool(config.opt['test'].get('fix_hand', False)) and config.opt['mode'] == 'test'
+
+    def _fix_hand_pose_map(self):    # network/avatar.py:61-67 (called without arguments at main_avatar.py:584)
+        import glob
+
+        import config
+        import numpy as np
+        import torch
+
+        from animatablegaussians_amd import exr
+        paths = sorted(glob.glob(config.opt['train']['data']['data_dir'] + '/smpl_pos_map/%08d.exr' % config.opt['test']['fix_hand_id']))
+        m = exr.imread(paths[0])
+        half = m.shape[1] // 2
+        m = np.concatenate([m[:, :half], m[:, half:]], 2).transpose((2, 0, 1))
+        return torch.from_numpy(np.ascontiguousarray(m)).to(torch.float32).to(config.device)[:3]

@@ -43,6 +43,10 @@ def _haar():
     return {"ll": lo.T * lo, "lh": hi.T * lo, "hl": lo.T * hi, "hh": hi.T * hi}
 
 
+class _Holder(torch.nn.Module):
+    """Bare container: gives a tensor the reference's dotted state_dict path.  Never called."""
+
+
 class DualStyleUNet(torch.nn.Module):
     """Encoder (pose map -> 6 feature levels) + two style-modulated decoders (front / back maps)."""
 
@@ -56,107 +60,137 @@ class DualStyleUNet(torch.nn.Module):
         self.inp_size, self.inp_ch, self.out_ch, self.out_size = inp_size, inp_ch, out_ch, out_size
         self.style_dim, self.n_mlp, self.lr_mlp = style_dim, n_mlp, lr_mlp
         log_in, log_mid, log_out = int(math.log2(inp_size)), int(math.log2(middle_size)), int(math.log2(out_size)) - 1
-        self._ref_names = {}
+        self._slots = {}                    # reference state_dict key -> (holder module, leaf name)
+        self._learnable = []                # keys of the parameters, in named_parameters() order
 
-        # ---- learnable tensors, under the reference's state_dict names --------------------------------------------
+        # ---- every tensor of the reference module's state_dict, under the reference's names AND in its order ------------
+        # The tensors live in a tree of bare holder modules shaped like the reference's module tree (dual_styleunet.py:
+        # 636-760), declared in the reference's registration order, so that ``state_dict()`` / ``load_state_dict()`` /
+        # ``parameters()`` are interchangeable with the reference's: main_avatar.py:777-813 saves and strictly loads
+        # ``avatar_net.state_dict()``, and Adam's state is indexed by parameter order.  The holders never run; the forward
+        # below is table-driven.  Constant FIR / Haar kernels are stored (the reference stores them) but not read.
+        for top in ("style", "comb_convs", "from_rgbs", "cond_convs", "conv_in", "convs1", "convs2", "to_rgbs1", "to_rgbs2",
+                    "noises", "iwt"):
+            self.add_module(top, _Holder())
+        blur, blur_up = _fir(blur_kernel), _fir(blur_kernel, 4.0)
         for i in range(n_mlp):
             self._param(f"style.{i + 1}.weight", torch.randn(style_dim, style_dim) / lr_mlp)
             self._param(f"style.{i + 1}.bias", torch.zeros(style_dim))
 
         c0 = ch[inp_size // 2]
-        self._conv_layer_params("conv_in", inp_ch, c0, 3, downsample=True)
         self._conv_layer_params("comb_convs.0", 2 * c0, c0, 3)
         self.enc = []                       # (level index, in channels, out channels)
         cin = c0
         for n, i in enumerate(range(log_in - 2, log_mid - 1, -1)):
             cout = ch[2 ** i]
+            self._const(f"from_rgbs.{n}.downsample.kernel", blur)
             self._conv_layer_params(f"from_rgbs.{n}.conv", inp_ch, cin, 1)
             self._conv_layer_params(f"cond_convs.{n}.conv1", cin, cin, 3)
             self._conv_layer_params(f"cond_convs.{n}.conv2", cin, cout, 3, downsample=True)
             self._conv_layer_params(f"comb_convs.{n + 1}", cout * (2 if i > log_mid else 1), cout, 3)
             self.enc.append((n, cin, cout))
             cin = cout
+        self._conv_layer_params("conv_in", inp_ch, c0, 3, downsample=True)
         self.n_comb = len(self.enc) + 1
 
+        self.num_layers = 2 * (log_out - log_mid)
+        for layer in range(self.num_layers):
+            res = 2 ** ((layer + 2 * (log_mid + 1)) // 2)
+            self._const(f"noises.noise_{layer}", torch.randn(1, 1, res, res))
         self.dec = []                       # (stage, in channels, out channels)
         cin = ch[middle_size]
         for n, i in enumerate(range(log_mid + 1, log_out + 1)):
             cout = ch[2 ** i]
             for b in (1, 2):
-                self._styled_conv_params(f"convs{b}.{2 * n}", cin, cout)
-                self._styled_conv_params(f"convs{b}.{2 * n + 1}", cout, cout)
+                self._styled_conv_params(f"convs{b}.{2 * n}", cin, cout, blur_up)
+                self._styled_conv_params(f"convs{b}.{2 * n + 1}", cout, cout, None)
+                self._param(f"to_rgbs{b}.{n}.bias", torch.zeros(1, out_ch * 4, 1, 1))
+                self._const(f"to_rgbs{b}.{n}.upsample.kernel", blur_up)
+                self._haar_consts(f"to_rgbs{b}.{n}.iwt", inverse=True)
+                self._haar_consts(f"to_rgbs{b}.{n}.dwt", inverse=False)
                 self._param(f"to_rgbs{b}.{n}.conv.weight", torch.randn(1, out_ch * 4, cout, 1, 1))
                 self._param(f"to_rgbs{b}.{n}.conv.modulation.weight", torch.randn(cout, style_dim))
                 self._param(f"to_rgbs{b}.{n}.conv.modulation.bias", torch.ones(cout))
-                self._param(f"to_rgbs{b}.{n}.bias", torch.zeros(1, out_ch * 4, 1, 1))
             self.dec.append((n, cin, cout))
             cin = cout
-        self.num_layers = 2 * len(self.dec)
+        self._haar_consts("iwt", inverse=True)
         self.n_latent = log_out * 2 - (log_mid * 2 - 1) + 1
-        for layer in range(self.num_layers):
-            res = 2 ** ((layer + 2 * (log_mid + 1)) // 2)
-            self.register_buffer(self._attr(f"noises.noise_{layer}"), torch.randn(1, 1, res, res))
+        self._learnable = [k for k, _ in self.named_parameters()]
 
-        # ---- constant filters ---------------------------------------------------------------------------------
-        self.register_buffer("_k_blur", _fir(blur_kernel), persistent=False)           # Blur before stride-2 conv, Downsample
-        self.register_buffer("_k_blur_up", _fir(blur_kernel, 4.0), persistent=False)   # Blur after conv_transpose, Upsample
-        for name, k in _haar().items():
-            self.register_buffer("_dwt_" + name, k.contiguous(), persistent=False)
-            self.register_buffer("_iwt_" + name, (-k if name in ("lh", "hl") else k).contiguous(), persistent=False)
+        # ---- the filters the forward reads (non-persistent: not part of the checkpoint) ---------------------------
+        self.register_buffer("_k_blur", blur.clone(), persistent=False)            # Blur before stride-2 conv, Downsample
+        self.register_buffer("_k_blur_up", blur_up.clone(), persistent=False)      # Blur after conv_transpose, Upsample
 
     # ---- parameter bookkeeping ------------------------------------------------------------------------------------
-    @staticmethod
-    def _attr(ref_name):
-        return ref_name.replace(".", "__")
+    def _declare(self, ref_name, value, learnable):
+        *path, leaf = ref_name.split(".")
+        m = self
+        for part in path:
+            if part not in m._modules:
+                m.add_module(part, _Holder())
+            m = m._modules[part]
+        if learnable:
+            m.register_parameter(leaf, torch.nn.Parameter(value))
+        else:
+            m.register_buffer(leaf, value.clone())
+        self._slots[ref_name] = (m, leaf)
 
     def _param(self, ref_name, value):
-        self.register_parameter(self._attr(ref_name), torch.nn.Parameter(value))
-        self._ref_names[ref_name] = self._attr(ref_name)
+        self._declare(ref_name, value, True)
+
+    def _const(self, ref_name, value):
+        self._declare(ref_name, value, False)
+
+    def _haar_consts(self, prefix, inverse):                                  # dual_styleunet.py:387-416
+        for name, k in _haar().items():
+            self._const(f"{prefix}.{name}", -k if inverse and name in ("lh", "hl") else k)
 
     def _p(self, ref_name):
-        return getattr(self, self._attr(ref_name))
+        m, leaf = self._slots[ref_name]
+        return getattr(m, leaf)
 
     def _conv_layer_params(self, prefix, cin, cout, k, downsample=False):
         # ConvLayer = [Blur] + EqualConv2d(bias=False) + FusedLeakyReLU(bias)   (dual_styleunet.py:326-371)
         base = 1 if downsample else 0
+        if downsample:
+            self._const(f"{prefix}.0.kernel", _fir((1, 3, 3, 1)))
         self._param(f"{prefix}.{base}.weight", torch.randn(cout, cin, k, k))
         self._param(f"{prefix}.{base + 1}.bias", torch.zeros(cout))
 
-    def _styled_conv_params(self, prefix, cin, cout):
+    def _styled_conv_params(self, prefix, cin, cout, blur_up):
         self._param(f"{prefix}.conv.weight", torch.randn(1, cout, cin, 3, 3))
+        if blur_up is not None:                                               # upsampling ModulatedConv2d owns a Blur (:186-193)
+            self._const(f"{prefix}.conv.blur.kernel", blur_up)
         self._param(f"{prefix}.conv.modulation.weight", torch.randn(cin, self.style_dim))
         self._param(f"{prefix}.conv.modulation.bias", torch.ones(cin))
         self._param(f"{prefix}.noise.weight", torch.zeros(1))
         self._param(f"{prefix}.activate.bias", torch.zeros(cout))
 
+    _CONST_SUFFIX = (".kernel", ".ll", ".lh", ".hl", ".hh")
+
     def reference_state_dict(self):
-        """Learnable tensors + noise maps under the reference module's state_dict keys."""
-        sd = {ref: getattr(self, attr).detach() for ref, attr in self._ref_names.items()}
-        for layer in range(self.num_layers):
-            sd[f"noises.noise_{layer}"] = getattr(self, self._attr(f"noises.noise_{layer}"))
-        return sd
+        """Learnable tensors + noise maps under the reference module's state_dict keys (``state_dict()`` minus the constant
+        FIR / Haar kernels)."""
+        return {k: v.detach() for k, v in self.state_dict().items() if not k.endswith(self._CONST_SUFFIX)}
 
     @torch.no_grad()
     def load_reference_state_dict(self, sd, strict=True):
-        """Load the ``state_dict`` of the reference's DualStyleUNet.  Its constant buffers (``*.kernel``, ``*.ll`` ...)
-        are recomputed here and ignored; anything else unknown or missing raises when ``strict``."""
-        const_suffix = (".kernel", ".ll", ".lh", ".hl", ".hh")
-        seen = set()
+        """Load the ``state_dict`` of the reference's DualStyleUNet, with or without its constant buffers (``*.kernel``,
+        ``*.ll`` ...: they are the same constants here).  Anything else unknown or missing raises when ``strict``.
+        ``load_state_dict`` itself is the reference's (every key required when strict)."""
+        own = self.state_dict()
+        full = {k: v for k, v in own.items() if k.endswith(self._CONST_SUFFIX)}
         for key, value in sd.items():
-            if key.endswith(const_suffix):
-                continue
-            attr = self._attr(key)
-            if key in self._ref_names or key.startswith("noises.noise_") and hasattr(self, attr):
-                dst = getattr(self, attr)
-                if tuple(dst.shape) != tuple(value.shape):
-                    raise RuntimeError(f"{key}: checkpoint shape {tuple(value.shape)} != {tuple(dst.shape)}")
-                dst.copy_(value)
-                seen.add(key)
+            if key in own:
+                if tuple(own[key].shape) != tuple(value.shape):
+                    raise RuntimeError(f"{key}: checkpoint shape {tuple(value.shape)} != {tuple(own[key].shape)}")
+                full[key] = value
             elif strict:
                 raise RuntimeError(f"unexpected key in reference state_dict: {key}")
-        missing = [k for k in self._ref_names if k not in seen]
+        missing = [k for k in own if k not in full]
         if strict and missing:
             raise RuntimeError(f"missing keys in reference state_dict: {missing[:5]}{' ...' if len(missing) > 5 else ''}")
+        self.load_state_dict(full, strict=False)
 
     # ---- building blocks ------------------------------------------------------------------------------------------
     def _conv_layer(self, x, prefix, downsample=False):
@@ -297,7 +331,7 @@ class DualStyleUNet(torch.nn.Module):
             w_latent = w_latent[:, 0]
         if noise is None:
             noise = [None] * self.num_layers if randomize_noise else \
-                [getattr(self, self._attr(f"noises.noise_{i}")) for i in range(self.num_layers)]
+                [self._p(f"noises.noise_{i}") for i in range(self.num_layers)]
         return w_latent, noise
 
     def forward_views(self, styles, condition_img, view_features, input_is_latent=False, noise=None, randomize_noise=True):

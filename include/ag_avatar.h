@@ -44,12 +44,20 @@ typedef struct AgGatherArgs {
     float* colors;              /* [N,3] */
 } AgGatherArgs;
 
+/*
+ * The three parts can be requested separately, the way the reference trainer's pre-training pass calls them
+ * (main_avatar.py:126-160 -> AvatarNet.get_positions / get_others / get_colors one at a time): a part is produced when its
+ * output pointer(s) are set -- `positions` | `opacity`+`scales`+`rotations` (all three or none) | `colors` -- and only that
+ * part's inputs are read.  A null MAP pointer of a requested part stands for an all-zero network output, which yields the
+ * canonical model's own getters (GaussianModel.get_xyz / get_opacity / get_scaling / get_rotation,
+ * gaussians/gaussian_model.py:115-147).
+ */
 int ag_gather_activate_forward(const AgGatherArgs* args, void* stream);
 
 /*
  * Backward: `grads` carries dL/d{positions, opacity, scales, rotations, colors} in the output slots of AgGatherArgs
  * (the map / raw pointers are the forward inputs).  Writes the full gradient maps (zero outside the mask), i.e. what
- * autograd produces for the reference's index/permute/cat/split chain.
+ * autograd produces for the reference's index/permute/cat/split chain.  A null gradient-map pointer skips that part.
  */
 int ag_gather_activate_backward(const AgGatherArgs* fwd_inputs_and_grads, float* dL_dposition_map /*[1,6,S,S]*/,
                                 float* dL_dother_map /*[1,16,S,S]*/, float* dL_dcolor_map /*[1,6,S,S]*/, void* stream);

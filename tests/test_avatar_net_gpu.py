@@ -55,7 +55,7 @@ def test_pose_map_and_viewdir_features_match_reference_formulation(net):
     np.testing.assert_allclose(got_pose.cpu().numpy(), ref_pose.numpy(), rtol=1e-5, atol=1e-6)
 
     net.eval()
-    w = [getattr(net, f"viewdir_net__{i}__{k}").detach().cpu() for i in (0, 2) for k in ("weight", "bias")]
+    w = [getattr(net.viewdir_net[i], k).detach().cpu() for i in (0, 2) for k in ("weight", "bias")]
     ref_f, ref_b = ao.get_viewdir_feat(cano, nml, mask, net.lbs.cpu(), A, items['extr'].cpu(), *w)
     got_f, got_b = net.get_viewdir_feat(items)
     assert got_f.shape == (1, 128, 128, 128)
@@ -137,14 +137,14 @@ def test_render_views_shares_the_pose_dependent_work_without_changing_results(ne
     for v in views:
         loss_of(net.render({**pose_items, **v})).backward()
     want = {k: getattr(net, k[0])._p(k[1]).grad.clone() for k in probe}
-    want_vd = net.viewdir_net__0__weight.grad.clone()
+    want_vd = net.viewdir_net[0].weight.grad.clone()
     net.zero_grad(set_to_none=True)
     sum(loss_of(r) for r in net.render_views(pose_items, views)).backward()
     for k in probe:
         got = getattr(net, k[0])._p(k[1]).grad
         scale = float(want[k].abs().max())
         assert float((got - want[k]).abs().max()) <= 2e-3 * scale + 1e-12, (k, float((got - want[k]).abs().max()), scale)
-    assert float((net.viewdir_net__0__weight.grad - want_vd).abs().max()) <= 2e-3 * float(want_vd.abs().max())
+    assert float((net.viewdir_net[0].weight.grad - want_vd).abs().max()) <= 2e-3 * float(want_vd.abs().max())
     net.zero_grad(set_to_none=True)
 
 
@@ -181,23 +181,20 @@ def test_graph_captured_networks_reproduce_eager_results(net):
 
 def test_reference_state_dict_roundtrip(net):
     import torch
-    sd = {}
-    for prefix in ("color_net", "position_net", "other_net"):
-        for k, v in getattr(net, prefix).reference_state_dict().items():
-            sd[f"{prefix}.{k}"] = v.detach().clone() + 1.0
-        sd[f"{prefix}.conv_in.0.kernel"] = torch.zeros(4, 4)
-    for i in (0, 2):
-        for k in ("weight", "bias"):
-            sd[f"viewdir_net.{i}.{k}"] = getattr(net, f"viewdir_net__{i}__{k}").detach().clone() + 1.0
+    const = (".kernel", ".ll", ".lh", ".hl", ".hh")
+    full = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    assert "color_net.conv_in.0.kernel" in full and "viewdir_net.2.bias" in full and "other_net.noises.noise_11" in full
+    sd = {k: (v if k.endswith(const) else v + 1.0) for k, v in full.items()}
     before = float(net.color_net._p("style.1.bias").detach().sum())
-    net.load_reference_state_dict(sd)
+    net.load_state_dict(sd, strict=True)                                  # what main_avatar.py:797 does
     assert abs(float(net.color_net._p("style.1.bias").detach().sum()) - (before + 512)) < 1e-2
+    assert abs(float(net.viewdir_net[0].bias.detach().sum()) - float(full["viewdir_net.0.bias"].sum()) - 64) < 1e-3
     with pytest.raises(RuntimeError):
         net.load_reference_state_dict({**sd, "bogus.weight": torch.zeros(1)})
-    # restore
-    for k in sd:
-        sd[k] = sd[k] - 1.0
-    net.load_reference_state_dict(sd)
+    # a checkpoint without the constant buffers (written by round-1 code) still loads through load_reference_state_dict
+    net.load_reference_state_dict({k: v for k, v in full.items() if not k.endswith(const)})
+    for k, v in net.state_dict().items():
+        assert torch.equal(v, full[k]), k
 
 
 def test_fix_hand_fades_the_hands_into_the_mean_hands_frame(net):

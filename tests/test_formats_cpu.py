@@ -204,7 +204,15 @@ def test_checkpoint_files_use_the_reference_layout(tmp_path):
     for must in ("color_net.style.1.weight", "position_net.conv_in.1.weight", "other_net.to_rgbs1.5.bias", "color_net.noises.noise_0",
                  "viewdir_net.0.weight", "viewdir_net.2.bias", "color_net.convs2.10.conv.weight"):
         assert must in keys, must
-    assert not any(k.endswith((".kernel", ".ll", ".hh")) for k in keys)
+    # exactly the reference AvatarNet's keys, in its order (fixture from the reference modules): three networks, then viewdir_net
+    import json
+    layout = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "state_layout.json")))
+    want_keys = [f"{n}.{k}" for n, oc in (("color_net", 3), ("position_net", 3), ("other_net", 8)) for k, _, _ in layout[f"out_ch_{oc}"]["keys"]]
+    want_keys += [f"viewdir_net.{k}" for k, _ in layout["avatar_net"]["viewdir_net"]]
+    assert list(d['avatar_net']) == want_keys
+    want_params = [f"{n}.{k}" for n, oc in (("color_net", 3), ("position_net", 3), ("other_net", 8)) for k in layout[f"out_ch_{oc}"]["param_order"]]
+    want_params += [f"viewdir_net.{k}" for k, _ in layout["avatar_net"]["viewdir_net"]]
+    assert [k for k, _ in net.named_parameters()] == want_params          # Adam state is indexed by this order
     want = {k: v.clone() for k, v in checkpoint.avatar_state_dict(net).items()}
     with torch.no_grad():
         for p in net.parameters():

@@ -41,13 +41,40 @@ def test_reference_state_dict_names_and_shapes():
     assert have == want
     assert net.n_latent == 14 and net.num_layers == 12
     sd = net.reference_state_dict()
-    sd["conv_in.0.kernel"] = torch.zeros(4, 4)      # constant buffers of the reference are accepted and ignored
+    assert "conv_in.0.kernel" not in sd             # constants: part of state_dict(), optional for load_reference_state_dict
     net.load_reference_state_dict(sd)
+    net.load_reference_state_dict(net.state_dict())
     with pytest.raises(RuntimeError):
         net.load_reference_state_dict({**sd, "bogus.weight": torch.zeros(1)})
     sd.pop("style.1.bias")
     with pytest.raises(RuntimeError):
         net.load_reference_state_dict(sd)
+
+
+def test_state_dict_is_the_reference_modules_layout():
+    """``state_dict()`` keys / order / shapes, ``named_parameters()`` order (what Adam indexes its state by) and the constant FIR /
+    Haar buffers equal the reference module's -- fixture produced by the reference's own DualStyleUNet
+    (tests/golden/make_golden_state_layout.py) for both configurations network/avatar.py:34-36 builds.  This is what lets
+    main_avatar.py:777-813 (strict ``load_state_dict``, ``optm.load_state_dict``) exchange files between the two."""
+    import json
+    import torch
+    from animatablegaussians_amd.styleunet import DualStyleUNet
+    layout = json.load(open(os.path.join(os.path.dirname(GOLD), "state_layout.json")))
+    for out_ch in (3, 8):
+        g = layout[f"out_ch_{out_ch}"]
+        net = DualStyleUNet(inp_size=512, inp_ch=3, out_ch=out_ch, out_size=1024, style_dim=512, n_mlp=2)
+        sd = net.state_dict()
+        assert [[k, list(v.shape)] for k, v in sd.items()] == [[k, s] for k, s, _ in g["keys"]]
+        params = dict(net.named_parameters())
+        assert [k for k, _, kind in g["keys"] if kind == "param"] == [k for k in sd if k in params]
+        assert list(params) == g["param_order"] == net._learnable
+        assert sum(p.numel() for p in params.values()) == g["n_params"]
+        for k, v in g["constants"].items():
+            assert torch.equal(sd[k], torch.tensor(v)), k
+        # the reference's strict loader semantics on the full dict
+        net.load_state_dict({k: v.clone() for k, v in sd.items()}, strict=True)
+        with pytest.raises(RuntimeError):
+            net.load_state_dict({k: v for k, v in sd.items() if k != "iwt.ll"}, strict=True)
 
 
 @pytest.mark.gpu
@@ -80,8 +107,8 @@ def test_dual_styleunet_forward_backward_vs_reference_golden():
     rows = []   # (ours, reference fp32, name)
     d = np.abs(pose.grad[0, :, ::8, ::8].cpu().numpy() - gold["pose_grad_sub8"]).max() / float(gold["pose_grad_max"])
     rows.append((float(d), float(gold["err32:pose_grad_sub8"]), "pose"))
-    for ref_name, attr in net._ref_names.items():
-        g = getattr(net, attr).grad
+    for ref_name in net._learnable:
+        g = net._p(ref_name).grad
         assert g is not None, ref_name
         gmax = float(gold["gmax:" + ref_name])
         d = np.abs(_sub(g) - gold["grad:" + ref_name]).max() / max(gmax, 1e-30)
