@@ -102,7 +102,7 @@ SYMBOLS = [
     ("ag_raster_mark_visible", ctypes.c_int, [c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
     ("ag_prof_kernel_name", ctypes.c_char_p, [c_i32]),
     ("ag_prof_enable", ctypes.c_int, [ctypes.c_uint32]),
-    ("ag_prof_collect", ctypes.c_int, [ctypes.POINTER(c_i32), ctypes.POINTER(c_f)]),
+    ("ag_prof_collect", ctypes.c_int, [ctypes.POINTER(c_i32), ctypes.POINTER(c_f), ctypes.POINTER(ctypes.c_double)]),
     ("ag_debug_wave_reduce16", ctypes.c_int, [c_vp, c_vp, c_vp]),
     ("ag_debug_atomic_rate", ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
     ("ag_noise_bias_act_forward", ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_float,
@@ -173,7 +173,8 @@ def lib() -> ctypes.CDLL:
     return _lib
 
 
-AG_K_COUNT = 7
+AG_K_COUNT = 9
+AG_K_BLEND_BACKWARD, AG_K_GATHER_CONV, AG_K_WGRAD = 5, 7, 8      # include/ag_raster.h AgKernelId
 
 
 def prof_enable(kernel_ids) -> None:
@@ -185,10 +186,19 @@ def prof_enable(kernel_ids) -> None:
 
 def prof_collect():
     """{kernel name: (launches, total ms)} for the launches bracketed since the last collect."""
+    n, ms, work = prof_collect_work()
+    return {k: (n[k], ms[k]) for k in n}
+
+
+def prof_collect_work():
+    """({name: launches}, {name: total ms}, {name: declared work (FLOPs for the convolution kernels)})."""
     n = (c_i32 * AG_K_COUNT)()
     ms = (c_f * AG_K_COUNT)()
-    check(lib().ag_prof_collect(n, ms), "ag_prof_collect")
-    return {lib().ag_prof_kernel_name(i).decode(): (int(n[i]), float(ms[i])) for i in range(AG_K_COUNT)}
+    wk = (ctypes.c_double * AG_K_COUNT)()
+    check(lib().ag_prof_collect(n, ms, wk), "ag_prof_collect")
+    names = [lib().ag_prof_kernel_name(i).decode() for i in range(AG_K_COUNT)]
+    return ({k: int(n[i]) for i, k in enumerate(names)}, {k: float(ms[i]) for i, k in enumerate(names)},
+            {k: float(wk[i]) for i, k in enumerate(names)})
 
 
 def check(rc: int, what: str) -> None:

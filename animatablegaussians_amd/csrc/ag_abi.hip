@@ -27,35 +27,45 @@ int check_hip(hipError_t e, const char* what)
 }
 
 // ---- kernel timing log ---------------------------------------------------------------------------------------
+// One record per bracketed launch: its own event pair (created on the device the launch runs on), the launch stream
+// and the work the caller declared for it.  A ProfScope keeps the index of ITS record, so launches of the same kernel
+// from several threads / streams / devices never pair each other's events.
 static uint32_t g_prof_mask = 0;
-struct ProfRec { int id; hipEvent_t a, b; };
+struct ProfRec { int id, dev; hipEvent_t a, b; double work; };
 static std::vector<ProfRec> g_prof_log;
-static std::vector<hipEvent_t> g_prof_pool;
+static std::vector<std::pair<int, hipEvent_t>> g_prof_pool;   // (device, event)
 static std::mutex g_prof_mu;
 
-static hipEvent_t prof_event()
+static hipEvent_t prof_event(int dev)
 {
-    if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
+    for (size_t i = g_prof_pool.size(); i-- > 0;)
+        if (g_prof_pool[i].first == dev) {
+            hipEvent_t e = g_prof_pool[i].second;
+            g_prof_pool.erase(g_prof_pool.begin() + (long)i);
+            return e;
+        }
     hipEvent_t e = nullptr;
     (void)hipEventCreate(&e);
     return e;
 }
 
-void prof_begin(int id, hipStream_t s)
+int prof_begin(int id, hipStream_t s, double work)
 {
-    if (!(g_prof_mask & (1u << id))) return;
+    if (!(g_prof_mask & (1u << id))) return -1;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    ProfRec r{ id, prof_event(), prof_event() };
+    ProfRec r{ id, dev, prof_event(dev), prof_event(dev), work };
     (void)hipEventRecord(r.a, s);
     g_prof_log.push_back(r);
+    return (int)g_prof_log.size() - 1;
 }
 
-void prof_end(int id, hipStream_t s)
+void prof_end(int handle, hipStream_t s)
 {
-    if (!(g_prof_mask & (1u << id))) return;
+    if (handle < 0) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    for (size_t i = g_prof_log.size(); i-- > 0;)
-        if (g_prof_log[i].id == id) { (void)hipEventRecord(g_prof_log[i].b, s); break; }
+    if ((size_t)handle < g_prof_log.size()) (void)hipEventRecord(g_prof_log[handle].b, s);
 }
 
 // One pinned word per thread for the num_rendered read-back (the reference's blocking cudaMemcpy,
@@ -233,7 +243,8 @@ int ag_raster_backward(const AgRasterBackwardArgs* a, void* stream)
 const char* ag_prof_kernel_name(int32_t id)
 {
     static const char* names[AG_K_COUNT] = { "preprocess_kernel", "tile_scan_kernel", "scatter_kernel", "tile_sort_kernel",
-                                             "blend_forward_kernel", "blend_backward_kernel", "preprocess_backward_kernel" };
+                                             "blend_forward_kernel", "blend_backward_kernel", "preprocess_backward_kernel",
+                                             "gather_conv_kernel", "wgrad_kernel" };
     return (id >= 0 && id < AG_K_COUNT) ? names[id] : "";
 }
 
@@ -244,19 +255,22 @@ int ag_prof_enable(uint32_t mask)
     return AG_OK;
 }
 
-int ag_prof_collect(int32_t* launches, float* total_ms)
+int ag_prof_collect(int32_t* launches, float* total_ms, double* work)
 {
     if (!launches || !total_ms) return AG_ERR_INVALID_ARGUMENT;
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    for (int i = 0; i < AG_K_COUNT; i++) { launches[i] = 0; total_ms[i] = 0.f; }
-    int rc = AG_OK;
+    for (int i = 0; i < AG_K_COUNT; i++) { launches[i] = 0; total_ms[i] = 0.f; if (work) work[i] = 0.0; }
+    int rc = AG_OK, cur = 0;
+    (void)hipGetDevice(&cur);
     for (auto& r : g_prof_log) {
         float ms = 0.f;
+        (void)hipSetDevice(r.dev);
         if (hipEventSynchronize(r.b) != hipSuccess || hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) rc = AG_ERR_HIP;
-        else { launches[r.id]++; total_ms[r.id] += ms; }
-        g_prof_pool.push_back(r.a);
-        g_prof_pool.push_back(r.b);
+        else { launches[r.id]++; total_ms[r.id] += ms; if (work) work[r.id] += r.work; }
+        g_prof_pool.push_back({ r.dev, r.a });
+        g_prof_pool.push_back({ r.dev, r.b });
     }
+    (void)hipSetDevice(cur);
     g_prof_log.clear();
     return rc;
 }

@@ -14,6 +14,8 @@
 //      workgroups over the non-empty tiles in two size classes (<= 2048 and <= 8192 entries; a global bitonic network beyond).
 // The sorted point_list and ranges are bit-identical to the reference's for every input, and the data moved is
 // 8 B + 4 B per instance once, instead of 6+ radix passes over 12 B pairs.
+#include <mutex>
+
 #include "ag_common.h"
 
 namespace ag {
@@ -372,13 +374,20 @@ int launch_bin_sort(const AgRasterForwardArgs& a, int R, hipStream_t s)
                        reinterpret_cast<const GaussRec*>(gb + gl.rec), reinterpret_cast<uint32_t*>(ib + il.cursor), keys,
                        reinterpret_cast<const uint32_t*>(ib + il.num_rendered)); }
     if (check_hip(hipGetLastError(), "scatter_kernel")) return AG_ERR_HIP;
-    static bool attr_set = false;
     constexpr size_t kSmallLds = 2ull * kSortSmallCap * sizeof(uint64_t), kLargeLds = 2ull * kSortLargeCap * sizeof(uint64_t);
-    if (!attr_set) {
-        if (check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_sort_kernel<1024, true, 8>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLargeLds), "sort LDS attr"))
-            return AG_ERR_HIP;
-        attr_set = true;
+    {
+        // function attributes are per device: remember which devices have it (a bit per ordinal), under a lock
+        static std::mutex mu;
+        static uint64_t done = 0;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        std::lock_guard<std::mutex> lk(mu);
+        if (dev < 0 || dev >= 64 || !((done >> dev) & 1)) {
+            if (check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_sort_kernel<1024, true, 8>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLargeLds), "sort LDS attr"))
+                return AG_ERR_HIP;
+            if (dev >= 0 && dev < 64) done |= 1ull << dev;
+        }
     }
     {
         ProfScope ps(AG_K_TILE_SORT, s);

@@ -149,12 +149,15 @@ inline __host__ __device__ char* aligned_base(const void* p)
 void set_error(const char* fmt, ...);
 
 // Optional event bracketing of kernel launches (ag_prof_* in the ABI).  Usage: { ProfScope ps(AG_K_X, stream); launch; }
-void prof_begin(int kernel_id, hipStream_t s);
-void prof_end(int kernel_id, hipStream_t s);
+// `work` = what the launch computes in the kernel's roofline unit (FLOPs for the convolutions), summed by ag_prof_collect.
+int prof_begin(int kernel_id, hipStream_t s, double work);
+void prof_end(int handle, hipStream_t s);
 struct ProfScope {
-    int id; hipStream_t s;
-    ProfScope(int id_, hipStream_t s_) : id(id_), s(s_) { prof_begin(id, s); }
-    ~ProfScope() { prof_end(id, s); }
+    int handle; hipStream_t s;
+    ProfScope(int id, hipStream_t s_, double work = 0.0) : handle(prof_begin(id, s_, work)), s(s_) {}
+    ~ProfScope() { prof_end(handle, s); }
+    ProfScope(const ProfScope&) = delete;
+    ProfScope& operator=(const ProfScope&) = delete;
 };
 int check_hip(hipError_t e, const char* what);
 

@@ -21,6 +21,7 @@
 // after them (one LDS-only barrier per K step).
 #include "ag_common.h"
 #include "../../include/ag_conv.h"
+#include "../../include/ag_raster.h"   // AgKernelId (timing hooks)
 
 namespace ag {
 
@@ -629,6 +630,7 @@ static int launch_gather(GatherProblem& gp, int bm, float* partial, hipStream_t 
     gp.partial = splits > 1 ? partial : nullptr;
     const int BN = bn_of(bm);
     dim3 grid((N + BN - 1) / BN, gp.Mpad / bm, splits);
+    ProfScope ps(AG_K_GATHER_CONV, s, 2.0 * gp.M * (double)N * gp.ntaps * gp.Cg);      // covers the split-K finish too
     if (bm == 64) hipLaunchKernelGGL((gather_conv_kernel<1, 2, 2, 4>), grid, dim3(512), 0, s, gp);
     else          hipLaunchKernelGGL((gather_conv_kernel<2, 1, 2, 4>), grid, dim3(512), 0, s, gp);
     int rc = check_hip(hipGetLastError(), "gather_conv_kernel");
@@ -810,6 +812,7 @@ int ag_conv_backward_weight(const AgConvDesc* d, const float* x, const float* dy
     splits = (Kp + wp.ksplit_len - 1) / wp.ksplit_len;
     if ((rc = check_hip(hipMemsetAsync(dw, 0, (size_t)wp.Mw * Nw * sizeof(float), s), "memset dw"))) return rc;
     dim3 grid((Nw + BN - 1) / BN, (wp.Mw + bm - 1) / bm, splits);
+    ProfScope ps(AG_K_WGRAD, s, 2.0 * wp.Mw * (double)Kp * Nw);
     if (bm == 64) hipLaunchKernelGGL((wgrad_kernel<1, 2, 2, 4>), grid, dim3(512), 0, s, wp);
     else          hipLaunchKernelGGL((wgrad_kernel<2, 1, 2, 4>), grid, dim3(512), 0, s, wp);
     return check_hip(hipGetLastError(), "wgrad_kernel");

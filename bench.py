@@ -50,6 +50,8 @@ def main() -> None:
                     "previous one.  Measured 1: 2460, 2: 2875, 3: 2350, 4: 2675 views/s on one box; kernel durations unchanged")
     ap.add_argument("--engine-threads", action="store_true", help="keep autograd's multithreaded engine (default: backward nodes "
                     "run on the calling thread)")
+    ap.add_argument("--no-full-step", action="store_true", help="skip the full_step / roofline_mfma legs (BASELINE configs[2]: the whole "
+                    "training iteration with the three StyleUNets, ~15 s) -- profiling runs of the rasterizer")
     args = ap.parse_args()
 
     import numpy as np
@@ -215,18 +217,24 @@ def main() -> None:
     value = args.gpus * args.steps / elapsed
     ms_per_step = 1e3 * elapsed / args.steps
 
-    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the committed summary of
-    # the separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes over the same workload is reported (calibrated on
-    # a 256 MiB copy: FETCH_SIZE x2.0 on gfx950, WRITE_SIZE x1.0 -- profiles/traffic_probe.py, traffic_summarize.py).
-    traffic, traffic_src = None, None
-    tpath = os.path.join(ROOT, "profiles", "r01l_traffic.json")
-    if os.path.exists(tpath):
-        try:
-            with open(tpath) as f:
-                traffic = json.load(f)["kernels"]["ag::blend_backward_kernel"]["hbm_bytes"]
-            traffic_src = "profiles/r01l_traffic.json (rocprofv3 PMC passes, bytes per launch)"
-        except Exception:
-            traffic = None
+    # HBM traffic of the dominant kernel comes from PMC counters, which cannot be read from inside this process: the separate
+    # rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes over this command are summarised under profiles/ (README there); the
+    # line itself carries only what THIS run measured, so `traffic` is null.
+    traffic = None
+
+    # the same workload with dependent steps on ONE stream (what a sequential trainer sees), next to the pipelined headline
+    seq = None
+    if world == 1 and streams is not None:
+        n_seq = max(50, min(args.steps, 400))
+        for i in range(20):
+            step_on(i)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for i in range(n_seq):
+            step_on(i)
+        torch.cuda.synchronize(dev)
+        seq = {"views_per_s": round(n_seq / (time.perf_counter() - t1), 1), "steps": n_seq,
+               "note": "one HIP stream, every step ordered after the previous one"}
 
     out = {
         "metric": "rendered views/sec (fwd+bwd) @1024^2, ~250k Gaussians",
@@ -241,7 +249,7 @@ def main() -> None:
         },
         "roofline": {
             "kernel": "blend_backward_kernel", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
             "algorithmic_bytes_per_launch": int(alg_dom), "avg_launch_us": round(dom_us, 2), "launches_timed": n_dom,
             "whole_step_algorithmic_GBps": round(alg_step / (ms_per_step * 1e-3) / 1e9, 2),
             "note": "VALU/LDS/atomic-bound kernel reported against HBM as SURVEY.md 8(d) prescribes",
@@ -249,6 +257,19 @@ def main() -> None:
     }
     if breakdown is not None:
         out["kernels_us"] = breakdown
+    if seq is not None:
+        out["sequential"] = seq
+    if world == 1 and not args.no_full_step:
+        # BASELINE configs[2] and the MFMA roofline north_star asks for, measured in this process (about 15 s): the whole training
+        # iteration at the reference's batch shape (1 view per step) and at 4 views of one pose per step, and the convolution kernels'
+        # own rate from HIP events around every launch of one network forward + backward
+        import bench_avatar
+        torch.autograd.set_multithreading_enabled(True)      # the networks' six-stream backward uses autograd's worker threads
+        for leaf in leaves:
+            leaf.grad = None
+        torch.cuda.empty_cache()
+        out["roofline_mfma"] = bench_avatar.conv_roofline(dev)
+        out["full_step"] = bench_avatar.full_step_probe(dev)
 
     if not args.no_cpu_baseline and world == 1:            # reported at N = 1 only (it costs ~25 s of host time)
         out["cpu_baseline"] = cpu_baseline(av, cams_np, up, W, H)

@@ -38,6 +38,173 @@ MFMA_F32_PEAK_TF = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 
 NET_FWD_GFLOP = 585.8         # per DualStyleUNet forward (profiles/conv_layers.py)
 
 
+def joint_transforms(J, dev, seed=7, max_angle=3.14159265 / 6, max_shift=0.05):
+    """J random rigid transforms (rotations <= 30 deg, translations <= 5 cm): SURVEY.md 8d config 3."""
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    ax = torch.nn.functional.normalize(torch.randn(J, 3, generator=g))
+    ang = torch.rand(J, generator=g) * max_angle
+    K = torch.zeros(J, 3, 3)
+    K[:, 0, 1], K[:, 0, 2], K[:, 1, 0], K[:, 1, 2], K[:, 2, 0], K[:, 2, 1] = -ax[:, 2], ax[:, 1], ax[:, 2], -ax[:, 0], -ax[:, 1], ax[:, 0]
+    A = torch.eye(4)[None].repeat(J, 1, 1)
+    A[:, :3, :3] = torch.eye(3)[None] + torch.sin(ang)[:, None, None] * K + (1 - torch.cos(ang))[:, None, None] * (K @ K)
+    A[:, :3, 3] = (torch.rand(J, 3, generator=g) - 0.5) * 2 * max_shift
+    return A.to(dev)
+
+
+class TrainingStep:
+    """The training iteration of config 3 as a callable: ``step(i, V)`` renders V cameras of one pose, takes the loss, back-propagates,
+    exchanges gradients (N > 1) and applies fused Adam.  Shared by this script and by bench.py's ``full_step`` leg."""
+
+    def __init__(self, dev, viewdirs=True, lpips=False, world=1, rank=0):
+        import numpy as np
+        import torch
+        from animatablegaussians_amd import synth
+        from animatablegaussians_amd.avatar import AvatarNet
+        from animatablegaussians_amd.parallel import BucketedGradSync
+        torch.manual_seed(31359)                                    # the reference's seed (main_avatar.py:817)
+        self.dev, self.world, self.rank = dev, world, rank
+        self.net = net = AvatarNet.synthetic({'with_viewdirs': viewdirs}, device=dev)
+        self.n_params = sum(p.numel() for p in net.parameters())
+        A = joint_transforms(net.lbs.shape[1], dev)
+        W = H = 1024
+        cams = synth.free_view_cameras(8, img=W)
+        self.views = [{'cano2live_jnt_mats': A, 'cano2live_jnt_mats_woRoot': A,
+                       'extr': torch.from_numpy(np.ascontiguousarray(c["extr"])).float().to(dev),
+                       'intr': torch.from_numpy(np.ascontiguousarray(c["intr"])).float().to(dev), 'img_w': W, 'img_h': H} for c in cams]
+        self.target = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(11)).to(dev)
+        net.train()
+        self.sync = BucketedGradSync(list(net.parameters()))
+        self.opt = torch.optim.Adam(net.parameters(), lr=5e-4, fused=True)      # one pass over the 224 M parameters
+        self.lp = None
+        if lpips:
+            from animatablegaussians_amd import losses
+            from animatablegaussians_amd.lpips import LPIPS
+            self.lp = LPIPS(net='vgg').to(dev)
+            m = torch.from_numpy(synth.body_mask(H).copy()).to(dev)
+            self.gt_items = {'color_img': self.target, 'mask_img': m, 'boundary_mask_img': torch.zeros_like(m),
+                             'mask_bbox': losses.mask_bbox(synth.body_mask(H))}      # from the host copy, as a data loader would
+            self.bg_dev = torch.zeros(3, device=dev)
+            self.weights = {'l1': 1.0, 'mask': 0.1, 'lpips': 0.1, 'offset': 0.005}
+
+    def loss_of(self, out):
+        import torch
+        if self.lp is not None:
+            from animatablegaussians_amd import losses
+            return losses.training_loss(out, self.gt_items, self.bg_dev, self.weights, lpips=self.lp, patch_size=512)[0]
+        return (out['rgb_map'] - self.target).abs().mean() + 0.005 * torch.linalg.norm(out['offset'], dim=-1).mean()
+
+    def cameras(self, i, V):
+        return [self.views[((i * self.world + self.rank) * V + j) % len(self.views)] for j in range(V)]
+
+    def infer(self, i, V=1):
+        import torch
+        mine = self.cameras(i, V)
+        items = dict(mine[0])
+        self.net.get_pose_map(items)
+        with torch.no_grad():
+            self.net.render(items, bg_color=(0., 0., 0.)) if V == 1 else self.net.render_views(items, mine, bg_color=(0., 0., 0.))
+
+    def __call__(self, i, V=1):
+        mine = self.cameras(i, V)
+        items = dict(mine[0])
+        self.net.get_pose_map(items)
+        self.sync.zero()
+        if V == 1:
+            loss = self.loss_of(self.net.render(items, bg_color=(0., 0., 0.)))
+        else:
+            loss = sum(self.loss_of(o) for o in self.net.render_views(items, mine, bg_color=(0., 0., 0.))) / V
+        loss.backward()
+        self.sync.finish()
+        self.opt.step()
+
+
+def timed(fn, steps, warmup, dev):
+    """ms per call of fn(i) over `steps` calls after `warmup`, device-synchronised on both sides."""
+    import torch
+    for i in range(warmup):
+        fn(i)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        fn(warmup + i)
+    torch.cuda.synchronize(dev)
+    return 1e3 * (time.perf_counter() - t0) / steps
+
+
+def conv_roofline(dev, steps=2):
+    """MFMA roofline of the convolution kernels, measured live: one DualStyleUNet (the colour / position configuration) forward +
+    backward on ONE stream with every gather-conv / wgrad launch bracketed by HIP events on its launch stream (ag_prof_*); achieved =
+    the launches' own FLOPs (2 per multiply-add of the un-padded implicit GEMM, summed by the library) / their summed duration."""
+    import numpy as np
+    import torch
+    from animatablegaussians_amd import _lib, synth
+    from animatablegaussians_amd.styleunet import DualStyleUNet
+    torch.manual_seed(31359)
+    net = DualStyleUNet(inp_size=512, inp_ch=3, out_ch=3, out_size=1024, style_dim=512, n_mlp=2).to(dev)
+    pose = synth.pose_map(512).to(dev)
+    style = (torch.ones(1, 512) / np.sqrt(512)).to(dev)
+    G = torch.randn(1, 6, 1024, 1024, generator=torch.Generator().manual_seed(4242)).to(dev)
+
+    def fwd(_i):
+        with torch.no_grad():
+            net([style], pose, randomize_noise=False)
+
+    def one(_i):
+        net.zero_grad(set_to_none=True)
+        images, _ = net([style], pose, randomize_noise=False)
+        (images * G).sum().backward()
+
+    one(0)
+    fwd_ms = timed(fwd, steps + 1, 1, dev)              # wall time of the pass as the product runs it (two decoder streams)
+    both_ms = timed(one, steps + 1, 1, dev)
+    prev = os.environ.get("AG_SINGLE_STREAM")
+    os.environ["AG_SINGLE_STREAM"] = "1"                # per-kernel durations: no co-running kernels
+    try:
+        one(0)
+        torch.cuda.synchronize(dev)
+        _lib.prof_enable([_lib.AG_K_GATHER_CONV, _lib.AG_K_WGRAD])
+        for i in range(steps):
+            one(i)
+        torch.cuda.synchronize(dev)
+        n, ms, work = _lib.prof_collect_work()
+        _lib.prof_enable([])
+    finally:
+        if prev is None:
+            os.environ.pop("AG_SINGLE_STREAM", None)
+        else:
+            os.environ["AG_SINGLE_STREAM"] = prev
+    out = {"bound": "mfma", "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "traffic": None,
+           "network_forward_ms": round(fwd_ms, 2), "network_forward_backward_ms": round(both_ms, 2),
+           "network_forward_TFLOPs": round(NET_FWD_GFLOP / fwd_ms, 1), "network_forward_backward_TFLOPs": round(3 * NET_FWD_GFLOP / both_ms, 1)}
+    tot_w = tot_ms = 0.0
+    for k in ("gather_conv_kernel", "wgrad_kernel"):
+        if n[k]:
+            out[k] = {"launches_timed": n[k], "avg_launch_us": round(1e3 * ms[k] / n[k], 2), "TFLOPs": round(work[k] / (ms[k] * 1e-3) / 1e12, 2),
+                      "GFLOP_per_network_pass": round(work[k] / steps / 1e9, 1)}
+            tot_w += work[k]
+            tot_ms += ms[k]
+    ach = tot_w / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
+    out.update({"kernel": "gather_conv_kernel + wgrad_kernel (every convolution of one DualStyleUNet forward + backward, one stream)",
+                "achieved": round(ach, 2), "frac": round(ach / MFMA_F32_PEAK_TF, 4),
+                "whole_network_frac": round(3 * NET_FWD_GFLOP / both_ms / MFMA_F32_PEAK_TF, 4),
+                "note": "achieved = FLOPs of the bracketed launches / their summed HIP-event durations; whole_network_frac prices the "
+                        "586 GFLOP x 3 of a forward + backward against the wall time of the whole pass (all non-conv kernels and gaps included)"})
+    return out
+
+
+def full_step_probe(dev, steps1=6, steps4=4):
+    """bench.py's ``full_step`` leg: BASELINE configs[2] -- the whole training iteration (3 StyleUNets + assembly + LBS + raster,
+    loss, backward, fused Adam) at 1 view per step (the reference's own batch shape) and at 4 views of one pose per step."""
+    step = TrainingStep(dev)
+    ms1 = timed(lambda i: step(i, 1), steps1, 2, dev)
+    ms4 = timed(lambda i: step(i, 4), steps4, 2, dev)
+    return {"workload": "BASELINE configs[2]: StyleUNet x3 + LBS + raster fwd+bwd + L1/offset loss + fused Adam, 268 k Gaussians @1024^2",
+            "views_per_s_1view_per_step": round(1e3 / ms1, 2), "ms_per_step_1view": round(ms1, 2),
+            "views_per_s_4views_per_step": round(4e3 / ms4, 2), "ms_per_step_4views": round(ms4, 2),
+            "steps_timed": [steps1, steps4], "parameters": step.n_params}
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -50,15 +217,11 @@ def main() -> None:
     ap.add_argument("--graphs", action="store_true", help="with --infer: run the networks from captured hipGraphs")
     ap.add_argument("--views", type=int, default=1, help="cameras of the same pose per step (multi-view step: "
                     "pose-dependent work shared through AvatarNet.render_views)")
+    ap.add_argument("--conv-roofline", action="store_true", help="only print the in-run MFMA roofline of the convolution kernels")
     args = ap.parse_args()
 
-    import numpy as np
     import torch
     import torch.distributed as dist
-
-    from animatablegaussians_amd import synth
-    from animatablegaussians_amd.avatar import AvatarNet
-    from animatablegaussians_amd.parallel import BucketedGradSync
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -78,69 +241,19 @@ def main() -> None:
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    if args.conv_roofline:
+        print(json.dumps({"roofline_mfma": conv_roofline(dev)}), flush=True)
+        return
 
-    torch.manual_seed(31359)                                    # the reference's seed (main_avatar.py:817)
-    net = AvatarNet.synthetic({'with_viewdirs': not args.no_viewdirs}, device=dev)
-    n_params = sum(p.numel() for p in net.parameters())
-    J = net.lbs.shape[1]
-    g = torch.Generator().manual_seed(7)
-    ax = torch.nn.functional.normalize(torch.randn(J, 3, generator=g))
-    ang = torch.rand(J, generator=g) * (np.pi / 6)
-    K = torch.zeros(J, 3, 3)
-    K[:, 0, 1], K[:, 0, 2], K[:, 1, 0], K[:, 1, 2], K[:, 2, 0], K[:, 2, 1] = -ax[:, 2], ax[:, 1], ax[:, 2], -ax[:, 0], -ax[:, 1], ax[:, 0]
-    A = torch.eye(4)[None].repeat(J, 1, 1)
-    A[:, :3, :3] = torch.eye(3)[None] + torch.sin(ang)[:, None, None] * K + (1 - torch.cos(ang))[:, None, None] * (K @ K)
-    A[:, :3, 3] = (torch.rand(J, 3, generator=g) - 0.5) * 0.1
-    A = A.to(dev)
-    W = H = 1024
-    cams = synth.free_view_cameras(8, img=W)
-    views = [{'cano2live_jnt_mats': A, 'cano2live_jnt_mats_woRoot': A,
-              'extr': torch.from_numpy(np.ascontiguousarray(c["extr"])).float().to(dev),
-              'intr': torch.from_numpy(np.ascontiguousarray(c["intr"])).float().to(dev), 'img_w': W, 'img_h': H} for c in cams]
-    target = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(11)).to(dev)
-
+    ts = TrainingStep(dev, viewdirs=not args.no_viewdirs, lpips=args.lpips and not args.infer, world=world, rank=rank)
+    net, n_params, lp = ts.net, ts.n_params, ts.lp
+    V = args.views
     if args.infer:
         net.eval()
         net.enable_graphs(args.graphs)
-        sync = opt = None
+        step = lambda i: ts.infer(i, V)      # noqa: E731
     else:
-        net.train()
-        sync = BucketedGradSync(list(net.parameters()))
-        opt = torch.optim.Adam(net.parameters(), lr=5e-4, fused=True)      # one pass over the 224 M parameters
-
-    V = args.views
-    lp = None
-    if args.lpips and not args.infer:
-        from animatablegaussians_amd import losses, synth as _synth
-        from animatablegaussians_amd.lpips import LPIPS
-        lp = LPIPS(net='vgg').to(dev)
-        m = torch.from_numpy(_synth.body_mask(H).copy()).to(dev)
-        gt_items = {'color_img': target, 'mask_img': m, 'boundary_mask_img': torch.zeros_like(m),
-                    'mask_bbox': losses.mask_bbox(_synth.body_mask(H))}      # from the host copy, as a data loader would
-        bg_dev = torch.zeros(3, device=dev)
-        weights = {'l1': 1.0, 'mask': 0.1, 'lpips': 0.1, 'offset': 0.005}
-
-    def loss_of(out):
-        if lp is not None:
-            return losses.training_loss(out, gt_items, bg_dev, weights, lpips=lp, patch_size=512)[0]
-        return (out['rgb_map'] - target).abs().mean() + 0.005 * torch.linalg.norm(out['offset'], dim=-1).mean()
-
-    def step(i: int):
-        mine = [views[((i * world + rank) * V + j) % len(views)] for j in range(V)]      # this rank's cameras of the step
-        items = dict(mine[0])
-        net.get_pose_map(items)
-        if args.infer:
-            with torch.no_grad():
-                net.render(items, bg_color=(0., 0., 0.)) if V == 1 else net.render_views(items, mine, bg_color=(0., 0., 0.))
-            return
-        sync.zero()
-        if V == 1:
-            loss = loss_of(net.render(items, bg_color=(0., 0., 0.)))
-        else:
-            loss = sum(loss_of(o) for o in net.render_views(items, mine, bg_color=(0., 0., 0.))) / V
-        loss.backward()
-        sync.finish()
-        opt.step()
+        step = lambda i: ts(i, V)            # noqa: E731
 
     def sync_all():
         if world > 1:

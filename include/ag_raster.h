@@ -173,8 +173,10 @@ int ag_raster_mark_visible(int32_t P, const float* means3D, const float* viewmat
 /*
  * Kernel timing hooks (bench.py).  ag_prof_enable(mask) makes every subsequent launch of a kernel whose bit is set
  * in `mask` be bracketed by a pair of HIP events recorded on the launch stream; ag_prof_collect synchronises those
- * events and returns, per kernel id, the number of bracketed launches and their summed duration in milliseconds,
- * then clears the log.  mask == 0 (the default) disables recording entirely.
+ * events and returns, per kernel id, the number of bracketed launches, their summed duration in milliseconds and
+ * (work != NULL) the summed work the launches declared -- FLOPs (2 per multiply-add of the un-padded problem) for the two
+ * convolution kernels of ag_conv.h, 0 for the others -- then clears the log.  mask == 0 (the default) disables recording
+ * entirely.  Every record keeps its own event pair, stream and device, so concurrent streams / threads / devices can be timed.
  */
 enum AgKernelId {
     AG_K_PREPROCESS = 0,
@@ -184,11 +186,13 @@ enum AgKernelId {
     AG_K_BLEND_FORWARD = 4,
     AG_K_BLEND_BACKWARD = 5,
     AG_K_PREPROCESS_BACKWARD = 6,
-    AG_K_COUNT = 7
+    AG_K_GATHER_CONV = 7,       /* ag_conv.h: forward / input-gradient implicit GEMM (+ its split-K finish) */
+    AG_K_WGRAD = 8,             /* ag_conv.h: weight-gradient implicit GEMM */
+    AG_K_COUNT = 9
 };
 const char* ag_prof_kernel_name(int32_t kernel_id);
 int ag_prof_enable(uint32_t kernel_mask);
-int ag_prof_collect(int32_t* launches /*[AG_K_COUNT]*/, float* total_ms /*[AG_K_COUNT]*/);
+int ag_prof_collect(int32_t* launches /*[AG_K_COUNT]*/, float* total_ms /*[AG_K_COUNT]*/, double* work /*[AG_K_COUNT] or NULL*/);
 
 /*
  * Test hook (tests/ only): runs the wave64 transposed butterfly reduction used by the blend backward on one

@@ -34,3 +34,18 @@ def test_bench_json_line():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "views/s" and c["cores"] >= 1 and c["value"] > 0 and isinstance(c["sample"], str)
     assert d["value"] > 100 * c["value"]
+    # the dependent-step rate on one stream is reported next to the pipelined headline and cannot beat it by much
+    assert d["sequential"]["views_per_s"] > 0 and d["sequential"]["views_per_s"] < 1.2 * d["value"]
+    # BASELINE configs[2] (whole training iteration) and the MFMA roofline of the convolutions, measured in the same process
+    f = d["full_step"]
+    assert abs(f["views_per_s_1view_per_step"] * f["ms_per_step_1view"] - 1000.0) < 5.0
+    assert abs(f["views_per_s_4views_per_step"] * f["ms_per_step_4views"] - 4000.0) < 20.0
+    assert f["views_per_s_4views_per_step"] > f["views_per_s_1view_per_step"] > 1.0 and f["parameters"] > 2.2e8
+    m = d["roofline_mfma"]
+    assert m["bound"] == "mfma" and m["unit"] == "TFLOP/s" and m["peak"] == 157.3 and abs(m["frac"] - m["achieved"] / m["peak"]) < 1e-3
+    assert 0.05 < m["frac"] < 1.0 and m["whole_network_frac"] <= m["frac"] + 0.05
+    for k in ("gather_conv_kernel", "wgrad_kernel"):
+        assert m[k]["launches_timed"] > 0 and 1.0 < m[k]["TFLOPs"] < 157.3
+    # every convolution FLOP of a forward + backward is accounted for: 586 GFLOP x 3 (forward, input gradient, weight gradient)
+    total = m["gather_conv_kernel"]["GFLOP_per_network_pass"] + m["wgrad_kernel"]["GFLOP_per_network_pass"]
+    assert abs(total - 3 * 585.8) < 0.03 * 3 * 585.8, total
