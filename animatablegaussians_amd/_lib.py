@@ -78,7 +78,7 @@ class AgHandFuseArgs(ctypes.Structure):
 
 
 class AgConvDesc(ctypes.Structure):
-    _fields_ = [(n, c_i32) for n in ("kind", "Cin", "Cout", "H", "W", "k", "stride", "padding")]
+    _fields_ = [(n, c_i32) for n in ("kind", "Cin", "Cout", "H", "W", "k", "stride", "padding")] + [("weight_scale", c_f)]
 
 
 class AgSmplxModel(ctypes.Structure):

@@ -24,9 +24,10 @@ def _stream(dev):
     return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
 
-def _desc(kind, Cin, Cout, H, W, k, stride, padding):
+def _desc(kind, Cin, Cout, H, W, k, stride, padding, weight_scale=1.0):
     d = _lib.AgConvDesc()
     d.kind, d.Cin, d.Cout, d.H, d.W, d.k, d.stride, d.padding = kind, Cin, Cout, H, W, k, stride, padding
+    d.weight_scale = float(weight_scale)
     return d
 
 
@@ -37,7 +38,7 @@ def _workspace(d, dev):
 
 class _Conv(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, bias, out_scale, kind, stride, padding):
+    def forward(ctx, x, w, bias, out_scale, kind, stride, padding, weight_scale=1.0):
         L = _lib.lib()
         if x.dim() != 4 or x.shape[0] != 1:
             raise RuntimeError("MFMA conv path: batch must be 1 (the product renders one pose per step)")
@@ -49,7 +50,10 @@ class _Conv(torch.autograd.Function):
         Cout = int(w.shape[0] if kind == AG_CONV else w.shape[1])
         if (kind == AG_CONV and w.shape[1] != Cin) or (kind == AG_CONV_TRANSPOSE and w.shape[0] != Cin) or w.shape[-2] != k:
             raise RuntimeError("weight shape does not match the input channels / square kernel")
-        d = _desc(kind, Cin, Cout, H, W, k, stride, padding)
+        if out_scale is not None and out_scale.requires_grad:
+            raise RuntimeError("MFMA conv path: out_scale is a constant of the node (no gradient is produced for it); pass a detached "
+                               "tensor, or differentiate the demodulation through `weight` as ModulatedConv2d does")
+        d = _desc(kind, Cin, Cout, H, W, k, stride, padding, weight_scale)
         oh, ow = ctypes.c_int32(), ctypes.c_int32()
         _lib.check(L.ag_conv_output_size(ctypes.byref(d), ctypes.byref(oh), ctypes.byref(ow)), "ag_conv_output_size")
         y = torch.empty((1, Cout, oh.value, ow.value), dtype=torch.float32, device=x.device)
@@ -60,18 +64,18 @@ class _Conv(torch.autograd.Function):
             _lib.check(L.ag_conv_forward(ctypes.byref(d), _p(x), _p(w), _p(sc), _p(b), _p(y), _p(ws), n, _stream(x.device)),
                        "ag_conv_forward")
         ctx.save_for_backward(x, w, sc)
-        ctx.cfg = (kind, stride, padding, bias is not None)
+        ctx.cfg = (kind, stride, padding, bias is not None, float(weight_scale))
         return y
 
     @staticmethod
     def backward(ctx, gy):
         L = _lib.lib()
         x, w, sc = ctx.saved_tensors
-        kind, stride, padding, has_bias = ctx.cfg
+        kind, stride, padding, has_bias, weight_scale = ctx.cfg
         _, Cin, H, W = x.shape
         k = int(w.shape[-1])
         Cout = int(w.shape[0] if kind == AG_CONV else w.shape[1])
-        d = _desc(kind, Cin, Cout, H, W, k, stride, padding)
+        d = _desc(kind, Cin, Cout, H, W, k, stride, padding, weight_scale)
         gy = gy.contiguous()
         gbias = gy.sum((0, 2, 3)) if has_bias else None
         gscale = None
@@ -90,20 +94,22 @@ class _Conv(torch.autograd.Function):
                 gw = torch.empty_like(w)
                 _lib.check(L.ag_conv_backward_weight(ctypes.byref(d), _p(x), _p(gy), _p(gw), _p(ws), n, _stream(x.device)),
                            "ag_conv_backward_weight")
-        return gx, gw, gbias, gscale, None, None, None
+        return gx, gw, gbias, gscale, None, None, None, None
 
 
 def _one(v):
     return int(v[0]) if isinstance(v, (tuple, list)) else int(v)
 
 
-def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, out_scale=None):
+def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, out_scale=None, weight_scale=1.0):
+    """``weight_scale``: convolve with ``weight * weight_scale`` (EqualConv2d, dual_styleunet.py:100-117) without materialising the
+    scaled tensor -- the product is formed while the weights are re-packed; the weight gradient is w.r.t. ``weight``."""
     if _one(dilation) != 1 or groups != 1:
         raise RuntimeError("MFMA conv path: dilation 1 and groups 1 only")
-    return _Conv.apply(input, weight, bias, out_scale, AG_CONV, _one(stride), _one(padding))
+    return _Conv.apply(input, weight, bias, out_scale, AG_CONV, _one(stride), _one(padding), weight_scale)
 
 
 def conv_transpose2d(input, weight, bias=None, stride=1, padding=0, output_padding=0, groups=1, dilation=1, out_scale=None):
     if _one(dilation) != 1 or groups != 1 or _one(output_padding) != 0:
         raise RuntimeError("MFMA conv path: dilation 1, groups 1, output_padding 0 only")
-    return _Conv.apply(input, weight, bias, out_scale, AG_CONV_TRANSPOSE, _one(stride), _one(padding))
+    return _Conv.apply(input, weight, bias, out_scale, AG_CONV_TRANSPOSE, _one(stride), _one(padding), 1.0)

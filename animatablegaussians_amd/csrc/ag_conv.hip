@@ -28,6 +28,10 @@ namespace ag {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: HIP's float4 struct in arrays defeats SROA (scratch spills)
 
+#ifndef AG_CONV_WAVES_PER_SIMD
+#define AG_CONV_WAVES_PER_SIMD 4     // __launch_bounds__ 2nd argument (waves per SIMD): 4 = two 8-wave workgroups per CU (<= 128 VGPRs)
+#endif
+
 constexpr int BK = 16;
 constexpr int LDK = BK + 4;     // row pitch in floats: 80 B keeps b128 accesses aligned and spreads 16 rows over all 64 banks
 constexpr int kMaxTaps = 16;
@@ -89,30 +93,48 @@ __device__ __forceinline__ void mma_tile(const float* __restrict__ As, const flo
 // ------------------------------------------------------------------------------------------------------------------
 // gather-conv
 // ------------------------------------------------------------------------------------------------------------------
+constexpr int kMaxClasses = 4;
+
+// One output class: the whole output of a plain gather, or one of the 4 output-parity classes of a stride-2 scatter
+// (transposed conv forward, input gradient of a stride-2 conv).  All classes of a problem run in ONE launch: blockIdx.x walks
+// the classes' N tiles back to back (heaviest class first), so a layer whose classes have 256 tiles each still fills the chip.
+struct GatherClass {
+    int gh, gw, y0, x0;    // class grid, and its origin in the output (output pixel = (y0 + gy * os, x0 + gx * os))
+    int ntaps, nkt;        // K tiles of the class = ntaps * Cpad / 16 (K tile = 16 channels of ONE tap)
+    int tile_begin;        // first blockIdx.x of the class
+    int col_begin;         // first column of the class in the split-K partial image [z][Mpad][Ncols]
+    long long at_off;      // float offset of the class's packed weights inside At
+    int zero_weights;      // degenerate class (no tap reaches it): its weights are packed as zeros
+    int pad_;
+    int dy[kMaxTaps], dx[kMaxTaps];
+};
+
 struct GatherProblem {
     const float* xin;      // [Cg][Hg][Wg]
-    const float* At;       // tile-blocked packed weights [Mpad / BM][Kpad / 16][BM][16], K tile = (channel block, tap)
+    const float* At;       // per class: tile-blocked packed weights [Mpad / BM][nkt][BM][16]
     float* yout;           // [M][OHf][OWf]
     const float* out_scale;
     const float* bias;
     int Cg, Cpad, Hg, Wg;  // Cpad = channels rounded up to BK: every K tile lies inside one tap
     int M, Mpad, OHf, OWf;
-    int gh, gw, y0, ys, x0, xs;     // class grid -> output coordinates
-    int sy, sx, ntaps;
-    int Kpad;              // ntaps * Cpad
+    int os;                // output stride of the class grids (1: plain gather, 2: parity classes)
+    int sy, sx;            // input stride of the gather
+    int nclasses, Ncols;   // Ncols = sum over classes of gh * gw
     int kt_per_split;      // K tiles per blockIdx.z slice (gridDim.z == 1: all of them)
-    float* partial;        // gridDim.z > 1: raw accumulators go to partial[z][Mpad][N] and reduce_splits_kernel finishes
-    int dy[kMaxTaps], dx[kMaxTaps];
+    float* partial;        // gridDim.z > 1: raw accumulators go to partial[z][Mpad][Ncols] and reduce_splits_kernel finishes
+    GatherClass cls[kMaxClasses];
 };
 
 // K is ordered (channel block of 16, tap, channel in block), so the 16 rows of a K tile are 16 consecutive channels of ONE tap:
 // the tap (and with it the input offset and the padding test) is a wave-uniform scalar per tile, each thread keeps the
 // 16-bit in-bounds mask of its output pixel over the taps (consecutive tiles walk the taps of one channel block, so the
 // shifted re-reads of the same input lines stay in L1/L2), and the gathers of a tile are unconditional loads
-// `global_load_dword v, v_off, s[base]` (uniform 64-bit channel base, 32-bit per-thread pixel offset) -- all in flight
-// under the MFMAs; padding is applied when the tile is written to LDS.
+// `global_load_dword v, v_off, s[base]` (uniform 64-bit channel base, 32-bit per-thread byte offset) -- all in flight
+// under the MFMAs; spatial padding is applied when the tile is written to LDS.  Nothing in the K loop touches memory for
+// bookkeeping: the per-tap input offsets sit in one VGPR (lane t = tap t) and are fetched with v_readlane; channels past Cg (only
+// the 3- and 12-channel inputs have them) are clamped to the last real channel -- their packed weights are zero.
 template <int WMB, int WNB, int WVM, int WVN>
-__global__ void __launch_bounds__(64 * WVM * WVN) gather_conv_kernel(GatherProblem p)
+__global__ void __launch_bounds__(64 * WVM * WVN, AG_CONV_WAVES_PER_SIMD) gather_conv_kernel(GatherProblem p)
 {
     using T = Tile<WMB, WNB, WVM, WVN>;
     constexpr int BM = T::BM, BN = T::BN, NT = T::NT;
@@ -125,21 +147,30 @@ __global__ void __launch_bounds__(64 * WVM * WVN) gather_conv_kernel(GatherProbl
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WVN, wn = wave % WVN;
-    const int N = p.gh * p.gw;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+
+    // class of this workgroup (wave-uniform)
+    int ci = 0;
+#pragma unroll
+    for (int c = 1; c < kMaxClasses; c++)
+        if (c < p.nclasses && (int)blockIdx.x >= p.cls[c].tile_begin) ci = c;
+    const GatherClass& cl = p.cls[ci];
+    const int gw = cl.gw, ntaps = cl.ntaps;
+    const int N = cl.gh * gw;
+    const int m0 = blockIdx.y * BM, n0 = ((int)blockIdx.x - cl.tile_begin) * BN;
 
     const int n_loc = tid % BN, g = (wave * 64) / BN;   // g is wave-uniform (BN >= 64)
     const int n = n0 + n_loc;
     const bool n_ok = n < N;
-    const int gy = n_ok ? n / p.gw : 0, gx = n_ok ? n - (n / p.gw) * p.gw : 0;
+    const int gy = n_ok ? n / gw : 0, gx = n_ok ? n - (n / gw) * gw : 0;
     const int iy0 = gy * p.sy, ix0 = gx * p.sx;
-    const size_t plane = (size_t)p.Hg * p.Wg;
     uint32_t vmask = 0;
-    for (int t = 0; t < p.ntaps; t++) {
-        const int iy = iy0 + p.dy[t], ix = ix0 + p.dx[t];
+    for (int t = 0; t < ntaps; t++) {
+        const int iy = iy0 + cl.dy[t], ix = ix0 + cl.dx[t];
         if (n_ok && iy >= 0 && iy < p.Hg && ix >= 0 && ix < p.Wg) vmask |= 1u << t;
     }
     const int pix = iy0 * p.Wg + ix0;
+    const int tl = lane & (kMaxTaps - 1);
+    const int toff_vec = cl.dy[tl] * p.Wg + cl.dx[tl];          // lane t: input offset of tap t (lanes >= ntaps: unused)
 
     f32x16 acc[WMB][WNB];
 #pragma unroll
@@ -149,12 +180,17 @@ __global__ void __launch_bounds__(64 * WVM * WVN) gather_conv_kernel(GatherProbl
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-    const int nkt_all = p.Kpad / BK, ctiles = p.Cpad / BK;
-    const int kt_beg = blockIdx.z * p.kt_per_split, kt_end = min(nkt_all, kt_beg + p.kt_per_split);
-    // K tile kt = (channel block kt / ntaps, tap kt % ntaps)
-    int c0_cur = (kt_beg / p.ntaps) * BK, t_cur = kt_beg % p.ntaps;           // wave-uniform (first channel, tap) of the next tile to load
-    (void)ctiles;
-    const float* a_tiles = p.At + (size_t)blockIdx.y * nkt_all * (BM * BK);
+    const int nkt_all = cl.nkt;
+    const int kt_beg = min(nkt_all, (int)blockIdx.z * p.kt_per_split), kt_end = min(nkt_all, kt_beg + p.kt_per_split);
+    const int nkt = kt_end - kt_beg;                       // may be 0 for the short classes of a split launch: zeros are written
+    // K tile kt = (channel block kt / ntaps, tap kt % ntaps); running (tap, first channel, pointers) of the next tile to load
+    int t_cur = kt_beg % ntaps;
+    int c_cur = (kt_beg / ntaps) * BK + g * KG;
+    const size_t plane_b = (size_t)p.Hg * p.Wg * sizeof(float);
+    const char* const xin_b = reinterpret_cast<const char*>(p.xin);
+    const int c_last = p.Cg - 1;
+    const char* a_ptr = reinterpret_cast<const char*>(p.At + cl.at_off + ((size_t)blockIdx.y * nkt_all + kt_beg) * (BM * BK));
+    const uint32_t a_voff = (uint32_t)min(tid, AF - 1) * 16u;       // threads past the tile re-read its last float4
 
     // Three-stage software pipeline.  While the MFMAs of tile k run from operand registers, tile k+1 moves
     // registers -> LDS -> operand registers (one barrier, placed in the middle of the MFMA phase so that the LDS write
@@ -163,31 +199,24 @@ __global__ void __launch_bounds__(64 * WVM * WVN) gather_conv_kernel(GatherProbl
     struct Stage {
         f32x4 ra;
         float rb[KG];
-        bool tap_ok;        // rb[] are real samples for this thread's pixel (else spatial padding -> 0)
-        uint32_t cmask;     // bit j: row j is a real channel (else channel padding -> 0, wave-uniform); both applied at the LDS write
+        bool tap_ok;        // rb[] are real samples for this thread's pixel (else spatial padding -> 0 at the LDS write)
     };
     Stage S[2];
     Operands<WMB, WNB> O[2];
     const bool a_thread = tid < AF;
-    const int a_f4 = min(tid, AF - 1);
-    auto gload = [&](int kt, Stage& st) {
-        const float* a_base = a_tiles + (size_t)kt * (BM * BK);                 // uniform; the tile is one contiguous BM*64-byte run
-        st.ra = *reinterpret_cast<const f32x4*>(a_base + a_f4 * 4);            // unconditional (threads past the tile re-read its last float4)
+    auto gload = [&](Stage& st) {
+        st.ra = *reinterpret_cast<const f32x4*>(a_ptr + a_voff);
+        a_ptr += BM * BK * sizeof(float);
         st.tap_ok = (vmask >> t_cur) & 1u;
-        const int toff = p.dy[t_cur] * p.Wg + p.dx[t_cur];                      // uniform
-        const uint32_t voff = st.tap_ok ? (uint32_t)(pix + toff) : 0u;
-        const int cfirst = c0_cur + g * KG;
-        const float* cbase = p.xin + (size_t)cfirst * plane;                    // uniform
-        st.cmask = 0;
+        const int toff = __builtin_amdgcn_readlane(toff_vec, t_cur);
+        const uint32_t voff = st.tap_ok ? (uint32_t)(pix + toff) * 4u : 0u;
 #pragma unroll
         for (int j = 0; j < KG; j++) {
-            const bool cok = (cfirst + j) < p.Cg;                               // uniform: false only in the padded last channel tile
-            const float* src = cok ? cbase + (size_t)j * plane : p.xin;
-            st.rb[j] = src[voff];
-            st.cmask |= cok ? (1u << j) : 0u;
+            const char* src = xin_b + (size_t)min(c_cur + j, c_last) * plane_b;     // uniform
+            st.rb[j] = *reinterpret_cast<const float*>(src + voff);
         }
         t_cur++;
-        if (t_cur == p.ntaps) { t_cur = 0; c0_cur += BK; }
+        if (t_cur == ntaps) { t_cur = 0; c_cur += BK; }
     };
     auto lstore = [&](int buf, const Stage& st) {
         float* As = As0 + buf * BM * LDK;
@@ -197,7 +226,7 @@ __global__ void __launch_bounds__(64 * WVM * WVN) gather_conv_kernel(GatherProbl
         for (int q = 0; q < KG / 4; q++) {
             f32x4 v;
 #pragma unroll
-            for (int e = 0; e < 4; e++) v[e] = (st.tap_ok && ((st.cmask >> (4 * q + e)) & 1u)) ? st.rb[4 * q + e] : 0.f;
+            for (int e = 0; e < 4; e++) v[e] = st.tap_ok ? st.rb[4 * q + e] : 0.f;
             *reinterpret_cast<f32x4*>(Bs + n_loc * LDK + g * KG + 4 * q) = v;
         }
     };
@@ -205,53 +234,54 @@ __global__ void __launch_bounds__(64 * WVM * WVN) gather_conv_kernel(GatherProbl
         read_operands<WMB, WNB>(As0 + buf * BM * LDK, Bs0 + buf * BN * LDK, wm, wn, lane, o);
     };
 
-    const int nkt = kt_end - kt_beg;
-    gload(kt_beg, S[0]);
-    if (nkt > 1) gload(kt_beg + 1, S[1]);
-    lstore(0, S[0]);
-    lds_barrier();
-    lread(0, O[0]);
-    // Steady-state step for tile kt (kt + 2 < nkt): branch-free, so the compiler's vmcnt bookkeeping stays exact and the
-    // wait before the LDS write covers only the loads issued one step earlier.
-    auto step_full = [&](int kt, Stage& s_same, Stage& s_next, Operands<WMB, WNB>& o_cur, Operands<WMB, WNB>& o_next) {
-        gload(kt_beg + kt + 2, s_same);                          // s_same held tile kt, already written to LDS
-        mma_half<WMB, WNB>(o_cur, 0, acc);
-        lstore((kt + 1) & 1, s_next);
+    if (nkt > 0) {
+        gload(S[0]);
+        if (nkt > 1) gload(S[1]);
+        lstore(0, S[0]);
         lds_barrier();
-        lread((kt + 1) & 1, o_next);
-        mma_half<WMB, WNB>(o_cur, 1, acc);
-    };
-    auto step_tail = [&](int kt, Stage& s_next, Operands<WMB, WNB>& o_cur, Operands<WMB, WNB>& o_next, bool has_next) {
-        mma_half<WMB, WNB>(o_cur, 0, acc);
-        if (has_next) {
+        lread(0, O[0]);
+        // Steady-state step for tile kt (kt + 2 < nkt): branch-free, so the compiler's vmcnt bookkeeping stays exact and the
+        // wait before the LDS write covers only the loads issued one step earlier.
+        auto step_full = [&](int kt, Stage& s_same, Stage& s_next, Operands<WMB, WNB>& o_cur, Operands<WMB, WNB>& o_next) {
+            gload(s_same);                                           // s_same held tile kt, already written to LDS
+            mma_half<WMB, WNB>(o_cur, 0, acc);
             lstore((kt + 1) & 1, s_next);
             lds_barrier();
             lread((kt + 1) & 1, o_next);
+            mma_half<WMB, WNB>(o_cur, 1, acc);
+        };
+        auto step_tail = [&](int kt, Stage& s_next, Operands<WMB, WNB>& o_cur, Operands<WMB, WNB>& o_next, bool has_next) {
+            mma_half<WMB, WNB>(o_cur, 0, acc);
+            if (has_next) {
+                lstore((kt + 1) & 1, s_next);
+                lds_barrier();
+                lread((kt + 1) & 1, o_next);
+            }
+            mma_half<WMB, WNB>(o_cur, 1, acc);
+        };
+        int kt = 0;
+        for (; kt + 3 < nkt; kt += 2) {
+            step_full(kt, S[0], S[1], O[0], O[1]);
+            step_full(kt + 1, S[1], S[0], O[1], O[0]);
         }
-        mma_half<WMB, WNB>(o_cur, 1, acc);
-    };
-    int kt = 0;
-    for (; kt + 3 < nkt; kt += 2) {
-        step_full(kt, S[0], S[1], O[0], O[1]);
-        step_full(kt + 1, S[1], S[0], O[1], O[0]);
-    }
-    const int rem = nkt - kt;                                    // 1, 2 or 3 tiles left, kt even
-    if (rem == 3) {
-        step_full(kt, S[0], S[1], O[0], O[1]);
-        step_tail(kt + 1, S[0], O[1], O[0], true);
-        step_tail(kt + 2, S[1], O[0], O[1], false);
-    } else if (rem == 2) {
-        step_tail(kt, S[1], O[0], O[1], true);
-        step_tail(kt + 1, S[0], O[1], O[0], false);
-    } else {
-        step_tail(kt, S[1], O[0], O[1], false);
+        const int rem = nkt - kt;                                    // 1, 2 or 3 tiles left, kt even
+        if (rem == 3) {
+            step_full(kt, S[0], S[1], O[0], O[1]);
+            step_tail(kt + 1, S[0], O[1], O[0], true);
+            step_tail(kt + 2, S[1], O[0], O[1], false);
+        } else if (rem == 2) {
+            step_tail(kt, S[1], O[0], O[1], true);
+            step_tail(kt + 1, S[0], O[1], O[0], false);
+        } else {
+            step_tail(kt, S[1], O[0], O[1], false);
+        }
     }
     // (the gather kernel above and the wgrad kernel below share this loop shape)
 
     // epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
     const int col = lane & 31, rbase = 4 * (lane >> 5);
     if (gridDim.z > 1) {
-        float* part = p.partial + (size_t)blockIdx.z * p.Mpad * N;
+        float* part = p.partial + (size_t)blockIdx.z * p.Mpad * p.Ncols + cl.col_begin;
 #pragma unroll
         for (int i = 0; i < WMB; i++)
 #pragma unroll
@@ -261,7 +291,7 @@ __global__ void __launch_bounds__(64 * WVM * WVN) gather_conv_kernel(GatherProbl
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
                     const int m = m0 + (wm * WMB + i) * 32 + (r & 3) + 8 * (r >> 2) + rbase;
-                    part[(size_t)m * N + nn] = acc[i][j][r];
+                    part[(size_t)m * p.Ncols + nn] = acc[i][j][r];
                 }
             }
         return;
@@ -272,8 +302,8 @@ __global__ void __launch_bounds__(64 * WVM * WVN) gather_conv_kernel(GatherProbl
     for (int j = 0; j < WNB; j++) {
         nn[j] = n0 + (wn * WNB + j) * 32 + col;
         const int q = min(nn[j], N - 1);
-        const int oy = q / p.gw, ox = q - oy * p.gw;
-        opix[j] = (size_t)(p.y0 + oy * p.ys) * p.OWf + (p.x0 + ox * p.xs);
+        const int oy = q / gw, ox = q - oy * gw;
+        opix[j] = (size_t)(cl.y0 + oy * p.os) * p.OWf + (cl.x0 + ox * p.os);
     }
     const bool has_scale = p.out_scale != nullptr, has_bias = p.bias != nullptr;
 #pragma unroll
@@ -290,38 +320,54 @@ __global__ void __launch_bounds__(64 * WVM * WVN) gather_conv_kernel(GatherProbl
         }
 }
 
-// split-K finish: y = (sum_z partial[z][m][n]) * out_scale[m] + bias[m], in a fixed order (deterministic)
+// split-K finish: y = (sum_z partial[z][m][col]) * out_scale[m] + bias[m], in a fixed order (deterministic)
 __global__ void __launch_bounds__(256) reduce_splits_kernel(GatherProblem p, int splits)
 {
-    const int N = p.gh * p.gw;
-    const long long total = (long long)p.M * N;
-    const size_t zstride = (size_t)p.Mpad * N;
+    const int Nc = p.Ncols;
+    const long long total = (long long)p.M * Nc;
+    const size_t zstride = (size_t)p.Mpad * Nc;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int m = (int)(i / N), nn = (int)(i - (long long)m * N);
+        const int m = (int)(i / Nc), colg = (int)(i - (long long)m * Nc);
         float v = 0.f;
         for (int z = 0; z < splits; z++) v += p.partial[z * zstride + i];
         if (p.out_scale) v *= p.out_scale[m];
         if (p.bias) v += p.bias[m];
-        const int oy = nn / p.gw, ox = nn - oy * p.gw;
-        p.yout[(size_t)m * p.OHf * p.OWf + (size_t)(p.y0 + oy * p.ys) * p.OWf + (p.x0 + ox * p.xs)] = v;
+        int ci = 0;
+#pragma unroll
+        for (int c = 1; c < kMaxClasses; c++)
+            if (c < p.nclasses && colg >= p.cls[c].col_begin) ci = c;
+        const int nn = colg - p.cls[ci].col_begin;
+        const int oy = nn / p.cls[ci].gw, ox = nn - oy * p.cls[ci].gw;
+        p.yout[(size_t)m * p.OHf * p.OWf + (size_t)(p.cls[ci].y0 + oy * p.os) * p.OWf + (p.cls[ci].x0 + ox * p.os)] = v;
     }
 }
 
-// weight re-pack into the tile-blocked image: At[m / BM][kt][m % BM][kl] = w[c * stride_c + m * stride_m + tapoff[t]]
-// with K tile kt = (c / 16) * ntaps + t and kl = c % 16, zero padded
+// weight re-pack into the tile-blocked images of all classes in one launch:
+//   At[class][m / BM][kt][m % BM][kl] = w[c * stride_c + m * stride_m + tapoff[class][t]]
+// with K tile kt = (c / 16) * ntaps + t and kl = c % 16, zero padded; optional exact scalar pre-multiplication (EqualConv2d's
+// `weight * scale`, dual_styleunet.py:114-117: the same fp32 product the reference forms before its convolution)
 struct PackProblem {
     const float* w;
     float* At;
-    int C, Cpad, M, Mpad, BM, ntaps, Kpad;
+    int C, Cpad, M, Mpad, BM, nclasses;
     long long stride_c, stride_m;
-    int tapoff[kMaxTaps];
+    float wscale;
+    int has_wscale;
+    int ntaps[kMaxClasses], zero[kMaxClasses];
+    long long begin[kMaxClasses + 1];        // element offsets of the classes inside At
+    int tapoff[kMaxClasses][kMaxTaps];
 };
 
 __global__ void __launch_bounds__(256) pack_weights_kernel(PackProblem p)
 {
-    const long long total = (long long)p.Kpad * p.Mpad;
-    const int nkt = p.Kpad / BK;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long total = p.begin[p.nclasses];
+    for (long long i0 = (long long)blockIdx.x * 256 + threadIdx.x; i0 < total; i0 += (long long)gridDim.x * 256) {
+        int ci = 0;
+#pragma unroll
+        for (int c = 1; c < kMaxClasses; c++)
+            if (c < p.nclasses && i0 >= p.begin[c]) ci = c;
+        const long long i = i0 - p.begin[ci];
+        const int ntaps = p.ntaps[ci], nkt = ntaps * (p.Cpad / BK);
         // destination-major enumeration (coalesced writes): i = ((mt * nkt + kt) * BM + ml) * 16 + kl
         const int kl = (int)(i & 15);
         long long q = i >> 4;
@@ -329,10 +375,13 @@ __global__ void __launch_bounds__(256) pack_weights_kernel(PackProblem p)
         q /= p.BM;
         const int kt = (int)(q % nkt), mt = (int)(q / nkt);
         const int m = mt * p.BM + ml;
-        const int cb = kt / p.ntaps, t = kt - cb * p.ntaps, c = cb * BK + kl;   // K tile = (channel block, tap)
+        const int cb = kt / ntaps, t = kt - cb * ntaps, c = cb * BK + kl;   // K tile = (channel block, tap)
         float v = 0.f;
-        if (c < p.C && m < p.M) v = p.w[c * p.stride_c + m * p.stride_m + p.tapoff[t]];
-        p.At[i] = v;
+        if (c < p.C && m < p.M && !p.zero[ci]) {
+            v = p.w[c * p.stride_c + m * p.stride_m + p.tapoff[ci][t]];
+            if (p.has_wscale) v *= p.wscale;
+        }
+        p.At[i0] = v;
     }
 }
 
@@ -345,6 +394,7 @@ struct WgradProblem {
     float* c;              // [Mw][Cg * ntaps], zero-initialised
     int Mw, Cg, Hg, Wg, gh, gw, sy, sx, ntaps;
     int ksplit_len;        // pixels per split (multiple of BK)
+    float wscale;          // the forward convolved with w * wscale: dL/dw = wscale * dL/d(w * wscale)
     int dy[kMaxTaps], dx[kMaxTaps];
 };
 
@@ -494,7 +544,7 @@ __global__ void __launch_bounds__(64 * WVM * WVN) wgrad_kernel(WgradProblem p)
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int m = m0 + (wm * WMB + i) * 32 + (r & 3) + 8 * (r >> 2) + rbase;
-                if (m < p.Mw) atomicAdd(p.c + (size_t)m * Nw + nn, acc[i][j][r]);   // 32 lanes = 128 contiguous bytes
+                if (m < p.Mw) atomicAdd(p.c + (size_t)m * Nw + nn, acc[i][j][r] * p.wscale);   // 32 lanes = 128 contiguous bytes
             }
         }
 }
@@ -581,62 +631,77 @@ static void out_size(const AgConvDesc* d, int& OH, int& OW)
     }
 }
 
-// One gather-conv launch = one tap subset.  `taps` lists (ky, kx) of the subset.
+// Tap subset of one class.  `taps` lists (ky, kx) of the subset.
 struct TapSet { int n; int ky[kMaxTaps], kx[kMaxTaps]; };
 
 // Tile height: 64 rows when that wastes fewer padded rows than 128 (the 64-channel layers at 512^2, the 12-channel ToRGB)
 static int pick_bm(int M) { return round_up(M, 64) < round_up(M, 128) ? 64 : 128; }
 static int bn_of(int bm) { return bm == 64 ? 256 : 128; }
 
-static int launch_pack(const float* w, float* At, int C, int Cpad, int M, int Mpad, int bm, int Kpad, long long stride_c,
-                       long long stride_m, const TapSet& ts, int k, hipStream_t s)
-{
-    PackProblem pp;
-    pp.w = w; pp.At = At; pp.C = C; pp.Cpad = Cpad; pp.M = M; pp.Mpad = Mpad; pp.BM = bm; pp.ntaps = ts.n; pp.Kpad = Kpad;
-    pp.stride_c = stride_c; pp.stride_m = stride_m;
-    for (int t = 0; t < ts.n; t++) pp.tapoff[t] = ts.ky[t] * k + ts.kx[t];
-    const long long total = (long long)Kpad * Mpad;
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, s, pp);
-    return check_hip(hipGetLastError(), "pack_weights_kernel");
-}
+static float wscale_of(const AgConvDesc* d) { return d->weight_scale == 0.f ? 1.f : d->weight_scale; }
 
 // Split-K policy.  A 128 x 128 tile per workgroup leaves the chip idle when M * N is small (the 512-channel layers at
 // 8^2 .. 64^2 have 4 .. 128 tiles for 256 CUs) and the K loop (up to 576 tiles) becomes the critical path; slices of K go
 // to blockIdx.z until ~3 workgroups per CU exist, each keeping >= 4 K tiles, partial sums capped at kMaxPartialBytes.
 constexpr size_t kMaxPartialBytes = size_t(96) << 20;
-static int choose_splits(int Mpad, int bm, int N, int Kpad)
+static int choose_splits(long long tiles, int Mpad, int Ncols, int nkt)
 {
-    const int BN = bn_of(bm);
-    const long long tiles = (long long)((N + BN - 1) / BN) * (Mpad / bm);
-    const int nkt = Kpad / BK;
     if (tiles >= 512 || nkt < 8) return 1;
     long long s = (768 + tiles - 1) / tiles;
     if (s > nkt / 4) s = nkt / 4;
-    const long long cap = (long long)(kMaxPartialBytes / ((size_t)Mpad * N * sizeof(float)));
+    const long long cap = (long long)(kMaxPartialBytes / ((size_t)Mpad * Ncols * sizeof(float)));
     if (s > cap) s = cap;
     return s < 2 ? 1 : (int)s;
 }
 
-static int launch_gather(GatherProblem& gp, int bm, float* partial, hipStream_t s)
+// Fills tile_begin / col_begin / at_off / nkt of the classes (dy, dx, gh, gw, y0, x0, ntaps set by the caller), packs the
+// weights of all classes with one launch and runs them with one launch (+ one split-K finish).
+static int pack_and_launch(GatherProblem& gp, const TapSet* taps, int bm, const float* w, long long stride_c, long long stride_m,
+                           float wscale, int k, float* At, float* partial, hipStream_t s)
 {
-    const int N = gp.gh * gp.gw;
-    if (N <= 0) return AG_OK;
-    const int nkt = gp.Kpad / BK;
-    int splits = choose_splits(gp.Mpad, bm, N, gp.Kpad);
-    gp.kt_per_split = (nkt + splits - 1) / splits;
-    splits = (nkt + gp.kt_per_split - 1) / gp.kt_per_split;
-    gp.partial = splits > 1 ? partial : nullptr;
     const int BN = bn_of(bm);
-    dim3 grid((N + BN - 1) / BN, gp.Mpad / bm, splits);
-    ProfScope ps(AG_K_GATHER_CONV, s, 2.0 * gp.M * (double)N * gp.ntaps * gp.Cg);      // covers the split-K finish too
+    PackProblem pp;
+    pp.w = w; pp.At = At; pp.C = gp.Cg; pp.Cpad = gp.Cpad; pp.M = gp.M; pp.Mpad = gp.Mpad; pp.BM = bm; pp.nclasses = gp.nclasses;
+    pp.stride_c = stride_c; pp.stride_m = stride_m; pp.wscale = wscale; pp.has_wscale = wscale != 1.f;
+    long long tiles = 0, at = 0;
+    int cols = 0, nkt_max = 0;
+    for (int c = 0; c < gp.nclasses; c++) {
+        GatherClass& cl = gp.cls[c];
+        cl.nkt = cl.ntaps * (gp.Cpad / BK);
+        cl.tile_begin = (int)tiles; cl.col_begin = cols; cl.at_off = at; cl.pad_ = 0;
+        const int N = cl.gh * cl.gw;
+        tiles += (N + BN - 1) / BN;
+        cols += N;
+        pp.begin[c] = at; pp.ntaps[c] = cl.ntaps; pp.zero[c] = cl.zero_weights;
+        for (int t = 0; t < cl.ntaps; t++) pp.tapoff[c][t] = taps[c].ky[t] * k + taps[c].kx[t];
+        at += (long long)cl.nkt * BK * gp.Mpad;
+        if (cl.nkt > nkt_max) nkt_max = cl.nkt;
+    }
+    pp.begin[gp.nclasses] = at;
+    gp.Ncols = cols;
+    if (tiles == 0) return AG_OK;
+    int blocks = (int)((at + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, s, pp);
+    int rc = check_hip(hipGetLastError(), "pack_weights_kernel");
+    if (rc) return rc;
+
+    int splits = choose_splits(tiles * (gp.Mpad / bm), gp.Mpad, cols, nkt_max);
+    gp.kt_per_split = (nkt_max + splits - 1) / splits;
+    splits = (nkt_max + gp.kt_per_split - 1) / gp.kt_per_split;
+    gp.partial = splits > 1 ? partial : nullptr;
+    gp.At = At;
+    dim3 grid((unsigned)tiles, gp.Mpad / bm, splits);
+    double flops = 0.0;
+    for (int c = 0; c < gp.nclasses; c++)
+        if (!gp.cls[c].zero_weights) flops += 2.0 * gp.M * (double)gp.cls[c].gh * gp.cls[c].gw * gp.cls[c].ntaps * gp.Cg;
+    ProfScope ps(AG_K_GATHER_CONV, s, flops);      // covers the split-K finish too
     if (bm == 64) hipLaunchKernelGGL((gather_conv_kernel<1, 2, 2, 4>), grid, dim3(512), 0, s, gp);
     else          hipLaunchKernelGGL((gather_conv_kernel<2, 1, 2, 4>), grid, dim3(512), 0, s, gp);
-    int rc = check_hip(hipGetLastError(), "gather_conv_kernel");
+    rc = check_hip(hipGetLastError(), "gather_conv_kernel");
     if (rc || splits == 1) return rc;
-    const long long total = (long long)gp.M * N;
-    int blocks = (int)((total + 255) / 256);
+    const long long total = (long long)gp.M * cols;
+    blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(reduce_splits_kernel, dim3(blocks), dim3(256), 0, s, gp, splits);
     return check_hip(hipGetLastError(), "reduce_splits_kernel");
@@ -673,9 +738,9 @@ size_t ag_conv_workspace_bytes(const AgConvDesc* d)
     return packed_bytes(d) + kMaxPartialBytes + 512;
 }
 
-// Shared by forward / backward-input: which GEMM(s) to run.
-//   mode 0: plain gather with all taps (sy = sx = stride_in), tap offset = sign * k - pad_off
-//   mode 1: 4 output-parity classes of a stride-2 "scatter" (transposed conv forward, or input gradient of a stride-2 conv)
+// Shared by forward / backward-input: which GEMM to run.
+//   plain gather with all taps (sy = sx = stride_in), tap offset = sign * k - pad_off, one class
+//   or the 4 output-parity classes of a stride-2 "scatter" (transposed conv forward, input gradient of a stride-2 conv)
 static int run_gather_family(const AgConvDesc* d, bool backward_input, const float* xin, const float* w, const float* out_scale,
                              const float* bias, float* yout, void* workspace, size_t workspace_bytes, hipStream_t s)
 {
@@ -699,35 +764,36 @@ static int run_gather_family(const AgConvDesc* d, bool backward_input, const flo
     stride_c = backward_input ? s_co : s_ci;
     stride_m = backward_input ? s_ci : s_co;
     gp.Cg = Cg; gp.Hg = Hg; gp.Wg = Wg; gp.M = M; const int bm = pick_bm(M); gp.Mpad = round_up(M, bm); gp.OHf = OHf; gp.OWf = OWf;
+    gp.Cpad = round_up(Cg, BK);
+    TapSet taps[kMaxClasses];
 
     // "gather" cases: forward conv, input gradient of a transposed conv (a stride-2 conv over dy), input gradient of a
     // stride-1 conv (taps mirrored).  "scatter" cases (stride 2): transposed conv forward, input gradient of a stride-2 conv.
     const bool scatter = (conv && backward_input && d->stride == 2) || (!conv && !backward_input);
     if (!scatter) {
-        TapSet ts; ts.n = k2;
+        TapSet& ts = taps[0]; ts.n = k2;
         for (int ky = 0; ky < k; ky++) for (int kx = 0; kx < k; kx++) { ts.ky[ky * k + kx] = ky; ts.kx[ky * k + kx] = kx; }
-        gp.ntaps = k2; gp.Cpad = round_up(Cg, BK); gp.Kpad = k2 * gp.Cpad;
-        gp.gh = OHf; gp.gw = OWf; gp.y0 = 0; gp.ys = 1; gp.x0 = 0; gp.xs = 1;
+        GatherClass& cl = gp.cls[0];
+        gp.nclasses = 1; gp.os = 1;
+        cl.ntaps = k2; cl.gh = OHf; cl.gw = OWf; cl.y0 = 0; cl.x0 = 0; cl.zero_weights = 0;
         if (conv && !backward_input) {                 // y[oy] <- x[oy*s - p + ky]
             gp.sy = gp.sx = d->stride;
-            for (int t = 0; t < k2; t++) { gp.dy[t] = ts.ky[t] - d->padding; gp.dx[t] = ts.kx[t] - d->padding; }
+            for (int t = 0; t < k2; t++) { cl.dy[t] = ts.ky[t] - d->padding; cl.dx[t] = ts.kx[t] - d->padding; }
         } else if (conv) {                             // stride-1 conv, dx[iy] <- dy[iy + p - ky]
             gp.sy = gp.sx = 1;
-            for (int t = 0; t < k2; t++) { gp.dy[t] = d->padding - ts.ky[t]; gp.dx[t] = d->padding - ts.kx[t]; }
+            for (int t = 0; t < k2; t++) { cl.dy[t] = d->padding - ts.ky[t]; cl.dx[t] = d->padding - ts.kx[t]; }
         } else {                                       // transposed conv, dx[iy] <- dy[2 iy + ky]
             gp.sy = gp.sx = 2;
-            for (int t = 0; t < k2; t++) { gp.dy[t] = ts.ky[t]; gp.dx[t] = ts.kx[t]; }
+            for (int t = 0; t < k2; t++) { cl.dy[t] = ts.ky[t]; cl.dx[t] = ts.kx[t]; }
         }
-        gp.At = At;
-        int rc = launch_pack(w, At, Cg, gp.Cpad, M, gp.Mpad, bm, gp.Kpad, stride_c, stride_m, ts, k, s);
-        if (rc) return rc;
-        return launch_gather(gp, bm, partial, s);
+        for (int t = k2; t < kMaxTaps; t++) cl.dy[t] = cl.dx[t] = 0;
+        return pack_and_launch(gp, taps, bm, w, stride_c, stride_m, wscale_of(d), k, At, partial, s);
     }
     // scatter with stride 2: output coordinate o = 2*i + ky - poff  (poff = padding for the conv gradient, 0 for convT).
     // Class (qy, qx) = parity of the output coordinate; it receives only taps with ky = (o + poff) mod 2, from
     // input i = (o + poff - ky) / 2 = g + (q + poff - ky) / 2 with o = q + 2 g.
     const int poff = conv ? d->padding : 0;
-    size_t at_off = 0;
+    gp.nclasses = 0; gp.os = 2; gp.sy = gp.sx = 1;
     for (int qy = 0; qy < 2; qy++)
         for (int qx = 0; qx < 2; qx++) {
             TapSet ts; ts.n = 0;
@@ -738,27 +804,28 @@ static int run_gather_family(const AgConvDesc* d, bool backward_input, const flo
                     ts.ky[ts.n] = ky; ts.kx[ts.n] = kx; ts.n++;
                 }
             }
-            gp.gh = (OHf - qy + 1) / 2; gp.gw = (OWf - qx + 1) / 2;
-            gp.y0 = qy; gp.ys = 2; gp.x0 = qx; gp.xs = 2;
-            if (gp.gh <= 0 || gp.gw <= 0) continue;
-            gp.Cg = Cg;
+            GatherClass cl;
+            cl.gh = (OHf - qy + 1) / 2; cl.gw = (OWf - qx + 1) / 2;
+            cl.y0 = qy; cl.x0 = qx; cl.zero_weights = 0;
+            if (cl.gh <= 0 || cl.gw <= 0) continue;
             if (ts.n == 0) {
-                // no tap reaches this class (possible for k = 1): the outputs are out_scale*0 + bias; handled by a
-                // degenerate GEMM over one all-zero K tile (zero channels)
+                // no tap reaches this class (possible for k = 1): the outputs are out_scale*0 + bias; handled as a class over
+                // one tap with all-zero packed weights
                 ts.n = 1; ts.ky[0] = 0; ts.kx[0] = 0;
-                gp.Cg = 0;
+                cl.zero_weights = 1;
             }
-            gp.ntaps = ts.n; gp.Cpad = round_up(Cg, BK); gp.Kpad = ts.n * gp.Cpad;
-            gp.sy = gp.sx = 1;
-            for (int t = 0; t < ts.n; t++) { gp.dy[t] = (qy + poff - ts.ky[t]) / 2; gp.dx[t] = (qx + poff - ts.kx[t]) / 2; }
+            cl.ntaps = ts.n;
+            for (int t = 0; t < kMaxTaps; t++) { cl.dy[t] = 0; cl.dx[t] = 0; }
             // floor division for negative odd numerators never happens: numerators are even by construction
-            gp.At = At + at_off;
-            int rc = launch_pack(w, At + at_off, gp.Cg, gp.Cpad, M, gp.Mpad, bm, gp.Kpad, stride_c, stride_m, ts, k, s);
-            if (rc) return rc;
-            if ((rc = launch_gather(gp, bm, partial, s))) return rc;
-            at_off += (size_t)gp.Kpad * gp.Mpad;
+            for (int t = 0; t < ts.n; t++) { cl.dy[t] = (qy + poff - ts.ky[t]) / 2; cl.dx[t] = (qx + poff - ts.kx[t]) / 2; }
+            if (cl.zero_weights) { cl.dy[0] = 0; cl.dx[0] = 0; }
+            // heaviest class first: insertion by descending tap count
+            int pos = gp.nclasses;
+            while (pos > 0 && gp.cls[pos - 1].ntaps < cl.ntaps) { gp.cls[pos] = gp.cls[pos - 1]; taps[pos] = taps[pos - 1]; pos--; }
+            gp.cls[pos] = cl; taps[pos] = ts;
+            gp.nclasses++;
         }
-    return AG_OK;
+    return pack_and_launch(gp, taps, bm, w, stride_c, stride_m, wscale_of(d), k, At, partial, s);
 }
 
 int ag_conv_forward(const AgConvDesc* d, const float* x, const float* w, const float* out_scale, const float* bias, float* y,
@@ -800,7 +867,7 @@ int ag_conv_backward_weight(const AgConvDesc* d, const float* x, const float* dy
         wp.sy = wp.sx = 2;
         for (int t = 0; t < k2; t++) { wp.dy[t] = t / k; wp.dx[t] = t % k; }
     }
-    wp.c = dw; wp.ntaps = k2;
+    wp.c = dw; wp.ntaps = k2; wp.wscale = wscale_of(d);
     const int Kp = wp.gh * wp.gw, Nw = wp.Cg * k2;
     const int bm = pick_bm(wp.Mw), BN = bn_of(bm);
     const int tiles = ((Nw + BN - 1) / BN) * ((wp.Mw + bm - 1) / bm);

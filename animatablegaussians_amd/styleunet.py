@@ -197,12 +197,12 @@ class DualStyleUNet(torch.nn.Module):
         base = 1 if downsample else 0
         w = self._p(f"{prefix}.{base}.weight")
         k = w.shape[-1]
-        w = w * (1 / math.sqrt(w.shape[1] * k * k))                      # EqualConv2d scale (:100-114)
-        if downsample:
+        scale = 1 / math.sqrt(w.shape[1] * k * k)                        # EqualConv2d: conv(x, weight * scale) (:100-117); the
+        if downsample:                                                   # product is formed inside the weight re-pack
             x = upfirdn2d_nchw(x, self._k_blur, pad=(2, 2))              # p = (4 - 2) + (k - 1), k = 3 (:339-345)
-            x = agc.conv2d(x, w, stride=2, padding=0)
+            x = agc.conv2d(x, w, stride=2, padding=0, weight_scale=scale)
         else:
-            x = agc.conv2d(x, w, stride=1, padding=k // 2)
+            x = agc.conv2d(x, w, stride=1, padding=k // 2, weight_scale=scale)
         return noise_bias_act(x, None, None, self._p(f"{prefix}.{base + 1}.bias"))
 
     def _modulated_weight(self, prefix, w_latent, demodulate, transposed=False):

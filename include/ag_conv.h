@@ -33,6 +33,10 @@ typedef struct AgConvDesc {
     int32_t k;             /* square kernel size */
     int32_t stride;        /* 1 or 2 (AG_CONV_TRANSPOSE: 2) */
     int32_t padding;       /* AG_CONV only */
+    float weight_scale;    /* the convolution uses w * weight_scale (EqualConv2d's `self.weight * self.scale`,
+                              dual_styleunet.py:100-117: formed as that fp32 product while the weights are re-packed, so the result
+                              equals convolving with the pre-scaled tensor); dw is the gradient w.r.t. the UN-scaled w.
+                              0 is read as 1 (no scaling) */
 } AgConvDesc;
 
 /* Output spatial size of the described convolution. */

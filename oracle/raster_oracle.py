@@ -39,6 +39,12 @@ def lib():
     return _lib
 
 
+def set_exp_scale(s: float) -> None:
+    """Conditioning probe: multiply every exp() of the blend loops by ``s`` (1.0 = bit-identical to the reference build).  See
+    ``ago_set_exp_scale`` in raster_oracle.c; callers must reset it to 1.0."""
+    lib().ago_set_exp_scale(c_f(s))
+
+
 def _p(a: Optional[np.ndarray]):
     if a is None:
         return None

@@ -17,10 +17,10 @@ seen = collections.Counter()
 orig = agc._Conv.apply
 
 
-def spy(x, w, bias, out_scale, kind, stride, padding):
+def spy(x, w, bias, out_scale, kind, stride, padding, weight_scale=1.0):
     cout = w.shape[0] if kind == agc.AG_CONV else w.shape[1]
     seen[(kind, x.shape[1], cout, x.shape[2], x.shape[3], w.shape[-1], stride, padding)] += 1
-    return orig(x, w, bias, out_scale, kind, stride, padding)
+    return orig(x, w, bias, out_scale, kind, stride, padding, weight_scale)
 
 
 agc._Conv.apply = spy

@@ -142,19 +142,25 @@ def assert_image_parity(gpu, ref, atol=1e-4, fragile_atol=6e-3, max_fragile_frac
         assert (d[np.broadcast_to(frag[None], d.shape)] <= fragile_atol * scale[np.broadcast_to(frag[None], d.shape)]).all(), f"{k}: fragile pixel off by more than one threshold term"
     nc = gpu["n_contrib"] != ref["n_contrib"]
     assert not (nc & ~frag).any(), f"n_contrib differs at {int((nc & ~frag).sum())} non-fragile pixels"
+    worst = max(float((np.abs(gpu[k] - ref[k]) / np.maximum(1.0, np.abs(ref[k])))[:, ~frag].max()) for k in ("color", "depth", "alpha"))
+    print(f"\n[parity] image {ref['color'].shape[2]}x{ref['color'].shape[1]}: {frag.mean():.2e} of pixels fragile (cap {max_fragile_frac:g}), "
+          f"worst non-fragile image difference {worst:.2e} (bar {atol:g})")
 
 
 _SLOT_OF = {"dL_dmeans2D": (0, 1, None), "dL_dconic": (2, 3, None, 4), "dL_dopacity": (5,), "dL_dcolors": (6, 7, 8),
             "dL_ddepths": (9,)}
 
 
-def assert_accum_parity(got, ref, rtol=1e-4, k_eps=64.0):
+def assert_accum_parity(got, ref, rtol=1e-4, k_eps=64.0, ref_perturbed=None, k_sens=0.0):
     """Blend-backward accumulators vs the fp64-accumulated oracle.
 
     |got - ref| <= rtol*|ref| + k_eps*eps_fp32*sum|term| + 1e-7: the first term is the stated 1e-4 fp32 bar, the
     second is the spread between admissible float summation orders of the reference's atomicAdds (any order is
-    "the reference"), with abs_sum measured by the oracle."""
+    "the reference"), with abs_sum measured by the oracle.  ``ref_perturbed`` (end-to-end comparisons only): the oracle's result
+    with every exp() scaled by 1 + 2^-20 -- k_sens * |ref_perturbed - ref| is the reference algorithm's own movement under a
+    rounding-sized change of its transcendental, added per element.  Returns the worst ratio to the limit."""
     eps = float(np.finfo(np.float32).eps)
+    worst_all = 0.0
     for name, slots in _SLOT_OF.items():
         g = np.asarray(got[name], np.float64)
         r = np.asarray(ref[name], np.float64)
@@ -165,9 +171,13 @@ def assert_accum_parity(got, ref, rtol=1e-4, k_eps=64.0):
                 continue
             d = np.abs(g[:, col] - r[:, col])
             lim = rtol * np.abs(r[:, col]) + k_eps * eps * ref["abs_sum"][:, slot].astype(np.float64) + 1e-7
+            if ref_perturbed is not None:
+                lim = lim + k_sens * np.abs(np.asarray(ref_perturbed[name], np.float64)[:, col] - r[:, col])
             worst = float((d / lim).max()) if d.size else 0.0
+            worst_all = max(worst_all, worst)
             assert worst <= 1.0, (f"{name}[:, {col}]: {int((d > lim).sum())} of {d.size} over tolerance, worst ratio "
                                   f"{worst:.2f}, max |diff| {d.max():.3e}, ref max {np.abs(r[:, col]).max():.3e}")
+    return worst_all
 
 
 def assert_rows_close(got, ref, name, rtol=1e-4, row_rtol=1e-5):

@@ -199,16 +199,51 @@ def _check_backward(scene, cam):
     for k, v in e2e.items():   # routing check: a mis-wired gradient is off by O(1), atomic-order noise by ~1e-6
         np.testing.assert_allclose(v.reshape(own[k].shape), own[k], rtol=1e-3, atol=1e-4 * max(1.0, np.abs(own[k]).max()),
                                    err_msg="autograd " + k)
-    # ... and end to end against the oracle's backward evaluated on the alpha map the GPU forward saved.  (Comparing
-    # with oracle-forward -> oracle-backward instead would mostly measure the reference algorithm's own conditioning:
-    # its backward restarts from T_final = 1 - alpha_out and divides by it, so one ulp of forward rounding in alpha_out
-    # is amplified by up to 1/T_final = 1e4 at saturated pixels; see DESIGN.md "backward conditioning".)
+    # (4) TRUE end to end -- GPU forward -> GPU blend backward on its OWN saved state against oracle forward -> oracle blend backward
+    # -- at the stated bar, with no outlier budget.  The reference's backward restarts from T_final = 1 - alpha_out and divides by
+    # it, so a forward rounding difference d_alpha of alpha_out (itself far inside the 1e-4 image bar) enters EVERY backward term of
+    # that pixel as d_alpha / T_final -- for the reference against itself (atomics in another order, FMA contraction, another exp)
+    # as much as for us (DESIGN.md "backward conditioning").  A pixel is ill-conditioned when T_final < 1e-2 (a 1e-6 forward
+    # difference, ~10 ulp over a long list, already costs 1e-4), or when the MEASURED forward difference moves its terms by more
+    # than 2e-5 relative.  With the upstream gradients of those (and of the fragile pixels) zeroed on both sides, every accumulator
+    # element must meet 1e-4*|ref| + the float summation-order slack + 16x the reference algorithm's own movement under a
+    # rounding-sized change of exp() (oracle re-run with every exp() scaled by 1 + 2^-20: per-element condition estimate).
+    # Together with (2) -- the streaming stage is a verified function of the accumulators -- this bounds every API gradient.  The
+    # masked fractions are printed and capped so they cannot grow silently.
+    frag = ref["fragile"].astype(bool)
+    ro.set_exp_scale(1.0 + 2.0 ** -20)
+    try:
+        ref_p = h.oracle_forward(scene, cam)
+    finally:
+        ro.set_exp_scale(1.0)
+    flips = ref_p["fragile"].astype(bool) | (ref_p["n_contrib"] != ref["n_contrib"])
+    t_fin = 1.0 - ref["alpha"][0].astype(np.float64)
+    sat = t_fin < 1e-2
+    amp = np.abs(fw["alpha"][0].astype(np.float64) - ref["alpha"][0]) > 2e-5 * t_fin
+    ill = sat | amp
+    assert ill.mean() < 0.25 and (flips & ~frag).mean() < 5e-3, f"{ill.mean():.3f} of pixels ill-conditioned, {flips.mean():.2e} flip"
+    keep = (~(frag | flips | ill)).astype(np.float32)[None]
+    wc = {k: np.ascontiguousarray(scene[k] * keep) for k in ("dL_dcolor", "dL_ddepth", "dL_dalpha")}
+    acc_wc = ro.backward_blend(ref, scene["colors"], scene["bg"], wc["dL_dcolor"], wc["dL_ddepth"], wc["dL_dalpha"])
+    ro.set_exp_scale(1.0 + 2.0 ** -20)
+    try:
+        acc_p = ro.backward_blend(ref_p, scene["colors"], scene["bg"], wc["dL_dcolor"], wc["dL_ddepth"], wc["dL_dalpha"])
+    finally:
+        ro.set_exp_scale(1.0)
+    worst_wc = h.assert_accum_parity(h.gpu_native_backward(fw, wc), acc_wc, k_eps=512.0, ref_perturbed=acc_p, k_sens=16.0)
+    # ... and the ill-conditioned rest, through autograd, against the oracle's backward evaluated on the alpha map the GPU forward
+    # saved (which removes the forward-rounding amplification but not the repeated division by (1 - alpha) near saturation): loose.
     gref = h.oracle_backward(dict(ref, alpha=fw["alpha"]), scene, cam, grads)
+    loose = 0.0
     for k, v in e2e.items():
         d = np.abs(v.astype(np.float64).reshape(gref[k].shape) - gref[k])
         lim = 1e-3 * np.abs(gref[k]) + 1e-4 * np.abs(gref[k]).max(axis=1, keepdims=True) + 1e-6
-        frac = float((d > lim).mean())
-        assert frac < 1e-3, f"end-to-end {k}: {frac:.2e} of elements beyond the coarse bound"
+        loose = max(loose, float((d > lim).mean()))
+        assert (d > lim).mean() < 1e-3, f"end-to-end {k}: {(d > lim).mean():.2e} of elements beyond the coarse bound"
+    print(f"\n[parity] P={ref['radii'].shape[0]} {cam['img_w']}x{cam['img_h']}: fragile pixels {frag.mean():.2e} (+ {(flips & ~frag).mean():.2e} "
+          f"that flip under the exp probe), ill-conditioned {ill.mean():.2e} (T_final < 1e-2: {sat.mean():.2e}, forward difference "
+          f"amplified past 2e-5: {(amp & ~sat).mean():.2e}); well-conditioned set: every accumulator element within the 1e-4 bound "
+          f"(worst ratio {worst_wc:.2f}); all pixels: {loose:.2e} of gradient elements beyond 1e-3*|ref| + 1e-4*rowmax")
 
 
 @pytest.mark.parametrize("P,img", [(10000, 512), (3000, 500)])
@@ -380,6 +415,39 @@ def test_full_size_1m_gaussians_2048_properties():
         scale = np.abs(g1[k]).max()
         assert np.abs(g2[k] - 2.0 * g1[k]).max() <= 2e-4 * scale, k
     del torch
+
+
+def test_full_size_1m_gaussians_2048_vs_oracle():
+    """BASELINE configs[4] scale against the oracle itself (not only invariants): 1.07 M Gaussians, one 2048^2 view, f = 2200.  The C
+    oracle's blend loops run OpenMP-parallel over tiles, so the comparison is seconds on the GPU box's host cores: per-Gaussian
+    state, sorted instance list and tile ranges bit-exact, images within 1e-4 outside oracle-flagged fragile pixels, blend-backward
+    accumulators on the same saved state within the accumulator tolerance, streaming backward within the row tolerance."""
+    import time
+    from oracle import raster_oracle as ro
+    S, W = 2048, 2048
+    av = synth.avatar_map_gaussians(S)
+    scene = dict(av, **synth.free_view_cameras(8, img=W, focal=2200.0)[3])
+    scene.update(synth.upstream_grads(W, W, 17))
+    cam = h.cam_of(scene)
+    t0 = time.perf_counter()
+    ref = h.oracle_forward(scene, cam)
+    t_ref = time.perf_counter() - t0
+    assert ref["radii"].shape[0] > 1_000_000 and ref["num_rendered"] > 2_000_000
+    gpu = h.gpu_native_forward(scene, cam)
+    _bitexact(gpu, ref)
+    h.assert_image_parity(gpu, ref)
+    frag = ref["fragile"].astype(bool)
+    print(f"\nconfigs[4] vs oracle: P={ref['radii'].shape[0]} R={ref['num_rendered']} oracle forward {t_ref:.1f} s, "
+          f"fragile pixels {frag.mean():.2e}, max colour diff outside them "
+          f"{np.abs(gpu['color'] - ref['color'])[:, ~frag].max():.2e}")
+    grads = _masked_grads(scene, ref)
+    acc_ref = ro.backward_blend(ref, scene["colors"], scene["bg"], grads["dL_dcolor"], grads["dL_ddepth"], grads["dL_dalpha"])
+    got = h.gpu_native_backward(gpu, grads, alphas=ref["alpha"])
+    h.assert_accum_parity(got, acc_ref, k_eps=128.0)      # tile lists up to ~8000 entries: twice the summation-order slack of the small scenes
+    pre = ro.backward_preprocess(ref, got, scene["means3D"], scene["scales"], scene["rotations"], cam["viewmatrix"], cam["projmatrix"],
+                                 cam["tanfovx"], cam["tanfovy"])
+    for k, rr in (("dL_dmeans3D", 1e-5), ("dL_dcov3D", 1e-5), ("dL_dscales", 1e-5), ("dL_drotations", 3e-5)):
+        h.assert_rows_close(got[k], pre[k], k, row_rtol=rr)
 
 
 def test_optimistic_forward_is_bit_identical_and_survives_overflow():
