@@ -19,6 +19,8 @@
 // so each lane's 8 operand values of a 32-row block are two ds_read_b128 (8 per wave and tile instead of 32 scalar
 // reads).  Global->register loads of tile k+1 are issued before the MFMAs of tile k and written to the other LDS buffer
 // after them (one LDS-only barrier per K step).
+#include <algorithm>
+
 #include "ag_common.h"
 #include "../../include/ag_conv.h"
 #include "../../include/ag_raster.h"   // AgKernelId (timing hooks)
@@ -398,8 +400,11 @@ struct WgradProblem {
     int dy[kMaxTaps], dx[kMaxTaps];
 };
 
-template <int WMB, int WNB, int WVM, int WVN>
-__global__ void __launch_bounds__(64 * WVM * WVN) wgrad_kernel(WgradProblem p)
+// AVEC: the rows of A are 16-byte aligned (pixel count a multiple of 4, always true in the product): one dwordx4 per thread and
+// tile; the scalar form is kept for arbitrary sizes.  Everything in the K loop is branch-free: loads are unconditional from clamped
+// addresses, validity (image border, end of the K slice) travels as a bit mask and is applied at the LDS write.
+template <int WMB, int WNB, int WVM, int WVN, bool AVEC>
+__global__ void __launch_bounds__(64 * WVM * WVN, AG_CONV_WAVES_PER_SIMD) wgrad_kernel(WgradProblem p)
 {
     using T = Tile<WMB, WNB, WVM, WVN>;
     constexpr int BM = T::BM, BN = T::BN, NT = T::NT;
@@ -421,7 +426,6 @@ __global__ void __launch_bounds__(64 * WVM * WVN) wgrad_kernel(WgradProblem p)
     const int am = tid >> 2, aq = (tid & 3) * 4;
     const bool a_thread = am < BM && (m0 + am) < p.Mw;
     const float* a_row = p.a + (size_t)min(m0 + am, p.Mw - 1) * Kp;
-    const bool a_vec = (Kp & 3) == 0;                  // rows 16-byte aligned, every 4-group entirely inside or outside [kbeg, kend)
     // B loader: pixel bk of the tile (lanes run along pixels), columns bn, bn + BSTEP, ...; a column = (channel, tap) is fixed per
     // thread for the whole kernel: its plane + tap offset and its tap displacement live in registers
     const int bk = tid & 15, bn = tid >> 4;
@@ -435,9 +439,11 @@ __global__ void __launch_bounds__(64 * WVM * WVN) wgrad_kernel(WgradProblem p)
         col_dx[j] = p.dx[t];
         col_off[j] = c * plane + p.dy[t] * p.Wg + p.dx[t];
     }
-    // this thread's pixel of the NEXT tile to load, tracked incrementally (no division in the loop)
+    // this thread's pixel of the NEXT tile to load, advanced by BK pixels per tile without a division or a loop:
+    // BK = qstep * gw + rstep with rstep < gw, so one conditional wrap is exact for every grid width
     int kpix = kbeg + bk;
     int gy = kpix / p.gw, gx = kpix - gy * p.gw;
+    const int qstep = BK / p.gw, rstep = BK - qstep * p.gw;
 
     f32x16 acc[WMB][WNB];
 #pragma unroll
@@ -456,12 +462,16 @@ __global__ void __launch_bounds__(64 * WVM * WVN) wgrad_kernel(WgradProblem p)
     Operands<WMB, WNB> O[2];
     auto gload = [&](int k0, Stage& st) {
         const int ka = k0 + aq;
-        const bool a_ok = a_thread && ka < kend;
-        if (a_vec) {
+        const bool a_ok = a_thread && ka < kend;      // AVEC: every 4-group lies entirely inside or outside [kbeg, kend)
+        if constexpr (AVEC) {
             st.ra = *reinterpret_cast<const f32x4*>(a_row + (a_ok ? ka : 0));
         } else {
 #pragma unroll
-            for (int q = 0; q < 4; q++) st.ra[q] = (a_ok && ka + q < kend) ? a_row[ka + q] : 0.f;
+            for (int q = 0; q < 4; q++) {
+                const bool in = a_ok && ka + q < kend;
+                const float v = a_row[in ? ka + q : 0];
+                st.ra[q] = in ? v : 0.f;
+            }
         }
         uint32_t ok = a_ok ? 0x80000000u : 0u;
         const bool k_ok = kpix < kend;
@@ -469,14 +479,17 @@ __global__ void __launch_bounds__(64 * WVM * WVN) wgrad_kernel(WgradProblem p)
         const int pixoff = iy0 * p.Wg + ix0;
 #pragma unroll
         for (int j = 0; j < BC; j++) {
-            const bool in = k_ok && (unsigned)(iy0 + col_dy[j]) < (unsigned)p.Hg && (unsigned)(ix0 + col_dx[j]) < (unsigned)p.Wg;
+            const bool in = k_ok & ((unsigned)(iy0 + col_dy[j]) < (unsigned)p.Hg) & ((unsigned)(ix0 + col_dx[j]) < (unsigned)p.Wg);
             st.rb[j] = p.xin[in ? col_off[j] + pixoff : 0];
             ok |= in ? (1u << j) : 0u;
         }
         st.ok = ok;
         kpix += BK;
-        gx += BK;
-        while (gx >= p.gw) { gx -= p.gw; gy++; }
+        gx += rstep;
+        gy += qstep;
+        const bool wrap = gx >= p.gw;
+        gx -= wrap ? p.gw : 0;
+        gy += wrap ? 1 : 0;
     };
     auto lstore = [&](int buf, const Stage& st) {
         float* As = As0 + buf * BM * LDK;
@@ -641,17 +654,29 @@ static int bn_of(int bm) { return bm == 64 ? 256 : 128; }
 static float wscale_of(const AgConvDesc* d) { return d->weight_scale == 0.f ? 1.f : d->weight_scale; }
 
 // Split-K policy.  A 128 x 128 tile per workgroup leaves the chip idle when M * N is small (the 512-channel layers at
-// 8^2 .. 64^2 have 4 .. 128 tiles for 256 CUs) and the K loop (up to 576 tiles) becomes the critical path; slices of K go
-// to blockIdx.z until ~3 workgroups per CU exist, each keeping >= 4 K tiles, partial sums capped at kMaxPartialBytes.
+// 8^2 .. 64^2 have 4 .. 128 tiles for 256 CUs) and the K loop (up to 576 tiles) becomes the critical path, so slices of K go to
+// blockIdx.z.  The chip holds kSlots workgroups at once (two 8-wave workgroups per CU); the split count minimises
+//     rounds(s) * (K tiles per slice + fixed cost of a workgroup)  +  cost of the partial-sum pass (grows with s)
+// where rounds = ceil(workgroups / kSlots): it lands on grids that fill the slots once or twice instead of one and a half times.
 constexpr size_t kMaxPartialBytes = size_t(96) << 20;
+constexpr int kSlots = 512;
 static int choose_splits(long long tiles, int Mpad, int Ncols, int nkt)
 {
-    if (tiles >= 512 || nkt < 8) return 1;
-    long long s = (768 + tiles - 1) / tiles;
-    if (s > nkt / 4) s = nkt / 4;
+    if (nkt < 8) return 1;
     const long long cap = (long long)(kMaxPartialBytes / ((size_t)Mpad * Ncols * sizeof(float)));
-    if (s > cap) s = cap;
-    return s < 2 ? 1 : (int)s;
+    const int smax = (int)std::min<long long>(std::min<long long>(nkt / 4, cap), 96);
+    // unit = the time of one K tile in a workgroup (~0.45 us).  A workgroup costs ~10 units of prologue / epilogue; splitting adds the
+    // finish launch (~9 units) and, per split, one write + one read of the fp32 output at ~3 TB/s
+    const double per_split = 8.0 * (double)Mpad * Ncols / 3e12 / 0.45e-6;
+    int best = 1;
+    double best_cost = 1e30;
+    for (int sp = 1; sp <= std::max(1, smax); sp++) {
+        const long long rounds = (tiles * sp + kSlots - 1) / kSlots;
+        const int per = (nkt + sp - 1) / sp;
+        const double cost = (double)rounds * (per + 10.0) + (sp > 1 ? 9.0 + per_split * sp : 0.0);
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = sp; }
+    }
+    return best;
 }
 
 // Fills tile_begin / col_begin / at_off / nkt of the classes (dy, dx, gh, gw, y0, x0, ntaps set by the caller), packs the
@@ -871,17 +896,33 @@ int ag_conv_backward_weight(const AgConvDesc* d, const float* x, const float* dy
     const int Kp = wp.gh * wp.gw, Nw = wp.Cg * k2;
     const int bm = pick_bm(wp.Mw), BN = bn_of(bm);
     const int tiles = ((Nw + BN - 1) / BN) * ((wp.Mw + bm - 1) / bm);
-    int splits = (1536 + tiles - 1) / tiles;                 // ~6 workgroups per CU in flight or queued (measured flat from 768 to 2048)
-    const int max_splits = (Kp + 4 * BK - 1) / (4 * BK);     // at least 4 K tiles per split
-    if (splits > max_splits) splits = max_splits;
-    if (splits < 1) splits = 1;
+    // pixel slices: fill the kSlots resident workgroups a whole number of times (the float-atomic traffic of the epilogue grows
+    // with the split count, so no more rounds than needed), at least 8 K tiles per slice
+    const int nkt_all = (Kp + BK - 1) / BK;
+    int splits = 1;
+    {
+        double best_cost = 1e30;
+        const int smax = std::max(1, std::min(nkt_all / 8, 4096));
+        for (int sp = 1; sp <= smax; sp++) {
+            const long long rounds = ((long long)tiles * sp + kSlots - 1) / kSlots;
+            const int per = (nkt_all + sp - 1) / sp;
+            const double cost = (double)rounds * (per + 24.0);      // 24 K-tile-times: prologue + the 16 K-float atomic epilogue
+            if (cost < best_cost - 1e-9) { best_cost = cost; splits = sp; }
+        }
+    }
     wp.ksplit_len = round_up((Kp + splits - 1) / splits, BK);
     splits = (Kp + wp.ksplit_len - 1) / wp.ksplit_len;
     if ((rc = check_hip(hipMemsetAsync(dw, 0, (size_t)wp.Mw * Nw * sizeof(float), s), "memset dw"))) return rc;
     dim3 grid((Nw + BN - 1) / BN, (wp.Mw + bm - 1) / bm, splits);
     ProfScope ps(AG_K_WGRAD, s, 2.0 * wp.Mw * (double)Kp * Nw);
-    if (bm == 64) hipLaunchKernelGGL((wgrad_kernel<1, 2, 2, 4>), grid, dim3(512), 0, s, wp);
-    else          hipLaunchKernelGGL((wgrad_kernel<2, 1, 2, 4>), grid, dim3(512), 0, s, wp);
+    const bool avec = (Kp & 3) == 0;      // rows of A 16-byte aligned
+    if (bm == 64) {
+        if (avec) hipLaunchKernelGGL((wgrad_kernel<1, 2, 2, 4, true>), grid, dim3(512), 0, s, wp);
+        else      hipLaunchKernelGGL((wgrad_kernel<1, 2, 2, 4, false>), grid, dim3(512), 0, s, wp);
+    } else {
+        if (avec) hipLaunchKernelGGL((wgrad_kernel<2, 1, 2, 4, true>), grid, dim3(512), 0, s, wp);
+        else      hipLaunchKernelGGL((wgrad_kernel<2, 1, 2, 4, false>), grid, dim3(512), 0, s, wp);
+    }
     return check_hip(hipGetLastError(), "wgrad_kernel");
 }
 
