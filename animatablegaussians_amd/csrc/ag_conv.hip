@@ -20,6 +20,7 @@
 // reads).  Global->register loads of tile k+1 are issued before the MFMAs of tile k and written to the other LDS buffer
 // after them (one LDS-only barrier per K step).
 #include <algorithm>
+#include <cstdlib>
 
 #include "ag_common.h"
 #include "../../include/ag_conv.h"
@@ -655,25 +656,31 @@ static float wscale_of(const AgConvDesc* d) { return d->weight_scale == 0.f ? 1.
 
 // Split-K policy.  A 128 x 128 tile per workgroup leaves the chip idle when M * N is small (the 512-channel layers at
 // 8^2 .. 64^2 have 4 .. 128 tiles for 256 CUs) and the K loop (up to 576 tiles) becomes the critical path, so slices of K go to
-// blockIdx.z.  The chip holds kSlots workgroups at once (two 8-wave workgroups per CU); the split count minimises
-//     rounds(s) * (K tiles per slice + fixed cost of a workgroup)  +  cost of the partial-sum pass (grows with s)
-// where rounds = ceil(workgroups / kSlots): it lands on grids that fill the slots once or twice instead of one and a half times.
+// blockIdx.z.  Model fitted to profiles/conv_split_sweep.py (r2_split_sweep*.log): a CU works through the workgroups it is dealt;
+// two co-resident ones finish in ~1.8x the time of one, so with W workgroups a CU's share is r = ceil(W / 256) of them and the
+// launch takes  (K tiles per slice) * (r == 1 ? 1 : 0.9 r)  + per-workgroup fixed cost * r  (+ the partial-sum pass, growing with
+// the split count).  It lands on W = 256 or 512 instead of 384 (half the CUs with two workgroups, the rest with one: +20 %).
+// (Dealing the slices to XCDs -- all tiles of a slice on one L2 -- was measured too: no gain, r2_split_sweep2.log.)
 constexpr size_t kMaxPartialBytes = size_t(96) << 20;
-constexpr int kSlots = 512;
+constexpr int kCUs = 256;
+static double lanes_cost(long long W, int per, double fixed)
+{
+    const long long r = (W + kCUs - 1) / kCUs;
+    return per * (r <= 1 ? 1.0 : 0.9 * r) + fixed * r;
+}
 static int choose_splits(long long tiles, int Mpad, int Ncols, int nkt)
 {
     if (nkt < 8) return 1;
     const long long cap = (long long)(kMaxPartialBytes / ((size_t)Mpad * Ncols * sizeof(float)));
     const int smax = (int)std::min<long long>(std::min<long long>(nkt / 4, cap), 96);
-    // unit = the time of one K tile in a workgroup (~0.45 us).  A workgroup costs ~10 units of prologue / epilogue; splitting adds the
-    // finish launch (~9 units) and, per split, one write + one read of the fp32 output at ~3 TB/s
-    const double per_split = 8.0 * (double)Mpad * Ncols / 3e12 / 0.45e-6;
+    // unit = the time of one K tile in a workgroup (~0.45 us).  Splitting adds the finish launch (~6 units) and, per split, one
+    // write + one read of the fp32 output at ~6 TB/s (L2 / Infinity Cache resident for these sizes)
+    const double per_split = 8.0 * (double)Mpad * Ncols / 6e12 / 0.45e-6;
     int best = 1;
     double best_cost = 1e30;
     for (int sp = 1; sp <= std::max(1, smax); sp++) {
-        const long long rounds = (tiles * sp + kSlots - 1) / kSlots;
         const int per = (nkt + sp - 1) / sp;
-        const double cost = (double)rounds * (per + 10.0) + (sp > 1 ? 9.0 + per_split * sp : 0.0);
+        const double cost = lanes_cost(tiles * sp, per, 10.0) + (sp > 1 ? 6.0 + per_split * sp : 0.0);
         if (cost < best_cost - 1e-9) { best_cost = cost; best = sp; }
     }
     return best;
@@ -712,6 +719,11 @@ static int pack_and_launch(GatherProblem& gp, const TapSet* taps, int bm, const 
     if (rc) return rc;
 
     int splits = choose_splits(tiles * (gp.Mpad / bm), gp.Mpad, cols, nkt_max);
+    if (const char* forced = getenv("AG_CONV_SPLITS")) {       // measurement hook (profiles/conv_split_sweep.py)
+        const int f = atoi(forced);
+        const long long cap = (long long)(kMaxPartialBytes / ((size_t)gp.Mpad * cols * sizeof(float)));
+        if (f >= 1) splits = (int)std::min<long long>(std::min(f, std::max(1, nkt_max)), std::max<long long>(1, cap));
+    }
     gp.kt_per_split = (nkt_max + splits - 1) / splits;
     splits = (nkt_max + gp.kt_per_split - 1) / gp.kt_per_split;
     gp.partial = splits > 1 ? partial : nullptr;
@@ -896,19 +908,21 @@ int ag_conv_backward_weight(const AgConvDesc* d, const float* x, const float* dy
     const int Kp = wp.gh * wp.gw, Nw = wp.Cg * k2;
     const int bm = pick_bm(wp.Mw), BN = bn_of(bm);
     const int tiles = ((Nw + BN - 1) / BN) * ((wp.Mw + bm - 1) / bm);
-    // pixel slices: fill the kSlots resident workgroups a whole number of times (the float-atomic traffic of the epilogue grows
-    // with the split count, so no more rounds than needed), at least 8 K tiles per slice
+    // pixel slices: same CU-share model as the gather kernel; a workgroup's fixed cost is its prologue plus the 16 K float atomics of
+    // its epilogue (~6 K-tile-times); at least 8 K tiles per slice
     const int nkt_all = (Kp + BK - 1) / BK;
     int splits = 1;
     {
         double best_cost = 1e30;
         const int smax = std::max(1, std::min(nkt_all / 8, 4096));
         for (int sp = 1; sp <= smax; sp++) {
-            const long long rounds = ((long long)tiles * sp + kSlots - 1) / kSlots;
-            const int per = (nkt_all + sp - 1) / sp;
-            const double cost = (double)rounds * (per + 24.0);      // 24 K-tile-times: prologue + the 16 K-float atomic epilogue
+            const double cost = lanes_cost((long long)tiles * sp, (nkt_all + sp - 1) / sp, 6.0);
             if (cost < best_cost - 1e-9) { best_cost = cost; splits = sp; }
         }
+    }
+    if (const char* forced = getenv("AG_WGRAD_SPLITS")) {      // measurement hook (profiles/conv_split_sweep.py)
+        const int f = atoi(forced);
+        if (f >= 1) splits = std::min(f, std::max(1, nkt_all));
     }
     wp.ksplit_len = round_up((Kp + splits - 1) / splits, BK);
     splits = (Kp + wp.ksplit_len - 1) / wp.ksplit_len;
