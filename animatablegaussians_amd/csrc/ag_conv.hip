@@ -348,11 +348,14 @@ __global__ void __launch_bounds__(256) reduce_splits_kernel(GatherProblem p, int
 // weight re-pack into the tile-blocked images of all classes in one launch:
 //   At[class][m / BM][kt][m % BM][kl] = w[c * stride_c + m * stride_m + tapoff[class][t]]
 // with K tile kt = (c / 16) * ntaps + t and kl = c % 16, zero padded; optional exact scalar pre-multiplication (EqualConv2d's
-// `weight * scale`, dual_styleunet.py:114-117: the same fp32 product the reference forms before its convolution)
+// `weight * scale`, dual_styleunet.py:114-117: the same fp32 product the reference forms before its convolution).
+// One workgroup moves a 16 (m) x 16 (c) x k*k block through LDS: in the source one of the two indices is contiguous with the taps
+// (16 * k*k floats per row of the other index: coalesced reads), in the destination every (class, tap) is one 1-KB run [16 m][16 c]
+// (coalesced writes) -- 38 MB for the 1024 -> 512 layer in ~15 us instead of 90 with a gather per element.
 struct PackProblem {
     const float* w;
     float* At;
-    int C, Cpad, M, Mpad, BM, nclasses;
+    int C, Cpad, M, Mpad, BM, nclasses, k2;
     long long stride_c, stride_m;
     float wscale;
     int has_wscale;
@@ -363,28 +366,35 @@ struct PackProblem {
 
 __global__ void __launch_bounds__(256) pack_weights_kernel(PackProblem p)
 {
-    const long long total = p.begin[p.nclasses];
-    for (long long i0 = (long long)blockIdx.x * 256 + threadIdx.x; i0 < total; i0 += (long long)gridDim.x * 256) {
-        int ci = 0;
-#pragma unroll
-        for (int c = 1; c < kMaxClasses; c++)
-            if (c < p.nclasses && i0 >= p.begin[c]) ci = c;
-        const long long i = i0 - p.begin[ci];
-        const int ntaps = p.ntaps[ci], nkt = ntaps * (p.Cpad / BK);
-        // destination-major enumeration (coalesced writes): i = ((mt * nkt + kt) * BM + ml) * 16 + kl
-        const int kl = (int)(i & 15);
-        long long q = i >> 4;
-        const int ml = (int)(q % p.BM);
-        q /= p.BM;
-        const int kt = (int)(q % nkt), mt = (int)(q / nkt);
-        const int m = mt * p.BM + ml;
-        const int cb = kt / ntaps, t = kt - cb * ntaps, c = cb * BK + kl;   // K tile = (channel block, tap)
+    __shared__ float blk[16][16 * kMaxTaps + 1];
+    const int tid = threadIdx.x;
+    const int cb = blockIdx.x, m16 = blockIdx.y;             // channel block, 16-row group
+    const int k2 = p.k2, run = 16 * k2;
+    const bool m_inner = p.stride_m == k2;                   // else stride_c == k2: channels contiguous with the taps
+    // load: 16 rows of the outer index, each one contiguous run of 16 * k2 floats
+    for (int e = tid; e < 16 * run; e += 256) {
+        const int o = e / run, r = e - o * run;              // r = inner * k2 + tap
+        const int inner = r / k2;
+        const int c = cb * 16 + (m_inner ? o : inner), m = m16 * 16 + (m_inner ? inner : o);
         float v = 0.f;
-        if (c < p.C && m < p.M && !p.zero[ci]) {
-            v = p.w[c * p.stride_c + m * p.stride_m + p.tapoff[ci][t]];
+        if (c < p.C && m < p.M) {
+            v = p.w[(long long)c * p.stride_c + (long long)m * p.stride_m + (r - inner * k2)];
             if (p.has_wscale) v *= p.wscale;
         }
-        p.At[i0] = v;
+        blk[o][r] = v;
+    }
+    __syncthreads();
+    const int ml = tid >> 4, kl = tid & 15;                  // destination element (m, c) of the block
+    const int m = m16 * 16 + ml;
+    const int mt = m / p.BM, mrow = m - mt * p.BM;
+    const int o = m_inner ? kl : ml, inner = m_inner ? ml : kl;
+    const int ctiles = p.Cpad / BK;
+    for (int ci = 0; ci < p.nclasses; ci++) {
+        const int ntaps = p.ntaps[ci];
+        const long long nkt = (long long)ntaps * ctiles;
+        float* dst = p.At + p.begin[ci] + ((mt * nkt + (long long)cb * ntaps) * p.BM + mrow) * 16 + kl;
+        const bool zero = p.zero[ci] != 0;
+        for (int t = 0; t < ntaps; t++) dst[(long long)t * p.BM * 16] = zero ? 0.f : blk[o][inner * k2 + p.tapoff[ci][t]];
     }
 }
 
@@ -712,9 +722,9 @@ static int pack_and_launch(GatherProblem& gp, const TapSet* taps, int bm, const 
     pp.begin[gp.nclasses] = at;
     gp.Ncols = cols;
     if (tiles == 0) return AG_OK;
-    int blocks = (int)((at + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, s, pp);
+    pp.k2 = k * k;
+    if ((stride_c != pp.k2 && stride_m != pp.k2) || pp.k2 > kMaxTaps) { set_error("pack: unexpected weight strides"); return AG_ERR_INVALID_ARGUMENT; }
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(gp.Cpad / BK, gp.Mpad / 16), dim3(256), 0, s, pp);
     int rc = check_hip(hipGetLastError(), "pack_weights_kernel");
     if (rc) return rc;
 
@@ -738,7 +748,7 @@ static int pack_and_launch(GatherProblem& gp, const TapSet* taps, int bm, const 
     rc = check_hip(hipGetLastError(), "gather_conv_kernel");
     if (rc || splits == 1) return rc;
     const long long total = (long long)gp.M * cols;
-    blocks = (int)((total + 255) / 256);
+    int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(reduce_splits_kernel, dim3(blocks), dim3(256), 0, s, gp, splits);
     return check_hip(hipGetLastError(), "reduce_splits_kernel");
