@@ -122,14 +122,18 @@ constexpr int kBwdWavesPerSimd = 6;
 // (512-workgroup grid) 64 -> 128 entries per flush measured 189 -> 172 us; with the 2048-workgroup grid the 21 KiB this
 // saves buy the third resident workgroup instead: 154 -> 135 us (same-box A/B).  (One shared slab filled with LDS float
 // atomics would need 5 KiB only, but measured 240-300 us.)
-constexpr int kSub = 64;
-constexpr int kPartStride = kSub + 4;
+// Round 2: the slabs are double-buffered, so ONE barrier per sub-chunk orders everything (compute k -> barrier -> flush k and, without
+// a second barrier, compute k+1 into the other slab: a wave can only write slab (k+1)&1 after every wave has passed barrier k, i.e.
+// after every wave finished flush k-1, the last reader of that slab) and the flush's LDS reads / atomics of the fast waves overlap
+// the blending of the slow ones.  Two 32-entry slabs cost the LDS of one 64-entry slab: still 3 workgroups per CU.
+constexpr int kSub = 32;
+constexpr int kPartStride = kSub + 2;     // == 2 (mod 32): the flush's (component, entry) lanes of a 32-lane LDS access hit 20 distinct banks
 
 __global__ void __launch_bounds__(kBlendThreads, kBwdWavesPerSimd) blend_backward_kernel(BlendBwdParams p)
 {
     constexpr int NW = kBlendThreads / 64;
     __shared__ float4 s_rec[kChunk * 3];
-    __shared__ float s_part[kBlendThreads / 64][10][kPartStride];   // per-wave sums over its 4 pixels: plain stores, no LDS atomics
+    __shared__ float s_part[2][kBlendThreads / 64][10][kPartStride];   // per-wave sums over its 4 pixels: plain stores, no LDS atomics
     __shared__ uint32_t s_gid[kChunk];
     __shared__ int s_wave_cnt[2][NW];
     __shared__ uint32_t s_wave_max[NW];
@@ -141,6 +145,7 @@ __global__ void __launch_bounds__(kBlendThreads, kBwdWavesPerSimd) blend_backwar
     const float ddelx_dx = 0.5f * (float)p.W, ddely_dy = 0.5f * (float)p.H;
     const float bg0 = p.bg[0], bg1 = p.bg[1], bg2 = p.bg[2];
 
+    int pb = 0;                                   // slab parity, toggled per sub-chunk for the whole kernel
     ItemIter it(blockIdx.x, gridDim.x, n_active);
     uint32_t tr, rg;
     bool have = it.next(tr, rg);
@@ -259,7 +264,7 @@ __global__ void __launch_bounds__(kBlendThreads, kBwdWavesPerSimd) blend_backwar
                 const float alpha = fminf(0.99f, b.y * G);
                 const bool act = ev && (__float_as_uint(c.z) <= last_contributor) && (power <= 0.0f) && (alpha >= 1.0f / 255.0f);
                 const int vbase = (row == 0) ? 0 : (row == 1) ? 3 : (row == 2) ? 5 : 8;
-                float* part = &s_part[wave][vbase][idx - sb];
+                float* part = &s_part[pb][wave][vbase][idx - sb];
                 if (!__any(act)) {
                     if (ev) { part[0] = 0.f; part[kPartStride] = 0.f; if (!(row & 1)) part[2 * kPartStride] = 0.f; }
                     continue;
@@ -355,11 +360,11 @@ __global__ void __launch_bounds__(kBlendThreads, kBwdWavesPerSimd) blend_backwar
                 if (ent < sub_n && comp < 10) {
                     float acc = 0.f;
 #pragma unroll
-                    for (int w = 0; w < NW; w++) acc += s_part[w][comp][ent];
+                    for (int w = 0; w < NW; w++) acc += s_part[pb][w][comp][ent];
                     if (acc != 0.f) atomicAdd(p.accum + (size_t)s_gid[sb + ent] * kAccumFloats + comp, acc);
                 }
             }
-            lds_barrier();   // s_part reusable
+            pb ^= 1;         // no second barrier: the next sub-chunk goes to the other slab
             }
 
             // ---- cull of the next chunk ----
