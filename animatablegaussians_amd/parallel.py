@@ -63,15 +63,23 @@ class BucketedGradSync:
     * xGMI is point-to-point (7 links x ~153 GB/s per GPU) and ring collectives are per-link bound, so buckets are few
       and large (default 128 MB: ~7 collectives per step) rather than DDP's 25 MB.
 
+    * A bucket's gradients can come from several HIP streams; each hook records an event on its own stream and the launch
+      waits for all of them (the collective itself only orders after the launching stream).
+    * One ``backward()`` per step.  A second gradient for the same parameter in one step raises (its bucket may already be
+      reducing); ``defer_to_finish=True`` supports several backward calls per step by reducing everything in ``finish()``.
+
     Usage per step: ``sync.zero()`` -> forward/backward (hooks fire) -> ``sync.finish()`` -> optimizer step.
     Works on any backend (``nccl`` = RCCL on the GPU node, ``gloo`` in the CPU tests); with world size 1 it only
     provides the flat gradient storage."""
 
-    def __init__(self, params: Sequence[torch.nn.Parameter], bucket_bytes: int = 128 << 20, average: bool = True):
+    def __init__(self, params: Sequence[torch.nn.Parameter], bucket_bytes: int = 128 << 20, average: bool = True,
+                 defer_to_finish: bool = False):
         self.params = [p for p in params if p.requires_grad]
         self.average = average
+        self.defer_to_finish = defer_to_finish
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device
+        self._cuda = dev.type == "cuda"
         self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
         # reverse order: the last-registered parameters (decoder heads) get their gradients first
         order = list(reversed(self.params))
@@ -91,40 +99,77 @@ class BucketedGradSync:
             b_count += 1
         self.buckets.append((b_start, off))
         self._pending_init.append(b_count)
+        self._world = dist.get_world_size() if dist.is_initialized() else 1
+        self._arm()
+        self._handles = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+
+    def _arm(self):
         self._pending = list(self._pending_init)
         self._works = []
-        self._world = dist.get_world_size() if dist.is_initialized() else 1
-        self._handles = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+        self._fired = set()
+        self._events = [[] for _ in self.buckets]      # per bucket: one event per gradient, on the stream that accumulated it
+        self._launched = [False] * len(self.buckets)
 
     def zero(self):
         """Start of a step: clear the flat gradient buffer and re-arm the buckets."""
+        if any(w is not None for w in self._works):
+            raise RuntimeError("BucketedGradSync.zero() while collectives of the previous step are in flight: call finish() first")
         self.flat.zero_()
-        self._pending = list(self._pending_init)
-        self._works = []
+        self._arm()
+
+    def _launch(self, b):
+        """All-reduce bucket b.  Its gradients may have been accumulated on several HIP streams (the networks run their decoder
+        branches on side streams and autograd replays every node on its recording stream), while the collective only orders itself
+        after the CURRENT stream: wait for every gradient's own event first."""
+        s, e = self.buckets[b]
+        if self._cuda:
+            cur = torch.cuda.current_stream(self.flat.device)
+            for ev in self._events[b]:
+                cur.wait_event(ev)
+        self._events[b] = []
+        self._launched[b] = True
+        self._works.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, async_op=True))
 
     def _on_grad(self, p):
         # autograd accumulated into the existing .grad view in place; guard against it having been replaced
         if p.grad.data_ptr() < self.flat.data_ptr() or p.grad.data_ptr() >= self.flat.data_ptr() + self.flat.numel() * 4:
             raise RuntimeError("a parameter's .grad was re-allocated; use BucketedGradSync.zero(), not zero_grad(set_to_none=True)")
         b = self._bucket_of[p]
+        if self._cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.flat.device))     # the hook runs on the stream that accumulated this gradient
+            self._events[b].append(ev)
+        if self.defer_to_finish:
+            return
+        if id(p) in self._fired:
+            # a second backward() in the same step (one loss per view, gradient accumulation) would write into a bucket whose
+            # all-reduce is already in flight or done: replicas diverge silently.  Refuse.
+            raise RuntimeError("BucketedGradSync: a parameter received a second gradient in one step after its bucket was armed for "
+                               "launch; call backward() once per step, or construct with defer_to_finish=True (all buckets are then "
+                               "reduced in finish())")
+        self._fired.add(id(p))
         self._pending[b] -= 1
         if self._pending[b] == 0 and self._world > 1:
-            s, e = self.buckets[b]
-            self._works.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, async_op=True))
+            self._launch(b)
 
     def finish(self):
-        """End of backward: launch buckets whose parameters received no gradient this step, wait, average."""
+        """End of backward: launch the buckets that have not been launched (parameters without gradient this step, or
+        ``defer_to_finish``), wait, average."""
         if self._world > 1:
-            for b, left in enumerate(self._pending):
-                if left > 0:
-                    s, e = self.buckets[b]
-                    self._works.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, async_op=True))
-                    self._pending[b] = 0
+            for b in range(len(self.buckets)):
+                if not self._launched[b]:
+                    self._launch(b)
             for w in self._works:
                 w.wait()
             self._works = []
             if self.average:
                 self.flat /= self._world
+        elif self._cuda:
+            cur = torch.cuda.current_stream(self.flat.device)
+            for evs in self._events:
+                for ev in evs:
+                    cur.wait_event(ev)
+        self._events = [[] for _ in self.buckets]
 
     def close(self):
         for h in self._handles:

@@ -202,6 +202,37 @@ def main() -> None:
         _lib.prof_enable([])
         breakdown = {k: round(1e3 * ms / max(n, 1), 2) for k, (n, ms) in bd.items()}
 
+    # N > 1: the exchange north_star names for the full training step -- the bucketed all-reduce of the three networks' gradients
+    # (223.6 M fp32 = 895 MB, parallel.BucketedGradSync's 128-MB buckets) -- timed on its own after the headline region, so the
+    # scaling runs record what RCCL over xGMI delivers for it even though the headline workload is raster-only
+    exchange = None
+    if world > 1:
+        n_el = 223648936
+        buf = torch.zeros(n_el, device=dev)
+        cap = (128 << 20) // 4
+        cuts = [(o, min(n_el, o + cap)) for o in range(0, n_el, cap)]
+
+        def allreduce_all():
+            works = [dist.all_reduce(buf[a:b], async_op=True) for a, b in cuts]
+            for w in works:
+                w.wait()
+
+        for _ in range(2):
+            allreduce_all()
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        t2 = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            allreduce_all()
+        torch.cuda.synchronize(dev)
+        dt = torch.tensor([(time.perf_counter() - t2) / reps], device=dev, dtype=torch.float64)
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        ms = 1e3 * float(dt.item())
+        exchange = {"what": "bucketed all-reduce of the StyleUNet gradients (223.6 M fp32, 128-MB buckets), not part of `value`",
+                    "bytes": 4 * n_el, "ms": round(ms, 3), "bus_GBps": round(2 * (world - 1) / world * 4 * n_el / (ms * 1e-3) / 1e9, 1)}
+        del buf
+
     if rank != 0:
         if world > 1:
             dist.barrier()
@@ -259,6 +290,8 @@ def main() -> None:
         out["kernels_us"] = breakdown
     if seq is not None:
         out["sequential"] = seq
+    if exchange is not None:
+        out["exchange_styleunet"] = exchange
     if world == 1 and not args.no_full_step:
         # BASELINE configs[2] and the MFMA roofline north_star asks for, measured in this process (about 15 s): the whole training
         # iteration at the reference's batch shape (1 view per step) and at 4 views of one pose per step, and the convolution kernels'

@@ -49,3 +49,26 @@ def test_bench_json_line():
     # every convolution FLOP of a forward + backward is accounted for: 586 GFLOP x 3 (forward, input gradient, weight gradient)
     total = m["gather_conv_kernel"]["GFLOP_per_network_pass"] + m["wgrad_kernel"]["GFLOP_per_network_pass"]
     assert abs(total - 3 * 585.8) < 0.03 * 3 * 585.8, total
+
+
+def test_bench_two_ranks_control_flow_on_one_gpu():
+    """The N > 1 launch exactly as the driver issues it (python -m torch.distributed.run, one rank per process), with the gloo
+    transport so that both ranks can share this box's single GPU: a functional check of the sharded path, the max-over-ranks timing
+    and the extra exchange record -- never a measurement."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, AG_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "30", "--warmup", "10"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 30 and d["scaling"] == "weak" and "view-sharded x2" in d["config"]["parallelism"]
+    assert abs(d["value"] * d["ms_per_step"] - 2000.0) < 20.0                      # whole-job aggregate: 2 ranks x steps / time
+    assert "cpu_baseline" not in d and "full_step" not in d                        # N = 1 only
+    x = d["exchange_styleunet"]
+    assert x["bytes"] == 4 * 223648936 and x["ms"] > 0 and x["bus_GBps"] > 0

@@ -99,8 +99,41 @@ def _bucket_worker(rank, world, port, out):
         ok = ok and all(torch.allclose(a, b, rtol=1e-5, atol=1e-7) for a, b in zip(got, want))
         ok = ok and bool((unused.grad == 0).all())
         ok = ok and all(p.grad.data_ptr() >= sync.flat.data_ptr() for p in params)   # still views of the flat buffer
-    out[rank] = bool(ok)
+    # a second backward in the same step must not silently write into buckets that are already reducing
+    sync.zero()
+    x, y = data(rank)
+    ((net(x) - y) ** 2).mean().backward()
+    try:
+        ((net(x) - y) ** 2).mean().backward()
+        ok = False
+    except RuntimeError as e:
+        ok = ok and "second gradient" in str(e)
+    sync.finish()
     sync.close()
+    # defer_to_finish: two backward calls per step (one loss per view), everything reduced in finish()
+    for p in params:
+        p.grad = None
+    sync2 = BucketedGradSync(params, bucket_bytes=1024, defer_to_finish=True)
+    sync2.zero()
+    for v in range(2):
+        x, y = data(rank + 10 * v)
+        (((net(x) - y) ** 2).mean() / 2).backward()
+    sync2.finish()
+    got = [p.grad.clone() for p in net.parameters()]
+    want = None
+    for r in range(world):
+        for v in range(2):
+            ref = [p.detach().clone().requires_grad_(True) for p in net.parameters()]
+            xr, yr = data(r + 10 * v)
+            h = torch.relu(torch.nn.functional.linear(xr, ref[0], ref[1]))
+            h = torch.relu(torch.nn.functional.linear(h, ref[2], ref[3]))
+            (((torch.nn.functional.linear(h, ref[4], ref[5]) - yr) ** 2).mean() / 2).backward()
+            gs = [p.grad for p in ref]
+            want = gs if want is None else [a + b for a, b in zip(want, gs)]
+    want = [w / world for w in want]
+    ok = ok and all(torch.allclose(a, b, rtol=1e-5, atol=1e-7) for a, b in zip(got, want))
+    out[rank] = bool(ok)
+    sync2.close()
     dist.destroy_process_group()
 
 
