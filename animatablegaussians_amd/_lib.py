@@ -68,7 +68,7 @@ class AgGatherArgs(ctypes.Structure):
 
 class AgLbsArgs(ctypes.Structure):
     _fields_ = [("N", c_i32), ("J", c_i32)] + [(n, c_vp) for n in (
-        "lbs", "jnt_mats", "positions", "rotations", "out_positions", "out_rotations")]
+        "lbs", "jnt_mats", "positions", "rotations", "out_positions", "out_rotations", "sp_idx", "sp_w")] + [("K", c_i32), ("reserved", c_i32)]
 
 
 class AgHandFuseArgs(ctypes.Structure):

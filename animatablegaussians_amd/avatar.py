@@ -38,6 +38,12 @@ class AvatarRenderCore(nn.Module):
                         ("rotation_raw", rotation_raw), ("lbs", lbs)):
             self.register_buffer(name, t.float().contiguous(), persistent=False)
         assert self.pix.numel() == self.xyz.shape[0] == self.lbs.shape[0]
+        self.lbs_sparse = ops.SparseLbs.build(self.lbs) if self.lbs.is_cuda else None      # None: dense rows (or a CPU-side construction)
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self.lbs_sparse = ops.SparseLbs.build(self.lbs) if self.lbs.is_cuda else None      # follows the buffers across .to() / .cuda()
+        return out
 
     @classmethod
     def synthetic(cls, S: int = 1024, J: int = 55, seed: int = 31359, device="cuda") -> "AvatarRenderCore":
@@ -70,7 +76,7 @@ class AvatarRenderCore(nn.Module):
                 bg_color: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
         g = self.assemble(position_map, other_map, color_map)
         offset = g['positions'] - self.xyz                       # nonrigid_offset, avatar.py:211
-        g['positions'], g['rotations'] = ops.lbs_transform(g['positions'], g['rotations'], self.lbs, cano2live_jnt_mats)
+        g['positions'], g['rotations'] = ops.lbs_transform(g['positions'], g['rotations'], self.lbs, cano2live_jnt_mats, self.lbs_sparse)
         if bg_color is None:
             bg_color = torch.zeros(3, device=position_map.device)
         r = render3(g, bg_color, extr, intr, img_w, img_h)
@@ -285,12 +291,12 @@ class AvatarNet(nn.Module):
             q[:, 0] = 1.0
             self._unit_quat = q
         mats = jnt_mats.to(torch.float32).contiguous()
-        pts, _ = ops.lbs_transform(self.core.xyz, self._unit_quat, self.core.lbs, mats)
+        pts, _ = ops.lbs_transform(self.core.xyz, self._unit_quat, self.core.lbs, mats, self.core.lbs_sparse)
         if vectors is None:
             return pts, None
         rot_only = mats.clone()
         rot_only[:, :3, 3] = 0.0
-        vec, _ = ops.lbs_transform(vectors.contiguous(), self._unit_quat, self.core.lbs, rot_only)
+        vec, _ = ops.lbs_transform(vectors.contiguous(), self._unit_quat, self.core.lbs, rot_only, self.core.lbs_sparse)
         return pts, vec
 
     @torch.no_grad()
@@ -433,7 +439,7 @@ class AvatarNet(nn.Module):
         """:84-91: skin ``positions`` and ``rotations`` of ``gaussian_vals`` (in place, as the reference) with the blended joint
         matrices of ``items['cano2live_jnt_mats']``."""
         gaussian_vals['positions'], gaussian_vals['rotations'] = ops.lbs_transform(
-            gaussian_vals['positions'], gaussian_vals['rotations'], self.core.lbs, items['cano2live_jnt_mats'])
+            gaussian_vals['positions'], gaussian_vals['rotations'], self.core.lbs, items['cano2live_jnt_mats'], self.core.lbs_sparse)
         return gaussian_vals
 
     def _fix_hand_pose_map(self):
@@ -477,7 +483,7 @@ class AvatarNet(nn.Module):
                 self.hand_rotations)
         offset = g['positions'] - self.core.xyz                                                                   # :211
         g['positions'], g['rotations'] = ops.lbs_transform(g['positions'], g['rotations'], self.core.lbs,
-                                                           items['cano2live_jnt_mats'])
+                                                           items['cano2live_jnt_mats'], self.core.lbs_sparse)
         r = render3(g, bg, items['extr'], items['intr'], items['img_w'], items['img_h'])
         ret = {'rgb_map': r['render'].permute(1, 2, 0), 'mask_map': r['mask'].permute(1, 2, 0), 'offset': offset,
                'pos_map': self._canvas(position_map)}
@@ -536,7 +542,7 @@ class AvatarNet(nn.Module):
             g = self.core.assemble(position_map, other_map, color_map)
             offset = g['positions'] - self.core.xyz
             if live is None:                                   # camera-independent: skin once
-                live = ops.lbs_transform(g['positions'], g['rotations'], self.core.lbs, items['cano2live_jnt_mats'])
+                live = ops.lbs_transform(g['positions'], g['rotations'], self.core.lbs, items['cano2live_jnt_mats'], self.core.lbs_sparse)
             g['positions'], g['rotations'] = live
             r = render3(g, bg, v['extr'], v['intr'], v['img_w'], v['img_h'])
             ret = {'rgb_map': r['render'].permute(1, 2, 0), 'mask_map': r['mask'].permute(1, 2, 0), 'offset': offset,

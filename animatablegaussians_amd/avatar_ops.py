@@ -176,23 +176,63 @@ def canonical_activations(pix, S, opacity_raw, scaling_raw, rotation_raw):
     return tuple(out)
 
 
+class SparseLbs:
+    """Sparse form of the blend-weight rows ``lbs [N, J]`` for the skinning kernels: K = the largest number of non-zeros in a row,
+    ``idx [K, N]`` uint8 joints (ascending within a row) and ``w [K, N]`` weights, zero padded.  Rows sampled from the SMPL-X
+    skinning weights by barycentric interpolation have <= 12 non-zeros of 55 (gen_data/gen_pos_maps.py:24-39,132): the kernels
+    then read 5 K instead of 220 bytes per Gaussian; results equal the dense path's (exact zeros do not change a sum).
+    ``SparseLbs.build`` returns None when a row has more than ``max_k`` non-zeros (weights sampled from the diffused weight volume,
+    gen_pos_maps.py:129-130): the dense kernels are used then."""
+
+    def __init__(self, idx, w):
+        self.idx, self.w, self.K = idx, w, int(idx.shape[0])
+
+    @staticmethod
+    @torch.no_grad()
+    def build(lbs: torch.Tensor, max_k: int = 16):
+        N, J = lbs.shape
+        if J > 256 or N == 0:
+            return None
+        nz = lbs != 0
+        K = int(nz.sum(1).max())
+        if K == 0 or K > max_k:
+            return None
+        # the K first non-zero columns of every row in ascending order: sort columns by (is zero, column index)
+        key = (~nz).to(torch.int32) * J + torch.arange(J, device=lbs.device, dtype=torch.int32)[None]
+        cols = torch.argsort(key, dim=1, stable=True)[:, :K]
+        w = torch.gather(lbs, 1, cols)                      # zeros where a row has fewer than K non-zeros
+        return SparseLbs(cols.to(torch.uint8).t().contiguous(), w.to(torch.float32).t().contiguous())
+
+
+def _lbs_args(N, J, lbs, jnt_mats, positions, rotations, out_p, out_r, sparse):
+    a = _lib.AgLbsArgs()
+    a.N, a.J = N, J
+    a.jnt_mats, a.positions, a.rotations = _p(jnt_mats), _p(positions), _p(rotations)
+    a.out_positions, a.out_rotations = _p(out_p), _p(out_r)
+    if sparse is not None:
+        a.sp_idx, a.sp_w, a.K = _p(sparse.idx), _p(sparse.w), sparse.K
+    else:
+        a.lbs = _p(lbs)
+    return a
+
+
 class _LbsTransform(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, positions, rotations, lbs, jnt_mats):
+    def forward(ctx, positions, rotations, lbs, jnt_mats, sparse):
         L = _lib.lib()
         positions, rotations = _chk(positions, "positions"), _chk(rotations, "rotations")
         lbs, jnt_mats = _chk(lbs, "lbs"), _chk(jnt_mats, "jnt_mats")
         N, J, dev = int(positions.shape[0]), int(lbs.shape[1]), positions.device
         if tuple(jnt_mats.shape) != (J, 4, 4) or lbs.shape[0] != N or tuple(rotations.shape) != (N, 4):
             raise RuntimeError("expected positions [N,3], rotations [N,4], lbs [N,J], jnt_mats [J,4,4]")
+        if sparse is not None and tuple(sparse.idx.shape) != (sparse.K, N):
+            raise RuntimeError("sparse blend weights do not match the number of Gaussians")
         out_p, out_r = torch.empty_like(positions), torch.empty_like(rotations)
-        a = _lib.AgLbsArgs()
-        a.N, a.J = N, J
-        a.lbs, a.jnt_mats, a.positions, a.rotations = _p(lbs), _p(jnt_mats), _p(positions), _p(rotations)
-        a.out_positions, a.out_rotations = _p(out_p), _p(out_r)
+        a = _lbs_args(N, J, lbs, jnt_mats, positions, rotations, out_p, out_r, sparse)
         with torch.cuda.device(dev):
             _lib.check(L.ag_lbs_forward(ctypes.byref(a), _stream(dev)), "ag_lbs_forward")
         ctx.save_for_backward(positions, rotations, lbs, jnt_mats)
+        ctx.sparse = sparse
         return out_p, out_r
 
     @staticmethod
@@ -203,18 +243,15 @@ class _LbsTransform(torch.autograd.Function):
         g_p = _chk(g_p, "grad") if g_p is not None else torch.zeros_like(positions)
         g_r = _chk(g_r, "grad") if g_r is not None else torch.zeros_like(rotations)
         dp, dr = torch.empty_like(positions), torch.empty_like(rotations)
-        a = _lib.AgLbsArgs()
-        a.N, a.J = N, J
-        a.lbs, a.jnt_mats, a.positions, a.rotations = _p(lbs), _p(jnt_mats), _p(positions), _p(rotations)
-        a.out_positions, a.out_rotations = _p(g_p), _p(g_r)
+        a = _lbs_args(N, J, lbs, jnt_mats, positions, rotations, g_p, g_r, ctx.sparse)
         with torch.cuda.device(dev):
             _lib.check(L.ag_lbs_backward(ctypes.byref(a), _p(dp), _p(dr), _stream(dev)), "ag_lbs_backward")
-        return dp, dr, None, None   # lbs weights and joint matrices are data, not parameters
+        return dp, dr, None, None, None   # lbs weights and joint matrices are data, not parameters
 
 
-def lbs_transform(positions, rotations, lbs, jnt_mats):
-    """-> (live positions [N,3], live rotations [N,4])."""
-    return _LbsTransform.apply(positions, rotations, lbs, jnt_mats)
+def lbs_transform(positions, rotations, lbs, jnt_mats, sparse=None):
+    """-> (live positions [N,3], live rotations [N,4]).  ``sparse``: ``SparseLbs.build(lbs)`` (or None: dense rows)."""
+    return _LbsTransform.apply(positions, rotations, lbs, jnt_mats, sparse)
 
 
 def hand_fuse(positions, opacity, scales, rotations, xyz, left_mano_v, right_mano_v, centre, hand_positions, hand_opacity,

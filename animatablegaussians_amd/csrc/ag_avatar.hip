@@ -130,6 +130,22 @@ __device__ __forceinline__ void blend_matrix(const float* row, const float* __re
     }
 }
 
+// The same blend from the sparse form of the weight rows: K (joint, weight) pairs per Gaussian in ascending joint order, padded
+// with zero weights, stored [K][N] so that lanes read consecutive addresses.  Skipping the exact zeros of a row leaves every
+// partial sum unchanged (x + 0 * a == x), so the result equals the dense loop's bit for bit (up to the sign of an exact zero).
+__device__ __forceinline__ void blend_matrix_sparse(const uint8_t* __restrict__ idx, const float* __restrict__ wts, int K, int N, int n,
+                                                    const float* __restrict__ jnt, float (&M)[12])
+{
+#pragma unroll
+    for (int k = 0; k < 12; k++) M[k] = 0.f;
+    for (int s = 0; s < K; s++) {
+        const float w = wts[(size_t)s * N + n];
+        const float* A = jnt + 16 * (int)idx[(size_t)s * N + n];
+#pragma unroll
+        for (int k = 0; k < 12; k++) M[k] += w * A[k];
+    }
+}
+
 // Coalesced load of the 64 weight rows of this wave into its LDS slab (row stride J).
 __device__ __forceinline__ void stage_rows(const float* __restrict__ lbs, int N, int J, int first, float* slab, int lane)
 {
@@ -149,18 +165,24 @@ __device__ __forceinline__ void quat_to_mat(const float (&q)[4], float (&R)[9], 
     R[6] = two_s * (i * k - j * r);     R[7] = two_s * (j * k + i * r);     R[8] = 1 - two_s * (i * i + j * j);
 }
 
+template <bool SPARSE>
 __global__ void __launch_bounds__(256) lbs_forward_kernel(AgLbsArgs a)
 {
     extern __shared__ float lds[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int first = (blockIdx.x * 4 + wave) * 64;
     if (first >= a.N) return;
-    float* slab = lds + (size_t)wave * 64 * a.J;
-    stage_rows(a.lbs, a.N, a.J, first, slab, lane);
     const int n = first + lane;
-    if (n >= a.N) return;
     float M[12];
-    blend_matrix(slab + lane * a.J, a.jnt_mats, a.J, M);
+    if constexpr (SPARSE) {
+        if (n >= a.N) return;
+        blend_matrix_sparse(a.sp_idx, a.sp_w, a.K, a.N, n, a.jnt_mats, M);
+    } else {
+        float* slab = lds + (size_t)wave * 64 * a.J;
+        stage_rows(a.lbs, a.N, a.J, first, slab, lane);
+        if (n >= a.N) return;
+        blend_matrix(slab + lane * a.J, a.jnt_mats, a.J, M);
+    }
     const float px = a.positions[3 * n], py = a.positions[3 * n + 1], pz = a.positions[3 * n + 2];
     a.out_positions[3 * n + 0] = M[0] * px + M[1] * py + M[2] * pz + M[3];
     a.out_positions[3 * n + 1] = M[4] * px + M[5] * py + M[6] * pz + M[7];
@@ -192,6 +214,7 @@ __global__ void __launch_bounds__(256) lbs_forward_kernel(AgLbsArgs a)
     for (int c = 0; c < 4; c++) a.out_rotations[4 * n + c] = cand[c] / den;
 }
 
+template <bool SPARSE>
 __global__ void __launch_bounds__(256) lbs_backward_kernel(AgLbsArgs a, float* __restrict__ g_positions,
                                                           float* __restrict__ g_rotations)
 {
@@ -199,12 +222,17 @@ __global__ void __launch_bounds__(256) lbs_backward_kernel(AgLbsArgs a, float* _
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int first = (blockIdx.x * 4 + wave) * 64;
     if (first >= a.N) return;
-    float* slab = lds + (size_t)wave * 64 * a.J;
-    stage_rows(a.lbs, a.N, a.J, first, slab, lane);
     const int n = first + lane;
-    if (n >= a.N) return;
     float M[12];
-    blend_matrix(slab + lane * a.J, a.jnt_mats, a.J, M);
+    if constexpr (SPARSE) {
+        if (n >= a.N) return;
+        blend_matrix_sparse(a.sp_idx, a.sp_w, a.K, a.N, n, a.jnt_mats, M);
+    } else {
+        float* slab = lds + (size_t)wave * 64 * a.J;
+        stage_rows(a.lbs, a.N, a.J, first, slab, lane);
+        if (n >= a.N) return;
+        blend_matrix(slab + lane * a.J, a.jnt_mats, a.J, M);
+    }
 
     // positions: dL/dp = M3^T g
     const float gx = a.out_positions[3 * n], gy = a.out_positions[3 * n + 1], gz = a.out_positions[3 * n + 2];
@@ -372,8 +400,10 @@ static int check_lbs(const AgLbsArgs* a)
 {
     if (!a || a->N < 0 || a->J < 1 || a->J > kMaxJ) { set_error("bad lbs sizes (1 <= J <= %d)", kMaxJ); return AG_ERR_INVALID_ARGUMENT; }
     if (a->N == 0) return AG_OK;
-    if (!a->lbs || !a->jnt_mats || !a->positions || !a->rotations || !a->out_positions || !a->out_rotations) {
-        set_error("null pointer in AgLbsArgs");
+    const bool sparse = a->K > 0;
+    if ((sparse ? (!a->sp_idx || !a->sp_w || a->K > a->J) : !a->lbs) || !a->jnt_mats || !a->positions || !a->rotations || !a->out_positions ||
+        !a->out_rotations) {
+        set_error("null pointer in AgLbsArgs (dense: lbs; sparse, K > 0: sp_idx + sp_w, K <= J)");
         return AG_ERR_INVALID_ARGUMENT;
     }
     return AG_OK;
@@ -390,8 +420,13 @@ int ag_lbs_forward(const AgLbsArgs* a, void* stream)
 {
     int rc = check_lbs(a);
     if (rc || a->N == 0) return rc;
-    const int lds = lbs_lds_bytes(a->J, reinterpret_cast<const void*>(&lbs_forward_kernel));
-    hipLaunchKernelGGL(lbs_forward_kernel, dim3((a->N + 255) / 256), dim3(256), lds, reinterpret_cast<hipStream_t>(stream), *a);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (a->K > 0) {
+        hipLaunchKernelGGL(lbs_forward_kernel<true>, dim3((a->N + 255) / 256), dim3(256), 0, s, *a);
+    } else {
+        const int lds = lbs_lds_bytes(a->J, reinterpret_cast<const void*>(&lbs_forward_kernel<false>));
+        hipLaunchKernelGGL(lbs_forward_kernel<false>, dim3((a->N + 255) / 256), dim3(256), lds, s, *a);
+    }
     return check_hip(hipGetLastError(), "lbs_forward_kernel");
 }
 
@@ -400,9 +435,13 @@ int ag_lbs_backward(const AgLbsArgs* a, float* g_positions, float* g_rotations, 
     int rc = check_lbs(a);
     if (rc || a->N == 0) return rc;
     if (!g_positions || !g_rotations) { set_error("null gradient output"); return AG_ERR_INVALID_ARGUMENT; }
-    const int lds = lbs_lds_bytes(a->J, reinterpret_cast<const void*>(&lbs_backward_kernel));
-    hipLaunchKernelGGL(lbs_backward_kernel, dim3((a->N + 255) / 256), dim3(256), lds, reinterpret_cast<hipStream_t>(stream), *a,
-                       g_positions, g_rotations);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (a->K > 0) {
+        hipLaunchKernelGGL(lbs_backward_kernel<true>, dim3((a->N + 255) / 256), dim3(256), 0, s, *a, g_positions, g_rotations);
+    } else {
+        const int lds = lbs_lds_bytes(a->J, reinterpret_cast<const void*>(&lbs_backward_kernel<false>));
+        hipLaunchKernelGGL(lbs_backward_kernel<false>, dim3((a->N + 255) / 256), dim3(256), lds, s, *a, g_positions, g_rotations);
+    }
     return check_hip(hipGetLastError(), "lbs_backward_kernel");
 }
 

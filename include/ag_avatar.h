@@ -72,6 +72,14 @@ typedef struct AgLbsArgs {
     const float* rotations;     /* [N,4] */
     float* out_positions;       /* [N,3]  (backward: dL/d out_positions, input) */
     float* out_rotations;       /* [N,4]  (backward: dL/d out_rotations, input) */
+    /* Sparse form of `lbs` (K > 0 selects it; `lbs` may then be NULL).  Blend-weight rows interpolated from the SMPL-X skinning weights
+     * have at most ~12 non-zeros out of 55 (gen_data/gen_pos_maps.py:24-39,132): K (joint, weight) pairs per Gaussian, ascending
+     * joints, zero-weight padded, stored [K][N] -- 5 K bytes per Gaussian instead of 4 J.  Skipping exact zeros leaves every partial
+     * sum of the blend unchanged, so results equal the dense path's. */
+    const uint8_t* sp_idx;      /* [K, N] joint indices */
+    const float* sp_w;          /* [K, N] weights */
+    int32_t K;                  /* 0: dense */
+    int32_t reserved;
 } AgLbsArgs;
 
 int ag_lbs_forward(const AgLbsArgs* args, void* stream);

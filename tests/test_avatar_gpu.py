@@ -123,6 +123,50 @@ def test_lbs_all_matrix_to_quaternion_branches():
     _close(grot.grad, rot.grad, "dL_drotations", 1e-4)
 
 
+def test_sparse_lbs_rows_give_the_dense_results():
+    """blend-weight rows are mostly exact zeros; the (joint, weight)-pair form reads 5 K instead of 4 J bytes per
+    Gaussian and must give the DENSE kernels' results bit for bit (a skipped term is + 0 * A), forward and backward; rows with too
+    many non-zeros (weights sampled from the diffused volume) fall back to the dense path."""
+    import torch
+    from animatablegaussians_amd import avatar_ops as ops
+    d = _synthetic(seed=3)
+    lbs = d["lbs"].cuda()
+    # ragged sparsity: 1..6 non-zeros per row, a few rows with a single joint
+    N, J = lbs.shape
+    g = torch.Generator().manual_seed(5)
+    extra = torch.rand(N, J, generator=g).cuda() * (torch.rand(N, J, generator=g).cuda() < 0.03)
+    lbs = lbs + extra
+    lbs[::7] = 0
+    lbs[::7, 11] = 1.0
+    lbs = (lbs / lbs.sum(1, keepdim=True)).contiguous()
+    sp = ops.SparseLbs.build(lbs)
+    assert sp is not None and 4 <= sp.K <= 16 and sp.idx.dtype == torch.uint8 and tuple(sp.idx.shape) == (sp.K, N)
+    # the pairs reproduce the rows
+    back = torch.zeros_like(lbs).t().contiguous()
+    back.scatter_add_(0, sp.idx.long(), sp.w)
+    assert torch.equal(back.t(), lbs)
+    assert bool((sp.idx[1:].long() >= sp.idx[:-1].long())[sp.w[1:] != 0].all())           # ascending joints within a row
+    pos = d["xyz"].cuda().requires_grad_(True)
+    rot = torch.nn.functional.normalize(torch.randn(N, 4, generator=g)).cuda().requires_grad_(True)
+    A = d["jnt_mats"].cuda()
+    up = [torch.randn(N, 3, generator=g).cuda(), torch.randn(N, 4, generator=g).cuda()]
+    outs = {}
+    for name, sparse in (("dense", None), ("sparse", sp)):
+        pos.grad = rot.grad = None
+        p, r = ops.lbs_transform(pos, rot, lbs, A, sparse)
+        torch.autograd.backward([p, r], up)
+        outs[name] = [t.detach().clone() for t in (p, r, pos.grad, rot.grad)]
+    for a, b, what in zip(outs["dense"], outs["sparse"], ("positions", "rotations", "dL_dpositions", "dL_drotations")):
+        assert torch.equal(a, b), f"{what}: sparse differs from dense by {float((a - b).abs().max()):.3e}"
+    # dense rows: no sparse form
+    assert ops.SparseLbs.build(torch.softmax(torch.randn(100, J, generator=g), 1).cuda()) is None
+    # the avatar core picks it up by itself
+    from animatablegaussians_amd.avatar import AvatarRenderCore
+    core = AvatarRenderCore(d["mask"].cuda(), d["xyz"].cuda(), d["opacity_raw"].cuda(), d["scaling_raw"].cuda(), d["rotation_raw"].cuda(),
+                            d["lbs"].cuda())
+    assert core.lbs_sparse is not None and core.lbs_sparse.K == 4
+
+
 def test_avatar_render_core_end_to_end():
     """maps -> gather/activations -> LBS -> render3 -> rasterizer, forward and backward, against the composition of the
     torch oracle (assembly + skinning) with the C rasterizer oracle."""

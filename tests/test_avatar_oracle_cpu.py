@@ -1,0 +1,55 @@
+"""Third-party pin of the two pytorch3d 0.7.4 helpers restated in oracle/avatar_oracle.py (pytorch3d is absent from /root/reference
+and not installable here): ``quaternion_to_matrix`` / ``matrix_to_quaternion`` against ``scipy.spatial.transform.Rotation`` -- an
+independent implementation -- on orthonormal inputs, float64, both directions, insensitive to the q / -q ambiguity.  What scipy
+cannot pin (and this file says so): the behaviour on NON-orthonormal matrices (the blended LBS matrices are not rotations), where
+the restatement follows pytorch3d 0.7.4 ``transforms/rotation_conversions.py`` as published: four ``sqrt(max(0, 1 +- m00 +- m11 +-
+m22))`` candidates, arg-max row, division by ``2 * max(q_abs, 0.1)``, no sign standardisation -- tests/test_avatar_gpu.py covers
+those branches against the restatement itself."""
+import numpy as np
+import torch
+from scipy.spatial.transform import Rotation
+
+from oracle import avatar_oracle as ao
+
+
+def _random_unit_quats(n, seed):
+    q = np.random.RandomState(seed).standard_normal((n, 4))
+    return q / np.linalg.norm(q, axis=1, keepdims=True)
+
+
+def test_quaternion_to_matrix_matches_scipy_and_ignores_the_norm():
+    q = _random_unit_quats(2000, 0)                                   # (r, i, j, k)
+    want = Rotation.from_quat(q[:, [1, 2, 3, 0]]).as_matrix()         # scipy: (x, y, z, w)
+    got = ao.quaternion_to_matrix(torch.from_numpy(q)).numpy()
+    np.testing.assert_allclose(got, want, atol=1e-13)
+    # two_s = 2 / |q|^2: any non-zero scaling of q gives the same rotation (the LBS output quaternions are not unit)
+    s = np.random.RandomState(1).uniform(0.2, 5.0, (2000, 1))
+    np.testing.assert_allclose(ao.quaternion_to_matrix(torch.from_numpy(q * s)).numpy(), want, atol=1e-12)
+
+
+def test_matrix_to_quaternion_matches_scipy_up_to_sign_on_every_branch():
+    q = _random_unit_quats(4000, 2)
+    # make sure each of the four arg-max branches is exercised: force the largest component in turn
+    for c in range(4):
+        blk = q[c * 1000:(c + 1) * 1000]
+        blk[:, c] = np.sign(blk[:, c] + 1e-300) * (np.abs(blk).max(axis=1) + 0.5)
+        blk /= np.linalg.norm(blk, axis=1, keepdims=True)
+    R = Rotation.from_quat(q[:, [1, 2, 3, 0]]).as_matrix()
+    got = ao.matrix_to_quaternion(torch.from_numpy(R)).numpy()
+    branch = np.abs(got).argmax(axis=1)
+    assert set(branch.tolist()) == {0, 1, 2, 3}
+    sign = np.sign((got * q).sum(axis=1, keepdims=True))              # q and -q are the same rotation
+    np.testing.assert_allclose(got * sign, q, atol=1e-12)
+    np.testing.assert_allclose(np.linalg.norm(got, axis=1), 1.0, atol=1e-12)
+    # round trip through scipy's own converter
+    back = Rotation.from_matrix(R).as_quat()[:, [3, 0, 1, 2]]
+    sign2 = np.sign((got * back).sum(axis=1, keepdims=True))
+    np.testing.assert_allclose(got * sign2, back, atol=1e-12)
+
+
+def test_round_trip_and_float32_behaviour():
+    q = torch.from_numpy(_random_unit_quats(1000, 3)).float()
+    R = ao.quaternion_to_matrix(q)
+    q2 = ao.matrix_to_quaternion(R)
+    sign = torch.sign((q * q2).sum(-1, keepdim=True))
+    assert float((q2 * sign - q).abs().max()) < 5e-6
