@@ -49,7 +49,7 @@ class AgRasterBackwardArgs(ctypes.Structure):
         ("geom_buffer", c_vp), ("image_buffer", c_vp), ("binning_buffer", c_vp),
         ("dL_dmeans2D", c_vp), ("dL_dcolors", c_vp), ("dL_dopacity", c_vp), ("dL_dmeans3D", c_vp),
         ("dL_dcov3D", c_vp), ("dL_dsh", c_vp), ("dL_dscales", c_vp), ("dL_drotations", c_vp),
-        ("accum_buffer", c_vp), ("accum_bytes", c_sz),
+        ("accum_buffer", c_vp), ("accum_bytes", c_sz), ("accumulate", c_i32), ("reserved", c_i32),
     ]
 
 
@@ -99,6 +99,8 @@ SYMBOLS = [
     ("ag_raster_forward_render", ctypes.c_int, [ctypes.POINTER(AgRasterForwardArgs), c_i32, c_vp]),
     ("ag_raster_forward_optimistic", ctypes.c_int, [ctypes.POINTER(AgRasterForwardArgs), c_i32, c_vp, ctypes.POINTER(c_i32)]),
     ("ag_raster_backward", ctypes.c_int, [ctypes.POINTER(AgRasterBackwardArgs), c_vp]),
+    ("ag_raster_forward_backward", ctypes.c_int, [ctypes.POINTER(AgRasterForwardArgs), ctypes.POINTER(AgRasterBackwardArgs), c_i32, c_vp,
+                                                  ctypes.POINTER(c_i32)]),
     ("ag_raster_mark_visible", ctypes.c_int, [c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
     ("ag_prof_kernel_name", ctypes.c_char_p, [c_i32]),
     ("ag_prof_enable", ctypes.c_int, [ctypes.c_uint32]),

@@ -209,7 +209,7 @@ int ag_raster_forward_render(const AgRasterForwardArgs* a, int32_t R, void* stre
     return launch_blend_forward(*a, R, s);
 }
 
-int ag_raster_backward(const AgRasterBackwardArgs* a, void* stream)
+static int validate_backward(const AgRasterBackwardArgs* a)
 {
     if (!a) { set_error("null args"); return AG_ERR_INVALID_ARGUMENT; }
     if (a->P < 0 || a->W <= 0 || a->H <= 0 || a->num_rendered < 0) { set_error("bad sizes"); return AG_ERR_INVALID_ARGUMENT; }
@@ -220,6 +220,7 @@ int ag_raster_backward(const AgRasterBackwardArgs* a, void* stream)
             set_error("bad SH degree / coefficient count");
             return AG_ERR_INVALID_ARGUMENT;
         }
+        if (a->accumulate) { set_error("accumulate: colours-precomp path only"); return AG_ERR_UNSUPPORTED; }
     }
     if (!a->means3D || !a->radii || !a->bg || !a->viewmatrix || !a->projmatrix || !a->alphas || !a->dL_dout_color ||
         !a->dL_dout_depth || !a->dL_dout_alpha || !a->geom_buffer || !a->image_buffer) {
@@ -234,10 +235,57 @@ int ag_raster_backward(const AgRasterBackwardArgs* a, void* stream)
         return AG_ERR_INVALID_ARGUMENT;
     }
     if (!a->accum_buffer || a->accum_bytes < ag_raster_accum_bytes(a->P)) { set_error("accum_buffer too small"); return AG_ERR_SCRATCH_TOO_SMALL; }
+    return AG_OK;
+}
+
+int ag_raster_backward(const AgRasterBackwardArgs* a, void* stream)
+{
+    int rc = validate_backward(a);
+    if (rc || a->P == 0) return rc;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    int rc;
     if ((rc = launch_blend_backward(*a, s))) return rc;
     return launch_preprocess_backward(*a, s);
+}
+
+int ag_raster_forward_backward(const AgRasterForwardArgs* f, AgRasterBackwardArgs* b, int32_t capacity, void* stream,
+                               int32_t* num_rendered_host)
+{
+    if (!f || !b || !num_rendered_host) { set_error("null args"); return AG_ERR_INVALID_ARGUMENT; }
+    *num_rendered_host = 0;
+    if (capacity <= 0) { set_error("capacity must be positive"); return AG_ERR_INVALID_ARGUMENT; }
+    if (f->shs && !f->colors_precomp) { set_error("ag_raster_forward_backward: colours-precomp path only"); return AG_ERR_UNSUPPORTED; }
+    // complete the backward arguments from the forward's
+    b->P = f->P; b->W = f->W; b->H = f->H; b->sh_degree = f->sh_degree; b->sh_coeffs = f->sh_coeffs; b->num_rendered = capacity;
+    b->tan_fovx = f->tan_fovx; b->tan_fovy = f->tan_fovy; b->scale_modifier = f->scale_modifier;
+    b->bg = f->bg; b->means3D = f->means3D; b->radii = f->radii; b->colors_precomp = f->colors_precomp; b->shs = f->shs;
+    b->scales = f->scales; b->rotations = f->rotations; b->cov3D_precomp = f->cov3D_precomp;
+    b->viewmatrix = f->viewmatrix; b->projmatrix = f->projmatrix; b->campos = f->campos; b->alphas = f->out_alpha;
+    b->geom_buffer = f->geom_buffer; b->image_buffer = f->image_buffer; b->binning_buffer = f->binning_buffer;
+    int rc = validate_forward(f, true, capacity);
+    if (rc) return rc;
+    if ((rc = validate_backward(b))) return rc;
+    if (f->P == 0) return ag_raster_forward_render(f, 0, stream);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    int32_t* w = pinned_word();
+    hipEvent_t ev = plan_event();
+    if (!w || !ev) { set_error("hipHostMalloc / hipEventCreate failed"); return AG_ERR_HIP; }
+    if ((rc = launch_preprocess(*f, s))) return rc;
+    if ((rc = launch_tile_scan(*f, s, (uint32_t)capacity))) return rc;
+    ImageLayout il((size_t)f->W, (size_t)f->H);
+    const char* ib = aligned_base(f->image_buffer);
+    if ((rc = check_hip(hipMemcpyAsync(w, ib + il.num_rendered, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, s), "read num_rendered"))) return rc;
+    if ((rc = check_hip(hipEventRecord(ev, s), "record plan event"))) return rc;
+    if ((rc = launch_bin_sort(*f, capacity, s))) return rc;
+    if ((rc = launch_blend_forward(*f, capacity, s))) return rc;
+    if ((rc = launch_blend_backward(*b, s))) return rc;
+    if ((rc = launch_preprocess_backward(*b, s))) return rc;
+    if ((rc = check_hip(hipEventSynchronize(ev), "wait for the instance count"))) return rc;
+    *num_rendered_host = w[0];
+    if (w[2]) {
+        set_error("forward+backward: %d instances exceed the capacity of %d; redo the view with a larger capacity", w[0], capacity);
+        return AG_ERR_SCRATCH_TOO_SMALL;
+    }
+    return AG_OK;
 }
 
 const char* ag_prof_kernel_name(int32_t id)

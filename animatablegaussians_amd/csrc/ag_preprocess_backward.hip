@@ -70,6 +70,7 @@ struct PreBwdParams {
     float* __restrict__ dL_dcov3D;
     float* __restrict__ dL_dscales;
     float* __restrict__ dL_drotations;
+    int accumulate;                          // 1: add into the outputs (sum over the views of a step) instead of overwriting them
 };
 
 __global__ void __launch_bounds__(256) preprocess_backward_kernel(PreBwdParams p)
@@ -226,6 +227,20 @@ __global__ void __launch_bounds__(256) preprocess_backward_kernel(PreBwdParams p
         float* row = p.dL_dsh + (size_t)idx * p.sh_coeffs * 3;
         for (int i = first; i < 3 * p.sh_coeffs; i++) row[i] = 0.f;
     }
+    if (p.accumulate) {     // multi-view step: every Gaussian is owned by this thread, so plain read-modify-write sums the views
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            g_m2[k] += p.dL_dmeans2D[3 * idx + k];
+            g_col[k] += p.dL_dcolors[3 * idx + k];
+            g_mean[k] += p.dL_dmeans3D[3 * idx + k];
+            g_scale[k] += p.dL_dscales[3 * idx + k];
+        }
+        g_op += p.dL_dopacity[idx];
+#pragma unroll
+        for (int k = 0; k < 6; k++) g_cov[k] += p.dL_dcov3D[6 * idx + k];
+#pragma unroll
+        for (int k = 0; k < 4; k++) g_rot[k] += p.dL_drotations[4 * idx + k];
+    }
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         p.dL_dmeans2D[3 * idx + k] = g_m2[k];
@@ -258,6 +273,7 @@ int launch_preprocess_backward(const AgRasterBackwardArgs& a, hipStream_t s)
     p.dL_dmeans2D = a.dL_dmeans2D; p.dL_dcolors = a.dL_dcolors; p.dL_dopacity = a.dL_dopacity;
     p.dL_dmeans3D = a.dL_dmeans3D; p.dL_dcov3D = a.dL_dcov3D; p.dL_dscales = a.dL_dscales;
     p.dL_drotations = a.dL_drotations;
+    p.accumulate = a.accumulate;
     { ProfScope ps(AG_K_PREPROCESS_BACKWARD, s); hipLaunchKernelGGL(preprocess_backward_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, p); }
     return check_hip(hipGetLastError(), "preprocess_backward_kernel");
 }

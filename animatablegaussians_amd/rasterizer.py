@@ -331,3 +331,124 @@ class GaussianRasterizer(nn.Module):
         cov3D_precomp = empty if cov3D_precomp is None else cov3D_precomp
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
                                    self.raster_settings)
+
+
+class FusedRasterStep:
+    """Forward AND backward of camera views in one native call each (``ag_raster_forward_backward``), for callers that hold the upstream
+    image gradients when they render: the inner loop of a multi-view trainer, the throughput benchmark.  No autograd node, no Python
+    between the two halves, and the library owns what ``bench.py`` used to do by hand in round 1:
+
+    * consecutive views go to ``n_streams`` internal HIP streams in turn (views are independent; the one host wait per view -- the
+      instance count -- then overlaps the other stream's kernels);
+    * scratch (geometry / image / binning / accumulator buffers) is allocated once per stream and reused;
+    * ``accumulate=True`` sums the per-Gaussian gradients over the views of a step on the device (per stream, ``join()`` adds the
+      streams): the quantity view-sharded training exchanges.
+
+    Colours-precomp path only (what the avatar uses, ``gaussians/gaussian_renderer.py:84``).  Results equal
+    ``GaussianRasterizer`` + autograd on the same inputs (tests/test_raster_gpu.py)."""
+
+    _GRADS = (("dL_dmeans2D", 3), ("dL_dcolors", 3), ("dL_dopacity", 1), ("dL_dmeans3D", 3), ("dL_dcov3D", 6), ("dL_dscales", 3),
+              ("dL_drotations", 4))
+
+    def __init__(self, P: int, W: int, H: int, device, n_streams: int = 2):
+        self.P, self.W, self.H = int(P), int(W), int(H)
+        self.dev = torch.device(device)
+        self.key = (self.P, self.W, self.H, self.dev.index)
+        byte = dict(dtype=torch.uint8, device=self.dev)
+        self.slots = []
+        for _ in range(max(1, n_streams)):
+            grads = {name: torch.zeros((self.P, c), dtype=torch.float32, device=self.dev) for name, c in self._GRADS}
+            self.slots.append(dict(stream=torch.cuda.Stream(self.dev), grads=grads, used=False,
+                                   geom=torch.empty((_scratch_bytes("geom", self.P),), **byte),
+                                   img=torch.empty((_scratch_bytes("image", self.W, self.H),), **byte),
+                                   accum=torch.empty((_scratch_bytes("accum", self.P),), **byte), binning=None, cap=0))
+        self._next = 0
+
+    def _binning(self, slot, cap):
+        if slot["binning"] is None or slot["cap"] < cap:
+            slot["binning"] = torch.empty((_scratch_bytes("binning", cap),), dtype=torch.uint8, device=self.dev)
+            slot["cap"] = cap
+        return slot["binning"]
+
+    def view(self, rs: GaussianRasterizationSettings, means3D, colors, opacities, scales, rotations, g_color, g_depth, g_alpha,
+             accumulate: bool = False, slot: Optional[int] = None):
+        """Enqueue forward + backward of one view.  Returns ``(color, depth, alpha, radii, grads)``; ``grads`` is the slot's dict of
+        gradient arrays (valid on the slot's stream; ``join()`` before reading them from another stream)."""
+        L = _lib.lib()
+        P, W, H, dev = self.P, self.W, self.H, self.dev
+        if int(means3D.size(0)) != P or int(rs.image_width) != W or int(rs.image_height) != H:
+            raise RuntimeError("FusedRasterStep: sizes differ from the ones it was built for")
+        k = self._next % len(self.slots) if slot is None else int(slot)
+        self._next += 1
+        sl = self.slots[k]
+        f32 = dict(dtype=torch.float32, device=dev)
+        color, depth, alpha = torch.empty((NUM_CHANNELS, H, W), **f32), torch.empty((1, H, W), **f32), torch.empty((1, H, W), **f32)
+        radii = torch.empty((P,), dtype=torch.int32, device=dev)
+        if P == 0:
+            for t in (color, depth, alpha):
+                t.zero_()
+            return color, depth, alpha, radii, sl["grads"]
+        ins = [_f32c(t, n) for t, n in ((means3D, "means3D"), (colors, "colors_precomp"), (opacities, "opacities"), (scales, "scales"),
+                                        (rotations, "rotations"), (rs.bg, "bg"), (rs.viewmatrix, "viewmatrix"),
+                                        (rs.projmatrix, "projmatrix"), (rs.campos, "campos"), (g_color, "dL_dout_color"),
+                                        (g_depth, "dL_dout_depth"), (g_alpha, "dL_dout_alpha"))]
+        means3D, colors, opacities, scales, rotations, bg, viewmatrix, projmatrix, campos, g_color, g_depth, g_alpha = ins
+        a = _lib.AgRasterForwardArgs()
+        a.P, a.W, a.H = P, W, H
+        a.sh_degree = a.sh_coeffs = 0
+        a.prefiltered = int(bool(rs.prefiltered))
+        a.tan_fovx, a.tan_fovy, a.scale_modifier = float(rs.tanfovx), float(rs.tanfovy), float(rs.scale_modifier)
+        a.bg = _ptr(bg); a.means3D = _ptr(means3D); a.colors_precomp = _ptr(colors); a.opacities = _ptr(opacities)
+        a.scales = _ptr(scales); a.rotations = _ptr(rotations)
+        a.viewmatrix = _ptr(viewmatrix); a.projmatrix = _ptr(projmatrix); a.campos = _ptr(campos)
+        a.out_color = _ptr(color); a.out_depth = _ptr(depth); a.out_alpha = _ptr(alpha); a.radii = _ptr(radii)
+        a.geom_buffer = _ptr(sl["geom"]); a.geom_bytes = sl["geom"].numel()
+        a.image_buffer = _ptr(sl["img"]); a.image_bytes = sl["img"].numel()
+        b = _lib.AgRasterBackwardArgs()
+        b.dL_dout_color = _ptr(g_color); b.dL_dout_depth = _ptr(g_depth); b.dL_dout_alpha = _ptr(g_alpha)
+        g = sl["grads"]
+        b.dL_dmeans2D = _ptr(g["dL_dmeans2D"]); b.dL_dcolors = _ptr(g["dL_dcolors"]); b.dL_dopacity = _ptr(g["dL_dopacity"])
+        b.dL_dmeans3D = _ptr(g["dL_dmeans3D"]); b.dL_dcov3D = _ptr(g["dL_dcov3D"]); b.dL_dscales = _ptr(g["dL_dscales"])
+        b.dL_drotations = _ptr(g["dL_drotations"])
+        b.accum_buffer = _ptr(sl["accum"]); b.accum_bytes = sl["accum"].numel()
+        b.accumulate = int(bool(accumulate and sl["used"]))       # the slot's first view of a step writes, later ones add
+        st = sl["stream"]
+        st.wait_stream(torch.cuda.current_stream(dev))            # inputs were produced on the caller's stream
+        R = ctypes.c_int32(0)
+        with _on_device(dev):
+            cap = _capacity.get(self.key) or (4 * P + 4096)
+            while True:
+                binning = self._binning(sl, cap)
+                a.binning_buffer = _ptr(binning); a.binning_bytes = binning.numel()
+                rc = L.ag_raster_forward_backward(ctypes.byref(a), ctypes.byref(b), cap, ctypes.c_void_p(st.cuda_stream), ctypes.byref(R))
+                if rc != _lib.AG_ERR_SCRATCH_TOO_SMALL:
+                    _lib.check(rc, "ag_raster_forward_backward")
+                    break
+                cap = int(R.value) + int(R.value) // 4 + 1024     # outgrown: the sums are untouched, redo the view
+        want = int(R.value) + int(R.value) // 4 + 1024
+        if want > _capacity.get(self.key, 0):
+            _capacity[self.key] = want
+        sl["used"] = True
+        for t in ins + [color, depth, alpha, radii]:
+            t.record_stream(st)                                   # allocator: still in use on the internal stream
+        return color, depth, alpha, radii, g
+
+    def join(self):
+        """Order the caller's stream after every internal stream and return the gradients summed over the slots that were used since
+        the last ``join()`` (``{name: [P, c] tensor}``; the tensors belong to slot 0 and are overwritten by its next view)."""
+        cur = torch.cuda.current_stream(self.dev)
+        for sl in self.slots:
+            cur.wait_stream(sl["stream"])
+        used = [sl for sl in self.slots if sl["used"]]
+        for sl in self.slots:
+            sl["used"] = False
+        if not used:
+            return None
+        base = used[0]["grads"]
+        for sl in used[1:]:
+            for name, _ in self._GRADS:
+                base[name].add_(sl["grads"][name])
+        if used[0] is not self.slots[0]:
+            for name, _ in self._GRADS:
+                self.slots[0]["grads"][name].copy_(base[name])
+        return self.slots[0]["grads"]

