@@ -353,6 +353,8 @@ class FusedRasterStep:
     def __init__(self, P: int, W: int, H: int, device, n_streams: int = 2):
         self.P, self.W, self.H = int(P), int(W), int(H)
         self.dev = torch.device(device)
+        if self.dev.index is None:
+            self.dev = torch.device("cuda", torch.cuda.current_device())
         self.key = (self.P, self.W, self.H, self.dev.index)
         byte = dict(dtype=torch.uint8, device=self.dev)
         self.slots = []
