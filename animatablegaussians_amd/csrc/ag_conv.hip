@@ -28,6 +28,13 @@
 
 namespace ag {
 
+// ag_conv_pointwise.hip: 1 x 1 convolutions with <= 32 output rows or <= 4 input channels as streaming VALU kernels.
+// Return 1 when they handled the call, 0 when it is not theirs (the MFMA path below runs), < 0 on error.
+int pointwise_forward(const AgConvDesc* d, const float* x, const float* w, const float* out_scale, const float* bias, float* y, hipStream_t s);
+int pointwise_backward_input(const AgConvDesc* d, const float* dy, const float* w, float* dx, hipStream_t s);
+int pointwise_backward_weight(const AgConvDesc* d, const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes,
+                              hipStream_t s);
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: HIP's float4 struct in arrays defeats SROA (scratch spills)
 
@@ -881,6 +888,7 @@ int ag_conv_forward(const AgConvDesc* d, const float* x, const float* w, const f
     int rc = validate(d);
     if (rc) return rc;
     if (!x || !w || !y) { set_error("null conv tensor"); return AG_ERR_INVALID_ARGUMENT; }
+    if ((rc = pointwise_forward(d, x, w, out_scale, bias, y, reinterpret_cast<hipStream_t>(stream))) != 0) return rc < 0 ? rc : AG_OK;
     return run_gather_family(d, false, x, w, out_scale, bias, y, workspace, workspace_bytes, reinterpret_cast<hipStream_t>(stream));
 }
 
@@ -890,17 +898,18 @@ int ag_conv_backward_input(const AgConvDesc* d, const float* dy, const float* w,
     int rc = validate(d);
     if (rc) return rc;
     if (!dy || !w || !dx) { set_error("null conv tensor"); return AG_ERR_INVALID_ARGUMENT; }
+    if ((rc = pointwise_backward_input(d, dy, w, dx, reinterpret_cast<hipStream_t>(stream))) != 0) return rc < 0 ? rc : AG_OK;
     return run_gather_family(d, true, dy, w, nullptr, nullptr, dx, workspace, workspace_bytes, reinterpret_cast<hipStream_t>(stream));
 }
 
 int ag_conv_backward_weight(const AgConvDesc* d, const float* x, const float* dy, float* dw, void* workspace,
                             size_t workspace_bytes, void* stream)
 {
-    (void)workspace; (void)workspace_bytes;
     int rc = validate(d);
     if (rc) return rc;
     if (!x || !dy || !dw) { set_error("null conv tensor"); return AG_ERR_INVALID_ARGUMENT; }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if ((rc = pointwise_backward_weight(d, x, dy, dw, workspace, workspace_bytes, s)) != 0) return rc < 0 ? rc : AG_OK;
     int OH, OW;
     out_size(d, OH, OW);
     const int k = d->k, k2 = k * k;

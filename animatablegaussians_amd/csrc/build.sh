@@ -28,6 +28,7 @@ compile "$HERE/ag_preprocess_backward.hip" $FAST &
 compile "$HERE/ag_avatar.hip" $FAST &
 compile "$HERE/ag_styleunet_ops.hip" $FAST &
 compile "$HERE/ag_conv.hip" $FAST &
+compile "$HERE/ag_conv_pointwise.hip" $FAST &
 compile "$HERE/ag_lpips.hip" $FAST &
 compile "$HERE/ag_smplx.hip" $FAST &
 fail=0

@@ -19,6 +19,14 @@ CASES = [
     ("ct3x3_s2", "convT", 16, 32, 9, 7, 3, 2, 0),
     ("ct3x3_s2_big", "convT", 128, 64, 16, 16, 3, 2, 0),
     ("c3x3_512", "conv", 512, 512, 16, 16, 3, 1, 1),
+    # 1 x 1 convolutions that run as streaming VALU kernels (ag_conv_pointwise.hip): ToRGB heads (12 / 32 output rows) and FromRGB
+    # (3 input channels), pixel counts that are multiples of 4 (the MFMA path keeps the rest: c1x1_rgb_in above)
+    ("pw_torgb12_small", "conv", 512, 12, 16, 16, 1, 1, 0),
+    ("pw_torgb12_slices", "conv", 64, 12, 160, 132, 1, 1, 0),
+    ("pw_torgb32", "conv", 256, 32, 128, 130, 1, 1, 0),
+    ("pw_torgb16_odd_channels", "conv", 70, 16, 144, 116, 1, 1, 0),
+    ("pw_fromrgb", "conv", 3, 128, 32, 32, 1, 1, 0),
+    ("pw_fromrgb_512", "conv", 3, 512, 16, 16, 1, 1, 0),
 ]
 
 
@@ -53,6 +61,31 @@ def test_conv_forward_backward(case):
     _close(xg.grad, x.grad, name + " dL/dx")
     _close(wg.grad, w.grad, name + " dL/dw")
     _close(bg.grad, b.grad, name + " dL/db")
+
+
+@pytest.mark.parametrize("shape", [(64, 64, 20, 3, 1, 1), (3, 128, 16, 1, 1, 0), (128, 12, 16, 1, 1, 0), (32, 48, 19, 3, 2, 0)])
+def test_weight_scale_is_the_prescaled_convolution(shape):
+    """conv2d(x, w, weight_scale=s) == conv2d(x, w * s) (EqualConv2d, dual_styleunet.py:100-117), with the weight gradient taken
+    w.r.t. the UN-scaled w and an out_scale / bias epilogue on top -- MFMA path and the pointwise kernels."""
+    import torch
+    import torch.nn.functional as F
+    from animatablegaussians_amd import conv as agc
+    Cin, Cout, hw, k, stride, padding = shape
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(1, Cin, hw, hw, generator=g, requires_grad=True)
+    w = torch.randn(Cout, Cin, k, k, generator=g, requires_grad=True)
+    b = torch.randn(Cout, generator=g)
+    sc = torch.rand(Cout, generator=g) + 0.5
+    s = 1.0 / np.sqrt(Cin * k * k)
+    ref = F.conv2d(x, w * s, None, stride=stride, padding=padding) * sc.view(1, -1, 1, 1) + b.view(1, -1, 1, 1)
+    gy = torch.randn(ref.shape, generator=g)
+    ref.backward(gy)
+    xg, wg = (t.detach().cuda().requires_grad_(True) for t in (x, w))
+    out = agc.conv2d(xg, wg, b.cuda(), stride=stride, padding=padding, out_scale=sc.cuda(), weight_scale=s)
+    _close(out, ref, "forward")
+    out.backward(gy.cuda())
+    _close(xg.grad, x.grad, "dL/dx")
+    _close(wg.grad, w.grad, "dL/dw")
 
 
 def test_conv_out_scale_epilogue_and_errors():
