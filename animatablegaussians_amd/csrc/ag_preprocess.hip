@@ -96,6 +96,11 @@ __global__ void __launch_bounds__(256) preprocess_kernel(PreParams p)
     // one per instance (which serialise in L2 at ~5 M/s per address and cost 190 us at avatar scale).
     __shared__ int s_win[4];             // min x, min y, max x, max y (tile units, max exclusive)
     __shared__ uint32_t s_hist[kWinBins];
+    // The 48-byte records and the 24-byte covariances leave through LDS: a thread's own record would be 12 + 6 dword stores at a
+    // 48 / 24-byte lane stride (every store instruction touches 24 cache lines); staged, the workgroup writes its 12 + 6 KB as 16-byte
+    // stores, lanes along addresses.  Round 2: 14.8 -> see DESIGN.md section 5.
+    __shared__ __attribute__((aligned(16))) float s_rec[256 * 12];
+    __shared__ __attribute__((aligned(16))) float s_cov[256 * 6];
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (threadIdx.x == 0) { s_win[0] = 0x7fffffff; s_win[1] = 0x7fffffff; s_win[2] = 0; s_win[3] = 0; }
     __syncthreads();
@@ -106,6 +111,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(PreParams p)
     for (int i = 0; i < 16; i++) { V[i] = p.view[i]; Pm[i] = p.proj[i]; }
 
     int my_radii = 0;
+    bool cov_set = false, rec_set = false;
     uint32_t touched = 0;
     uint32_t rx0 = 0, ry0 = 0, rx1 = 0, ry1 = 0;
     const bool valid = idx < p.P;
@@ -144,7 +150,8 @@ __global__ void __launch_bounds__(256) preprocess_kernel(PreParams p)
             c3[3] = Sigma.m[1][1]; c3[4] = Sigma.m[1][2]; c3[5] = Sigma.m[2][2];
         }
 #pragma unroll
-        for (int k = 0; k < 6; k++) p.cov3Ds[6 * idx + k] = c3[k];
+        for (int k = 0; k < 6; k++) s_cov[6 * threadIdx.x + k] = c3[k];
+        cov_set = true;
 
         // computeCov2D, forward.cu:74-113
         float tx = V[0] * ox + V[4] * oy + V[8] * oz + V[12];
@@ -203,7 +210,8 @@ __global__ void __launch_bounds__(256) preprocess_kernel(PreParams p)
                 }
                 g.r2cut = r2;
                 g.pad = 0.f;
-                p.rec[idx] = g;
+                *reinterpret_cast<GaussRec*>(s_rec + 12 * threadIdx.x) = g;
+                rec_set = true;
                 rx0 = x0; ry0 = y0; rx1 = x1; ry1 = y1;
             }
         }
@@ -212,8 +220,36 @@ __global__ void __launch_bounds__(256) preprocess_kernel(PreParams p)
         p.radii[idx] = my_radii;
         p.tiles_touched[idx] = touched;
     }
+    // culled Gaussians: their record / covariance is never read (no tile list names them); zeros keep the scratch deterministic
+    if (!rec_set) {
+#pragma unroll
+        for (int k = 0; k < 12; k++) s_rec[12 * threadIdx.x + k] = 0.f;
+    }
+    if (!cov_set) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) s_cov[6 * threadIdx.x + k] = 0.f;
+    }
     window_accumulate(s_win, touched != 0, (int)rx0, (int)ry0, (int)rx1, (int)ry1);
     __syncthreads();
+    {
+        const int first = blockIdx.x * 256, nv = min(256, p.P - first);          // Gaussians of this workgroup
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        f4* drec = reinterpret_cast<f4*>(p.rec + first);                           // 48 B * 256 * blockIdx: 16-byte aligned
+        const f4* srec = reinterpret_cast<const f4*>(s_rec);
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const int i = threadIdx.x + 256 * j;
+            if (i < nv * 3) drec[i] = srec[i];
+        }
+        float* dcov = p.cov3Ds + (size_t)first * 6;                                // 24 B * 256 * blockIdx: 16-byte aligned
+        const int nf = nv * 6, nf4 = nf >> 2;
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int i = threadIdx.x + 256 * j;
+            if (i < nf4) reinterpret_cast<f4*>(dcov)[i] = reinterpret_cast<const f4*>(s_cov)[i];
+        }
+        if ((int)threadIdx.x < (nf & 3)) dcov[4 * nf4 + threadIdx.x] = s_cov[4 * nf4 + threadIdx.x];
+    }
     const int wx0 = s_win[0], wy0 = s_win[1];
     const int bw = s_win[2] - wx0, bh = s_win[3] - wy0;
     if (bw <= 0 || bh <= 0) return;                       // nothing visible in this workgroup (uniform)
