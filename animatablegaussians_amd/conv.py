@@ -8,12 +8,34 @@ Supported = what the product uses (batch 1, groups 1): conv2d k in {1,3,4}, stri
 from __future__ import annotations
 
 import ctypes
+import os
 
 import torch
 
 from . import _lib
 
 AG_CONV, AG_CONV_TRANSPOSE = 0, 1
+MATH_MODES = {"fp32": 0, "split_bf16": 1, "split_bf16x3": 2}      # include/ag_conv.h AgConvMath
+
+
+def set_math(mode: str) -> str:
+    """Arithmetic of the MFMA convolutions, process-wide: ``"split_bf16"`` (default: fp32 operands as three bf16 parts, six products
+    on the bf16 matrix pipe, fp32 accumulation -- products within 2^-23 of the exact ones), ``"fp32"`` (v_mfma_f32_32x32x2_f32) or
+    the opt-in ``"split_bf16x3"`` (three products, 3 * 2^-16 per product: not fp32-grade).  Returns the previous mode."""
+    if mode not in MATH_MODES:
+        raise ValueError(f"conv math mode must be one of {sorted(MATH_MODES)}")
+    prev = get_math()
+    _lib.check(_lib.lib().ag_conv_set_math(MATH_MODES[mode]), "ag_conv_set_math")
+    return prev
+
+
+def get_math() -> str:
+    m = _lib.lib().ag_conv_get_math()
+    return next(k for k, v in MATH_MODES.items() if v == m)
+
+
+if os.environ.get("AG_CONV_MATH"):          # A/B hook for the profiles/ scripts: initial mode of the process
+    set_math(os.environ["AG_CONV_MATH"])
 
 
 def _p(t):

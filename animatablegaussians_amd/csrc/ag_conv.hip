@@ -20,6 +20,7 @@
 // reads).  Global->register loads of tile k+1 are issued before the MFMAs of tile k and written to the other LDS buffer
 // after them (one LDS-only barrier per K step).
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 
 #include "ag_common.h"
@@ -134,6 +135,53 @@ struct GatherProblem {
     float* partial;        // gridDim.z > 1: raw accumulators go to partial[z][Mpad][Ncols] and reduce_splits_kernel finishes
     GatherClass cls[kMaxClasses];
 };
+
+// Epilogue shared by the gather kernels.  C/D layout of the 32 x 32 MFMAs: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+template <int WMB, int WNB>
+__device__ __forceinline__ void gather_epilogue(const GatherProblem& p, const GatherClass& cl, f32x16 (&acc)[WMB][WNB], int m0, int n0,
+                                                int N, int wm, int wn, int lane)
+{
+    const int gw = cl.gw;
+    const int col = lane & 31, rbase = 4 * (lane >> 5);
+    if (gridDim.z > 1) {
+        float* part = p.partial + (size_t)blockIdx.z * p.Mpad * p.Ncols + cl.col_begin;
+#pragma unroll
+        for (int i = 0; i < WMB; i++)
+#pragma unroll
+            for (int j = 0; j < WNB; j++) {
+                const int nn = n0 + (wn * WNB + j) * 32 + col;
+                if (nn >= N) continue;
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int m = m0 + (wm * WMB + i) * 32 + (r & 3) + 8 * (r >> 2) + rbase;
+                    part[(size_t)m * p.Ncols + nn] = acc[i][j][r];
+                }
+            }
+        return;
+    }
+    int nn[WNB];
+    size_t opix[WNB];
+#pragma unroll
+    for (int j = 0; j < WNB; j++) {
+        nn[j] = n0 + (wn * WNB + j) * 32 + col;
+        const int q = min(nn[j], N - 1);
+        const int oy = q / gw, ox = q - oy * gw;
+        opix[j] = (size_t)(cl.y0 + oy * p.os) * p.OWf + (cl.x0 + ox * p.os);
+    }
+    const bool has_scale = p.out_scale != nullptr, has_bias = p.bias != nullptr;
+#pragma unroll
+    for (int i = 0; i < WMB; i++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int m = m0 + (wm * WMB + i) * 32 + (r & 3) + 8 * (r >> 2) + rbase;
+            if (m >= p.M) continue;
+            const float sc = has_scale ? p.out_scale[m] : 1.f, bi = has_bias ? p.bias[m] : 0.f;
+            float* row = p.yout + (size_t)m * p.OHf * p.OWf;
+#pragma unroll
+            for (int j = 0; j < WNB; j++)
+                if (nn[j] < N) row[opix[j]] = acc[i][j][r] * sc + bi;
+        }
+}
 
 // K is ordered (channel block of 16, tap, channel in block), so the 16 rows of a K tile are 16 consecutive channels of ONE tap:
 // the tap (and with it the input offset and the padding test) is a wave-uniform scalar per tile, each thread keeps the
@@ -288,46 +336,259 @@ __global__ void __launch_bounds__(64 * WVM * WVN, AG_CONV_WAVES_PER_SIMD) gather
     }
     // (the gather kernel above and the wgrad kernel below share this loop shape)
 
-    // epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-    const int col = lane & 31, rbase = 4 * (lane >> 5);
-    if (gridDim.z > 1) {
-        float* part = p.partial + (size_t)blockIdx.z * p.Mpad * p.Ncols + cl.col_begin;
-#pragma unroll
-        for (int i = 0; i < WMB; i++)
-#pragma unroll
-            for (int j = 0; j < WNB; j++) {
-                const int nn = n0 + (wn * WNB + j) * 32 + col;
-                if (nn >= N) continue;
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const int m = m0 + (wm * WMB + i) * 32 + (r & 3) + 8 * (r >> 2) + rbase;
-                    part[(size_t)m * p.Ncols + nn] = acc[i][j][r];
-                }
-            }
-        return;
-    }
-    int nn[WNB];
-    size_t opix[WNB];
-#pragma unroll
-    for (int j = 0; j < WNB; j++) {
-        nn[j] = n0 + (wn * WNB + j) * 32 + col;
-        const int q = min(nn[j], N - 1);
-        const int oy = q / gw, ox = q - oy * gw;
-        opix[j] = (size_t)(cl.y0 + oy * p.os) * p.OWf + (cl.x0 + ox * p.os);
-    }
-    const bool has_scale = p.out_scale != nullptr, has_bias = p.bias != nullptr;
+    gather_epilogue<WMB, WNB>(p, cl, acc, m0, n0, N, wm, wn, lane);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// fp32 products on the bf16 matrix pipe: three-way split, six MFMAs per K tile
+// ------------------------------------------------------------------------------------------------------------------
+// v_mfma_f32_32x32x2_f32 retires 64 FLOP / clk / SIMD, v_mfma_f32_32x32x16_bf16 1024.  Every fp32 operand is written as the sum of
+// three bf16 numbers x = x0 + x1 + x2 (x0 = rn_bf16(x), x1 = rn_bf16(x - x0), x2 = rn_bf16(x - x0 - x1): each subtraction is exact
+// in fp32 and |x - x0 - x1 - x2| <= 2^-27 |x|), and a product a * b is formed as the six terms a_i b_j with i + j <= 2, each an
+// exact fp32 product inside the matrix core, accumulated in fp32.  The dropped terms (a1 b2, a2 b1, a2 b2, and the split
+// remainders) are <= 2^-23 |a| |b| in the worst case and ~2^-25 rms -- the size of the rounding of the fp32 product itself.  One K
+// tile of a 32 x 32 block costs 6 x 32 = 192 matrix-pipe cycles instead of 8 x 64 = 512.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+constexpr int kPlanes = 3;
+constexpr int kRowB = 2 * BK;        // bytes of one row (16 bf16) of a plane: two 16-byte chunks
+
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi)       // v_cvt_pk_bf16_f32 (round to nearest even)
+{
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){ lo, hi }, bf16x2));
+}
+// two fp32 values -> three words holding (lo, hi) bf16 pairs of the three planes
+__device__ __forceinline__ void split_pair(float x0, float x1, uint32_t& p0, uint32_t& p1, uint32_t& p2)
+{
+    p0 = pack_bf16(x0, x1);
+    const float r0 = x0 - __uint_as_float(p0 << 16), r1 = x1 - __uint_as_float(p0 & 0xffff0000u);
+    p1 = pack_bf16(r0, r1);
+    const float s0 = r0 - __uint_as_float(p1 << 16), s1 = r1 - __uint_as_float(p1 & 0xffff0000u);
+    p2 = pack_bf16(s0, s1);
+}
+// Byte offset of the 16-byte chunk (row, kh) inside a plane of 32-byte rows.  The XOR puts rows r and r + 8 (same banks at a 32-byte
+// pitch) on different halves, so the ds_read_b128 of 16 consecutive rows covers all 64 banks once.
+__device__ __forceinline__ int chunk_off(int row, int kh) { return row * kRowB + ((kh ^ ((row >> 3) & 1)) << 4); }
+
+template <int WMB, int WNB, int WVM, int WVN>
+struct SplitTile {
+    static constexpr int BM = 32 * WMB * WVM, BN = 32 * WNB * WVN, NT = 64 * WVM * WVN;
+    static constexpr int a_bytes = kPlanes * BM * kRowB, b_bytes = kPlanes * BN * kRowB;
+    static constexpr int lds_bytes = 2 * (a_bytes + b_bytes);
+};
+
+template <int WMB, int WNB>
+struct SplitOperands {
+    bf16x8 a[WMB][kPlanes], b[WNB][kPlanes];
+};
+
+// NTERMS = 6: all products a_i b_j with i + j <= 2; NTERMS = 3: i + j <= 1 (the third planes are not read)
+template <int WMB, int WNB, int BM, int BN, int NTERMS>
+__device__ __forceinline__ void read_split_operands(const char* __restrict__ As, const char* __restrict__ Bs, int wm, int wn, int lane,
+                                                    SplitOperands<WMB, WNB>& o)
+{
+    constexpr int NPL = NTERMS == 6 ? 3 : 2;
+    const int r = lane & 31, kh = lane >> 5;
 #pragma unroll
     for (int i = 0; i < WMB; i++)
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int m = m0 + (wm * WMB + i) * 32 + (r & 3) + 8 * (r >> 2) + rbase;
-            if (m >= p.M) continue;
-            const float sc = has_scale ? p.out_scale[m] : 1.f, bi = has_bias ? p.bias[m] : 0.f;
-            float* row = p.yout + (size_t)m * p.OHf * p.OWf;
+        for (int pl = 0; pl < NPL; pl++)
+            o.a[i][pl] = *reinterpret_cast<const bf16x8*>(As + pl * BM * kRowB + chunk_off((wm * WMB + i) * 32 + r, kh));
+#pragma unroll
+    for (int j = 0; j < WNB; j++)
+#pragma unroll
+        for (int pl = 0; pl < NPL; pl++)
+            o.b[j][pl] = *reinterpret_cast<const bf16x8*>(Bs + pl * BN * kRowB + chunk_off((wn * WNB + j) * 32 + r, kh));
+}
+
+// the products of one K tile, smallest terms first; the blocks of the wave alternate so consecutive MFMAs use different accumulators
+template <int WMB, int WNB, int NTERMS>
+__device__ __forceinline__ void mma_split(const SplitOperands<WMB, WNB>& o, f32x16 (&acc)[WMB][WNB])
+{
+    constexpr int ta[6] = { 2, 1, 0, 1, 0, 0 }, tb[6] = { 0, 1, 2, 0, 1, 0 };
+#pragma unroll
+    for (int t = 6 - NTERMS; t < 6; t++)
+#pragma unroll
+        for (int i = 0; i < WMB; i++)
 #pragma unroll
             for (int j = 0; j < WNB; j++)
-                if (nn[j] < N) row[opix[j]] = acc[i][j][r] * sc + bi;
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o.a[i][ta[t]], o.b[j][tb[t]], acc[i][j], 0, 0, 0);
+}
+
+// gather_conv_kernel on the split engine.  Same K order, same classes, same epilogue; differences: the packed weights arrive already
+// split (pack_weights_split_kernel: per K tile three planes [BM][16] bf16, chunks pre-swizzled, so the loader copies 16-byte chunks
+// straight through), the gathered activations are split by the loader thread between the global load and the LDS write, and one set
+// of operand registers is used (two would not fit beside the staging registers at 128 VGPRs): LDS reads of tile k are issued right
+// after the barrier, the split + LDS writes of tile k + 1 run under their latency, then the twelve MFMAs.
+// CEXACT: the channel count is a multiple of 16 (every layer but the 3- and 12-channel inputs): no channel clamp, the KG plane
+// pointers of a thread group are kernel constants in scalar registers and the channel-block advance is one scalar byte offset.
+template <int WMB, int WNB, int WVM, int WVN, bool CEXACT, int NTERMS>
+__global__ void __launch_bounds__(64 * WVM * WVN, AG_CONV_WAVES_PER_SIMD) gather_conv_split_kernel(GatherProblem p)
+{
+    using T = SplitTile<WMB, WNB, WVM, WVN>;
+    constexpr int BM = T::BM, BN = T::BN, NT = T::NT;
+    constexpr int G = NT / BN, KG = BK / G;           // B loader: G thread groups, each KG consecutive k's of a pixel
+    constexpr int AC = kPlanes * BM * 2;              // A loader: 16-byte chunks in a tile
+    constexpr bool A2 = AC > NT;                      // the first AC - NT threads move a second chunk
+    static_assert(AC <= 2 * NT && (KG == 4 || KG == 8) && BN >= 64, "loader shapes");
+    __shared__ __attribute__((aligned(16))) char smem[T::lds_bytes];
+    char* const As0 = smem;
+    char* const Bs0 = smem + 2 * T::a_bytes;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WVN, wn = wave % WVN;
+
+    int ci = 0;
+#pragma unroll
+    for (int c = 1; c < kMaxClasses; c++)
+        if (c < p.nclasses && (int)blockIdx.x >= p.cls[c].tile_begin) ci = c;
+    const GatherClass& cl = p.cls[ci];
+    const int gw = cl.gw, ntaps = cl.ntaps;
+    const int N = cl.gh * gw;
+    const int m0 = blockIdx.y * BM, n0 = ((int)blockIdx.x - cl.tile_begin) * BN;
+
+    const int n_loc = tid % BN, g = (wave * 64) / BN;
+    const int n = n0 + n_loc;
+    const bool n_ok = n < N;
+    const int gy = n_ok ? n / gw : 0, gx = n_ok ? n - (n / gw) * gw : 0;
+    const int iy0 = gy * p.sy, ix0 = gx * p.sx;
+    uint32_t vmask = 0;
+    for (int t = 0; t < ntaps; t++) {
+        const int iy = iy0 + cl.dy[t], ix = ix0 + cl.dx[t];
+        if (n_ok && iy >= 0 && iy < p.Hg && ix >= 0 && ix < p.Wg) vmask |= 1u << t;
+    }
+    const int pix = iy0 * p.Wg + ix0;
+    const int tl = lane & (kMaxTaps - 1);
+    const int toff_vec = cl.dy[tl] * p.Wg + cl.dx[tl];
+
+    f32x16 acc[WMB][WNB];
+#pragma unroll
+    for (int i = 0; i < WMB; i++)
+#pragma unroll
+        for (int j = 0; j < WNB; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    const int nkt_all = cl.nkt;
+    const int kt_beg = min(nkt_all, (int)blockIdx.z * p.kt_per_split), kt_end = min(nkt_all, kt_beg + p.kt_per_split);
+    const int nkt = kt_end - kt_beg;
+    int t_cur = kt_beg % ntaps;
+    int c_cur = (kt_beg / ntaps) * BK + g * KG;
+    const size_t plane_b = (size_t)p.Hg * p.Wg * sizeof(float);
+    const char* const xin_b = reinterpret_cast<const char*>(p.xin);
+    const int c_last = p.Cg - 1;
+    // packed weights: cl.at_off counts fp32-tile floats (BM * 16 per tile); a split tile has a_bytes = 6 bytes per element
+    const char* a_ptr = reinterpret_cast<const char*>(p.At) + (size_t)cl.at_off * 6 + ((size_t)blockIdx.y * nkt_all + kt_beg) * T::a_bytes;
+    const uint32_t a_voff0 = (uint32_t)min(tid, AC - 1) * 16u;
+    const uint32_t a_voff1 = (uint32_t)min(NT + tid, AC - 1) * 16u;
+    const bool a_thread0 = tid < AC;                  // wave-uniform (AC is a multiple of 64)
+    const bool a_thread1 = A2 && NT + tid < AC;
+    // LDS write position of this thread's KG values: row n_loc, k = g * KG ...
+    const int b_woff = chunk_off(n_loc, (g * KG) >> 3) + ((g * KG) & 7) * 2;
+
+    // uniform base pointers of the KG channel planes of the current channel block (scalar registers; refreshed once per block)
+    const char* cbase[KG];
+    uint32_t cb_off = 0;                              // CEXACT: byte offset of the current channel block (host checks the tensor < 4 GB)
+    const uint32_t cb_step = (uint32_t)(BK * plane_b);
+    auto set_bases = [&]() {
+#pragma unroll
+        for (int j = 0; j < KG; j++) cbase[j] = xin_b + (size_t)min(c_cur + j, c_last) * plane_b;
+    };
+    set_bases();
+
+    struct Stage {
+        u32x4 ra0, ra1;
+        float rb[KG];
+        bool tap_ok;
+    };
+    Stage S[2];
+    SplitOperands<WMB, WNB> O;
+    auto gload = [&](Stage& st) {
+        st.ra0 = *reinterpret_cast<const u32x4*>(a_ptr + a_voff0);
+        if constexpr (A2) st.ra1 = *reinterpret_cast<const u32x4*>(a_ptr + a_voff1);
+        a_ptr += T::a_bytes;
+        st.tap_ok = (vmask >> t_cur) & 1u;
+        const int toff = __builtin_amdgcn_readlane(toff_vec, t_cur);
+        const uint32_t voff = st.tap_ok ? (uint32_t)(pix + toff) * 4u + (CEXACT ? cb_off : 0u) : 0u;
+#pragma unroll
+        for (int j = 0; j < KG; j++) {
+            st.rb[j] = *reinterpret_cast<const float*>(cbase[j] + voff);     // global_load_dword v, v_off, s[base]
         }
+        t_cur++;
+        if constexpr (CEXACT) {
+            const bool wrap = t_cur == ntaps;
+            t_cur = wrap ? 0 : t_cur;
+            cb_off += wrap ? cb_step : 0u;
+        } else {
+            if (t_cur == ntaps) { t_cur = 0; c_cur += BK; set_bases(); }
+        }
+    };
+    auto lstore = [&](int buf, const Stage& st) {
+        char* As = As0 + buf * T::a_bytes;
+        char* Bs = Bs0 + buf * T::b_bytes;
+        if (a_thread0) *reinterpret_cast<u32x4*>(As + tid * 16) = st.ra0;
+        if constexpr (A2) {
+            if (a_thread1) *reinterpret_cast<u32x4*>(As + (NT + tid) * 16) = st.ra1;
+        }
+#pragma unroll
+        for (int q = 0; q < KG / 4; q++) {
+            u32x2 w0, w1, w2;
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                const float x0 = st.tap_ok ? st.rb[4 * q + 2 * e] : 0.f, x1 = st.tap_ok ? st.rb[4 * q + 2 * e + 1] : 0.f;
+                uint32_t a, b, c;
+                split_pair(x0, x1, a, b, c);
+                w0[e] = a; w1[e] = b; w2[e] = c;
+            }
+            *reinterpret_cast<u32x2*>(Bs + 0 * BN * kRowB + b_woff + 8 * q) = w0;
+            *reinterpret_cast<u32x2*>(Bs + 1 * BN * kRowB + b_woff + 8 * q) = w1;
+            *reinterpret_cast<u32x2*>(Bs + 2 * BN * kRowB + b_woff + 8 * q) = w2;
+        }
+    };
+    auto lread = [&](int buf) {
+        read_split_operands<WMB, WNB, BM, BN, NTERMS>(As0 + buf * T::a_bytes, Bs0 + buf * T::b_bytes, wm, wn, lane, O);
+    };
+
+    if (nkt > 0) {
+        gload(S[0]);
+        if (nkt > 1) gload(S[1]);
+        lstore(0, S[0]);
+        lds_barrier();
+        // steady state for tile kt (kt + 2 < nkt), branch-free
+        auto step_full = [&](int kt, Stage& s_same, Stage& s_next) {
+            lread(kt & 1);
+            gload(s_same);                         // tile kt + 2 into the registers whose tile (kt) is already in LDS
+            lstore((kt + 1) & 1, s_next);
+            mma_split<WMB, WNB, NTERMS>(O, acc);
+            lds_barrier();
+        };
+        auto step_tail = [&](int kt, Stage& s_next, bool has_next) {
+            lread(kt & 1);
+            if (has_next) lstore((kt + 1) & 1, s_next);
+            mma_split<WMB, WNB, NTERMS>(O, acc);
+            if (has_next) lds_barrier();
+        };
+        int kt = 0;
+        for (; kt + 3 < nkt; kt += 2) {
+            step_full(kt, S[0], S[1]);
+            step_full(kt + 1, S[1], S[0]);
+        }
+        const int rem = nkt - kt;
+        if (rem == 3) {
+            step_full(kt, S[0], S[1]);
+            step_tail(kt + 1, S[0], true);
+            step_tail(kt + 2, S[1], false);
+        } else if (rem == 2) {
+            step_tail(kt, S[1], true);
+            step_tail(kt + 1, S[0], false);
+        } else {
+            step_tail(kt, S[1], false);
+        }
+    }
+    gather_epilogue<WMB, WNB>(p, cl, acc, m0, n0, N, wm, wn, lane);
 }
 
 // split-K finish: y = (sum_z partial[z][m][col]) * out_scale[m] + bias[m], in a fixed order (deterministic)
@@ -402,6 +663,53 @@ __global__ void __launch_bounds__(256) pack_weights_kernel(PackProblem p)
         float* dst = p.At + p.begin[ci] + ((mt * nkt + (long long)cb * ntaps) * p.BM + mrow) * 16 + kl;
         const bool zero = p.zero[ci] != 0;
         for (int t = 0; t < ntaps; t++) dst[(long long)t * p.BM * 16] = zero ? 0.f : blk[o][inner * k2 + p.tapoff[ci][t]];
+    }
+}
+
+// pack_weights_kernel for the split engine: At[class][m / BM][kt][plane][m % BM][16 bf16, chunks swizzled as chunk_off()], the
+// fp32 value (after the optional scalar pre-multiplication) split three ways.  A thread owns two adjacent channels of a row
+// (one 32-bit word per plane) and every other tap.
+__global__ void __launch_bounds__(256) pack_weights_split_kernel(PackProblem p)
+{
+    __shared__ float blk[16][16 * kMaxTaps + 1];
+    const int tid = threadIdx.x;
+    const int cb = blockIdx.x, m16 = blockIdx.y;
+    const int k2 = p.k2, run = 16 * k2;
+    const bool m_inner = p.stride_m == k2;
+    for (int e = tid; e < 16 * run; e += 256) {
+        const int o = e / run, r = e - o * run;
+        const int inner = r / k2;
+        const int c = cb * 16 + (m_inner ? o : inner), m = m16 * 16 + (m_inner ? inner : o);
+        float v = 0.f;
+        if (c < p.C && m < p.M) {
+            v = p.w[(long long)c * p.stride_c + (long long)m * p.stride_m + (r - inner * k2)];
+            if (p.has_wscale) v *= p.wscale;
+        }
+        blk[o][r] = v;
+    }
+    __syncthreads();
+    const int ml = (tid >> 3) & 15, kp = tid & 7, th = tid >> 7;      // row, channel pair (2 kp, 2 kp + 1), tap parity
+    const int m = m16 * 16 + ml;
+    const int mt = m / p.BM, mrow = m - mt * p.BM;
+    const int o0 = m_inner ? 2 * kp : ml, o1 = m_inner ? 2 * kp + 1 : ml;
+    const int i0 = (m_inner ? ml : 2 * kp) * k2, i1 = (m_inner ? ml : 2 * kp + 1) * k2;
+    const int ctiles = p.Cpad / BK;
+    const size_t plane = (size_t)p.BM * kRowB;
+    for (int ci = 0; ci < p.nclasses; ci++) {
+        const int ntaps = p.ntaps[ci];
+        const long long nkt = (long long)ntaps * ctiles;
+        char* base = reinterpret_cast<char*>(p.At) + (size_t)p.begin[ci] * 6 + (size_t)(mt * nkt + (long long)cb * ntaps) * (kPlanes * plane)
+                     + chunk_off(mrow, kp >> 2) + (kp & 3) * 4;
+        const bool zero = p.zero[ci] != 0;
+        for (int t = th; t < ntaps; t += 2) {
+            const int to = p.tapoff[ci][t];
+            uint32_t a, b, c;
+            split_pair(zero ? 0.f : blk[o0][i0 + to], zero ? 0.f : blk[o1][i1 + to], a, b, c);
+            char* d = base + (size_t)t * (kPlanes * plane);
+            *reinterpret_cast<uint32_t*>(d) = a;
+            *reinterpret_cast<uint32_t*>(d + plane) = b;
+            *reinterpret_cast<uint32_t*>(d + 2 * plane) = c;
+        }
     }
 }
 
@@ -580,6 +888,187 @@ __global__ void __launch_bounds__(64 * WVM * WVN, AG_CONV_WAVES_PER_SIMD) wgrad_
         }
 }
 
+// wgrad_kernel on the split engine: both operands are activations, so both are split by their loader threads.  A: four consecutive
+// pixels of a row (one 8-byte LDS write per plane); B: one pixel of BC columns -- neighbouring lanes hold neighbouring pixels, so
+// lane pairs swap one value per column pair (DPP quad_perm) and every lane ends up with TWO adjacent pixels of one column of the pair:
+// a 4-byte LDS write per plane and column pair instead of four 2-byte ones.
+template <int WMB, int WNB, int WVM, int WVN, bool AVEC, int NTERMS>
+__global__ void __launch_bounds__(64 * WVM * WVN, AG_CONV_WAVES_PER_SIMD) wgrad_split_kernel(WgradProblem p)
+{
+    using T = SplitTile<WMB, WNB, WVM, WVN>;
+    constexpr int BM = T::BM, BN = T::BN, NT = T::NT;
+    constexpr int BSTEP = NT / 16;
+    constexpr int BC = BN / BSTEP;
+    static_assert(BM * 4 <= NT && BC % 2 == 0, "loader shapes");
+    __shared__ __attribute__((aligned(16))) char smem[T::lds_bytes];
+    char* const As0 = smem;
+    char* const Bs0 = smem + 2 * T::a_bytes;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WVN, wn = wave % WVN;
+    const int Kp = p.gh * p.gw, Nw = p.Cg * p.ntaps;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int kbeg = blockIdx.z * p.ksplit_len, kend = min(Kp, kbeg + p.ksplit_len);
+    if (kbeg >= kend) return;
+
+    const int am = tid >> 2, aq = (tid & 3) * 4;
+    const bool a_thread = am < BM && (m0 + am) < p.Mw;
+    const float* a_row = p.a + (size_t)min(m0 + am, p.Mw - 1) * Kp;
+    const int a_woff = chunk_off(min(am, BM - 1), aq >> 3) + (aq & 7) * 2;
+    const int bk = tid & 15, bn = tid >> 4;
+    const int plane = p.Hg * p.Wg;
+    int col_off[BC], col_dy[BC], col_dx[BC];
+#pragma unroll
+    for (int j = 0; j < BC; j++) {
+        const int nn = n0 + bn + BSTEP * j;
+        const int c = min(nn / p.ntaps, p.Cg - 1), t = nn % p.ntaps;
+        col_dy[j] = (nn < Nw) ? p.dy[t] : (1 << 28);
+        col_dx[j] = p.dx[t];
+        col_off[j] = c * plane + p.dy[t] * p.Wg + p.dx[t];
+    }
+    // after the pair swap an even lane writes pixels (bk, bk + 1) of the first column of each pair, an odd lane pixels (bk - 1, bk) of
+    // the second: LDS word of row (bn + BSTEP * j), k = bk & ~1
+    const int odd = bk & 1;
+    int b_woff[BC / 2];
+#pragma unroll
+    for (int h = 0; h < BC / 2; h++) {
+        const int row = bn + BSTEP * (2 * h + odd), k = bk & ~1;
+        b_woff[h] = chunk_off(row, k >> 3) + (k & 7) * 2;
+    }
+    int kpix = kbeg + bk;
+    int gy = kpix / p.gw, gx = kpix - gy * p.gw;
+    const int qstep = BK / p.gw, rstep = BK - qstep * p.gw;
+
+    f32x16 acc[WMB][WNB];
+#pragma unroll
+    for (int i = 0; i < WMB; i++)
+#pragma unroll
+        for (int j = 0; j < WNB; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    struct Stage {
+        f32x4 ra;
+        float rb[BC];
+        uint32_t ok;
+    };
+    Stage S[2];
+    SplitOperands<WMB, WNB> O;
+    auto gload = [&](int k0, Stage& st) {
+        const int ka = k0 + aq;
+        const bool a_ok = a_thread && ka < kend;
+        if constexpr (AVEC) {
+            st.ra = *reinterpret_cast<const f32x4*>(a_row + (a_ok ? ka : 0));
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const bool in = a_ok && ka + q < kend;
+                const float v = a_row[in ? ka + q : 0];
+                st.ra[q] = in ? v : 0.f;
+            }
+        }
+        uint32_t ok = a_ok ? 0x80000000u : 0u;
+        const bool k_ok = kpix < kend;
+        const int iy0 = gy * p.sy, ix0 = gx * p.sx;
+        const int pixoff = iy0 * p.Wg + ix0;
+#pragma unroll
+        for (int j = 0; j < BC; j++) {
+            const bool in = k_ok & ((unsigned)(iy0 + col_dy[j]) < (unsigned)p.Hg) & ((unsigned)(ix0 + col_dx[j]) < (unsigned)p.Wg);
+            st.rb[j] = p.xin[in ? col_off[j] + pixoff : 0];
+            ok |= in ? (1u << j) : 0u;
+        }
+        st.ok = ok;
+        kpix += BK;
+        gx += rstep;
+        gy += qstep;
+        const bool wrap = gx >= p.gw;
+        gx -= wrap ? p.gw : 0;
+        gy += wrap ? 1 : 0;
+    };
+    auto lstore = [&](int buf, const Stage& st) {
+        char* As = As0 + buf * T::a_bytes;
+        char* Bs = Bs0 + buf * T::b_bytes;
+        if (am < BM) {
+            f32x4 v = st.ra;
+            if (!(st.ok >> 31)) v = f32x4{ 0.f, 0.f, 0.f, 0.f };
+            u32x2 w0, w1, w2;
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                uint32_t a, b, c;
+                split_pair(v[2 * e], v[2 * e + 1], a, b, c);
+                w0[e] = a; w1[e] = b; w2[e] = c;
+            }
+            *reinterpret_cast<u32x2*>(As + 0 * BM * kRowB + a_woff) = w0;
+            *reinterpret_cast<u32x2*>(As + 1 * BM * kRowB + a_woff) = w1;
+            *reinterpret_cast<u32x2*>(As + 2 * BM * kRowB + a_woff) = w2;
+        }
+#pragma unroll
+        for (int h = 0; h < BC / 2; h++) {
+            const float v0 = ((st.ok >> (2 * h)) & 1u) ? st.rb[2 * h] : 0.f, v1 = ((st.ok >> (2 * h + 1)) & 1u) ? st.rb[2 * h + 1] : 0.f;
+            // even lane gives away its second-column value and keeps the first; odd lane the other way round
+            const float give = odd ? v0 : v1, keep = odd ? v1 : v0;
+            const float got = __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(give), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+            uint32_t a, b, c;
+            split_pair(odd ? got : keep, odd ? keep : got, a, b, c);        // (pixel k & ~1, pixel (k & ~1) + 1)
+            *reinterpret_cast<uint32_t*>(Bs + 0 * BN * kRowB + b_woff[h]) = a;
+            *reinterpret_cast<uint32_t*>(Bs + 1 * BN * kRowB + b_woff[h]) = b;
+            *reinterpret_cast<uint32_t*>(Bs + 2 * BN * kRowB + b_woff[h]) = c;
+        }
+    };
+    auto lread = [&](int buf) {
+        read_split_operands<WMB, WNB, BM, BN, NTERMS>(As0 + buf * T::a_bytes, Bs0 + buf * T::b_bytes, wm, wn, lane, O);
+    };
+
+    const int nkt = (kend - kbeg + BK - 1) / BK;
+    gload(kbeg, S[0]);
+    if (nkt > 1) gload(kbeg + BK, S[1]);
+    lstore(0, S[0]);
+    lds_barrier();
+    auto step_full = [&](int kt, Stage& s_same, Stage& s_next) {
+        lread(kt & 1);
+        gload(kbeg + (kt + 2) * BK, s_same);
+        lstore((kt + 1) & 1, s_next);
+        mma_split<WMB, WNB, NTERMS>(O, acc);
+        lds_barrier();
+    };
+    auto step_tail = [&](int kt, Stage& s_next, bool has_next) {
+        lread(kt & 1);
+        if (has_next) lstore((kt + 1) & 1, s_next);
+        mma_split<WMB, WNB, NTERMS>(O, acc);
+        if (has_next) lds_barrier();
+    };
+    int kt = 0;
+    for (; kt + 3 < nkt; kt += 2) {
+        step_full(kt, S[0], S[1]);
+        step_full(kt + 1, S[1], S[0]);
+    }
+    const int rem = nkt - kt;
+    if (rem == 3) {
+        step_full(kt, S[0], S[1]);
+        step_tail(kt + 1, S[0], true);
+        step_tail(kt + 2, S[1], false);
+    } else if (rem == 2) {
+        step_tail(kt, S[1], true);
+        step_tail(kt + 1, S[0], false);
+    } else {
+        step_tail(kt, S[1], false);
+    }
+
+    const int col = lane & 31, rbase = 4 * (lane >> 5);
+#pragma unroll
+    for (int i = 0; i < WMB; i++)
+#pragma unroll
+        for (int j = 0; j < WNB; j++) {
+            const int nn = n0 + (wn * WNB + j) * 32 + col;
+            if (nn >= Nw) continue;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int m = m0 + (wm * WMB + i) * 32 + (r & 3) + 8 * (r >> 2) + rbase;
+                if (m < p.Mw) atomicAdd(p.c + (size_t)m * Nw + nn, acc[i][j][r] * p.wscale);
+            }
+        }
+}
+
 // Matrix-pipe calibration: every wave issues `iters` x 4 independent v_mfma_f32_32x32x2_f32 back to back, no memory.
 // Used by profiles/mfma_peak.py to measure the attainable fp32 MFMA rate of the box the convolutions are priced against.
 __global__ void __launch_bounds__(256) mfma_rate_kernel(int iters, float* out)
@@ -604,7 +1093,6 @@ __global__ void __launch_bounds__(256) mfma_rate_kernel(int iters, float* out)
 
 // The same for v_mfma_f32_32x32x16_bf16 (fp32 accumulation): the rate a three-term bf16 split of the fp32 operands
 // (a_hi b_hi + a_hi b_lo + a_lo b_hi) would run on -- calibration only, nothing in the product uses it.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 __global__ void __launch_bounds__(256) mfma_rate_bf16_kernel(int iters, float* out)
 {
     f32x16 acc[4];
@@ -631,6 +1119,15 @@ __global__ void __launch_bounds__(256) mfma_rate_bf16_kernel(int iters, float* o
 // host side
 // ------------------------------------------------------------------------------------------------------------------
 static int round_up(int v, int a) { return (v + a - 1) / a * a; }
+
+// arithmetic of the MFMA convolutions (ag_conv_set_math): process-wide, read at every call
+static std::atomic<int> g_conv_math{ AG_CONV_MATH_SPLIT_BF16 };
+static int split_terms()        // 0: fp32 MFMA engine, else the number of bf16 products per fp32 product
+{
+    const int m = g_conv_math.load(std::memory_order_relaxed);
+    return m == AG_CONV_MATH_SPLIT_BF16 ? 6 : m == AG_CONV_MATH_SPLIT_BF16X3 ? 3 : 0;
+}
+static bool split_math() { return split_terms() != 0; }
 
 static int validate(const AgConvDesc* d)
 {
@@ -708,6 +1205,7 @@ static int choose_splits(long long tiles, int Mpad, int Ncols, int nkt)
 static int pack_and_launch(GatherProblem& gp, const TapSet* taps, int bm, const float* w, long long stride_c, long long stride_m,
                            float wscale, int k, float* At, float* partial, hipStream_t s)
 {
+    const bool split = split_math();
     const int BN = bn_of(bm);
     PackProblem pp;
     pp.w = w; pp.At = At; pp.C = gp.Cg; pp.Cpad = gp.Cpad; pp.M = gp.M; pp.Mpad = gp.Mpad; pp.BM = bm; pp.nclasses = gp.nclasses;
@@ -731,7 +1229,8 @@ static int pack_and_launch(GatherProblem& gp, const TapSet* taps, int bm, const 
     if (tiles == 0) return AG_OK;
     pp.k2 = k * k;
     if ((stride_c != pp.k2 && stride_m != pp.k2) || pp.k2 > kMaxTaps) { set_error("pack: unexpected weight strides"); return AG_ERR_INVALID_ARGUMENT; }
-    hipLaunchKernelGGL(pack_weights_kernel, dim3(gp.Cpad / BK, gp.Mpad / 16), dim3(256), 0, s, pp);
+    if (split) hipLaunchKernelGGL(pack_weights_split_kernel, dim3(gp.Cpad / BK, gp.Mpad / 16), dim3(256), 0, s, pp);
+    else       hipLaunchKernelGGL(pack_weights_kernel, dim3(gp.Cpad / BK, gp.Mpad / 16), dim3(256), 0, s, pp);
     int rc = check_hip(hipGetLastError(), "pack_weights_kernel");
     if (rc) return rc;
 
@@ -750,8 +1249,22 @@ static int pack_and_launch(GatherProblem& gp, const TapSet* taps, int bm, const 
     for (int c = 0; c < gp.nclasses; c++)
         if (!gp.cls[c].zero_weights) flops += 2.0 * gp.M * (double)gp.cls[c].gh * gp.cls[c].gw * gp.cls[c].ntaps * gp.Cg;
     ProfScope ps(AG_K_GATHER_CONV, s, flops);      // covers the split-K finish too
-    if (bm == 64) hipLaunchKernelGGL((gather_conv_kernel<1, 2, 2, 4>), grid, dim3(512), 0, s, gp);
-    else          hipLaunchKernelGGL((gather_conv_kernel<2, 1, 2, 4>), grid, dim3(512), 0, s, gp);
+    if (split) {
+        const bool cexact = gp.Cg % BK == 0 && (size_t)gp.Cg * gp.Hg * gp.Wg * sizeof(float) < (size_t(1) << 32);
+        const bool six = split_terms() == 6;
+#define AG_LAUNCH_SPLIT(WMB, WNB, CE, NTM) hipLaunchKernelGGL((gather_conv_split_kernel<WMB, WNB, 2, 4, CE, NTM>), grid, dim3(512), 0, s, gp)
+        if (bm == 64) {
+            if (cexact) { if (six) AG_LAUNCH_SPLIT(1, 2, true, 6); else AG_LAUNCH_SPLIT(1, 2, true, 3); }
+            else        { if (six) AG_LAUNCH_SPLIT(1, 2, false, 6); else AG_LAUNCH_SPLIT(1, 2, false, 3); }
+        } else {
+            if (cexact) { if (six) AG_LAUNCH_SPLIT(2, 1, true, 6); else AG_LAUNCH_SPLIT(2, 1, true, 3); }
+            else        { if (six) AG_LAUNCH_SPLIT(2, 1, false, 6); else AG_LAUNCH_SPLIT(2, 1, false, 3); }
+        }
+#undef AG_LAUNCH_SPLIT
+    } else {
+        if (bm == 64) hipLaunchKernelGGL((gather_conv_kernel<1, 2, 2, 4>), grid, dim3(512), 0, s, gp);
+        else          hipLaunchKernelGGL((gather_conv_kernel<2, 1, 2, 4>), grid, dim3(512), 0, s, gp);
+    }
     rc = check_hip(hipGetLastError(), "gather_conv_kernel");
     if (rc || splits == 1) return rc;
     const long long total = (long long)gp.M * cols;
@@ -782,7 +1295,7 @@ static size_t packed_bytes(const AgConvDesc* d)
 {
     const int Cmax = d->Cin > d->Cout ? d->Cin : d->Cout;
     const size_t kk = (size_t)round_up(Cmax, BK) * (d->k * d->k + 4);   // all tap subsets together (+ degenerate classes)
-    return align_up(kk * (size_t)round_up(Cmax, 128) * sizeof(float), 256);
+    return align_up(kk * (size_t)round_up(Cmax, 128) * 6, 256);      // 6 bytes per element: three bf16 planes (fp32 engine: 4)
 }
 
 size_t ag_conv_workspace_bytes(const AgConvDesc* d)
@@ -949,7 +1462,18 @@ int ag_conv_backward_weight(const AgConvDesc* d, const float* x, const float* dy
     dim3 grid((Nw + BN - 1) / BN, (wp.Mw + bm - 1) / bm, splits);
     ProfScope ps(AG_K_WGRAD, s, 2.0 * wp.Mw * (double)Kp * Nw);
     const bool avec = (Kp & 3) == 0;      // rows of A 16-byte aligned
-    if (bm == 64) {
+    if (split_math()) {
+        const bool six = split_terms() == 6;
+#define AG_LAUNCH_WSPLIT(WMB, WNB, AV, NTM) hipLaunchKernelGGL((wgrad_split_kernel<WMB, WNB, 2, 4, AV, NTM>), grid, dim3(512), 0, s, wp)
+        if (bm == 64) {
+            if (avec) { if (six) AG_LAUNCH_WSPLIT(1, 2, true, 6); else AG_LAUNCH_WSPLIT(1, 2, true, 3); }
+            else      { if (six) AG_LAUNCH_WSPLIT(1, 2, false, 6); else AG_LAUNCH_WSPLIT(1, 2, false, 3); }
+        } else {
+            if (avec) { if (six) AG_LAUNCH_WSPLIT(2, 1, true, 6); else AG_LAUNCH_WSPLIT(2, 1, true, 3); }
+            else      { if (six) AG_LAUNCH_WSPLIT(2, 1, false, 6); else AG_LAUNCH_WSPLIT(2, 1, false, 3); }
+        }
+#undef AG_LAUNCH_WSPLIT
+    } else if (bm == 64) {
         if (avec) hipLaunchKernelGGL((wgrad_kernel<1, 2, 2, 4, true>), grid, dim3(512), 0, s, wp);
         else      hipLaunchKernelGGL((wgrad_kernel<1, 2, 2, 4, false>), grid, dim3(512), 0, s, wp);
     } else {
@@ -958,6 +1482,17 @@ int ag_conv_backward_weight(const AgConvDesc* d, const float* x, const float* dy
     }
     return check_hip(hipGetLastError(), "wgrad_kernel");
 }
+
+int ag_conv_set_math(int mode)
+{
+    if (mode != AG_CONV_MATH_FP32_MFMA && mode != AG_CONV_MATH_SPLIT_BF16 && mode != AG_CONV_MATH_SPLIT_BF16X3) { set_error("unknown conv math mode"); return AG_ERR_INVALID_ARGUMENT; }
+    g_conv_math.store(mode, std::memory_order_relaxed);
+    return AG_OK;
+}
+
+int ag_conv_get_math(void) { return g_conv_math.load(std::memory_order_relaxed); }
+
+
 
 int ag_debug_mfma_rate_bf16(int blocks, int iters, float* out, void* stream)
 {

@@ -63,6 +63,19 @@ int ag_conv_backward_weight(const AgConvDesc* d, const float* x, const float* dy
 
 /* Calibration: `blocks` x 4 waves each issue iters x 4 independent v_mfma_f32_32x32x2_f32 (8192 FLOP each per wave) with
  * no memory traffic; time it to get the attainable fp32 MFMA rate of the device (profiles/mfma_peak.py). */
+/* Arithmetic of the MFMA convolutions (process-wide; the pointwise VALU kernels are plain fp32 either way).
+ *   AG_CONV_MATH_FP32_MFMA     v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulation.
+ *   AG_CONV_MATH_SPLIT_BF16    (default) every fp32 operand split into three bf16 parts (x = x0 + x1 + x2 to 2^-26 |x|), the six
+ *                              products a_i b_j with i + j <= 2 on v_mfma_f32_32x32x16_bf16, fp32 accumulation: each product is
+ *                              within 2^-23 |a| |b| of the exact one -- the size of fp32's own product rounding.
+ *   AG_CONV_MATH_SPLIT_BF16X3  opt-in: the three products with i + j <= 1, half the matrix work: each product within 3 * 2^-16 |a| |b|.
+ *                              Not fp32-grade; for scale, the reference's cuDNN path runs TF32 (2^-11 per operand) by default --
+ *                              conv2d_gradfix.py never disables it.
+ * Returns AG_OK / AG_ERR_INVALID_ARGUMENT. */
+typedef enum AgConvMath { AG_CONV_MATH_FP32_MFMA = 0, AG_CONV_MATH_SPLIT_BF16 = 1, AG_CONV_MATH_SPLIT_BF16X3 = 2 } AgConvMath;
+int ag_conv_set_math(int mode);
+int ag_conv_get_math(void);
+
 int ag_debug_mfma_rate(int blocks, int iters, float* out, void* stream);
 /* Same for v_mfma_f32_32x32x16_bf16 (calibration of the bf16-split option; not used by the product). */
 int ag_debug_mfma_rate_bf16(int blocks, int iters, float* out, void* stream);

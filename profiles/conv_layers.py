@@ -1,6 +1,6 @@
 """Per-layer view of the DualStyleUNet convolutions on the MFMA path: every distinct (kind, Cin, Cout, H, W, k, stride,
 pad) the network issues, how often, and the isolated time / TFLOP/s of its forward, input-gradient and weight-gradient.
-    python profiles/conv_layers.py [out.csv]"""
+    python profiles/conv_layers.py [out.csv] [fp32|split_bf16]"""
 import collections
 import os
 import sys
@@ -13,6 +13,8 @@ from animatablegaussians_amd import conv as agc, synth  # noqa: E402
 from animatablegaussians_amd.styleunet import DualStyleUNet  # noqa: E402
 
 dev = torch.device("cuda:0")
+if len(sys.argv) > 2:
+    agc.set_math(sys.argv[2])
 seen = collections.Counter()
 orig = agc._Conv.apply
 
@@ -61,7 +63,7 @@ for (kind, cin, cout, h, w, k, s, p), cnt in sorted(seen.items(), key=lambda kv:
 
 tot = [sum(r[8] * r[10 + i] for r in rows) for i in range(3)]
 totf = sum(r[8] * r[9] for r in rows)
-lines = ["kind,Cin,Cout,H,W,k,stride,pad,calls,GFLOP,fwd_us,dgrad_us,wgrad_us,fwd_TF,dgrad_TF,wgrad_TF,fwd_share"]
+lines = [f"# conv math: {agc.get_math()}", "kind,Cin,Cout,H,W,k,stride,pad,calls,GFLOP,fwd_us,dgrad_us,wgrad_us,fwd_TF,dgrad_TF,wgrad_TF,fwd_share"]
 for r in sorted(rows, key=lambda r: -r[8] * r[10]):
     lines.append(",".join(str(v) for v in r[:9]) + f",{r[9]:.2f},{r[10]:.1f},{r[11]:.1f},{r[12]:.1f},"
                  f"{r[9] / r[10] * 1e3:.1f},{r[9] / r[11] * 1e3:.1f},{r[9] / r[12] * 1e3:.1f},{r[8] * r[10] / tot[0]:.3f}")

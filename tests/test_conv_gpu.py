@@ -1,7 +1,9 @@
-"""MFMA convolutions (forward, input gradient, weight gradient) vs torch fp32 CPU convolution + autograd.
+"""MFMA convolutions (forward, input gradient, weight gradient) vs torch fp32 CPU convolution + autograd, in both arithmetic
+modes of include/ag_conv.h (three-way bf16 split on the bf16 matrix pipe = the default, and exact-product fp32 MFMA).
 
-Tolerance: exact-fp32 MFMA with a different summation order than the CPU reference over up to K = 4608 products:
-|diff| <= 1e-5 * (sum-magnitude scale) -- expressed as rtol 1e-4 on values with an absolute floor of 1e-5 * max|ref|."""
+Tolerance, the same for both modes: fp32 accumulation in a different order than the CPU reference over up to K = 4608 products:
+|diff| <= 1e-5 * (sum-magnitude scale) -- expressed as rtol 1e-4 on values with an absolute floor of 1e-5 * max|ref|.
+test_split_products_are_fp32_grade measures the two modes against an fp64 convolution."""
 import numpy as np
 import pytest
 
@@ -27,7 +29,26 @@ CASES = [
     ("pw_torgb16_odd_channels", "conv", 70, 16, 144, 116, 1, 1, 0),
     ("pw_fromrgb", "conv", 3, 128, 32, 32, 1, 1, 0),
     ("pw_fromrgb_512", "conv", 3, 512, 16, 16, 1, 1, 0),
+    # stride-1 gathers the row-patch kernel takes in split mode (whole 16-channel blocks, row length a multiple of 4, patch inside
+    # the LDS budget): several rows per 256-pixel tile, one row per tile, a ragged last tile, parity classes 65 / 64 wide of a
+    # transposed convolution and of a stride-2 input gradient, one tap per patch (1 x 1), more than 128 output rows
+    ("rows_c3x3_64", "conv", 32, 48, 64, 64, 3, 1, 1),
+    ("rows_c3x3_wide", "conv", 16, 130, 24, 256, 3, 1, 1),
+    ("rows_c3x3_odd_h", "conv", 48, 40, 37, 128, 3, 1, 1),
+    ("rows_c3x3_512wide", "conv", 16, 24, 9, 512, 3, 1, 1),
+    ("rows_ct3x3", "convT", 32, 16, 64, 64, 3, 2, 0),
+    ("rows_c3x3_s2_dgrad", "conv", 16, 32, 129, 129, 3, 2, 0),
+    ("rows_c1x1", "conv", 64, 160, 64, 64, 1, 1, 0),
+    ("rows_c3x3_k_split", "conv", 256, 64, 32, 32, 3, 1, 1),
 ]
+
+
+@pytest.fixture(params=["split_bf16", "fp32"])
+def math_mode(request):
+    from animatablegaussians_amd import conv as agc
+    prev = agc.set_math(request.param)
+    yield request.param
+    agc.set_math(prev)
 
 
 def _close(a, b, name):
@@ -39,7 +60,7 @@ def _close(a, b, name):
 
 
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
-def test_conv_forward_backward(case):
+def test_conv_forward_backward(case, math_mode):
     import torch
     import torch.nn.functional as F
     from animatablegaussians_amd import conv as agc
@@ -64,7 +85,7 @@ def test_conv_forward_backward(case):
 
 
 @pytest.mark.parametrize("shape", [(64, 64, 20, 3, 1, 1), (3, 128, 16, 1, 1, 0), (128, 12, 16, 1, 1, 0), (32, 48, 19, 3, 2, 0)])
-def test_weight_scale_is_the_prescaled_convolution(shape):
+def test_weight_scale_is_the_prescaled_convolution(shape, math_mode):
     """conv2d(x, w, weight_scale=s) == conv2d(x, w * s) (EqualConv2d, dual_styleunet.py:100-117), with the weight gradient taken
     w.r.t. the UN-scaled w and an out_scale / bias epilogue on top -- MFMA path and the pointwise kernels."""
     import torch
@@ -102,3 +123,85 @@ def test_conv_out_scale_epilogue_and_errors():
         agc.conv2d(x.cuda(), w.cuda(), None, stride=3)
     with pytest.raises(RuntimeError):
         agc.conv2d(torch.cat([x, x]).cuda(), w.cuda())
+
+
+@pytest.mark.parametrize("kind,Cin,Cout,hw,k,stride,padding", [("conv", 512, 512, 16, 3, 1, 1), ("conv", 128, 256, 33, 3, 2, 1),
+                                                                ("convT", 256, 128, 12, 3, 2, 0)])
+def test_split_products_are_fp32_grade(kind, Cin, Cout, hw, k, stride, padding):
+    """The contracts of the split modes (include/ag_conv.h), measured against an fp64 convolution of the same fp32 inputs, forward /
+    dL/dx / dL/dw, on inputs with a wide dynamic range (lognormal magnitudes, so the low parts of the split matter):
+      split_bf16    every product within 2^-23 |a| |b| of the exact one, fp32 accumulation: (a) the rms deviation is within 1.5x of the
+                    fp32-MFMA mode's, whose products are exact -- the accumulation order, not the split, sets the error; (b) no element
+                    deviates by more than 2^-19 sum |a| |b| (the bound the fp32-MFMA mode is held to as well: accumulation rounding).
+      split_bf16x3  every product within 3 * 2^-16 |a| |b|: no element deviates by more than 3 * 2^-16 sum |a| |b| (+ the accumulation
+                    bound); and it is measurably coarser than split_bf16 (the mode switch really changes the arithmetic)."""
+    import torch
+    import torch.nn.functional as F
+    from animatablegaussians_amd import conv as agc
+    g = torch.Generator().manual_seed(11)
+
+    def wide(*shape):
+        return torch.randn(*shape, generator=g) * torch.exp(1.5 * torch.randn(*shape, generator=g))
+
+    x = wide(1, Cin, hw, hw)
+    w = wide(*((Cout, Cin, k, k) if kind == "conv" else (Cin, Cout, k, k))) / np.sqrt(Cin * k * k)
+    f = (lambda a, b: F.conv2d(a, b, None, stride=stride, padding=padding)) if kind == "conv" else (lambda a, b: F.conv_transpose2d(a, b, None, stride=2))
+    xd, wd = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    ref = f(xd, wd)
+    gy = wide(*ref.shape)
+    ref.backward(gy.double())
+    xa, wa = x.abs().double().requires_grad_(True), w.abs().double().requires_grad_(True)      # sum |a| |b| of every output
+    mag = f(xa, wa)
+    mag.backward(gy.abs().double())
+    mags = (mag.detach(), xa.grad, wa.grad)
+    refs = (ref.detach(), xd.grad, wd.grad)
+    names = ("forward", "dL/dx", "dL/dw")
+    rms, worst = {}, {}
+    for mode in ("fp32", "split_bf16", "split_bf16x3"):
+        prev = agc.set_math(mode)
+        try:
+            xg, wg = (t.clone().cuda().requires_grad_(True) for t in (x, w))
+            fn = agc.conv2d if kind == "conv" else agc.conv_transpose2d
+            out = fn(xg, wg, None, stride=stride, padding=padding)
+            out.backward(gy.cuda())
+            got = (out.detach(), xg.grad, wg.grad)
+        finally:
+            agc.set_math(prev)
+        for name, a, r, m in zip(names, got, refs, mags):
+            d = (a.cpu().double() - r).abs()
+            worst[(mode, name)] = float((d / (m + 1e-300)).max())
+            rms[(mode, name)] = float(torch.sqrt((d * d).mean()))
+            print(f"{kind} {Cin}->{Cout} {mode:13s} {name:8s} max dev / sum|a||b| = 2^{np.log2(worst[(mode, name)] + 1e-300):6.2f}   rms dev = {rms[(mode, name)]:.3e}")
+    for name in names:
+        assert worst[("fp32", name)] <= 2.0 ** -19 and worst[("split_bf16", name)] <= 2.0 ** -19, (name, worst)
+        assert rms[("split_bf16", name)] <= 1.5 * rms[("fp32", name)] + 1e-12, (name, rms)
+        assert worst[("split_bf16x3", name)] <= 3 * 2.0 ** -16 + 2.0 ** -19, (name, worst)
+        assert rms[("split_bf16x3", name)] > 4.0 * rms[("split_bf16", name)], (name, rms)
+
+
+def test_three_product_mode_vs_torch():
+    """split_bf16x3 (opt-in) on the reference comparison of test_conv_forward_backward, at ITS contract: deviation from the fp32 CPU
+    convolution <= 1e-4 |ref| + 1e-4 max|ref| (products within 3 * 2^-16)."""
+    import torch
+    import torch.nn.functional as F
+    from animatablegaussians_amd import conv as agc
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(1, 64, 40, 36, generator=g, requires_grad=True)
+    w = (torch.randn(96, 64, 3, 3, generator=g) / 24.0).requires_grad_(True)
+    ref = F.conv2d(x, w, None, padding=1)
+    gy = torch.randn(ref.shape, generator=g)
+    ref.backward(gy)
+    prev = agc.set_math("split_bf16x3")
+    try:
+        assert agc.get_math() == "split_bf16x3"
+        xg, wg = (t.detach().cuda().requires_grad_(True) for t in (x, w))
+        out = agc.conv2d(xg, wg, None, padding=1)
+        out.backward(gy.cuda())
+    finally:
+        agc.set_math(prev)
+    for name, a, b in (("forward", out, ref), ("dL/dx", xg.grad, x.grad), ("dL/dw", wg.grad, w.grad)):
+        a, b = a.detach().cpu().double().numpy(), b.detach().double().numpy()
+        d = np.abs(a - b)
+        assert (d <= 1e-4 * np.abs(b) + 1e-4 * np.abs(b).max()).all(), (name, d.max(), np.abs(b).max())
+    with pytest.raises(ValueError):
+        agc.set_math("tf32")
