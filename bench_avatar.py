@@ -34,6 +34,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+MFMA_BF16_PEAK_TF = 2500.0      # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 MFMA_F32_PEAK_TF = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
 NET_FWD_GFLOP = 585.8         # per DualStyleUNet forward (profiles/conv_layers.py)
 
@@ -133,12 +134,13 @@ def timed(fn, steps, warmup, dev):
 
 
 def conv_roofline(dev, steps=2):
-    """MFMA roofline of the convolution kernels, measured live: one DualStyleUNet (the colour / position configuration) forward +
-    backward on ONE stream with every gather-conv / wgrad launch bracketed by HIP events on its launch stream (ag_prof_*); achieved =
-    the launches' own FLOPs (2 per multiply-add of the un-padded implicit GEMM, summed by the library) / their summed duration."""
+    """MFMA roofline of the convolution kernels, measured live, in the product's arithmetic (split_bf16: six bf16 products per fp32
+    product) and, beside it, in the fp32-MFMA mode.  One DualStyleUNet (the colour / position configuration) forward + backward on ONE
+    stream with every gather-conv / wgrad launch bracketed by HIP events on its launch stream (ag_prof_*); achieved = the launches' own
+    algorithmic FLOPs (2 per multiply-add of the un-padded implicit GEMM, summed by the library) / their summed duration."""
     import numpy as np
     import torch
-    from animatablegaussians_amd import _lib, synth
+    from animatablegaussians_amd import _lib, conv as agc, synth
     from animatablegaussians_amd.styleunet import DualStyleUNet
     torch.manual_seed(31359)
     net = DualStyleUNet(inp_size=512, inp_ch=3, out_ch=3, out_size=1024, style_dim=512, n_mlp=2).to(dev)
@@ -155,54 +157,100 @@ def conv_roofline(dev, steps=2):
         images, _ = net([style], pose, randomize_noise=False)
         (images * G).sum().backward()
 
-    one(0)
-    fwd_ms = timed(fwd, steps + 1, 1, dev)              # wall time of the pass as the product runs it (two decoder streams)
-    both_ms = timed(one, steps + 1, 1, dev)
-    prev = os.environ.get("AG_SINGLE_STREAM")
-    os.environ["AG_SINGLE_STREAM"] = "1"                # per-kernel durations: no co-running kernels
-    try:
+    def measure():
         one(0)
-        torch.cuda.synchronize(dev)
-        _lib.prof_enable([_lib.AG_K_GATHER_CONV, _lib.AG_K_WGRAD])
-        for i in range(steps):
-            one(i)
-        torch.cuda.synchronize(dev)
-        n, ms, work = _lib.prof_collect_work()
-        _lib.prof_enable([])
+        fwd_ms = timed(fwd, steps + 1, 1, dev)              # wall time of the pass as the product runs it (two decoder streams)
+        both_ms = timed(one, steps + 1, 1, dev)
+        prev = os.environ.get("AG_SINGLE_STREAM")
+        os.environ["AG_SINGLE_STREAM"] = "1"                # per-kernel durations: no co-running kernels
+        try:
+            one(0)
+            torch.cuda.synchronize(dev)
+            _lib.prof_enable([_lib.AG_K_GATHER_CONV, _lib.AG_K_WGRAD])
+            for i in range(steps):
+                one(i)
+            torch.cuda.synchronize(dev)
+            n, ms, work = _lib.prof_collect_work()
+            _lib.prof_enable([])
+        finally:
+            if prev is None:
+                os.environ.pop("AG_SINGLE_STREAM", None)
+            else:
+                os.environ["AG_SINGLE_STREAM"] = prev
+        r = {"network_forward_ms": round(fwd_ms, 2), "network_forward_backward_ms": round(both_ms, 2),
+             "network_forward_TFLOPs": round(NET_FWD_GFLOP / fwd_ms, 1), "network_forward_backward_TFLOPs": round(3 * NET_FWD_GFLOP / both_ms, 1)}
+        tot_w = tot_ms = 0.0
+        for k in ("gather_conv_kernel", "wgrad_kernel"):
+            if n[k]:
+                r[k] = {"launches_timed": n[k], "avg_launch_us": round(1e3 * ms[k] / n[k], 2), "TFLOPs": round(work[k] / (ms[k] * 1e-3) / 1e12, 2),
+                        "GFLOP_per_network_pass": round(work[k] / steps / 1e9, 1)}
+                tot_w += work[k]
+                tot_ms += ms[k]
+        r["achieved"] = round(tot_w / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0, 2)
+        return r, both_ms
+
+    mode0 = agc.get_math()
+    try:
+        agc.set_math("fp32")
+        f32, f32_both = measure()
+        f32.update({"peak": MFMA_F32_PEAK_TF, "frac": round(f32["achieved"] / MFMA_F32_PEAK_TF, 4),
+                    "whole_network_frac": round(3 * NET_FWD_GFLOP / f32_both / MFMA_F32_PEAK_TF, 4)})
+        agc.set_math(mode0)
+        out, both_ms = measure()
     finally:
-        if prev is None:
-            os.environ.pop("AG_SINGLE_STREAM", None)
-        else:
-            os.environ["AG_SINGLE_STREAM"] = prev
-    out = {"bound": "mfma", "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "traffic": None,
-           "network_forward_ms": round(fwd_ms, 2), "network_forward_backward_ms": round(both_ms, 2),
-           "network_forward_TFLOPs": round(NET_FWD_GFLOP / fwd_ms, 1), "network_forward_backward_TFLOPs": round(3 * NET_FWD_GFLOP / both_ms, 1)}
-    tot_w = tot_ms = 0.0
-    for k in ("gather_conv_kernel", "wgrad_kernel"):
-        if n[k]:
-            out[k] = {"launches_timed": n[k], "avg_launch_us": round(1e3 * ms[k] / n[k], 2), "TFLOPs": round(work[k] / (ms[k] * 1e-3) / 1e12, 2),
-                      "GFLOP_per_network_pass": round(work[k] / steps / 1e9, 1)}
-            tot_w += work[k]
-            tot_ms += ms[k]
-    ach = tot_w / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
-    out.update({"kernel": "gather_conv_kernel + wgrad_kernel (every convolution of one DualStyleUNet forward + backward, one stream)",
-                "achieved": round(ach, 2), "frac": round(ach / MFMA_F32_PEAK_TF, 4),
-                "whole_network_frac": round(3 * NET_FWD_GFLOP / both_ms / MFMA_F32_PEAK_TF, 4),
-                "note": "achieved = FLOPs of the bracketed launches / their summed HIP-event durations; whole_network_frac prices the "
-                        "586 GFLOP x 3 of a forward + backward against the wall time of the whole pass (all non-conv kernels and gaps included)"})
+        agc.set_math(mode0)
+    terms = {"split_bf16": 6, "split_bf16x3": 3}.get(mode0, 0)
+    ach = out["achieved"]
+    out.update({"bound": "mfma", "unit": "TFLOP/s", "traffic": None, "math": mode0,
+                "kernel": "gather_conv kernels + wgrad kernels (every convolution of one DualStyleUNet forward + backward, one stream)"})
+    if terms:
+        out.update({"executed": round(terms * ach, 1), "peak": MFMA_BF16_PEAK_TF, "frac": round(terms * ach / MFMA_BF16_PEAK_TF, 4),
+                    "frac_of_fp32_mfma_peak": round(ach / MFMA_F32_PEAK_TF, 4),
+                    "whole_network_frac_of_fp32_mfma_peak": round(3 * NET_FWD_GFLOP / both_ms / MFMA_F32_PEAK_TF, 4),
+                    "note": f"achieved = algorithmic fp32 FLOPs of the bracketed launches / their summed HIP-event durations; every fp32 product is "
+                            f"{terms} bf16 MFMA products, so executed = {terms} x achieved is what is priced against the dense bf16 MFMA peak.  "
+                            "With real (random-mantissa) operands the bf16 pipe is power-limited to ~0.66 of that peak on this part "
+                            "(profiles/r02_conv_split_engine.md)"})
+    else:
+        out.update({"peak": MFMA_F32_PEAK_TF, "frac": round(ach / MFMA_F32_PEAK_TF, 4)})
+    out["fp32_mfma_mode"] = f32
     return out
 
 
 def full_step_probe(dev, steps1=6, steps4=4):
     """bench.py's ``full_step`` leg: BASELINE configs[2] -- the whole training iteration (3 StyleUNets + assembly + LBS + raster,
-    loss, backward, fused Adam) at 1 view per step (the reference's own batch shape) and at 4 views of one pose per step."""
+    loss, backward, fused Adam) at 1 view per step (the reference's own batch shape) and at 4 views of one pose per step, in the product's
+    convolution arithmetic; the same two numbers in the other two modes of include/ag_conv.h beside them."""
+    from animatablegaussians_amd import conv as agc
+    import numpy as np
     step = TrainingStep(dev)
-    ms1 = timed(lambda i: step(i, 1), steps1, 2, dev)
-    ms4 = timed(lambda i: step(i, 4), steps4, 2, dev)
-    return {"workload": "BASELINE configs[2]: StyleUNet x3 + LBS + raster fwd+bwd + L1/offset loss + fused Adam, 268 k Gaussians @1024^2",
-            "views_per_s_1view_per_step": round(1e3 / ms1, 2), "ms_per_step_1view": round(ms1, 2),
-            "views_per_s_4views_per_step": round(4e3 / ms4, 2), "ms_per_step_4views": round(ms4, 2),
-            "steps_timed": [steps1, steps4], "parameters": step.n_params}
+    mode0 = agc.get_math()
+    modes = [mode0] + [m for m in ("fp32", "split_bf16x3") if m != mode0]
+    t1 = {m: [] for m in modes}
+    t4 = {m: [] for m in modes}
+    try:
+        for _rep in range(2):                    # blocks of steps alternate between the modes: clock / temperature history is shared
+            for m in modes:
+                agc.set_math(m)
+                t1[m].append(timed(lambda i: step(i, 1), steps1, 2, dev))
+                t4[m].append(timed(lambda i: step(i, 4), steps4, 2, dev))
+    finally:
+        agc.set_math(mode0)
+
+    def rec(m):
+        ms1, ms4 = float(np.median(t1[m])), float(np.median(t4[m]))
+        return {"views_per_s_1view_per_step": round(1e3 / ms1, 2), "ms_per_step_1view": round(ms1, 2),
+                "views_per_s_4views_per_step": round(4e3 / ms4, 2), "ms_per_step_4views": round(ms4, 2)}
+
+    out = {"workload": "BASELINE configs[2]: StyleUNet x3 + LBS + raster fwd+bwd + L1/offset loss + fused Adam, 268 k Gaussians @1024^2",
+           "conv_math": mode0}
+    out.update(rec(mode0))
+    out.update({"steps_timed": [2 * steps1, 2 * steps4], "parameters": step.n_params,
+                "note": "two blocks of steps per arithmetic mode, interleaved; medians"})
+    keys = {"fp32": "conv_math_fp32", "split_bf16x3": "conv_math_split_bf16x3_opt_in_not_fp32_grade", "split_bf16": "conv_math_split_bf16"}
+    for m in modes[1:]:
+        out[keys[m]] = rec(m)
+    return out
 
 
 def main() -> None:

@@ -43,11 +43,21 @@ def test_bench_json_line():
     assert abs(f["views_per_s_1view_per_step"] * f["ms_per_step_1view"] - 1000.0) < 5.0
     assert abs(f["views_per_s_4views_per_step"] * f["ms_per_step_4views"] - 4000.0) < 20.0
     assert f["views_per_s_4views_per_step"] > f["views_per_s_1view_per_step"] > 1.0 and f["parameters"] > 2.2e8
+    assert f["conv_math"] == "split_bf16" and f["conv_math_fp32"]["views_per_s_1view_per_step"] < f["views_per_s_1view_per_step"] * 1.05
+    assert f["conv_math_split_bf16x3_opt_in_not_fp32_grade"]["views_per_s_1view_per_step"] > f["views_per_s_1view_per_step"] * 0.9
     m = d["roofline_mfma"]
-    assert m["bound"] == "mfma" and m["unit"] == "TFLOP/s" and m["peak"] == 157.3 and abs(m["frac"] - m["achieved"] / m["peak"]) < 1e-3
-    assert 0.05 < m["frac"] < 1.0 and m["whole_network_frac"] <= m["frac"] + 0.05
+    # the product's arithmetic: six bf16 products per fp32 product, priced (executed = 6 x algorithmic) against the dense bf16 MFMA peak
+    assert m["bound"] == "mfma" and m["unit"] == "TFLOP/s" and m["math"] == "split_bf16" and m["peak"] == 2500.0
+    assert abs(m["executed"] - 6 * m["achieved"]) < 0.5 and abs(m["frac"] - m["executed"] / m["peak"]) < 1e-3 and 0.05 < m["frac"] < 1.0
+    assert abs(m["frac_of_fp32_mfma_peak"] - m["achieved"] / 157.3) < 1e-3
     for k in ("gather_conv_kernel", "wgrad_kernel"):
-        assert m[k]["launches_timed"] > 0 and 1.0 < m[k]["TFLOPs"] < 157.3
+        assert m[k]["launches_timed"] > 0 and 1.0 < m[k]["TFLOPs"] < 2500.0 / 6
+    # ... and the fp32-MFMA mode beside it, against its own peak
+    q = m["fp32_mfma_mode"]
+    assert q["peak"] == 157.3 and abs(q["frac"] - q["achieved"] / q["peak"]) < 1e-3 and 0.05 < q["frac"] < 1.0
+    assert q["whole_network_frac"] <= q["frac"] + 0.05 and q["achieved"] < m["achieved"]
+    for k in ("gather_conv_kernel", "wgrad_kernel"):
+        assert q[k]["launches_timed"] > 0 and 1.0 < q[k]["TFLOPs"] < 157.3
     # every convolution FLOP of a forward + backward is accounted for: 586 GFLOP x 3 (forward, input gradient, weight gradient)
     total = m["gather_conv_kernel"]["GFLOP_per_network_pass"] + m["wgrad_kernel"]["GFLOP_per_network_pass"]
     assert abs(total - 3 * 585.8) < 0.03 * 3 * 585.8, total
