@@ -205,13 +205,24 @@ class DualStyleUNet(torch.nn.Module):
             x = agc.conv2d(x, w, stride=1, padding=k // 2, weight_scale=scale)
         return noise_bias_act(x, None, None, self._p(f"{prefix}.{base + 1}.bias"))
 
-    def _modulated_weight(self, prefix, w_latent, demodulate, transposed=False):
+    def _stage_styles(self, branch, stages, w_latent):
+        """The modulation vectors of every modulated convolution of ``stages`` (two StyledConvs and one ToRGB each) from ONE GEMM:
+        EqualLinear(w_latent) with lr_mul 1 (:152-155) is ``w_latent @ (W * c)^T + b`` per convolution; here the 3 * len(stages)
+        weight matrices are stacked and ``c`` is the GEMM's alpha (c * (w_latent @ W^T) + b: the same value up to the rounding of the
+        scaling).  Replaces three small kernels per convolution forward (scale the weight, scale the bias, GEMV) and seven backward
+        with two concatenations and one GEMM per stage group.  Returns {convolution prefix: [B, C] style}."""
+        prefixes = [p for n in stages for p in (f"convs{branch}.{2 * n}.conv", f"convs{branch}.{2 * n + 1}.conv", f"to_rgbs{branch}.{n}.conv")]
+        ws = [self._p(f"{p}.modulation.weight") for p in prefixes]
+        bs = [self._p(f"{p}.modulation.bias") for p in prefixes]
+        W = torch.cat(ws, 0)
+        s = torch.addmm(torch.cat(bs, 0)[None], w_latent, W.t(), alpha=1 / math.sqrt(W.shape[1]))
+        return dict(zip(prefixes, torch.split(s, [w.shape[0] for w in ws], dim=1)))
+
+    def _modulated_weight(self, prefix, styles, demodulate, transposed=False):
         w = self._p(f"{prefix}.weight")                                  # [1, Cout, Cin, k, k]
-        mw, mb = self._p(f"{prefix}.modulation.weight"), self._p(f"{prefix}.modulation.bias")
-        style = F.linear(w_latent, mw * (1 / math.sqrt(mw.shape[1])), bias=mb * 1.0)    # EqualLinear, lr_mul 1 (:152-155)
         k = w.shape[-1]
         # (scale * W) * style, demodulated (:254-259), in one kernel; [Cout, Cin, k, k] or transposed for conv_transpose2d
-        return modulate_weight(w, style, 1 / math.sqrt(w.shape[2] * k * k), demodulate, transposed)
+        return modulate_weight(w, styles[prefix], 1 / math.sqrt(w.shape[2] * k * k), demodulate, transposed)
 
     def _styled_conv(self, x, prefix, w_latent, noise, upsample):
         weight = self._modulated_weight(f"{prefix}.conv", w_latent, True, transposed=upsample)
@@ -265,6 +276,10 @@ class DualStyleUNet(torch.nn.Module):
     VIEW_STAGE = 4      # the view-direction feature is added to the stage-4 activations (i == 8 at :881-883)
 
     def _decode_stages(self, branch, levels, w_latent, noise, out, skip, stages):
+        stages = list(stages)
+        if not stages:
+            return out, skip
+        w_latent = self._stage_styles(branch, stages, w_latent)          # from here on: {prefix: style}
         for n in stages:
             if n == 0:
                 out = self._conv_layer(levels[-1], f"comb_convs.{self.n_comb - 1}")
