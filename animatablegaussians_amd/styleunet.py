@@ -317,7 +317,8 @@ class DualStyleUNet(torch.nn.Module):
         out again while side-stream kernels -- forward now, backward later -- may still be reading it."""
         import os
         cur = torch.cuda.current_stream()
-        if os.environ.get("AG_SINGLE_STREAM") == "1" or torch.cuda.is_current_stream_capturing():
+        capturing = torch.cuda.is_current_stream_capturing()
+        if os.environ.get("AG_SINGLE_STREAM") == "1" or (capturing and os.environ.get("AG_CAPTURE_BRANCHES") != "1"):
             return [fn(1), fn(2)]
         if getattr(self, "_side_stream", None) is None or self._side_stream.device != cur.device:
             self._side_stream = torch.cuda.Stream(cur.device)

@@ -82,6 +82,19 @@ def upfirdn2d(input: torch.Tensor, kernel: torch.Tensor, up_x: int, up_y: int, d
 # double-backward Functions (fused_act.py:35-76, upfirdn2d.py:35-103) are never differentiated on the product path.
 # ---------------------------------------------------------------------------------------------------------------------
 _EMPTY = {}
+_FLIPPED = {}
+
+
+def _flipped(kernel):
+    """FIR kernel flipped in both axes (the backward of an upfirdn2d), cached per kernel tensor and version: the network's three FIR
+    kernels are constants, and a flip is one more small launch per upfirdn2d backward otherwise."""
+    key = (kernel.data_ptr(), kernel._version, tuple(kernel.shape))
+    f = _FLIPPED.get(key)
+    if f is None:
+        if len(_FLIPPED) > 64:
+            _FLIPPED.clear()
+        f = _FLIPPED[key] = torch.flip(kernel, [0, 1]).contiguous()
+    return f
 
 
 def _empty(dev):
@@ -145,7 +158,7 @@ class _UpFirDn2d(torch.autograd.Function):
         gx0, gy0 = kw - px0 - 1, kh - py0 - 1
         gx1 = w * up[0] - ow * down[0] + px0 - up[0] + 1
         gy1 = h * up[1] - oh * down[1] + py0 - up[1] + 1
-        g = upfirdn2d(gy.reshape(n * c, oh, ow, 1).contiguous(), torch.flip(kernel, [0, 1]).contiguous(), down[0], down[1],
+        g = upfirdn2d(gy.reshape(n * c, oh, ow, 1).contiguous(), _flipped(kernel), down[0], down[1],
                       up[0], up[1], gx0, gx1, gy0, gy1)
         return g.view(n, c, h, w), None, None, None, None
 
