@@ -19,14 +19,25 @@ There is no CPU path.
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 import torch.nn.functional as F
 
 from . import conv as agc
+from . import fused_layers
 from .styleunet_ops import fused_leaky_relu, haar_merge, haar_split, modulate_weight, noise_bias_act, upfirdn2d_nchw
 
 _SQRT2 = 2 ** 0.5
+# ConvLayer / StyledConv / ToRGB as one autograd node each (fused_layers.py: same kernels, same order, bit-identical results, a third of
+# the autograd nodes).  AG_UNFUSED_LAYERS=1 or set_fused_layers(False) runs the per-kernel chain (A/B and the equality test).
+_FUSED_LAYERS = os.environ.get("AG_UNFUSED_LAYERS") != "1"
+
+
+def set_fused_layers(on: bool) -> bool:
+    global _FUSED_LAYERS
+    prev, _FUSED_LAYERS = _FUSED_LAYERS, bool(on)
+    return prev
 
 
 def _fir(taps, gain=1.0):
@@ -198,12 +209,15 @@ class DualStyleUNet(torch.nn.Module):
         w = self._p(f"{prefix}.{base}.weight")
         k = w.shape[-1]
         scale = 1 / math.sqrt(w.shape[1] * k * k)                        # EqualConv2d: conv(x, weight * scale) (:100-117); the
-        if downsample:                                                   # product is formed inside the weight re-pack
+        bias = self._p(f"{prefix}.{base + 1}.bias")                      # product is formed inside the weight re-pack
+        if _FUSED_LAYERS:                                                # one autograd node for [blur +] conv + bias / activation
+            return fused_layers.conv_layer(x, w, bias, self._k_blur if downsample else None, scale, downsample)
+        if downsample:
             x = upfirdn2d_nchw(x, self._k_blur, pad=(2, 2))              # p = (4 - 2) + (k - 1), k = 3 (:339-345)
             x = agc.conv2d(x, w, stride=2, padding=0, weight_scale=scale)
         else:
             x = agc.conv2d(x, w, stride=1, padding=k // 2, weight_scale=scale)
-        return noise_bias_act(x, None, None, self._p(f"{prefix}.{base + 1}.bias"))
+        return noise_bias_act(x, None, None, bias)
 
     def _stage_styles(self, branch, stages, w_latent):
         """The modulation vectors of every modulated convolution of ``stages`` (two StyledConvs and one ToRGB each) from ONE GEMM:
@@ -225,6 +239,15 @@ class DualStyleUNet(torch.nn.Module):
         return modulate_weight(w, styles[prefix], 1 / math.sqrt(w.shape[2] * k * k), demodulate, transposed)
 
     def _styled_conv(self, x, prefix, w_latent, noise, upsample):
+        if _FUSED_LAYERS:
+            w = self._p(f"{prefix}.conv.weight")
+            k = w.shape[-1]
+            if noise is None:
+                hw = (2 * x.shape[2], 2 * x.shape[3]) if upsample else (x.shape[2], x.shape[3])
+                noise = torch.randn(1, 1, hw[0], hw[1], device=x.device, dtype=x.dtype)
+            return fused_layers.styled_conv(x, w, w_latent[f"{prefix}.conv"], noise, self._p(f"{prefix}.noise.weight"),
+                                            self._p(f"{prefix}.activate.bias"), self._k_blur_up if upsample else None,
+                                            1 / math.sqrt(w.shape[2] * k * k), upsample)
         weight = self._modulated_weight(f"{prefix}.conv", w_latent, True, transposed=upsample)
         if upsample:
             x = agc.conv_transpose2d(x, weight, stride=2, padding=0)
@@ -243,6 +266,10 @@ class DualStyleUNet(torch.nn.Module):
         return haar_merge(x)
 
     def _to_rgb(self, x, prefix, w_latent, skip):
+        if _FUSED_LAYERS:
+            w = self._p(f"{prefix}.conv.weight")
+            return fused_layers.to_rgb(x, w, w_latent[f"{prefix}.conv"], self._p(f"{prefix}.bias").reshape(-1), skip, self._k_blur_up,
+                                       1 / math.sqrt(w.shape[2] * w.shape[-1] * w.shape[-1]))
         weight = self._modulated_weight(f"{prefix}.conv", w_latent, False)
         out = agc.conv2d(x, weight, bias=self._p(f"{prefix}.bias").reshape(-1), stride=1, padding=0)   # bias in the conv epilogue
         if skip is not None:

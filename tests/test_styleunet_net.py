@@ -127,3 +127,40 @@ def test_dual_styleunet_forward_backward_vs_reference_golden():
         assert np.percentile(ours, q) <= 4 * np.percentile(ref, q), (q, np.percentile(ours, q), np.percentile(ref, q))
     for o, _, n in rows:
         assert o <= (0.25 if n.endswith("noise.weight") else 3e-2), (n, o)
+
+
+@pytest.mark.gpu
+def test_layer_level_autograd_nodes_equal_the_per_kernel_chain():
+    """fused_layers.py: ConvLayer / StyledConv / ToRGB as one autograd node each run the same kernels in the same order as the chain of
+    per-kernel Functions -- images bit-equal; gradients bit-equal except where float atomics sum in launch order (weight gradients of
+    the split-K / pixel-sliced convolutions, bias and noise-strength reductions): those within 1e-5 of the tensor's scale."""
+    import torch
+    from animatablegaussians_amd import styleunet, synth
+    from animatablegaussians_amd.styleunet import DualStyleUNet
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    net = DualStyleUNet(inp_size=512, inp_ch=3, out_ch=3, out_size=1024, style_dim=512, n_mlp=2).to(dev)
+    pose = synth.pose_map(512).to(dev)
+    style = (torch.ones(1, 512) / np.sqrt(512)).to(dev)
+    view = torch.randn(1, 128, 128, 128, generator=torch.Generator().manual_seed(2)).to(dev) * 0.1
+    G = torch.randn(1, 6, 1024, 1024, generator=torch.Generator().manual_seed(3)).to(dev)
+    res = {}
+    prev = styleunet.set_fused_layers(True)
+    try:
+        for fused in (True, False):
+            styleunet.set_fused_layers(fused)
+            for p in net.parameters():
+                p.grad = None
+            x = pose.clone().requires_grad_(True)
+            images, _ = net([style], x, randomize_noise=False, view_feature1=view, view_feature2=view)
+            (images * G).sum().backward()
+            res[fused] = (images.detach().clone(), x.grad.clone(), {k: net._p(k).grad.clone() for k in net._learnable})
+    finally:
+        styleunet.set_fused_layers(prev)
+    assert torch.equal(res[True][0], res[False][0])
+    worst = 0.0
+    for a, b in [(res[True][1], res[False][1])] + [(res[True][2][k], res[False][2][k]) for k in res[True][2]]:
+        worst = max(worst, float((a - b).abs().max() / (b.abs().max() + 1e-30)))
+    assert worst <= 1e-5, worst
+    assert set(res[True][2]) == set(res[False][2])
