@@ -53,6 +53,24 @@ def _unstash(ctx):
     return ctx.subs
 
 
+def _release(ctx):
+    """Drop the sub-steps' references again when the backward is done: they include the node's own output (the activation kernel's
+    backward reads it), and a reference from the node to its output that autograd does not know about is a cycle only the garbage
+    collector breaks -- gigabytes of activations per step would pile up until it runs."""
+    for s in ctx.subs:
+        if s is not None:
+            s.saved_tensors = ()
+
+
+def _releasing(backward):
+    def wrapped(ctx, *grads):
+        try:
+            return backward(ctx, *grads)
+        finally:
+            _release(ctx)
+    return wrapped
+
+
 class _ConvLayer(torch.autograd.Function):
     """[Blur] + EqualConv2d + FusedLeakyReLU(bias)."""
 
@@ -71,6 +89,7 @@ class _ConvLayer(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_releasing
     def backward(ctx, g):
         s_blur, s_conv, s_act = _unstash(ctx)
         nx, nw, nb = ctx.needs_input_grad[:3]
@@ -104,6 +123,7 @@ class _StyledConv(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_releasing
     def backward(ctx, g):
         s_mod, s_conv, s_blur, s_act = _unstash(ctx)
         nx, nw, ns, _, nnw, nb = ctx.needs_input_grad[:6]
@@ -139,6 +159,7 @@ class _ToRGB(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_releasing
     def backward(ctx, g):
         s_mod, s_conv, s_up = _unstash(ctx)
         nx, nw, ns, nb, nskip = ctx.needs_input_grad[:5]

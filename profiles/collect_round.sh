@@ -4,6 +4,8 @@
 #   <tag>_bench_kernel_stats.csv     rocprofv3 --kernel-trace --stats of the same command, summarised per kernel
 #   <tag>_conv_layers.csv            per-layer forward / dgrad / wgrad table of the DualStyleUNet convolutions
 #   <tag>_styleunet_kernel_stats.csv rocprofv3 summary of DualStyleUNet forward and forward + backward passes
+#   <tag>_conv_math_ab.txt           interleaved A/B of the three convolution arithmetic modes (network pass, training step)
+#   <tag>_host_vs_gpu.txt            host issue time against GPU time of the network pass and the training step
 cd "$(dirname "$0")/.."
 tag=${1:-rXX}
 export TMPDIR=/tmp
@@ -20,3 +22,5 @@ rocprofv3 --kernel-trace --stats -d /tmp/prof_su -o su -- python profiles/styleu
 db=$(find /tmp/prof_su -name "*.db" | head -1)
 python profiles/summarize_rocprof.py "$db" gpurun_out/${tag}_styleunet_kernel_stats.csv | head -8 | cut -c1-140
 grep -E "^fwd" gpurun_out/${tag}_styleunet_bench.log
+python profiles/conv_math_ab.py 3 > gpurun_out/${tag}_conv_math_ab.txt 2>&1; tail -3 gpurun_out/${tag}_conv_math_ab.txt
+python profiles/host_vs_gpu.py > gpurun_out/${tag}_host_vs_gpu.txt 2>&1; tail -3 gpurun_out/${tag}_host_vs_gpu.txt

@@ -2,6 +2,7 @@
     python profiles/conv_concurrency_probe.py [mode]"""
 import collections, os, sys, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["AG_UNFUSED_LAYERS"] = "1"       # the spy below hooks the per-kernel convolution node
 from animatablegaussians_amd import conv as agc, synth
 from animatablegaussians_amd.styleunet import DualStyleUNet
 dev = torch.device("cuda:0")

@@ -9,6 +9,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["AG_UNFUSED_LAYERS"] = "1"       # the layer list is collected by spying on the per-kernel convolution node
 from animatablegaussians_amd import conv as agc, synth  # noqa: E402
 from animatablegaussians_amd.styleunet import DualStyleUNet  # noqa: E402
 
