@@ -133,6 +133,23 @@ def timed(fn, steps, warmup, dev):
     return 1e3 * (time.perf_counter() - t0) / steps
 
 
+def timed_median(fn, steps, warmup, dev):
+    """median ms of `steps` individually synchronised calls (robust against a one-off stall, e.g. the allocator re-growing its pool
+    after the arithmetic mode changed)."""
+    import numpy as np
+    import torch
+    for i in range(warmup):
+        fn(i)
+    ts = []
+    for i in range(steps):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        fn(warmup + i)
+        torch.cuda.synchronize(dev)
+        ts.append(1e3 * (time.perf_counter() - t0))
+    return float(np.median(ts))
+
+
 def conv_roofline(dev, steps=2):
     """MFMA roofline of the convolution kernels, measured live, in the product's arithmetic (split_bf16: six bf16 products per fp32
     product) and, beside it, in the fp32-MFMA mode.  One DualStyleUNet (the colour / position configuration) forward + backward on ONE
@@ -159,8 +176,8 @@ def conv_roofline(dev, steps=2):
 
     def measure():
         one(0)
-        fwd_ms = timed(fwd, steps + 1, 1, dev)              # wall time of the pass as the product runs it (two decoder streams)
-        both_ms = timed(one, steps + 1, 1, dev)
+        fwd_ms = timed_median(fwd, 5, 2, dev)               # wall time of the pass as the product runs it (two decoder streams)
+        both_ms = timed_median(one, 5, 2, dev)
         prev = os.environ.get("AG_SINGLE_STREAM")
         os.environ["AG_SINGLE_STREAM"] = "1"                # per-kernel durations: no co-running kernels
         try:
