@@ -312,6 +312,66 @@ __global__ void __launch_bounds__(256) upfirdn2d_kernel(float* __restrict__ out,
     }
 }
 
+// The network's heavy FIR calls are plain 4 x 4 filters (up = down = 1: the blur behind every transposed convolution, the blur in front
+// of every stride-2 convolution, and their adjoints).  The general kernel above spends ~40 integer instructions (two 64-bit divisions)
+// and 16 dependent scalar loads per output: 203 us for the 64-channel 512^2 blur where the bytes take 27.  Here a thread produces a
+// 4 x 2 block of outputs from a 7 x 5 window read as ten 16-byte loads (alignment is free on this part: profiles/ub/load_rate.hip), grid
+// (x quads, row pairs, image) so there is no division at all; same accumulation order per output as the general kernel (rows, then
+// columns, ascending; out-of-image taps contribute exact zeros), hence the same bits.
+__global__ void __launch_bounds__(256) fir4x4_kernel(float* __restrict__ out, const float* __restrict__ input,
+                                                     const float* __restrict__ kernel, UpfirdnParams p)
+{
+    __shared__ float taps[16];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    if (threadIdx.x < 16) taps[threadIdx.x] = kernel[threadIdx.x];
+    __syncthreads();
+    const int ox0 = (blockIdx.x * 64 + tx) * 4, oy0 = (blockIdx.y * 4 + ty) * 2;
+    if (ox0 >= p.out_w || oy0 >= p.out_h) return;
+    const float* img = input + (size_t)blockIdx.z * p.in_h * p.in_w;
+    const int cx = ox0 - p.pad_x0, cy = oy0 - p.pad_y0;                 // window origin: columns cx .. cx + 6, rows cy .. cy + 4
+    float win[5][8];
+    const bool x_inside = cx >= 0 && cx + 8 <= p.in_w;
+#pragma unroll
+    for (int r = 0; r < 5; r++) {
+        const int iy = cy + r;
+        const bool row_ok = iy >= 0 && iy < p.in_h;
+        const float* row = img + (size_t)(row_ok ? iy : 0) * p.in_w;
+        if (row_ok && x_inside) {
+            const float4 a = *reinterpret_cast<const float4*>(row + cx), b = *reinterpret_cast<const float4*>(row + cx + 4);
+            win[r][0] = a.x; win[r][1] = a.y; win[r][2] = a.z; win[r][3] = a.w;
+            win[r][4] = b.x; win[r][5] = b.y; win[r][6] = b.z; win[r][7] = b.w;
+        } else {
+#pragma unroll
+            for (int c = 0; c < 7; c++) {
+                const int ix = cx + c;
+                win[r][c] = (row_ok && ix >= 0 && ix < p.in_w) ? row[ix] : 0.0f;
+            }
+            win[r][7] = 0.0f;
+        }
+    }
+    float* dst = out + ((size_t)blockIdx.z * p.out_h + oy0) * p.out_w + ox0;
+#pragma unroll
+    for (int dy = 0; dy < 2; dy++) {
+        if (oy0 + dy >= p.out_h) break;
+        float v[4] = { 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+        for (int y = 0; y < 4; y++)
+#pragma unroll
+            for (int x = 0; x < 4; x++) {
+                const float k = taps[(3 - y) * 4 + (3 - x)];
+#pragma unroll
+                for (int q = 0; q < 4; q++) v[q] = fmaf(win[dy + y][q + x], k, v[q]);
+            }
+        if (ox0 + 4 <= p.out_w && (((size_t)(dst + (size_t)dy * p.out_w)) & 15) == 0) {
+            *reinterpret_cast<float4*>(dst + (size_t)dy * p.out_w) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (ox0 + q < p.out_w) dst[(size_t)dy * p.out_w + q] = v[q];
+        }
+    }
+}
+
 }  // namespace ag
 
 using namespace ag;
@@ -425,6 +485,11 @@ int ag_upfirdn2d(float* out, const float* input, const float* kernel, int32_t ma
     if (p.out_h <= 0 || p.out_w <= 0) { set_error("upfirdn2d output would be empty (%d x %d)", p.out_h, p.out_w); return AG_ERR_INVALID_ARGUMENT; }
     if (major == 0) return AG_OK;
     if (!out || !input || !kernel) { set_error("null pointer"); return AG_ERR_INVALID_ARGUMENT; }
+    if (up_x == 1 && up_y == 1 && down_x == 1 && down_y == 1 && kernel_h == 4 && kernel_w == 4 && major <= 65535) {
+        dim3 grid((p.out_w + 255) / 256, (p.out_h + 7) / 8, major);
+        hipLaunchKernelGGL(fir4x4_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), out, input, kernel, p);
+        return check_hip(hipGetLastError(), "fir4x4_kernel");
+    }
     const long long total = (long long)major * p.out_h * p.out_w;
     long long blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;

@@ -101,6 +101,18 @@ def test_hip_ops_at_styleunet_sizes_vs_oracle():
     want = so.upfirdn2d(x, k4, 2, 2, 1, 1, 2, 1, 2, 1)
     assert got.shape[1:3] == (1024, 1024)
     np.testing.assert_allclose(got.cpu().numpy()[..., 0], want.numpy(), rtol=1e-5, atol=1e-6)
+    # the 4 x 4, up = down = 1 fast path (fir4x4_kernel): an ASYMMETRIC kernel (a flipped or transposed tap table must show), ragged
+    # sizes (widths that are not multiples of 4, single rows), every pad combination the network and its adjoints use and more
+    ka = torch.randn(4, 4, generator=g)
+    for (c, h, w) in [(3, 17, 19), (2, 5, 4), (1, 1, 9), (4, 64, 66), (2, 33, 7)]:
+        x = torch.randn(c, h, w, generator=g)
+        for pads in [(1, 1, 1, 1), (2, 2, 2, 2), (2, 1, 2, 1), (0, 3, 3, 0), (3, 3, 3, 3), (1, 2, 2, 1)]:
+            if h + pads[2] + pads[3] < 4 or w + pads[0] + pads[1] < 4:
+                continue
+            got = ops.upfirdn2d(x.cuda()[..., None].contiguous(), ka.cuda(), 1, 1, 1, 1, *pads)
+            want = so.upfirdn2d(x, ka, 1, 1, 1, 1, *pads)
+            assert got.shape[:3] == want.shape, (got.shape, want.shape)
+            np.testing.assert_allclose(got.cpu().numpy()[..., 0], want.numpy(), rtol=1e-5, atol=1e-5)
     with pytest.raises(RuntimeError):
         ops.upfirdn2d(torch.zeros(1, 2, 2, 1, device="cuda"), torch.zeros(4, 4, device="cuda"), 1, 1, 1, 1, 0, 0, 0, 0)   # empty output
 
