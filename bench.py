@@ -23,7 +23,13 @@ The JSON line also carries
   roofline     : dominant kernel (blend backward), ALGORITHMIC bytes/launch (8T + 44R + 28WH + 40P)
                  / its HIP-event duration measured live in the timed region, against 8 TB/s HBM3E;
   cpu_baseline : the CPU oracle (a restatement of the reference's CUDA kernels -- the reference has no CPU
-                 rasterizer) timed on this box's host cores on a bounded sample of the same workload.
+                 rasterizer) timed on this box's host cores on a bounded sample of the same workload;
+  full_step    : BASELINE configs[2], the whole training iteration (three StyleUNets + assembly + LBS + raster, loss, backward,
+                 fused Adam) at 1 and at 4 views per step, in the product's convolution arithmetic and, interleaved in the same
+                 process, in the other two modes of include/ag_conv.h;
+  roofline_mfma: the convolution kernels' own rate (HIP events around every launch of one network forward + backward), in the
+                 product's arithmetic against the dense bf16 MFMA peak (executed = 6 x algorithmic FLOPs) and in the fp32-MFMA
+                 mode against the fp32 MFMA peak.
 """
 from __future__ import annotations
 
