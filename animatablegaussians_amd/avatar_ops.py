@@ -52,7 +52,7 @@ class _GatherActivate(torch.autograd.Function):
         a.position_map, a.other_map, a.color_map = _p(position_map), _p(other_map), _p(color_map)
         a.xyz, a.opacity_raw, a.scaling_raw, a.rotation_raw = _p(xyz), _p(opacity_raw), _p(scaling_raw), _p(rotation_raw)
         a.positions, a.opacity, a.scales, a.rotations, a.colors = (_p(t) for t in out)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             _lib.check(L.ag_gather_activate_forward(ctypes.byref(a), _stream(dev)), "ag_gather_activate_forward")
         ctx.save_for_backward(position_map, other_map, color_map, pix, xyz, opacity_raw, scaling_raw, rotation_raw)
         return tuple(out)
@@ -72,7 +72,7 @@ class _GatherActivate(torch.autograd.Function):
         a.xyz, a.opacity_raw, a.scaling_raw, a.rotation_raw = _p(xyz), _p(opacity_raw), _p(scaling_raw), _p(rotation_raw)
         a.positions, a.opacity, a.scales, a.rotations, a.colors = (_p(t) for t in grads)
         gp, go, gc = (torch.empty_like(m) for m in (position_map, other_map, color_map))
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             _lib.check(L.ag_gather_activate_backward(ctypes.byref(a), _p(gp), _p(go), _p(gc), _stream(dev)),
                        "ag_gather_activate_backward")
         # the canonical Gaussian parameters are not optimised by the reference trainer (GaussianModel is not an
@@ -113,7 +113,7 @@ class _GatherPart(torch.autograd.Function):
             a.opacity, a.scales, a.rotations = (_p(t) for t in out)
         else:
             a.color_map, a.colors = _p(net_map), _p(out[0])
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             _lib.check(L.ag_gather_activate_forward(ctypes.byref(a), _stream(dev)), "ag_gather_activate_forward")
         ctx.part = part
         ctx.save_for_backward(net_map, pix, *raws)
@@ -141,7 +141,7 @@ class _GatherPart(torch.autograd.Function):
             go = _p(gm)
         else:
             a.colors, gc = _p(grads[0]), _p(gm)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             _lib.check(L.ag_gather_activate_backward(ctypes.byref(a), gp, go, gc, _stream(dev)), "ag_gather_activate_backward")
         return (None, gm, None) + (None,) * len(raws)
 
@@ -171,7 +171,7 @@ def canonical_activations(pix, S, opacity_raw, scaling_raw, rotation_raw):
     a.N, a.S, a.pix = N, int(S), _p(pix)
     a.opacity_raw, a.scaling_raw, a.rotation_raw = (_p(_chk(r, "canonical parameter")) for r in (opacity_raw, scaling_raw, rotation_raw))
     a.opacity, a.scales, a.rotations = (_p(t) for t in out)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         _lib.check(_lib.lib().ag_gather_activate_forward(ctypes.byref(a), _stream(dev)), "ag_gather_activate_forward")
     return tuple(out)
 
@@ -229,7 +229,7 @@ class _LbsTransform(torch.autograd.Function):
             raise RuntimeError("sparse blend weights do not match the number of Gaussians")
         out_p, out_r = torch.empty_like(positions), torch.empty_like(rotations)
         a = _lbs_args(N, J, lbs, jnt_mats, positions, rotations, out_p, out_r, sparse)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             _lib.check(L.ag_lbs_forward(ctypes.byref(a), _stream(dev)), "ag_lbs_forward")
         ctx.save_for_backward(positions, rotations, lbs, jnt_mats)
         ctx.sparse = sparse
@@ -244,7 +244,7 @@ class _LbsTransform(torch.autograd.Function):
         g_r = _chk(g_r, "grad") if g_r is not None else torch.zeros_like(rotations)
         dp, dr = torch.empty_like(positions), torch.empty_like(rotations)
         a = _lbs_args(N, J, lbs, jnt_mats, positions, rotations, g_p, g_r, ctx.sparse)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             _lib.check(L.ag_lbs_backward(ctypes.byref(a), _p(dp), _p(dr), _stream(dev)), "ag_lbs_backward")
         return dp, dr, None, None, None   # lbs weights and joint matrices are data, not parameters
 
@@ -276,6 +276,6 @@ def hand_fuse(positions, opacity, scales, rotations, xyz, left_mano_v, right_man
                 and t.shape[0] != a.N:
             raise RuntimeError(f"hand_fuse: {name} has {t.shape[0]} rows, expected {a.N}")
         setattr(a, name, t.data_ptr())
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         _lib.check(_lib.lib().ag_hand_fuse(ctypes.byref(a), _stream(dev)), "ag_hand_fuse")
     return tuple(outs)

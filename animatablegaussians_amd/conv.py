@@ -53,8 +53,14 @@ def _desc(kind, Cin, Cout, H, W, k, stride, padding, weight_scale=1.0):
     return d
 
 
+_WS_BYTES = {}
+
+
 def _workspace(d, dev):
-    n = _lib.lib().ag_conv_workspace_bytes(ctypes.byref(d))
+    key = (d.kind, d.Cin, d.Cout, d.k, d.stride, d.padding, d.H, d.W)
+    n = _WS_BYTES.get(key)
+    if n is None:                                   # a function of the descriptor only: asked once per layer shape
+        n = _WS_BYTES[key] = _lib.lib().ag_conv_workspace_bytes(ctypes.byref(d))
     return torch.empty((n,), dtype=torch.uint8, device=dev), n
 
 
@@ -76,13 +82,17 @@ class _Conv(torch.autograd.Function):
             raise RuntimeError("MFMA conv path: out_scale is a constant of the node (no gradient is produced for it); pass a detached "
                                "tensor, or differentiate the demodulation through `weight` as ModulatedConv2d does")
         d = _desc(kind, Cin, Cout, H, W, k, stride, padding, weight_scale)
-        oh, ow = ctypes.c_int32(), ctypes.c_int32()
-        _lib.check(L.ag_conv_output_size(ctypes.byref(d), ctypes.byref(oh), ctypes.byref(ow)), "ag_conv_output_size")
-        y = torch.empty((1, Cout, oh.value, ow.value), dtype=torch.float32, device=x.device)
+        if kind == AG_CONV:                         # ag_conv_output_size's formula (the native call validates the descriptor itself)
+            oh, ow = (H + 2 * padding - k) // stride + 1, (W + 2 * padding - k) // stride + 1
+        else:
+            oh, ow = (H - 1) * 2 + k, (W - 1) * 2 + k
+        if oh <= 0 or ow <= 0:
+            raise RuntimeError("MFMA conv path: kernel larger than the padded input")
+        y = torch.empty((1, Cout, oh, ow), dtype=torch.float32, device=x.device)
         ws, n = _workspace(d, x.device)
         b = bias.contiguous() if bias is not None else None
         sc = out_scale.contiguous() if out_scale is not None else None
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             _lib.check(L.ag_conv_forward(ctypes.byref(d), _p(x), _p(w), _p(sc), _p(b), _p(y), _p(ws), n, _stream(x.device)),
                        "ag_conv_forward")
         ctx.save_for_backward(x, w, sc)
@@ -107,7 +117,7 @@ class _Conv(torch.autograd.Function):
             gy = gy * sc.view(1, -1, 1, 1)
         ws, n = _workspace(d, x.device)
         gx = gw = None
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             if ctx.needs_input_grad[0]:
                 gx = torch.empty_like(x)
                 _lib.check(L.ag_conv_backward_input(ctypes.byref(d), _p(gy), _p(w), _p(gx), _p(ws), n, _stream(x.device)),

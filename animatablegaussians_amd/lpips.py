@@ -52,7 +52,7 @@ class _MaxPool2x2(torch.autograd.Function):
         _, C, H, W = x.shape
         y = torch.empty((1, C, H // 2, W // 2), dtype=torch.float32, device=x.device)
         arg = torch.empty((C, H // 2, W // 2), dtype=torch.uint8, device=x.device) if x.requires_grad else None
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             _lib.check(_lib.lib().ag_maxpool2x2_forward(_p(y), _p(arg), _p(x), C, H, W, _stream(x.device)), "ag_maxpool2x2_forward")
         ctx.shape = (C, H, W)
         ctx.save_for_backward(arg)
@@ -64,7 +64,7 @@ class _MaxPool2x2(torch.autograd.Function):
         C, H, W = ctx.shape
         gy = gy.contiguous()
         gx = torch.empty((1, C, H, W), dtype=torch.float32, device=gy.device)
-        with torch.cuda.device(gy.device):
+        with _lib.on_device(gy.device):
             _lib.check(_lib.lib().ag_maxpool2x2_backward(_p(gx), _p(gy), _p(arg), C, H, W, _stream(gy.device)), "ag_maxpool2x2_backward")
         return gx
 
@@ -82,7 +82,7 @@ class _LpipsLevel(torch.autograd.Function):
         if f1.shape != f0.shape or lin.numel() != C:
             raise RuntimeError("lpips level: feature stacks of equal shape and one weight per channel")
         out = torch.zeros(1, dtype=torch.float32, device=f0.device)
-        with torch.cuda.device(f0.device):
+        with _lib.on_device(f0.device):
             _lib.check(_lib.lib().ag_lpips_level_forward(_p(out), _p(f0), _p(f1), _p(lin), C, HW, _stream(f0.device)),
                        "ag_lpips_level_forward")
         ctx.save_for_backward(f0, f1, lin)
@@ -94,7 +94,7 @@ class _LpipsLevel(torch.autograd.Function):
         C, HW = int(f0.shape[1]), int(f0.shape[2] * f0.shape[3])
         gf0 = torch.empty_like(f0)
         g = g.contiguous()
-        with torch.cuda.device(f0.device):
+        with _lib.on_device(f0.device):
             _lib.check(_lib.lib().ag_lpips_level_backward(_p(gf0), _p(g), _p(f0), _p(f1), _p(lin), C, HW, _stream(f0.device)),
                        "ag_lpips_level_backward")
         return gf0, None, None        # the ground-truth features and the frozen channel weights receive no gradient

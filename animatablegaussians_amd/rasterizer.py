@@ -242,7 +242,7 @@ def native_mark_visible(means3D, viewmatrix, projmatrix):
         means3D = _f32c(means3D, "means3D")
         viewmatrix = _f32c(viewmatrix, "viewmatrix")
         projmatrix = _f32c(projmatrix, "projmatrix")
-        with torch.cuda.device(means3D.device):
+        with _lib.on_device(means3D.device):
             _lib.check(L.ag_raster_mark_visible(P, _ptr(means3D), _ptr(viewmatrix), _ptr(projmatrix), _ptr(present),
                                                 _stream_ptr(means3D.device)), "ag_raster_mark_visible")
     return present

@@ -43,7 +43,7 @@ def fused_bias_act(input: torch.Tensor, bias: torch.Tensor, refer: torch.Tensor,
     step_b = 1
     for i in range(2, x.dim()):
         step_b *= x.size(i)
-    with torch.cuda.device(x.device):
+    with _lib.on_device(x.device):
         _lib.check(_lib.lib().ag_fused_bias_act(_p(out), _p(x), _p(b), _p(ref), int(act), int(grad), float(alpha),
                                                 float(scale), x.numel(), step_b, b.numel() if b is not None else 0,
                                                 _stream(x.device)), "ag_fused_bias_act")
@@ -68,7 +68,7 @@ def upfirdn2d(input: torch.Tensor, kernel: torch.Tensor, up_x: int, up_y: int, d
         x = input.permute(0, 3, 1, 2).reshape(major * minor, in_h, in_w, 1).contiguous()
     out = torch.empty((x.shape[0], out_h, out_w, 1), dtype=torch.float32, device=input.device)
     k = kernel.to(torch.float32).contiguous()
-    with torch.cuda.device(input.device):
+    with _lib.on_device(input.device):
         _lib.check(_lib.lib().ag_upfirdn2d(_p(out), _p(x), _p(k), x.shape[0], in_h, in_w, kh, kw, up_x, up_y, down_x, down_y,
                                            pad_x0, pad_x1, pad_y0, pad_y1, _stream(input.device)), "ag_upfirdn2d")
     if minor != 1:
@@ -187,7 +187,7 @@ class _NoiseBiasAct(torch.autograd.Function):
             if noise.numel() != HW:
                 raise RuntimeError("noise must be [1, 1, H, W]")
         y = torch.empty_like(x)
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             _lib.check(_lib.lib().ag_noise_bias_act_forward(_p(y), _p(x), _p(noise), _p(noise_weight), _p(bias), C, HW,
                                                             float(slope), float(scale), _stream(x.device)),
                        "ag_noise_bias_act_forward")
@@ -204,7 +204,7 @@ class _NoiseBiasAct(torch.autograd.Function):
         # frozen parameters (the VGG trunk of LPIPS): no reduction, no buffer
         gb = torch.empty(C, dtype=torch.float32, device=y.device) if has_bias and ctx.needs_input_grad[3] else None
         gw = torch.empty(1, dtype=torch.float32, device=y.device) if has_nw and ctx.needs_input_grad[2] else None
-        with torch.cuda.device(y.device):
+        with _lib.on_device(y.device):
             _lib.check(_lib.lib().ag_noise_bias_act_backward(_p(gx), _p(gy), _p(y), _p(noise) if gw is not None else None, _p(gb), _p(gw),
                                                              C, HW, slope, scale, _stream(y.device)),
                        "ag_noise_bias_act_backward")
@@ -230,7 +230,7 @@ class _ModulateWeight(torch.autograd.Function):
             raise RuntimeError("modulate_weight: weight [.., Co, Ci, k, k] float32 on the GPU, style with Ci entries")
         out = torch.empty((Ci, Co, k, k) if transposed else (Co, Ci, k, k), dtype=torch.float32, device=w.device)
         dcoef = torch.empty(Co, dtype=torch.float32, device=w.device) if demodulate else None
-        with torch.cuda.device(w.device):
+        with _lib.on_device(w.device):
             _lib.check(_lib.lib().ag_modulate_weight_forward(_p(out), _p(dcoef), _p(w), _p(st), float(scale), int(demodulate), Co, Ci,
                                                              K2, int(transposed), _stream(w.device)), "ag_modulate_weight_forward")
         ctx.save_for_backward(w, st, dcoef)
@@ -244,7 +244,7 @@ class _ModulateWeight(torch.autograd.Function):
         g = g.contiguous()
         dW = torch.empty_like(w)
         ds = torch.empty(Ci, dtype=torch.float32, device=w.device)
-        with torch.cuda.device(w.device):
+        with _lib.on_device(w.device):
             _lib.check(_lib.lib().ag_modulate_weight_backward(_p(dW), _p(ds), _p(g), _p(w), _p(st), _p(dcoef), scale, int(demodulate),
                                                               Co, Ci, K2, int(transposed), _stream(w.device)),
                        "ag_modulate_weight_backward")
@@ -291,7 +291,7 @@ class _Block2x2(torch.autograd.Function):
                 raise RuntimeError("split expects even height and width")
             out = torch.empty((1, 4 * C, h, w), dtype=torch.float32, device=x.device)
         m = (ctypes.c_float * 16)(*matrix)
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             _lib.check(_lib.lib().ag_block2x2_transform(_p(out), _p(x), ctypes.cast(m, ctypes.c_void_p), int(merge), C, h, w,
                                                         _stream(x.device)), "ag_block2x2_transform")
         ctx.cfg = (matrix, merge)
