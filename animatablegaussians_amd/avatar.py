@@ -299,13 +299,21 @@ class AvatarNet(nn.Module):
         vec, _ = ops.lbs_transform(vectors.contiguous(), self._unit_quat, self.core.lbs, rot_only, self.core.lbs_sparse)
         return pts, vec
 
+    def _mask_index(self):
+        """Flat int64 positions of the canvas mask in ``canvas[mask]`` order (= core.pix): a boolean-mask assignment makes torch
+        compute them with nonzero() on every call, i.e. a device-to-host synchronisation per pose map and per view-direction map."""
+        idx = getattr(self, "_mask_index64", None)
+        if idx is None or idx.device != self.core.pix.device:
+            idx = self._mask_index64 = self.core.pix.long()
+        return idx
+
     @torch.no_grad()
     def get_pose_map(self, items):
         """Live position map [6, S/2, S/2] from ``cano2live_jnt_mats_woRoot``  (:149-159)."""
         live_pts, _ = self._blend_points(items['cano2live_jnt_mats_woRoot'])
         H, W = self.map_shape
         live = torch.zeros(H, W, 3, device=live_pts.device)
-        live[self.cano_smpl_mask] = live_pts
+        live.view(-1, 3).index_copy_(0, self._mask_index(), live_pts)   # == live[self.cano_smpl_mask] = live_pts without the host sync
         live = live.permute(2, 0, 1)[:, ::2, ::2]                  # F.interpolate(scale 0.5, 'nearest') == every 2nd sample
         live = torch.cat(torch.split(live, [W // 4, W // 4], 2), 0).contiguous()
         items.update({'smpl_pos_map': live})
@@ -323,7 +331,7 @@ class AvatarNet(nn.Module):
                 self._pose_cache = cache
             live_pts, live_nmls = cache[2], cache[3]
             extr = items['extr']
-            cam_pos = -torch.matmul(torch.linalg.inv(extr[:3, :3]), extr[:3, 3])
+            cam_pos = -torch.matmul(torch.linalg.inv_ex(extr[:3, :3])[0], extr[:3, 3])   # inv without the singularity read-back
             viewdirs = F.normalize(cam_pos[None] - live_pts, dim=-1, eps=1e-3)
             if self.training:
                 viewdirs = viewdirs + torch.randn_like(viewdirs) * 0.1
@@ -331,7 +339,7 @@ class AvatarNet(nn.Module):
             cosine = (live_nmls * viewdirs).sum(-1)
             H, W = self.map_shape
             vmap = torch.zeros(H, W, device=cosine.device)
-            vmap[self.cano_smpl_mask] = cosine
+            vmap.view(-1).index_copy_(0, self._mask_index(), cosine)     # == vmap[self.cano_smpl_mask] = cosine, no host sync
             vmap = vmap[None, None, ::2, ::2]
             front, back = (t.contiguous() for t in torch.split(vmap, [W // 4, W // 4], -1))
         weight = self.opt.get('weight_viewdirs', 1.)
