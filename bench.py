@@ -333,6 +333,31 @@ def main() -> None:
     }
     if breakdown is not None:
         out["kernels_us"] = breakdown
+        # algorithmic bytes per launch of every raster kernel (DESIGN.md section 4 / SURVEY.md 8d) against its one-stream duration
+        alg = {"preprocess_kernel": 112 * P, "tile_scan_kernel": 8 * T_tiles, "scatter_kernel": 20 * P + 12 * R_mean,
+               "tile_sort_kernel": 24 * R_mean, "blend_forward_kernel": 8 * T_tiles + 44 * R_mean + 24 * W * H,
+               "blend_backward_kernel": alg_dom, "preprocess_backward_kernel": 220 * P}
+        out["kernels_algorithmic_GBps"] = {k: round(alg[k] / (breakdown[k] * 1e-6) / 1e9, 1) for k in alg if breakdown.get(k, 0) > 0}
+        out["kernels_algorithmic_MB"] = {k: round(alg[k] / 1e6, 2) for k in alg}
+        # what a pure streaming kernel achieves at the same footprints on this box: a device copy moving as many bytes (half read, half
+        # written) as preprocess / scatter / preprocess backward do -- the ceiling a launch of that size can reach, fixed costs included
+        ceil = {}
+        for k in ("preprocess_kernel", "scatter_kernel", "preprocess_backward_kernel"):
+            n = int(alg[k] // 8)
+            a, b = torch.empty(n, device=dev), torch.empty(n, device=dev)
+            for _ in range(3):
+                b.copy_(a)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize(dev)
+            us = []
+            for _ in range(20):
+                e0.record()
+                b.copy_(a)
+                e1.record()
+                e1.synchronize()
+                us.append(1e3 * e0.elapsed_time(e1))
+            ceil[k] = {"copy_us": round(float(np.median(us)), 2), "copy_GBps": round(alg[k] / (float(np.median(us)) * 1e-6) / 1e9, 1)}
+        out["streaming_copy_of_the_same_bytes"] = ceil
     if seq is not None:
         out["sequential"] = seq
     if oper is not None:
