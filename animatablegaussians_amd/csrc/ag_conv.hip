@@ -632,25 +632,35 @@ struct PackProblem {
     int tapoff[kMaxClasses][kMaxTaps];
 };
 
+// 16 x 16 x k*k block of the natural weight layout -> LDS.  Thread (outer o, inner i) owns the k*k taps of one (row, channel) pair: they
+// are contiguous in memory and the pairs of consecutive threads follow each other, so a wave reads one contiguous run; all loads of a
+// thread are issued before the first LDS write (the earlier element-indexed loop ran k*k dependent iterations with two integer
+// divisions each).
+__device__ __forceinline__ void load_weight_block(float (&blk)[16][16 * kMaxTaps + 1], const PackProblem& p, int cb, int m16, int tid,
+                                                  bool m_inner)
+{
+    const int o = tid >> 4, inner = tid & 15, k2 = p.k2;
+    const int c = cb * 16 + (m_inner ? o : inner), m = m16 * 16 + (m_inner ? inner : o);
+    const bool ok = c < p.C && m < p.M;
+    const float* src = p.w + (ok ? (long long)c * p.stride_c + (long long)m * p.stride_m : 0);
+    float v[kMaxTaps];
+#pragma unroll
+    for (int t = 0; t < kMaxTaps; t++) v[t] = (ok && t < k2) ? src[t] : 0.f;
+    const float ws = p.has_wscale ? p.wscale : 1.f;
+#pragma unroll
+    for (int t = 0; t < kMaxTaps; t++)
+        if (t < k2) blk[o][inner * k2 + t] = p.has_wscale ? v[t] * ws : v[t];
+}
+
 __global__ void __launch_bounds__(256) pack_weights_kernel(PackProblem p)
 {
     __shared__ float blk[16][16 * kMaxTaps + 1];
     const int tid = threadIdx.x;
     const int cb = blockIdx.x, m16 = blockIdx.y;             // channel block, 16-row group
-    const int k2 = p.k2, run = 16 * k2;
+    const int k2 = p.k2;
     const bool m_inner = p.stride_m == k2;                   // else stride_c == k2: channels contiguous with the taps
     // load: 16 rows of the outer index, each one contiguous run of 16 * k2 floats
-    for (int e = tid; e < 16 * run; e += 256) {
-        const int o = e / run, r = e - o * run;              // r = inner * k2 + tap
-        const int inner = r / k2;
-        const int c = cb * 16 + (m_inner ? o : inner), m = m16 * 16 + (m_inner ? inner : o);
-        float v = 0.f;
-        if (c < p.C && m < p.M) {
-            v = p.w[(long long)c * p.stride_c + (long long)m * p.stride_m + (r - inner * k2)];
-            if (p.has_wscale) v *= p.wscale;
-        }
-        blk[o][r] = v;
-    }
+    load_weight_block(blk, p, cb, m16, tid, m_inner);
     __syncthreads();
     const int ml = tid >> 4, kl = tid & 15;                  // destination element (m, c) of the block
     const int m = m16 * 16 + ml;
@@ -674,19 +684,9 @@ __global__ void __launch_bounds__(256) pack_weights_split_kernel(PackProblem p)
     __shared__ float blk[16][16 * kMaxTaps + 1];
     const int tid = threadIdx.x;
     const int cb = blockIdx.x, m16 = blockIdx.y;
-    const int k2 = p.k2, run = 16 * k2;
+    const int k2 = p.k2;
     const bool m_inner = p.stride_m == k2;
-    for (int e = tid; e < 16 * run; e += 256) {
-        const int o = e / run, r = e - o * run;
-        const int inner = r / k2;
-        const int c = cb * 16 + (m_inner ? o : inner), m = m16 * 16 + (m_inner ? inner : o);
-        float v = 0.f;
-        if (c < p.C && m < p.M) {
-            v = p.w[(long long)c * p.stride_c + (long long)m * p.stride_m + (r - inner * k2)];
-            if (p.has_wscale) v *= p.wscale;
-        }
-        blk[o][r] = v;
-    }
+    load_weight_block(blk, p, cb, m16, tid, m_inner);
     __syncthreads();
     const int ml = (tid >> 3) & 15, kp = tid & 7, th = tid >> 7;      // row, channel pair (2 kp, 2 kp + 1), tap parity
     const int m = m16 * 16 + ml;
