@@ -150,7 +150,7 @@ def timed_median(fn, steps, warmup, dev):
     return float(np.median(ts))
 
 
-def conv_roofline(dev, steps=2):
+def conv_roofline(dev, steps=3):
     """MFMA roofline of the convolution kernels, measured live, in the product's arithmetic (split_bf16: six bf16 products per fp32
     product) and, beside it, in the fp32-MFMA mode.  One DualStyleUNet (the colour / position configuration) forward + backward on ONE
     stream with every gather-conv / wgrad launch bracketed by HIP events on its launch stream (ag_prof_*); achieved = the launches' own
@@ -181,7 +181,8 @@ def conv_roofline(dev, steps=2):
         prev = os.environ.get("AG_SINGLE_STREAM")
         os.environ["AG_SINGLE_STREAM"] = "1"                # per-kernel durations: no co-running kernels
         try:
-            one(0)
+            for i in range(4):                              # the clocks are at speed before the bracketed passes
+                one(i)
             torch.cuda.synchronize(dev)
             _lib.prof_enable([_lib.AG_K_GATHER_CONV, _lib.AG_K_WGRAD])
             for i in range(steps):
