@@ -230,6 +230,11 @@ __global__ void __launch_bounds__(256) scatter_kernel(int P, int gx, int gy, con
 //    compare-exchange stages of a bitonic network.  Two size classes: <= 2048 entries (256 threads, 32 KiB LDS) and
 //    <= 8192 (1024 threads, 128 KiB LDS).  Larger tiles (never reached by avatar-sized splats) fall back to an
 //    all-ascending bitonic network run directly on the global segment by one workgroup.
+//    Round 2 tried the opposite trade: a bitonic network held in registers (K consecutive keys per thread, stages at distance < K in
+//    registers, < 64 K between lanes with DPP / ds_swizzle / one bpermute, only the 3-10 widest stages through LDS + barriers).  Bit-
+//    identical (all raster tests), but 22 / 59 / 66 us on the front / oblique / side views against 21 / 36 / 48 here: the tiles of an
+//    avatar view are long (886 entries on average, up to 6015), so the network's n log^2 n exchanges cost more than this sort's chains
+//    of dependent LDS reads.  Not kept.
 // ---------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void cswap(uint64_t& a, uint64_t& b)
 {
