@@ -290,33 +290,14 @@ __device__ __forceinline__ void bitonic_sort_global(KeyPtr sk, uint32_t n, uint3
     }
 }
 
-// Workgroups walk the non-empty tiles in tile_scan_kernel's longest-first order with a grid stride, so only as many
-// workgroups are launched as can be resident (the 128 KiB class would otherwise queue 4096 one-per-CU launches).
-template <int NT, bool LARGE, int KPT>
-__global__ void __launch_bounds__(NT) tile_sort_kernel(const uint4* __restrict__ tile_order, const uint32_t* __restrict__ counts,
-                                                      uint64_t* __restrict__ keys, uint32_t* __restrict__ point_list)
+// LDS merge sort of one segment of n <= NT * KPT keys by the whole workgroup.  PRESORTED: the segment already consists of sorted runs
+// of `run0` keys (the chunk pass below), so the register sort and the merge rounds below run0 are skipped.  The result goes to
+// `out_list` (the low 32 bits: Gaussian indices) or, for a chunk, back to `out_keys`.
+template <int NT, int KPT, bool PRESORTED>
+__device__ __forceinline__ void sort_segment_lds(uint64_t* __restrict__ sk, const uint64_t* __restrict__ seg, uint32_t n, uint32_t run0,
+                                                 uint32_t* __restrict__ out_list, uint64_t* __restrict__ out_keys, int tid)
 {
-    extern __shared__ __attribute__((aligned(16))) uint64_t sk[];   // two buffers of NT * KPT keys
     constexpr uint32_t CAP = NT * KPT;
-    const uint32_t n_active = counts[1];
-    const int tid = threadIdx.x;
-    for (uint32_t rank = blockIdx.x; rank < n_active; rank += gridDim.x) {
-    const uint4 wd = tile_order[rank];
-    const uint2 rg = make_uint2(wd.y, wd.z);
-    const uint32_t n = rg.y - rg.x;
-    // size classes: the small kernel takes (0, kSortSmallCap], the large one everything above.  The order is by
-    // descending bit length of n, so once the large kernel meets a tile below 2048 entries it is done.
-    if (LARGE) { if (n < 2048u) break; if (n <= (uint32_t)kSortSmallCap) continue; }
-    else if (n > (uint32_t)kSortSmallCap) continue;
-    uint64_t* seg = keys + rg.x;
-    __syncthreads();   // LDS buffers of the previous tile are free
-    if (n > CAP) {
-        uint32_t m = 2;
-        while (m < n) m <<= 1;
-        bitonic_sort_global(seg, n, m, tid, NT);   // workgroup barriers order the exchanges (one CU, one L1)
-        for (uint32_t i = tid; i < n; i += NT) point_list[rg.x + i] = (uint32_t)seg[i];
-        continue;
-    }
     uint64_t* bufA = sk;
     uint64_t* bufB = sk + CAP;
     // 1. KPT keys per thread, sorted in registers; slots past n hold +inf and simply stay at the top
@@ -324,7 +305,7 @@ __global__ void __launch_bounds__(NT) tile_sort_kernel(const uint4* __restrict__
     const uint32_t base = (uint32_t)tid * (uint32_t)KPT;
 #pragma unroll
     for (int i = 0; i < KPT; i++) v[i] = (base + i < n) ? seg[base + i] : kKeyInf;
-    sort_regs<KPT>(v);
+    if (!PRESORTED) sort_regs<KPT>(v);
     if (base < n) {
 #pragma unroll
         for (int i = 0; i < KPT; i++) bufA[base + i] = v[i];
@@ -332,7 +313,7 @@ __global__ void __launch_bounds__(NT) tile_sort_kernel(const uint4* __restrict__
     __syncthreads();
     // 2. merge rounds over the first n8 = ceil(n / KPT) * KPT slots
     const uint32_t n8 = (n + (uint32_t)KPT - 1u) & ~((uint32_t)KPT - 1u);
-    for (uint32_t L = KPT; L < n8; L <<= 1) {
+    for (uint32_t L = PRESORTED ? run0 : (uint32_t)KPT; L < n8; L <<= 1) {
         if (base < n8) {
             const uint32_t ps = base & ~(2u * L - 1u);          // start of this thread's run pair
             const uint32_t o = base - ps;                        // first output index inside the merged pair
@@ -359,7 +340,59 @@ __global__ void __launch_bounds__(NT) tile_sort_kernel(const uint4* __restrict__
         __syncthreads();
         uint64_t* t = bufA; bufA = bufB; bufB = t;
     }
-    for (uint32_t i = tid; i < n; i += NT) point_list[rg.x + i] = (uint32_t)bufA[i];
+    if (out_list) { for (uint32_t i = tid; i < n; i += NT) out_list[i] = (uint32_t)bufA[i]; }
+    else          { for (uint32_t i = tid; i < n; i += NT) out_keys[i] = bufA[i]; }
+}
+
+// Workgroups walk the non-empty tiles in tile_scan_kernel's longest-first order with a grid stride, so only as many
+// workgroups are launched as can be resident (the 128 KiB class would otherwise queue 4096 one-per-CU launches).
+// Round 2: a tile of 2049 .. 8192 entries used to be sorted start to finish by ONE 1024-thread workgroup (36-48 us on the oblique and
+// side views, whose longest tiles have 3000-6000 entries, against 20 us for the small class).  Now the SMALL kernel also sorts the
+// 2048-entry chunks of those tiles (chunk item c of tile rank r goes to workgroup grid - 1 - (4 r + c) % grid, before its own tiles) and the
+// LARGE kernel only merges the <= 4 sorted runs (two merge rounds instead of ten).
+template <int NT, bool LARGE, int KPT>
+__global__ void __launch_bounds__(NT) tile_sort_kernel(const uint4* __restrict__ tile_order, const uint32_t* __restrict__ counts,
+                                                      uint64_t* __restrict__ keys, uint32_t* __restrict__ point_list)
+{
+    extern __shared__ __attribute__((aligned(16))) uint64_t sk[];   // two buffers of NT * KPT keys
+    constexpr uint32_t CAP = NT * KPT;
+    const uint32_t n_active = counts[1];
+    const int tid = threadIdx.x;
+    if (!LARGE) {
+        // chunk items of the large-class tiles (they lead tile_order: it is sorted by descending bit length of the count)
+        // dealt from the END of the grid: with fewer active tiles than workgroups (640 against 1280 on the avatar views) the chunks go to
+        // workgroups that have no tile of their own
+        for (uint32_t item = gridDim.x - 1u - blockIdx.x; item < 4u * n_active; item += gridDim.x) {
+            const uint4 wd = tile_order[item >> 2];
+            const uint32_t n = wd.z - wd.y;
+            if (n < 2048u) break;                                        // no large tile at this rank or behind it
+            if (n <= (uint32_t)kSortSmallCap || n > (uint32_t)kSortLargeCap) continue;
+            const uint32_t c0 = (item & 3u) * (uint32_t)kSortSmallCap;
+            if (c0 >= n) continue;
+            __syncthreads();   // LDS buffers of the previous item are free
+            uint64_t* seg = keys + wd.y + c0;
+            sort_segment_lds<NT, KPT, false>(sk, seg, min((uint32_t)kSortSmallCap, n - c0), 0u, nullptr, seg, tid);
+        }
+    }
+    for (uint32_t rank = blockIdx.x; rank < n_active; rank += gridDim.x) {
+    const uint4 wd = tile_order[rank];
+    const uint2 rg = make_uint2(wd.y, wd.z);
+    const uint32_t n = rg.y - rg.x;
+    // size classes: the small kernel takes (0, kSortSmallCap], the large one everything above.  The order is by
+    // descending bit length of n, so once the large kernel meets a tile below 2048 entries it is done.
+    if (LARGE) { if (n < 2048u) break; if (n <= (uint32_t)kSortSmallCap) continue; }
+    else if (n > (uint32_t)kSortSmallCap) continue;
+    uint64_t* seg = keys + rg.x;
+    __syncthreads();   // LDS buffers of the previous tile are free
+    if (n > CAP) {
+        uint32_t m = 2;
+        while (m < n) m <<= 1;
+        bitonic_sort_global(seg, n, m, tid, NT);   // workgroup barriers order the exchanges (one CU, one L1)
+        for (uint32_t i = tid; i < n; i += NT) point_list[rg.x + i] = (uint32_t)seg[i];
+        continue;
+    }
+    if (LARGE) sort_segment_lds<NT, KPT, true>(sk, seg, n, (uint32_t)kSortSmallCap, point_list + rg.x, nullptr, tid);
+    else       sort_segment_lds<NT, KPT, false>(sk, seg, n, 0u, point_list + rg.x, nullptr, tid);
     }
 }
 
