@@ -419,8 +419,12 @@ int ag_noise_bias_act_backward(float* gx, const float* gy, const float* y, const
         return AG_ERR_INVALID_ARGUMENT;
     }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (gbias && check_hip(hipMemsetAsync(gbias, 0, (size_t)C * sizeof(float), s), "memset gbias")) return AG_ERR_HIP;
-    if (gnoise_weight && check_hip(hipMemsetAsync(gnoise_weight, 0, sizeof(float), s), "memset gnw")) return AG_ERR_HIP;
+    if (gbias && gnoise_weight == gbias + C) {       // the caller put the scalar right behind the C bias sums: one fill for both
+        if (check_hip(hipMemsetAsync(gbias, 0, (size_t)(C + 1) * sizeof(float), s), "memset gbias+gnw")) return AG_ERR_HIP;
+    } else {
+        if (gbias && check_hip(hipMemsetAsync(gbias, 0, (size_t)C * sizeof(float), s), "memset gbias")) return AG_ERR_HIP;
+        if (gnoise_weight && check_hip(hipMemsetAsync(gnoise_weight, 0, sizeof(float), s), "memset gnw")) return AG_ERR_HIP;
+    }
     if (C == 0 || HW == 0) return AG_OK;
     const int chunks = (HW + kNbaChunk - 1) / kNbaChunk;
     hipLaunchKernelGGL(noise_bias_act_backward_kernel, dim3(C * chunks), dim3(256), 0, s, gx, gy, y, noise, gbias, gnoise_weight, C,

@@ -202,8 +202,13 @@ class _NoiseBiasAct(torch.autograd.Function):
         gy = gy.contiguous()
         gx = torch.empty_like(y)
         # frozen parameters (the VGG trunk of LPIPS): no reduction, no buffer
-        gb = torch.empty(C, dtype=torch.float32, device=y.device) if has_bias and ctx.needs_input_grad[3] else None
-        gw = torch.empty(1, dtype=torch.float32, device=y.device) if has_nw and ctx.needs_input_grad[2] else None
+        want_b, want_w = has_bias and ctx.needs_input_grad[3], has_nw and ctx.needs_input_grad[2]
+        if want_b and want_w:                       # one buffer, one fill: the noise-strength sum sits right behind the C bias sums
+            both = torch.empty(C + 1, dtype=torch.float32, device=y.device)
+            gb, gw = both[:C], both[C:]
+        else:
+            gb = torch.empty(C, dtype=torch.float32, device=y.device) if want_b else None
+            gw = torch.empty(1, dtype=torch.float32, device=y.device) if want_w else None
         with _lib.on_device(y.device):
             _lib.check(_lib.lib().ag_noise_bias_act_backward(_p(gx), _p(gy), _p(y), _p(noise) if gw is not None else None, _p(gb), _p(gw),
                                                              C, HW, slope, scale, _stream(y.device)),
