@@ -1,8 +1,13 @@
 // MFMA convolutions for the StyleUNet, batch 1, fp32 (gfx950).  See include/ag_conv.h.
 //
 // Replaces the cuDNN calls behind network/styleunet/conv2d_gradfix.py (conv2d / conv_transpose2d) and their
-// backward.  Every variant is one of two implicit GEMMs on v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32
-// accumulate; 157 TF peak = the fp32 vector rate, but it leaves the VALU free for the gather arithmetic):
+// backward.  Every variant is one of two implicit GEMMs, in one of two engines (ag_conv_set_math):
+//   * the split engine (default): fp32 operands as three bf16 parts, six products per fp32 product on
+//     v_mfma_f32_32x32x16_bf16, fp32 accumulation -- products within 2^-23 of exact (section "fp32 products on the bf16
+//     matrix pipe" below); an opt-in three-product form;
+//   * the fp32 engine: v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulate; 157 TF peak = the fp32 vector rate, but it
+//     leaves the VALU free for the gather arithmetic).
+// Both share the problem decomposition, the tiles, the K order, split-K and the epilogues:
 //
 //   gather-conv  Y[m][gy, gx] = sum_{t, c} A[m][(t, c)] * Xin[c][gy*sy + dy_t][gx*sx + dx_t]
 //       forward conv (any stride/pad), input gradient of a stride-1 conv (taps mirrored), input gradient of a transposed
