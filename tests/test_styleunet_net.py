@@ -198,3 +198,33 @@ def test_training_passes_do_not_pile_up_memory_without_the_garbage_collector():
         if was:
             gc.enable()
     assert max(seen[1:]) - min(seen[1:]) < (64 << 20), seen
+
+
+def test_stacked_modulation_gemm_equals_the_per_layer_equal_linear():
+    """DualStyleUNet._stage_styles: the EqualLinear modulation (dual_styleunet.py:152-155, lr_mul 1: F.linear(w, W * (1 / sqrt(512)), b)) of
+    every StyledConv / ToRGB of a stage group as one addmm on the stacked weights -- same values as the per-layer formula (CPU, fp64 as the
+    yardstick: both fp32 forms are within 2e-6 of it relative to the style scale), for both branches and both stage groups."""
+    import math
+    import torch
+    import torch.nn.functional as F
+    from animatablegaussians_amd.styleunet import DualStyleUNet
+
+    torch.manual_seed(3)
+    net = DualStyleUNet(inp_size=512, inp_ch=3, out_ch=3, out_size=1024, style_dim=512, n_mlp=2)
+    w_latent = torch.randn(1, 512)
+    n_stages = len(net.dec)
+    for branch in (1, 2):
+        for stages in (range(0, min(net.VIEW_STAGE + 1, n_stages)), range(net.VIEW_STAGE + 1, n_stages)):
+            stages = list(stages)
+            if not stages:
+                continue
+            got = net._stage_styles(branch, stages, w_latent)
+            assert len(got) == 3 * len(stages)
+            for prefix, style in got.items():
+                mw, mb = net._p(f"{prefix}.modulation.weight"), net._p(f"{prefix}.modulation.bias")
+                ref32 = F.linear(w_latent, mw * (1 / math.sqrt(mw.shape[1])), bias=mb * 1.0)
+                ref64 = F.linear(w_latent.double(), mw.double() * (1 / math.sqrt(mw.shape[1])), bias=mb.double())
+                assert style.shape == ref32.shape == (1, mw.shape[0])
+                scale = float(ref64.abs().max())
+                assert float((style.double() - ref64).abs().max()) <= 2e-6 * scale
+                assert float((ref32.double() - ref64).abs().max()) <= 2e-6 * scale
