@@ -129,6 +129,22 @@ constexpr int kBwdWavesPerSimd = 6;
 constexpr int kSub = 32;
 constexpr int kPartStride = kSub + 2;     // == 2 (mod 32): the flush's (component, entry) lanes of a 32-lane LDS access hit 20 distinct banks
 
+// AG_BWD_TIMELINE (diagnostic build only: profiles/ub/build_timeline.sh, profiles/bwd_wg_times.py): thread 0 of every workgroup stamps
+// each (tile, region) item with the 100-MHz wall clock at its start, after the n_contrib round trip + reduction, after the first
+// records arrived and were culled, and at its end, together with the item's size figures.  Not compiled into the product.
+#ifdef AG_BWD_TIMELINE
+struct TlItem {
+    uint32_t wg, seq, tile, region, list_len, wmax, survivors, steps, skipped, active_pairs, chunks, pad;
+    unsigned long long t0, t_hdr, t_rec, t_end;
+};
+constexpr uint32_t kTlMax = 16384;
+__device__ TlItem g_tl[kTlMax];
+__device__ uint32_t g_tl_n;
+#define TL(stmt) do { if (threadIdx.x == 0) { stmt; } } while (0)
+#else
+#define TL(stmt) do { } while (0)
+#endif
+
 __global__ void __launch_bounds__(kBlendThreads, kBwdWavesPerSimd) blend_backward_kernel(BlendBwdParams p)
 {
     constexpr int NW = kBlendThreads / 64;
@@ -153,7 +169,12 @@ __global__ void __launch_bounds__(kBlendThreads, kBwdWavesPerSimd) blend_backwar
     if (have) { hdr = p.tile_order[tr]; hdr.w = rg; }
     lds_barrier();
 
+#ifdef AG_BWD_TIMELINE
+    TlItem tl{};
+    uint32_t tl_seq = 0;
+#endif
     while (have) {
+        TL(tl = TlItem{}; tl.t0 = wall_clock64(); tl.wg = blockIdx.x; tl.seq = tl_seq++; tl.tile = hdr.x; tl.region = hdr.w; tl.list_len = hdr.z - hdr.y);
         uint32_t tr_n, rg_n;
         const bool have_n = it.next(tr_n, rg_n);
         uint4 hdr_n = make_uint4(0u, 0u, 0u, 0u);
@@ -193,6 +214,7 @@ __global__ void __launch_bounds__(kBlendThreads, kBwdWavesPerSimd) blend_backwar
 #pragma unroll
         for (int w = 0; w < NW; w++) wmax = max(wmax, s_wave_max[w]);
         const uint32_t rend = rbeg + wmax;   // walk [rbeg, rend) from the back
+        TL(tl.t_hdr = wall_clock64(); tl.wmax = wmax);
 
         // row state of the back-to-front walk
         float T = T_final;                                   // transmittance behind the entries processed so far
@@ -219,6 +241,7 @@ __global__ void __launch_bounds__(kBlendThreads, kBwdWavesPerSimd) blend_backwar
         unsigned long long mask = __ballot(keep);
         if (lane == 0) s_wave_cnt[0][wave] = __popcll(mask);
         lds_barrier();
+        TL(tl.t_rec = wall_clock64());
 
         int cpar = 0;
         for (uint32_t done_entries = 0; done_entries < wmax; done_entries += kChunk, cpar ^= 1) {
@@ -247,6 +270,7 @@ __global__ void __launch_bounds__(kBlendThreads, kBwdWavesPerSimd) blend_backwar
             }
             if (onn < wmax) id_next = p.point_list[rend - 1u - onn];
             lds_barrier();
+            TL(tl.survivors += K; tl.chunks++);
 
             // ---- kSub compacted entries at a time: 16 entries per step per pixel row, then flush ----
             for (int sb = 0; sb < K; sb += kSub) {
@@ -267,8 +291,12 @@ __global__ void __launch_bounds__(kBlendThreads, kBwdWavesPerSimd) blend_backwar
                 float* part = &s_part[pb][wave][vbase][idx - sb];
                 if (!__any(act)) {
                     if (ev) { part[0] = 0.f; part[kPartStride] = 0.f; if (!(row & 1)) part[2 * kPartStride] = 0.f; }
+                    TL(tl.skipped++);
                     continue;
                 }
+#ifdef AG_BWD_TIMELINE
+                { const unsigned long long am = __ballot(act); TL(tl.steps++; tl.active_pairs += __popcll(am)); }
+#endif
                 const float fac = act ? (1.0f - alpha) : 1.0f;
                 // affine maps g_e(S) = A S + B, A = fac, B = alpha * c (0 when inactive); inclusive row scan
                 const float al = act ? alpha : 0.f;
@@ -377,10 +405,33 @@ __global__ void __launch_bounds__(kBlendThreads, kBwdWavesPerSimd) blend_backwar
             if (lane == 0) s_wave_cnt[cpar ^ 1][wave] = __popcll(mask);
             lds_barrier();   // s_rec / s_gid reusable, next counts visible
         }
+#ifdef AG_BWD_TIMELINE
+        if (threadIdx.x == 0) {
+            tl.t_end = wall_clock64();
+            const uint32_t slot = atomicAdd(&g_tl_n, 1u);
+            if (slot < kTlMax) g_tl[slot] = tl;
+        }
+#endif
         hdr = hdr_n;
         have = have_n;
     }
 }
+
+#ifdef AG_BWD_TIMELINE
+// copies the records of the launches since the last call to the host and resets the log
+extern "C" int ag_debug_bwd_timeline(void* items, uint32_t capacity, uint32_t* count)
+{
+    uint32_t n = 0;
+    if (hipDeviceSynchronize() != hipSuccess) return AG_ERR_HIP;
+    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_tl_n), sizeof(n)) != hipSuccess) return AG_ERR_HIP;
+    const uint32_t m = n < capacity ? n : capacity;
+    if (m && hipMemcpyFromSymbol(items, HIP_SYMBOL(g_tl), (size_t)(m < kTlMax ? m : kTlMax) * sizeof(TlItem)) != hipSuccess) return AG_ERR_HIP;
+    const uint32_t zero = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_tl_n), &zero, sizeof(zero)) != hipSuccess) return AG_ERR_HIP;
+    *count = m < kTlMax ? m : kTlMax;
+    return AG_OK;
+}
+#endif
 
 // Calibration (profiles/atomic_rate.py): how many line-coalesced float atomics per second the memory side sustains -- the
 // ceiling of every design that flushes the backward's sums with less pre-reduction.  Each wave instruction adds to the first

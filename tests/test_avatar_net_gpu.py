@@ -107,6 +107,51 @@ def test_render_composes_the_verified_pieces_and_trains(net):
     net.zero_grad(set_to_none=True)
 
 
+def test_concurrently_streamed_step_equals_the_serialised_step(net, monkeypatch):
+    """Guard for the cross-wave packed-fp32 disturbance (profiles/r03_packed_fp32_hazard.md, stand-alone reproducer
+    profiles/ub/pk_hazard.hip): the whole training iteration with the three networks on their HIP streams, run three times, against the
+    same iteration with every kernel serialised on one stream (AG_SINGLE_STREAM=1).  Forward products are deterministic and must be
+    BIT-equal; the 224 M parameter gradients go through float atomics (split-K weight gradients, style / noise / bias reductions) whose
+    order differs between runs, so they are held to that noise: every element within 2e-5 of the tensor's largest gradient -- a product
+    term dropped by the disturbance changes an element by a multiple of that."""
+    import torch
+    items = _items(net)
+    net.get_pose_map(items)
+    net.train()
+    target = torch.rand(1024, 1024, 3, generator=torch.Generator().manual_seed(5)).cuda()
+    params = [(n, p) for n, p in net.named_parameters()]
+
+    def step():
+        torch.manual_seed(77)                                              # the training-mode view-direction jitter
+        net.zero_grad(set_to_none=True)
+        out = net.render(items, bg_color=(0., 0., 0.))
+        loss = (out['rgb_map'] - target).abs().mean() + 0.005 * torch.linalg.norm(out['offset'], dim=-1).mean()
+        loss.backward()
+        torch.cuda.synchronize()
+        return {k: out[k].detach().clone() for k in ('rgb_map', 'mask_map', 'offset', 'pos_map')}, [p.grad.clone() for _, p in params]
+
+    monkeypatch.setenv("AG_SINGLE_STREAM", "1")
+    ref_maps, ref_grads = step()
+    ref_maps2, ref_grads2 = step()                                         # the atomics' own run-to-run noise, serialised
+    monkeypatch.delenv("AG_SINGLE_STREAM")
+    for k in ref_maps:
+        assert torch.equal(ref_maps[k], ref_maps2[k]), k
+    noise = max(float((a - b).abs().max() / a.abs().max().clamp_min(1e-30)) for a, b in zip(ref_grads, ref_grads2))
+    worst = 0.0
+    for rep in range(3):
+        maps, grads = step()
+        for k in ref_maps:
+            assert torch.equal(ref_maps[k], maps[k]), (rep, k, float((ref_maps[k] - maps[k]).abs().max()))
+        for (name, _), a, b in zip(params, ref_grads, grads):
+            rel = float((a - b).abs().max() / a.abs().max().clamp_min(1e-30))
+            worst = max(worst, rel)
+            assert rel <= 2e-5, (rep, name, rel, noise)
+        del maps, grads
+    print(f"concurrent vs serialised: {sum(p.numel() for _, p in params) / 1e6:.1f} M gradients, worst relative deviation {worst:.2e} "
+          f"(serialised run-to-run: {noise:.2e})")
+    net.zero_grad(set_to_none=True)
+
+
 def test_render_views_shares_the_pose_dependent_work_without_changing_results(net):
     """render_views == render per view (eval: bit-identical images; training: summed gradients agree)."""
     import torch
