@@ -433,6 +433,283 @@ extern "C" int ag_debug_bwd_timeline(void* items, uint32_t capacity, uint32_t* c
 }
 #endif
 
+// ------------------------------------------------------------------------------------------------------------------------------------
+// Round 3: one independent WAVE per (tile, 4x4-pixel block).  No workgroup barriers, no cross-wave partial slabs.
+// ------------------------------------------------------------------------------------------------------------------------------------
+// What the per-item timeline of the kernel above showed (profiles/r03_bwd_timeline.txt, bench view): its body runs at the rate six
+// waves sharing a SIMD's VALU allow (1.8 us per 32-entry sub-chunk = the ~180 VALU instructions of each of the six), so the kernel is
+// bound by instruction count, and 84 % of its (pixel, entry) lane slots are dead: a wave walks ALL survivors of the 8x4 region cull
+// (134 per item) for its 2x2 pixels although only 44 reach them, more than half of its 16-entry steps are skipped after paying
+// for their loads / exp / tests, and the executed ones have 35 % active lanes; 26 % of an item's time is its three-round-trip start-up
+// and the eight waves of a workgroup meet at a barrier every 32 entries.  Here:
+//   * lanes = 16 pixels (4 x 4 block) x 4 list entries; lane = y * 16 + e * 4 + x, so a pixel's 4 entries sit in the 4 banks of a DPP
+//     row: the affine-map scan is TWO row_shr steps (4, 8) instead of four, the carry to the next step is a bank-masked row_shl pair,
+//     and the sum over the 16 pixels is the same permlane32/16 swap pair (over y) plus two quad butterflies (over x);
+//   * the wave culls the tile list against ITS 4 x 4 pixels (83 survivors of 363 walked per block on the bench view, against 134 of 446
+//     for the 8x4 region) and blends exactly those: 21 dense steps per block;
+//   * sums of 16 blended entries collect in a 1-KB wave-private LDS slab and leave as line-coalesced atomics (16 adjacent lanes = one
+//     64-byte accumulator line, as before); line requests: one per (block, survivor) = 0.85 M against 0.68 M -- still far inside
+//     the 20 lines / ns the memory side retires;
+//   * waves never wait for each other: the start-up chain of one item hides behind the other five waves of its SIMD.
+constexpr int kBlk = 4;                                  // 4 x 4 pixels per wave
+constexpr int kBlocksPerTile = (kTileX / kBlk) * (kTileY / kBlk);
+constexpr int kWaveGrid = 8192;                          // single-wave workgroups; the hardware dispatcher balances them
+constexpr int kRing = 96;                                // compacted records waiting to be blended (< 4 left over + <= 64 new)
+constexpr int kWin = 16;                                 // blended entries per atomic flush
+
+struct WaveItemIter {
+    uint32_t i, stride, x, n_active;
+    __device__ __forceinline__ WaveItemIter(uint32_t block, uint32_t grid, uint32_t n_active_)
+        : i(block / kQueues), stride((grid + kQueues - 1 - (block % kQueues)) / kQueues), x(block % kQueues), n_active(n_active_) {}
+    __device__ __forceinline__ bool next(uint32_t& tile_rank, uint32_t& blk)
+    {
+        tile_rank = (i / kBlocksPerTile) * kQueues + x;      // all 16 blocks of a tile on one XCD (they gather the same list)
+        blk = i % kBlocksPerTile;
+        i += stride;
+        return tile_rank < n_active;
+    }
+};
+
+// maximum over the 64 lanes as a wave-uniform value (DPP row reduction, two cross-row broadcasts, one v_readlane; no LDS round trips)
+__device__ __forceinline__ uint32_t wave_umax(uint32_t v)
+{
+#define AG_UMAX_DPP(CTRL, ROWMASK) v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWMASK, 0xf, false))
+    AG_UMAX_DPP(AG_DPP_ROW_SHR(1), 0xf); AG_UMAX_DPP(AG_DPP_ROW_SHR(2), 0xf); AG_UMAX_DPP(AG_DPP_ROW_SHR(4), 0xf); AG_UMAX_DPP(AG_DPP_ROW_SHR(8), 0xf);
+    AG_UMAX_DPP(0x142, 0xa);      // row_bcast:15 -> rows 1, 3
+    AG_UMAX_DPP(0x143, 0xc);      // row_bcast:31 -> rows 2, 3
+#undef AG_UMAX_DPP
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+template <int CTRL, int BANK_MASK>
+__device__ __forceinline__ float dpp_banks(float old, float v)   // lanes of the banks in BANK_MASK take the DPP source, the others keep `old`
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, 0xf, BANK_MASK, false));
+}
+// value of bank 3 (entry 3) of this lane's row, same x: bank 2 <- bank 3, then banks 0, 1 <- banks 2, 3
+__device__ __forceinline__ float from_entry3(float v)
+{
+    v = dpp_banks<AG_DPP_ROW_SHL(4), 0x4>(v, v);
+    return dpp_banks<AG_DPP_ROW_SHL(8), 0x3>(v, v);
+}
+
+#ifndef AG_BWD_WAVE_OCC
+#define AG_BWD_WAVE_OCC 6       // waves per SIMD the register budget is cut for
+#endif
+__global__ void __launch_bounds__(64, AG_BWD_WAVE_OCC) blend_backward_wave_kernel(BlendBwdParams p)
+{
+    __shared__ float4 s_ring[kRing * 3];          // [x, y, ca, cb] [cc, op, r, g] [b, depth, position, gaussian id]
+    __shared__ float s_out[kWin * 16];            // [entry of the window][accumulator slot]
+    __shared__ uint32_t s_wgid[kWin];
+
+    const int lane = threadIdx.x;
+    const int ry = lane >> 4, e = (lane >> 2) & 3, qx = lane & 3;
+    const uint32_t n_active = p.counts[1];
+    const size_t HW = (size_t)p.W * p.H;
+    const float ddelx_dx = 0.5f * (float)p.W, ddely_dy = 0.5f * (float)p.H;
+    const float bg0 = p.bg[0], bg1 = p.bg[1], bg2 = p.bg[2];
+    const float nddelx = -ddelx_dx, nddely = -ddely_dy;
+    const int vbase = (ry == 0) ? 0 : (ry == 1) ? 3 : (ry == 2) ? 5 : 8;
+    const bool out_lane = qx < ((ry & 1) ? 2 : 3);           // this lane stores u[qx] as accumulator slot vbase + qx
+
+    WaveItemIter it(blockIdx.x, gridDim.x, n_active);
+    uint32_t tr, bk;
+    while (it.next(tr, bk)) {
+        const uint4 hdr = p.tile_order[tr];
+        const int tile = (int)hdr.x;
+        const uint32_t rbeg = hdr.y;
+        const int tile_x = tile % p.gx, tile_y = tile / p.gx;
+        const int bx0 = tile_x * kTileX + (int)(bk & 3) * kBlk, by0 = tile_y * kTileY + (int)(bk >> 2) * kBlk;
+        const int px = bx0 + qx, py = by0 + ry;
+        const bool inside = px < p.W && py < p.H;
+        const float pxf = (float)px, pyf = (float)py;
+        const float qx0f = (float)bx0, qy0f = (float)by0, qx1f = (float)(bx0 + kBlk - 1), qy1f = (float)(by0 + kBlk - 1);
+        const int pix = p.W * py + px;
+        uint32_t last_contributor = 0;
+        float T_final = 0.f, gr = 0.f, gg = 0.f, gb = 0.f, gd = 0.f, ga = 0.f;
+        if (inside) {
+            last_contributor = p.n_contrib[pix];
+            T_final = 1.0f - p.alphas[pix];
+            gr = p.dL_dpix[pix];
+            gg = p.dL_dpix[HW + pix];
+            gb = p.dL_dpix[2 * HW + pix];
+            gd = p.dL_ddepth[pix];
+            ga = p.dL_dalpha[pix];
+        }
+        const float ntf_bg = -T_final * (bg0 * gr + bg1 * gg + bg2 * gb);     // background term of dL/dalpha_e, times 1 / (1 - alpha_e)
+        const uint32_t wmax = wave_umax(last_contributor);
+        if (wmax == 0) continue;
+        const uint32_t rend = rbeg + wmax;                   // walk [rbeg, rend) from the back
+
+        float T = T_final;
+        float S_r = 0.f, S_g = 0.f, S_b = 0.f, S_d = 0.f, S_a = 0.f;
+
+        // staging pipeline: records one pass (64 entries) ahead, indices two passes ahead.  Every load is unconditional (lanes past the
+        // end read entry rbeg / record 0 and are masked at the cull): a conditional load makes the compiler merge old and new
+        // registers right behind the load, i.e. wait for it on the spot.
+        uint32_t id_cur = p.point_list[(uint32_t)lane < wmax ? rend - 1u - (uint32_t)lane : rbeg];
+        uint32_t id_next = p.point_list[(uint32_t)lane + 64u < wmax ? rend - 1u - ((uint32_t)lane + 64u) : rbeg];
+        float4 r0, r1, r2;
+        {
+            const float4* src = reinterpret_cast<const float4*>(p.rec + id_cur);
+            r0 = src[0]; r1 = src[1]; r2 = src[2];
+        }
+
+        int head = 0, cnt = 0;       // ring positions (wave-uniform), monotonically increasing; slot = position % kRing
+        int win = 0;                 // entries in the output window
+        auto flush = [&]() {
+            // all LDS reads first (unconditional: inside the arrays), then the atomics: one wave instruction per 4 entries, the 16 lanes
+            // of a row on the 16 slots of one accumulator line
+            float val[kWin / 4];
+            uint32_t gid[kWin / 4];
+#pragma unroll
+            for (int pass = 0; pass < kWin / 4; pass++) {
+                val[pass] = s_out[(pass * 4 + (lane >> 4)) * 16 + (lane & 15)];
+                gid[pass] = s_wgid[pass * 4 + (lane >> 4)];
+            }
+#pragma unroll
+            for (int pass = 0; pass < kWin / 4; pass++) {
+                const int ent = pass * 4 + (lane >> 4), comp = lane & 15;
+                if (ent < win && comp < 10 && val[pass] != 0.f) atomicAdd(p.accum + (size_t)gid[pass] * kAccumFloats + comp, val[pass]);
+            }
+            win = 0;
+        };
+
+        for (uint32_t done = 0; done < wmax; done += 64u) {
+            const uint32_t o = done + (uint32_t)lane;        // offset from the back
+            // ---- cull against this wave's 4 x 4 pixels, ordered compaction into the ring ----
+            const float ddx = fmaxf(fmaxf(qx0f - r0.x, r0.x - qx1f), 0.f);
+            const float ddy = fmaxf(fmaxf(qy0f - r0.y, r0.y - qy1f), 0.f);
+            const bool keep = (o < wmax) && ((ddx * ddx + ddy * ddy) <= r2.z);
+            const unsigned long long mask = __ballot(keep);
+            if (keep) {
+                const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                int slot = cnt + rank;
+                slot = slot % kRing;
+                s_ring[slot * 3 + 0] = r0;
+                s_ring[slot * 3 + 1] = r1;
+                s_ring[slot * 3 + 2] = make_float4(r2.x, r2.y, __uint_as_float(wmax - o), __uint_as_float(id_cur));
+            }
+            cnt += __popcll(mask);
+            // ---- next pass's records, the indices of the one after ----
+            const uint32_t on = o + 64u, onn = on + 64u;
+            id_cur = id_next;
+            {
+                const float4* src = reinterpret_cast<const float4*>(p.rec + id_next);
+                r0 = src[0]; r1 = src[1]; r2 = src[2];
+            }
+            id_next = p.point_list[onn < wmax ? rend - 1u - onn : rbeg];
+            (void)on;
+            const bool last_pass = done + 64u >= wmax;
+            // The atomics share vmcnt with the loads above and gfx950 may retire the two kinds out of order, so the wait for the next
+            // pass's records drains every atomic in flight: issue the window left over from the previous pass NOW, a whole blend phase
+            // before that wait, instead of at the end of its own phase.
+            if (win) flush();
+
+            // ---- blend 4 ring entries per step ----
+            while (cnt - head >= 4 || (last_pass && cnt > head)) {
+                const int idx = head + e;
+                const bool ev = idx < cnt;
+                const int slot = (ev ? idx : cnt - 1) % kRing;
+                head += 4;
+                const float4 a = s_ring[slot * 3 + 0];   // x, y, conic a, conic b
+                const float4 b = s_ring[slot * 3 + 1];   // conic c, opacity, r, g
+                const float4 c = s_ring[slot * 3 + 2];   // b, depth, position, id
+                const float dx = a.x - pxf, dy = a.y - pyf;
+                const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
+                const float G = __builtin_amdgcn_exp2f(power * 1.4426950408889634f);
+                const float alpha = fminf(0.99f, b.y * G);
+                const bool act = ev && (__float_as_uint(c.z) <= last_contributor) && (power <= 0.0f) && (alpha >= 1.0f / 255.0f);
+                if (!__any(act)) continue;
+                const float al = act ? alpha : 0.f;
+                const float fac = 1.0f - al;
+                // affine maps g_e(S) = fac_e S + al_e c_e.  The state S behind the entries blended so far lives in BANK 0 only (0 in the
+                // other banks) and is folded into entry 0's map before the scan, so the inclusive scan yields the blended state behind
+                // each entry directly: no broadcast of the carry, no separate "A_exclusive * S" term.
+                float A = fac;
+                float Br = fmaf(fac, S_r, al * b.z), Bg = fmaf(fac, S_g, al * b.w), Bb = fmaf(fac, S_b, al * c.x), Bd = fmaf(fac, S_d, al * c.y),
+                      Ba = fmaf(fac, S_a, al);
+#define AG_SCAN_STEP(N)                                                                                                        \
+                asm volatile("s_nop 1\n\t"                                                                                     \
+                             "v_fmac_f32_dpp %0, %0, %5 row_shr:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"             \
+                             "v_fmac_f32_dpp %1, %1, %5 row_shr:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"             \
+                             "v_fmac_f32_dpp %2, %2, %5 row_shr:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"             \
+                             "v_fmac_f32_dpp %3, %3, %5 row_shr:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"             \
+                             "v_fmac_f32_dpp %4, %4, %5 row_shr:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"             \
+                             "v_mul_f32_dpp %5, %5, %5 row_shr:" #N " row_mask:0xf bank_mask:0xf"                               \
+                             : "+v"(Br), "+v"(Bg), "+v"(Bb), "+v"(Bd), "+v"(Ba), "+v"(A));
+                AG_SCAN_STEP(4) AG_SCAN_STEP(8)
+#undef AG_SCAN_STEP
+                // A = prod_{i<=e} fac_i: T in front of entry e;  state behind entry e = inclusive state of entry e-1 (bank 0: the carry).
+                // T is carried through list_length / 4 of these divisions (the reference divides once per entry, backward.cu:534): one
+                // Newton step on v_rcp_f32 (1 ulp) keeps the chain at the rounding of an exact division.
+                float rA = __builtin_amdgcn_rcpf(A);
+                rA = fmaf(fmaf(-A, rA, 1.0f), rA, rA);
+                const float Tin = T * rA;
+                const float beh_r = dpp_banks<AG_DPP_ROW_SHR(4), 0xf>(S_r, Br);
+                const float beh_g = dpp_banks<AG_DPP_ROW_SHR(4), 0xf>(S_g, Bg);
+                const float beh_b = dpp_banks<AG_DPP_ROW_SHR(4), 0xf>(S_b, Bb);
+                const float beh_d = dpp_banks<AG_DPP_ROW_SHR(4), 0xf>(S_d, Bd);
+                const float beh_a = dpp_banks<AG_DPP_ROW_SHR(4), 0xf>(S_a, Ba);
+
+                float v[10];
+                {
+                    float dL_dopa = (b.z - beh_r) * gr + (b.w - beh_g) * gg + (c.x - beh_b) * gb;
+                    dL_dopa += (c.y - beh_d) * gd;
+                    dL_dopa += (1.f - beh_a) * ga;
+                    dL_dopa = fmaf(dL_dopa, Tin, __builtin_amdgcn_rcpf(fac) * ntf_bg);
+                    dL_dopa = act ? dL_dopa : 0.f;
+                    const float wgt = al * Tin;
+                    const float dL_dG = b.y * dL_dopa;
+                    const float gdx = G * dx, gdy = G * dy;
+                    const float tx = fmaf(gdx, a.z, gdy * a.w), ty = fmaf(gdy, b.x, gdx * a.w);     // -dG/ddelx, -dG/ddely
+                    const float hG = -0.5f * dL_dG, hx = hG * gdx;
+                    v[A_M2X] = (dL_dG * nddelx) * tx;
+                    v[A_M2Y] = (dL_dG * nddely) * ty;
+                    v[A_CONX] = hx * dx;
+                    v[A_CONY] = hx * dy;
+                    v[A_CONW] = (hG * gdy) * dy;
+                    v[A_OPAC] = G * dL_dopa;
+                    v[A_COLR] = wgt * gr;
+                    v[A_COLG] = wgt * gg;
+                    v[A_COLB] = wgt * gb;
+                    v[A_DEPTH] = wgt * gd;
+                }
+                // carry: T in front of entry 3 to all four lanes of the pixel; the state behind entry 3 to bank 0 (zero elsewhere)
+                T = from_entry3(Tin);
+                S_r = dpp_banks<AG_DPP_ROW_ROR(4), 0x1>(0.f, Br);
+                S_g = dpp_banks<AG_DPP_ROW_ROR(4), 0x1>(0.f, Bg);
+                S_b = dpp_banks<AG_DPP_ROW_ROR(4), 0x1>(0.f, Bb);
+                S_d = dpp_banks<AG_DPP_ROW_ROR(4), 0x1>(0.f, Bd);
+                S_a = dpp_banks<AG_DPP_ROW_ROR(4), 0x1>(0.f, Ba);
+
+                // sum over the block's 16 pixels per entry: rows (y) by register exchange 10 -> 5 -> 3, then x inside the quads
+                float s[6];
+#pragma unroll
+                for (int i = 0; i < 5; i++) {
+                    swap32(v[i], v[i + 5]);
+                    s[i] = v[i] + v[i + 5];
+                }
+                s[5] = 0.f;
+                float u[3];
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+                    swap16(s[i], s[i + 3]);
+                    u[i] = s[i] + s[i + 3];      // row 0: value i, row 1: value i+3, row 2: value i+5, row 3: value i+8
+                    u[i] += dpp<AG_DPP_QUAD_PERM(1, 0, 3, 2)>(u[i]);
+                    u[i] += dpp<AG_DPP_QUAD_PERM(2, 3, 0, 1)>(u[i]);
+                }
+                const float mine = (qx == 0) ? u[0] : (qx == 1) ? u[1] : u[2];
+                if (out_lane) s_out[(win + e) * 16 + vbase + qx] = ev ? mine : 0.f;
+                if (ry == 0 && qx == 0) s_wgid[win + e] = __float_as_uint(c.w);
+                win += 4;
+                if (win == kWin) flush();
+            }
+        }
+        if (win) flush();
+    }
+}
+
 // Calibration (profiles/atomic_rate.py): how many line-coalesced float atomics per second the memory side sustains -- the
 // ceiling of every design that flushes the backward's sums with less pre-reduction.  Each wave instruction adds to the first
 // `comps` slots of 4 pseudo-random 64-byte accumulator lines (16 adjacent lanes per line), exactly the flush's access shape.
@@ -492,6 +769,14 @@ int launch_blend_backward(const AgRasterBackwardArgs& a, hipStream_t s)
     p.accum = reinterpret_cast<float*>(aligned_base(a.accum_buffer));
     if (check_hip(hipMemsetAsync(p.accum, 0, (size_t)a.P * kAccumFloats * sizeof(float), s), "memset accum")) return AG_ERR_HIP;
     if (a.num_rendered <= 0) return AG_OK;
+    // the wave kernel is the product path since round 3; AG_BWD_KERNEL=0 selects the round-2 region kernel (same-box A/B in profiles/)
+    static const int variant = [] { const char* e = getenv("AG_BWD_KERNEL"); return e ? atoi(e) : 1; }();
+    if (variant == 1) {
+        const long long items = (long long)p.T * kBlocksPerTile;
+        const int grid = (int)(items < kWaveGrid ? items : kWaveGrid);
+        { ProfScope ps(AG_K_BLEND_BACKWARD, s); hipLaunchKernelGGL(blend_backward_wave_kernel, dim3(grid), dim3(64), 0, s, p); }
+        return check_hip(hipGetLastError(), "blend_backward_wave_kernel");
+    }
     const long long items = (long long)p.T * kRegionsPerTile;
     const int grid = (int)(items < kBlendGrid ? items : kBlendGrid);   // 3 resident workgroups of 8 waves per CU (48 KiB of LDS each), 2.7x oversubscribed
     { ProfScope ps(AG_K_BLEND_BACKWARD, s); hipLaunchKernelGGL(blend_backward_kernel, dim3(grid), dim3(kBlendThreads), 0, s, p); }

@@ -443,7 +443,20 @@ def test_full_size_1m_gaussians_2048_vs_oracle():
     grads = _masked_grads(scene, ref)
     acc_ref = ro.backward_blend(ref, scene["colors"], scene["bg"], grads["dL_dcolor"], grads["dL_ddepth"], grads["dL_dalpha"])
     got = h.gpu_native_backward(gpu, grads, alphas=ref["alpha"])
-    h.assert_accum_parity(got, acc_ref, k_eps=128.0)      # tile lists up to ~8000 entries: twice the summation-order slack of the small scenes
+    # Tile lists up to ~8000 entries: twice the summation-order slack of the small scenes.  And, at 10.7 M accumulator elements, the
+    # far tail of the one error source the slack does not model: T is recovered by a chain of thousands of fp32 divisions, the
+    # reference (one division per entry) and any other grouping of that chain (16 entries per step in the region kernel, 4 in the wave
+    # kernel -- fewer roundings than the reference itself) drift apart like a random walk, and an element whose few terms all sit at
+    # the end of such a chain inherits that drift relative to its own size (measured with both kernels: identical error percentiles,
+    # one element of 10.7 M at 1.2x the bound).  The oracle prices it per element: its own movement when every exp() is scaled by
+    # 1 + 2^-20 (one rounding of alpha), times 4.
+    ro.set_exp_scale(1.0 + 2.0 ** -20)
+    try:
+        ref_p = h.oracle_forward(scene, cam)
+        acc_p = ro.backward_blend(ref_p, scene["colors"], scene["bg"], grads["dL_dcolor"], grads["dL_ddepth"], grads["dL_dalpha"])
+    finally:
+        ro.set_exp_scale(1.0)
+    h.assert_accum_parity(got, acc_ref, k_eps=128.0, ref_perturbed=acc_p, k_sens=4.0)
     pre = ro.backward_preprocess(ref, got, scene["means3D"], scene["scales"], scene["rotations"], cam["viewmatrix"], cam["projmatrix"],
                                  cam["tanfovx"], cam["tanfovy"])
     for k, rr in (("dL_dmeans3D", 1e-5), ("dL_dcov3D", 1e-5), ("dL_dscales", 1e-5), ("dL_drotations", 3e-5)):
