@@ -29,7 +29,11 @@ The JSON line also carries
                  process, in the other two modes of include/ag_conv.h;
   roofline_mfma: the convolution kernels' own rate (HIP events around every launch of one network forward + backward), in the
                  product's arithmetic against the dense bf16 MFMA peak (executed = 6 x algorithmic FLOPs) and in the fp32-MFMA
-                 mode against the fp32 MFMA peak.
+                 mode against the fp32 MFMA peak;
+  stress_1m_2048: BASELINE configs[4] on one GPU (1.07 M Gaussians, 2048^2): views/s, blend-backward us, algorithmic GB/s;
+  cpu_baseline_styleunet / cpu_baseline_lbs: SURVEY.md 8(d)(i)(ii) -- the reference's DualStyleUNet forward and forward + backward
+                 (oracle/dual_styleunet_oracle.py: the same torch CPU ops in the same order, pinned against the reference module's
+                 golden) and the reference's LBS einsum path (oracle/avatar_oracle.py) on this box's host cores.
 """
 from __future__ import annotations
 
@@ -63,6 +67,7 @@ def main() -> None:
                     "operator surface) in the headline loop instead of the library-owned forward+backward step")
     ap.add_argument("--no-full-step", action="store_true", help="skip the full_step / roofline_mfma legs (BASELINE configs[2]: the whole "
                     "training iteration with the three StyleUNets, ~15 s) -- profiling runs of the rasterizer")
+    ap.add_argument("--no-stress", action="store_true", help="skip the stress_1m_2048 leg (BASELINE configs[4] on one GPU, ~3 s)")
     args = ap.parse_args()
 
     import numpy as np
@@ -272,9 +277,19 @@ def main() -> None:
     ms_per_step = 1e3 * elapsed / args.steps
 
     # HBM traffic of the dominant kernel comes from PMC counters, which cannot be read from inside this process: the separate
-    # rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes over this command are summarised under profiles/ (README there); the
-    # line itself carries only what THIS run measured, so `traffic` is null.
-    traffic = None
+    # rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes over the same workload are summarised in profiles/traffic_head.json
+    # (profiles/traffic_probe.py + traffic_summarize.py, FETCH x 2.0 / WRITE x 1.0 from the calibration copy of that run); the line
+    # quotes that file for the kernel it times -- bytes per launch, like `achieved` -- and says so; null when the file has no entry.
+    traffic, traffic_src = None, None
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic_head.json")) as f:
+            tj = json.load(f)
+        hit = [v for k, v in tj.get("kernels", {}).items() if "blend_backward_wave_kernel" in k]
+        if hit:
+            traffic = int(hit[0]["hbm_bytes"])
+            traffic_src = "profiles/traffic_head.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, same workload; not this run)"
+    except (OSError, ValueError, KeyError):
+        pass
 
     # the same workload with dependent steps on ONE stream (what a sequential trainer sees), next to the pipelined headline
     seq = None
@@ -324,8 +339,9 @@ def main() -> None:
             "parallelism": "1 process" if world == 1 else f"view-sharded x{world}, RCCL all-reduce of per-Gaussian grads (14 f32 each)",
         },
         "roofline": {
-            "kernel": "blend_backward_kernel", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+            "kernel": "blend_backward_wave_kernel" if os.environ.get("AG_BWD_KERNEL", "1") != "0" else "blend_backward_kernel",
+            "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": int(alg_dom), "avg_launch_us": round(dom_us, 2), "launches_timed": n_dom,
             "whole_step_algorithmic_GBps": round(alg_step / (ms_per_step * 1e-3) / 1e9, 2),
             "note": "VALU/LDS/atomic-bound kernel reported against HBM as SURVEY.md 8(d) prescribes",
@@ -376,12 +392,146 @@ def main() -> None:
         out["roofline_mfma"] = bench_avatar.conv_roofline(dev)
         out["full_step"] = bench_avatar.full_step_probe(dev)
 
-    if not args.no_cpu_baseline and world == 1:            # reported at N = 1 only (it costs ~25 s of host time)
+    if world == 1 and not args.no_stress:
+        for leaf in leaves:
+            leaf.grad = None
+        del fused
+        torch.cuda.empty_cache()
+        out["stress_1m_2048"] = stress_1m_2048(dev)
+    if not args.no_cpu_baseline and world == 1:            # reported at N = 1 only (bounded samples: ~25 s + ~20 s of host time)
         out["cpu_baseline"] = cpu_baseline(av, cams_np, up, W, H)
+        out["cpu_baseline_lbs"] = cpu_baseline_lbs()
+        out["cpu_baseline_styleunet"] = cpu_baseline_styleunet()
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def stress_1m_2048(dev, steps: int = 60, warmup: int = 12):
+    """BASELINE configs[4] on ONE GPU: 1.07 M Gaussians (the 2048 x 4096 front|back canvas), one 2048^2 view per step, f = 2200, the same
+    library-owned forward + backward step as the headline on three internal streams; blend-backward duration from HIP events on its
+    launch stream in a one-stream pass.  Parity at this size: tests/test_raster_gpu.py::test_full_size_1m_gaussians_2048_vs_oracle."""
+    import numpy as np
+    import torch
+    from animatablegaussians_amd import _lib, camera, synth
+    from animatablegaussians_amd.rasterizer import FusedRasterStep, GaussianRasterizationSettings, native_rasterize_gaussians
+    S = 2048
+    av = synth.avatar_map_gaussians(S)
+    P = av["means3D"].shape[0]
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    g = [t(av[k]) for k in ("means3D", "colors", "opacities", "scales", "rotations")]
+    bg = t(av["bg"])
+    settings = []
+    for c in synth.free_view_cameras(8, img=S, focal=2200.0):
+        cm = camera.camera_from_intr_extr(c["extr"], c["intr"], S, S)
+        settings.append(GaussianRasterizationSettings(image_height=S, image_width=S, tanfovx=cm["tanfovx"], tanfovy=cm["tanfovy"], bg=bg,
+                                                      scale_modifier=1.0, viewmatrix=t(cm["viewmatrix"]), projmatrix=t(cm["projmatrix"]),
+                                                      sh_degree=0, campos=t(cm["campos"]), prefiltered=False, debug=False))
+    up = synth.upstream_grads(S, S, 999)
+    gc, gd, ga = t(up["dL_dcolor"]), t(up["dL_ddepth"]), t(up["dL_dalpha"])
+    fused = FusedRasterStep(P, S, S, dev, n_streams=3)
+
+    def step(i, slot=None):
+        fused.view(settings[i % 8], g[0], g[1], g[2], g[3], g[4], gc, gd, ga, slot=(i % 3) if slot is None else slot)
+
+    def sync():
+        fused.join()
+        torch.cuda.synchronize(dev)
+
+    for i in range(warmup):
+        step(i)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(warmup + i)
+    sync()
+    dt = time.perf_counter() - t0
+    _lib.prof_enable([5])
+    for i in range(24):
+        step(i, slot=0)
+    sync()
+    n, ms = _lib.prof_collect()["blend_backward_kernel"]
+    _lib.prof_enable([])
+    empty = torch.Tensor([])
+    with torch.no_grad():
+        R = [native_rasterize_gaussians(s.bg, g[0], g[1], g[2], g[3], g[4], 1.0, empty, s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy, S, S,
+                                        empty, 0, s.campos, False, False)[0] for s in settings]
+    R_mean = float(np.mean(R))
+    T_tiles = (S // 16) ** 2
+    us = 1e3 * ms / max(n, 1)
+    alg_dom = 8 * T_tiles + 44 * R_mean + 28 * S * S + 40 * P
+    alg_step = 392 * P + 132 * R_mean + 52 * S * S + 24 * T_tiles
+    return {"workload": "BASELINE configs[4] on one GPU: 2048 x 4096 canvas, 1 view @2048^2 per step, raster fwd+bwd (library-owned step, 3 streams)",
+            "gaussians": P, "instances_per_view": int(R_mean), "steps": steps, "views_per_s": round(steps / dt, 1),
+            "ms_per_step": round(1e3 * dt / steps, 4), "blend_backward_avg_launch_us": round(us, 1),
+            "blend_backward_algorithmic_GBps": round(alg_dom / (us * 1e-6) / 1e9, 1), "blend_backward_frac_of_hbm": round(alg_dom / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+            "whole_step_algorithmic_GBps": round(alg_step / (dt / steps) / 1e9, 1)}
+
+
+def cpu_baseline_lbs(reps: int = 5):
+    """the reference's LBS path (network/avatar.py:84-91: einsum over the [N, 55] weights, pytorch3d quaternion <-> matrix)
+    as restated in oracle/avatar_oracle.py, torch CPU, all host cores; the synthetic subject's 268 348 Gaussians."""
+    import numpy as np
+    import torch
+    from animatablegaussians_amd import synth
+    from oracle import avatar_oracle as ao
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    av = synth.avatar_map_gaussians()
+    N, J = av["means3D"].shape[0], 55
+    gen = torch.Generator().manual_seed(3)
+    lbs = torch.softmax(torch.randn(N, J, generator=gen) * 4, dim=1)
+    A = torch.eye(4)[None].repeat(J, 1, 1) + 0.01 * torch.randn(J, 4, 4, generator=gen)
+    pos = torch.from_numpy(np.ascontiguousarray(av["means3D"])).requires_grad_(True)
+    rot = torch.nn.functional.normalize(torch.randn(N, 4, generator=gen)).requires_grad_(True)
+    fwd, both = [], []
+    for _ in range(reps + 1):
+        t0 = time.perf_counter()
+        p2, r2 = ao.transform_cano2live(pos, rot, lbs, A)
+        t1 = time.perf_counter()
+        (p2.sum() + r2.sum()).backward()
+        t2 = time.perf_counter()
+        pos.grad = rot.grad = None
+        fwd.append(t1 - t0)
+        both.append(t2 - t0)
+    f, b = float(np.median(fwd[1:])), float(np.median(both[1:]))
+    return {"forward_ms": round(1e3 * f, 2), "forward_backward_ms": round(1e3 * b, 2), "gaussians": N, "joints": J, "cores": cores, "kind": "port",
+            "sample": f"median of {reps} calls after one warm-up; torch {torch.__version__} CPU ops, dense [N, 55] weights as the reference stores them"}
+
+
+def cpu_baseline_styleunet():
+    """the reference's DualStyleUNet (512 -> 1024, the colour / position configuration) on this box's host cores: one
+    forward and one forward + backward of oracle/dual_styleunet_oracle.py -- F.conv2d / F.conv_transpose2d and the reference's pure-torch
+    upfirdn2d / fused_leaky_relu branches in the reference's order (pinned bit-for-rounding against the reference module's own golden by
+    tests/test_styleunet_oracle_cpu.py).  One pass each: ~10-60 s depending on the host."""
+    import numpy as np
+    import torch
+    from animatablegaussians_amd import synth
+    from animatablegaussians_amd.styleunet import DualStyleUNet
+    from oracle.dual_styleunet_oracle import DualStyleUNetOracle
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    shapes = {k: v.shape for k, v in DualStyleUNet(inp_size=512, inp_ch=3, out_ch=3, out_size=1024, style_dim=512, n_mlp=2).reference_state_dict().items()}
+    sd = synth.named_fill({k: torch.empty(s) for k, s in shapes.items()})
+    for k, v in sd.items():
+        if not k.startswith("noises."):
+            v.requires_grad_(True)
+    pose = synth.pose_map(512).requires_grad_(True)
+    style = torch.ones(1, 512) / np.sqrt(512)
+    net = DualStyleUNetOracle(sd)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        net.forward(style, pose)
+        fwd = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    images = net.forward(style, pose)
+    images.square().mean().backward()
+    both = time.perf_counter() - t0
+    return {"forward_s": round(fwd, 2), "forward_backward_s": round(both, 2), "networks": 1, "GFLOP_forward": 585.8, "cores": cores, "kind": "port",
+            "views_per_s_equivalent_3_networks": round(1.0 / (3 * both), 4),
+            "sample": "one DualStyleUNet forward (no grad) and one forward + backward, fp32, torch CPU (oneDNN) on all host cores; a training "
+                      "step of the reference evaluates three of these per view"}
 
 
 def cpu_baseline(av, cams_np, up, W, H, max_seconds: float = 25.0):

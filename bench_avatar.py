@@ -13,7 +13,7 @@ One step = one camera view of one pose, exactly what one iteration of the refere
 
 `--views V` (config 3 proper: "training step, 4 views"): V cameras of the SAME pose per step through
 `AvatarNet.render_views` -- position / other networks, 77 % of the colour network, the assembly and the LBS are evaluated
-(and back-propagated) once per step instead of once per view; measured 34 views/s at V = 4 against 10.9 at V = 1.
+(and back-propagated) once per step instead of once per view; measured (round 2, profiles/r02e_bench.json) 60 views/s at V = 4 against 18.6 at V = 1.
 
 Synthetic subject (AvatarNet.synthetic: 268 348 Gaussians on the 1024x2048 front|back canvas, 4-sparse LBS weights,
 55 random rigid joint transforms), default-initialised networks (224 M parameters), 8 free-view cameras round-robin.
@@ -235,10 +235,12 @@ def conv_roofline(dev, steps=3):
     return out
 
 
-def full_step_probe(dev, steps1=6, steps4=4):
+def full_step_probe(dev, block=4, blocks=5):
     """bench.py's ``full_step`` leg: BASELINE configs[2] -- the whole training iteration (3 StyleUNets + assembly + LBS + raster,
     loss, backward, fused Adam) at 1 view per step (the reference's own batch shape) and at 4 views of one pose per step, in the product's
-    convolution arithmetic; the same two numbers in the other two modes of include/ag_conv.h beside them."""
+    convolution arithmetic; the same two numbers in the other two modes of include/ag_conv.h beside them.  Per mode and batch shape:
+    ``blocks`` blocks of ``block`` pipelined steps (device-synchronised at the block ends), interleaved between the modes so that clock
+    and temperature history are shared; reported = the MEDIAN block (20 steps per figure), with the fastest and slowest beside it."""
     from animatablegaussians_amd import conv as agc
     import numpy as np
     step = TrainingStep(dev)
@@ -247,24 +249,26 @@ def full_step_probe(dev, steps1=6, steps4=4):
     t1 = {m: [] for m in modes}
     t4 = {m: [] for m in modes}
     try:
-        for _rep in range(2):                    # blocks of steps alternate between the modes: clock / temperature history is shared
+        for _rep in range(blocks):
             for m in modes:
                 agc.set_math(m)
-                t1[m].append(timed(lambda i: step(i, 1), steps1, 2, dev))
-                t4[m].append(timed(lambda i: step(i, 4), steps4, 2, dev))
+                t1[m].append(timed(lambda i: step(i, 1), block, 1 if _rep else 2, dev))
+                t4[m].append(timed(lambda i: step(i, 4), block, 1 if _rep else 2, dev))
     finally:
         agc.set_math(mode0)
 
     def rec(m):
-        ms1, ms4 = float(np.min(t1[m])), float(np.min(t4[m]))      # stalls (allocator growth at the first 4-view block) only ever add time
+        ms1, ms4 = float(np.median(t1[m])), float(np.median(t4[m]))
         return {"views_per_s_1view_per_step": round(1e3 / ms1, 2), "ms_per_step_1view": round(ms1, 2),
-                "views_per_s_4views_per_step": round(4e3 / ms4, 2), "ms_per_step_4views": round(ms4, 2)}
+                "views_per_s_4views_per_step": round(4e3 / ms4, 2), "ms_per_step_4views": round(ms4, 2),
+                "ms_per_step_1view_min_max": [round(float(np.min(t1[m])), 2), round(float(np.max(t1[m])), 2)],
+                "ms_per_step_4views_min_max": [round(float(np.min(t4[m])), 2), round(float(np.max(t4[m])), 2)]}
 
     out = {"workload": "BASELINE configs[2]: StyleUNet x3 + LBS + raster fwd+bwd + L1/offset loss + fused Adam, 268 k Gaussians @1024^2",
            "conv_math": mode0}
     out.update(rec(mode0))
-    out.update({"steps_timed": [2 * steps1, 2 * steps4], "parameters": step.n_params,
-                "note": "two blocks of steps per arithmetic mode, interleaved; the faster block of each"})
+    out.update({"steps_timed": [block * blocks, block * blocks], "parameters": step.n_params,
+                "note": f"{blocks} blocks of {block} pipelined steps per arithmetic mode and batch shape, interleaved; the median block"})
     keys = {"fp32": "conv_math_fp32", "split_bf16x3": "conv_math_split_bf16x3_opt_in_not_fp32_grade", "split_bf16": "conv_math_split_bf16"}
     for m in modes[1:]:
         out[keys[m]] = rec(m)

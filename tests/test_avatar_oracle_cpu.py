@@ -53,3 +53,28 @@ def test_round_trip_and_float32_behaviour():
     q2 = ao.matrix_to_quaternion(R)
     sign = torch.sign((q * q2).sum(-1, keepdim=True))
     assert float((q2 * sign - q).abs().max()) < 5e-6
+
+
+def test_matrix_to_quaternion_on_non_orthonormal_matrices_matches_the_independent_derivation():
+    """The branch LBS exercises (blended joint matrices are not rotations): the torch restatement in oracle/avatar_oracle.py against
+    tests/golden/m2q_nonorthonormal.npz -- a scalar float64 derivation of the published pytorch3d 0.7.4 algorithm written without
+    torch (tests/golden/make_golden_m2q.py: four clamped square roots, first arg-max, 0.1 floor, no sign standardisation) on 1 709
+    matrices: convex blends of 2-4 rotations, near-cancelling blends, nearly-zero matrices, exact ties.  Two independent
+    codings of the same published formula agreeing is the most this container can do: it is still NOT pytorch3d's own output, and
+    DESIGN.md keeps saying so."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "m2q_nonorthonormal.npz"))
+    M, q, row = g["M"], g["q"], g["row"]
+    assert set(row.tolist()) == {0, 1, 2, 3}
+    got = ao.matrix_to_quaternion(torch.from_numpy(M)).numpy()
+    np.testing.assert_allclose(got, q, rtol=1e-13, atol=1e-15)                     # float64: same operations, same order
+    got32 = ao.matrix_to_quaternion(torch.from_numpy(M).float()).numpy().astype(np.float64)
+    # float32: identical branch wherever the arg-max is not a near-tie; values to fp32 rounding of a division by >= 0.2
+    a = np.sqrt(np.maximum(0.0, np.stack([1 + M[:, 0, 0] + M[:, 1, 1] + M[:, 2, 2], 1 + M[:, 0, 0] - M[:, 1, 1] - M[:, 2, 2],
+                                          1 - M[:, 0, 0] + M[:, 1, 1] - M[:, 2, 2], 1 - M[:, 0, 0] - M[:, 1, 1] + M[:, 2, 2]], 1)))
+    top2 = np.sort(a, axis=1)[:, -2:]
+    clear = (top2[:, 1] - top2[:, 0]) > 1e-5
+    assert clear.mean() > 0.95
+    np.testing.assert_allclose(got32[clear], q[clear], rtol=0, atol=2e-6 * max(1.0, float(np.abs(q).max())))
+    # and the composition LBS uses: q' = m2q(M @ q2m(q)) keeps the blended matrix's scale (the output quaternions are not unit)
+    assert float(np.abs(np.linalg.norm(q[:1200], axis=1) - 1.0).max()) > 1e-2

@@ -156,7 +156,7 @@ def _masked_grads(scene, ref):
     return {k: np.ascontiguousarray(scene[k] * keep) for k in ("dL_dcolor", "dL_ddepth", "dL_dalpha")}
 
 
-def _check_backward(scene, cam):
+def _check_backward(scene, cam, ill_expected):
     """Three-level backward parity:
     (1) blend-backward accumulators on the SAME saved forward state (the oracle's alpha map is passed as the
         `alphas` input, exactly as the reference's backward takes it) vs the fp64-accumulated oracle;
@@ -221,7 +221,33 @@ def _check_backward(scene, cam):
     sat = t_fin < 1e-2
     amp = np.abs(fw["alpha"][0].astype(np.float64) - ref["alpha"][0]) > 2e-5 * t_fin
     ill = sat | amp
-    assert ill.mean() < 0.25 and (flips & ~frag).mean() < 5e-3, f"{ill.mean():.3f} of pixels ill-conditioned, {flips.mean():.2e} flip"
+    # cap = 1.5 x the fraction measured for this scene (`ill_expected`, printed below by `pytest -s`) + 5e-4: the exemption cannot grow silently
+    assert ill.mean() <= 1.5 * ill_expected + 5e-4 and (flips & ~frag).mean() < 5e-3, \
+        f"{ill.mean():.4f} of pixels ill-conditioned (measured when the cap was set: {ill_expected}), {flips.mean():.2e} flip"
+    # Evidence for the exemption, printed per scene: the REFERENCE'S OWN gradients (oracle against oracle with every exp() scaled by
+    # 1 + 2^-20, i.e. one rounding of alpha) on the exempted pixels and on the kept ones.  Measured: 268 k avatar @1024^2 -- exempted
+    # pixels: the reference moves by 7.7e-4 / 4.6e-3 / 4.5e-2 of an element's value (50th / 90th / 99th percentile), kept pixels
+    # 1.9e-6 / 1.3e-5 / 1.1e-4; 10 k random scene -- 1.7e-5 / 1.2e-4 / 1.2e-3 against 2.2e-6 / 1.6e-5 / 1.5e-4.  The 1e-4 bar is not
+    # defined on the exempted set: the reference does not meet it against itself there.
+    evidence = {}
+    for label, m in (("exempted", ill & ~(frag | flips)), ("kept", ~(ill | frag | flips))):
+        km = m.astype(np.float32)[None]
+        gm = {k: np.ascontiguousarray(scene[k] * km) for k in ("dL_dcolor", "dL_ddepth", "dL_dalpha")}
+        a0 = ro.backward_blend(ref, scene["colors"], scene["bg"], gm["dL_dcolor"], gm["dL_ddepth"], gm["dL_dalpha"])
+        ro.set_exp_scale(1.0 + 2.0 ** -20)
+        try:
+            a1 = ro.backward_blend(ref_p, scene["colors"], scene["bg"], gm["dL_dcolor"], gm["dL_ddepth"], gm["dL_dalpha"])
+        finally:
+            ro.set_exp_scale(1.0)
+        rel = []
+        for name, slots in h._SLOT_OF.items():
+            for col, slot in enumerate(slots):
+                if slot is not None:
+                    r0, r1 = np.asarray(a0[name], np.float64)[:, col], np.asarray(a1[name], np.float64)[:, col]
+                    big = np.abs(r0) > 1e-6 * max(np.abs(r0).max(), 1e-300)
+                    rel.append(np.abs(r1 - r0)[big] / np.abs(r0)[big])
+        rel = np.concatenate(rel) if rel else np.zeros(1)
+        evidence[label] = np.percentile(rel, [50, 90, 99]) if rel.size else np.zeros(3)
     keep = (~(frag | flips | ill)).astype(np.float32)[None]
     wc = {k: np.ascontiguousarray(scene[k] * keep) for k in ("dL_dcolor", "dL_ddepth", "dL_dalpha")}
     acc_wc = ro.backward_blend(ref, scene["colors"], scene["bg"], wc["dL_dcolor"], wc["dL_ddepth"], wc["dL_dalpha"])
@@ -243,7 +269,9 @@ def _check_backward(scene, cam):
     print(f"\n[parity] P={ref['radii'].shape[0]} {cam['img_w']}x{cam['img_h']}: fragile pixels {frag.mean():.2e} (+ {(flips & ~frag).mean():.2e} "
           f"that flip under the exp probe), ill-conditioned {ill.mean():.2e} (T_final < 1e-2: {sat.mean():.2e}, forward difference "
           f"amplified past 2e-5: {(amp & ~sat).mean():.2e}); well-conditioned set: every accumulator element within the 1e-4 bound "
-          f"(worst ratio {worst_wc:.2f}); all pixels: {loose:.2e} of gradient elements beyond 1e-3*|ref| + 1e-4*rowmax")
+          f"(worst ratio {worst_wc:.2f}); all pixels: {loose:.2e} of gradient elements beyond 1e-3*|ref| + 1e-4*rowmax\n"
+          f"         the reference against itself under exp * (1 + 2^-20), relative movement of its accumulator elements p50/p90/p99: "
+          + "; ".join(f"{k} pixels {v[0]:.1e}/{v[1]:.1e}/{v[2]:.1e}" for k, v in evidence.items()))
 
 
 @pytest.mark.parametrize("P,img", [(10000, 512), (3000, 500)])
@@ -252,7 +280,7 @@ def test_backward_config1(P, img):
     if img == 500:
         scene["img_w"], scene["img_h"] = 500, 300
         scene.update(synth.upstream_grads(500, 300, 5))
-    _check_backward(scene, h.cam_of(scene))
+    _check_backward(scene, h.cam_of(scene), ill_expected=0.0292 if img == 512 else 0.0003)
 
 
 def test_backward_cov3d_precomp():
@@ -260,7 +288,7 @@ def test_backward_cov3d_precomp():
     cam = h.cam_of(scene)
     ref0 = h.oracle_forward(scene, cam)
     scene2 = dict(scene, cov3D_precomp=ref0["cov3D"].copy(), scales=None, rotations=None)
-    _check_backward(scene2, cam)
+    _check_backward(scene2, cam, ill_expected=0.0)
 
 
 def test_avatar_config2_forward_backward():
@@ -274,7 +302,7 @@ def test_avatar_config2_forward_backward():
     gpu = h.gpu_native_forward(scene, cam)
     _bitexact(gpu, ref)
     h.assert_image_parity(gpu, ref)
-    _check_backward(scene, cam)
+    _check_backward(scene, cam, ill_expected=0.1101)
 
 
 def test_mark_visible():

@@ -78,7 +78,23 @@ def test_state_dict_is_the_reference_modules_layout():
 
 
 @pytest.mark.gpu
-def test_dual_styleunet_forward_backward_vs_reference_golden():
+@pytest.mark.parametrize("math", ["split_bf16", "fp32"])
+def test_dual_styleunet_forward_backward_vs_reference_golden(math):
+    """Both arithmetic paths of the convolutions (include/ag_conv.h: the default six-product bf16 split and the fp32 MFMA) end to end
+    against the fixture the reference module produced."""
+    import torch
+    from animatablegaussians_amd import conv as agc
+    from animatablegaussians_amd import synth
+    from animatablegaussians_amd.styleunet import DualStyleUNet
+
+    prev = agc.set_math(math)
+    try:
+        _golden_body(math)
+    finally:
+        agc.set_math(prev)
+
+
+def _golden_body(math):
     import torch
     from animatablegaussians_amd import synth
     from animatablegaussians_amd.styleunet import DualStyleUNet
@@ -116,7 +132,7 @@ def test_dual_styleunet_forward_backward_vs_reference_golden():
     ours, ref = np.array([o for o, _, _ in rows]), np.array([r for _, r, _ in rows])
     out_dir = os.environ.get("AG_TEST_REPORT_DIR")
     if out_dir:
-        with open(os.path.join(out_dir, "styleunet_grad_report.txt"), "w") as f:
+        with open(os.path.join(out_dir, f"styleunet_grad_report_{math}.txt"), "w") as f:
             for o, r, n in fwd_rows:
                 f.write(f"forward {n}: ours {o:.3e} ref32 {r:.3e}\n")
             for q in (50, 75, 90, 95, 99, 100):
@@ -125,8 +141,10 @@ def test_dual_styleunet_forward_backward_vs_reference_golden():
                 f.write(f"ours {o:.3e} ref32 {r:.3e} {n}\n")
     for q in (50, 75, 90, 95, 99):
         assert np.percentile(ours, q) <= 4 * np.percentile(ref, q), (q, np.percentile(ours, q), np.percentile(ref, q))
+    # per-tensor caps: 3e-2 of the tensor's largest gradient; the noise-strength scalars (one number each, a sum over a whole feature map
+    # of products with mixed signs) are where the reference's own fp32 deviates most from its fp64 (6e-2): twice that
     for o, _, n in rows:
-        assert o <= (0.25 if n.endswith("noise.weight") else 3e-2), (n, o)
+        assert o <= (0.12 if n.endswith("noise.weight") else 3e-2), (n, o)
 
 
 @pytest.mark.gpu

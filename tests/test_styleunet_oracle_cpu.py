@@ -1,0 +1,51 @@
+"""Pins oracle/dual_styleunet_oracle.py -- the plain-torch CPU restatement of the reference's DualStyleUNet.forward that bench.py times
+as `cpu_baseline_styleunet` -- against the fixture the REFERENCE MODULE ITSELF produced (tests/golden/make_golden_dual_styleunet.py):
+forward images and every parameter gradient, in float32 (the reference as shipped).  The restatement runs the same torch CPU ops
+in the same order, so it must agree with the reference's own float32 run to rounding: held here to 2x the reference's float32-vs-float64
+deviation + 1e-6 per stored tensor."""
+import os
+
+import numpy as np
+import torch
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "dual_styleunet_512_1024.npz")
+
+
+def _sub(t, n=256):
+    f = t.detach().flatten()
+    step = max(1, f.numel() // n)
+    return f[::step][:n].double().numpy()
+
+
+def test_cpu_oracle_of_the_whole_network_matches_the_reference_modules_golden():
+    from animatablegaussians_amd import synth
+    from oracle.dual_styleunet_oracle import DualStyleUNetOracle
+    gold = np.load(GOLD)
+    shapes = {k[len("shape:"):]: tuple(int(v) for v in gold[k]) for k in gold.files if k.startswith("shape:")}
+    sd = synth.named_fill({k: torch.empty(s) for k, s in shapes.items()})
+    learn = [k for k in sd if not k.startswith("noises.")]
+    for k in learn:
+        sd[k].requires_grad_(True)
+    pose = synth.pose_map(512).requires_grad_(True)
+    style = torch.ones(1, 512) / np.sqrt(512)
+    torch.set_num_threads(os.cpu_count() or 1)
+    images = DualStyleUNetOracle(sd).forward(style, pose)
+    assert images.shape == (1, 6, 1024, 1024)
+    scale = float(gold["images_max"])
+    for key, got in (("images_sub16", images[0, :, ::16, ::16]), ("images_crop_a", images[0, :, 500:532, 500:532]),
+                     ("images_crop_b", images[0, :, 100:132, 700:732])):
+        d = np.abs(got.detach().numpy() - gold[key]).max() / scale
+        assert d <= 2 * float(gold["err32:" + key]) + 1e-6, (key, d, float(gold["err32:" + key]))
+    G = torch.randn(images.shape, generator=torch.Generator().manual_seed(4242))
+    (images * G).sum().backward()
+    d = np.abs(pose.grad[0, :, ::8, ::8].numpy() - gold["pose_grad_sub8"]).max() / float(gold["pose_grad_max"])
+    assert d <= 2 * float(gold["err32:pose_grad_sub8"]) + 1e-6, d
+    worst = 0.0
+    for k in learn:
+        g = sd[k].grad
+        assert g is not None, k
+        d = np.abs(_sub(g) - gold["grad:" + k]).max() / max(float(gold["gmax:" + k]), 1e-30)
+        lim = 2 * float(gold["err32:grad:" + k]) + 1e-6
+        worst = max(worst, d / lim)
+        assert d <= lim, (k, d, lim)
+    print(f"oracle vs the reference module's golden: {len(learn)} parameter gradients, worst ratio to 2x the reference's own fp32 noise {worst:.2f}")
