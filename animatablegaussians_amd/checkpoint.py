@@ -28,11 +28,22 @@ def save_ckpt(path: str, net, optm=None, epoch_idx: int = 0, iter_idx: int = 0, 
 def load_ckpt(path: str, net, optm=None, load_optm: bool = True):
     """-> (epoch_idx, iter_idx), as the reference's ``load_ckpt``."""
     net_dict = torch.load(os.path.join(path, 'net.pt'), map_location='cpu')
+    legacy = False
     if 'avatar_net' in net_dict:
-        net.load_state_dict(net_dict['avatar_net'])
+        sd = net_dict['avatar_net']
+        own = net.state_dict()
+        const = ('.kernel', '.ll', '.lh', '.hl', '.hh')
+        legacy = any(k.endswith(const) and k not in sd for k in own)
+        if legacy and hasattr(net, 'load_reference_state_dict'):
+            # written by this package before round 2 (no constant blur / Haar buffers, other parameter order): the constants are the same
+            # here, so the learnable tensors load by name; its optm.pt is indexed by the OLD parameter order and is refused below
+            print('[WARNING] net.pt without the constant FIR / Haar buffers (pre-round-2 layout): loading by name; optm.pt is skipped')
+            net.load_reference_state_dict(sd)
+        else:
+            net.load_state_dict(sd)
     else:
         print('[WARNING] Cannot find "avatar_net" from the network checkpoint!')
-    if load_optm and optm is not None and os.path.exists(os.path.join(path, 'optm.pt')):
+    if load_optm and not legacy and optm is not None and os.path.exists(os.path.join(path, 'optm.pt')):
         optm_dict = torch.load(os.path.join(path, 'optm.pt'), map_location='cpu')
         if 'avatar_net' in optm_dict:
             optm.load_state_dict(optm_dict['avatar_net'])

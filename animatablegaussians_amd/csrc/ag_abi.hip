@@ -31,8 +31,9 @@ int check_hip(hipError_t e, const char* what)
 // and the work the caller declared for it.  A ProfScope keeps the index of ITS record, so launches of the same kernel
 // from several threads / streams / devices never pair each other's events.
 static uint32_t g_prof_mask = 0;
-struct ProfRec { int id, dev; hipEvent_t a, b; double work; };
+struct ProfRec { int id, dev; hipEvent_t a, b; double work; bool ended; };
 static std::vector<ProfRec> g_prof_log;
+static int g_prof_gen = 0;       // bumped by every ag_prof_collect: a handle taken before a collect must not touch the refilled log
 static std::vector<std::pair<int, hipEvent_t>> g_prof_pool;   // (device, event)
 static std::mutex g_prof_mu;
 
@@ -55,17 +56,21 @@ int prof_begin(int id, hipStream_t s, double work)
     int dev = 0;
     (void)hipGetDevice(&dev);
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    ProfRec r{ id, dev, prof_event(dev), prof_event(dev), work };
+    if (g_prof_log.size() >= (1u << 20)) return -1;
+    ProfRec r{ id, dev, prof_event(dev), prof_event(dev), work, false };
     (void)hipEventRecord(r.a, s);
     g_prof_log.push_back(r);
-    return (int)g_prof_log.size() - 1;
+    return ((g_prof_gen & 0x3ff) << 20) | (int)(g_prof_log.size() - 1);      // generation in the upper bits
 }
 
 void prof_end(int handle, hipStream_t s)
 {
     if (handle < 0) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    if ((size_t)handle < g_prof_log.size()) (void)hipEventRecord(g_prof_log[handle].b, s);
+    const size_t idx = (size_t)(handle & 0xfffff);
+    if ((handle >> 20) != (g_prof_gen & 0x3ff) || idx >= g_prof_log.size()) return;   // another thread collected in between: record dropped
+    (void)hipEventRecord(g_prof_log[idx].b, s);
+    g_prof_log[idx].ended = true;
 }
 
 // One pinned word per thread for the num_rendered read-back (the reference's blocking cudaMemcpy,
@@ -313,13 +318,15 @@ int ag_prof_collect(int32_t* launches, float* total_ms, double* work)
     for (auto& r : g_prof_log) {
         float ms = 0.f;
         (void)hipSetDevice(r.dev);
-        if (hipEventSynchronize(r.b) != hipSuccess || hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) rc = AG_ERR_HIP;
+        if (!r.ended) { /* begun on another thread, not ended yet: not measured */ }
+        else if (hipEventSynchronize(r.b) != hipSuccess || hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) rc = AG_ERR_HIP;
         else { launches[r.id]++; total_ms[r.id] += ms; if (work) work[r.id] += r.work; }
         g_prof_pool.push_back({ r.dev, r.a });
         g_prof_pool.push_back({ r.dev, r.b });
     }
     (void)hipSetDevice(cur);
     g_prof_log.clear();
+    g_prof_gen++;
     return rc;
 }
 

@@ -6,10 +6,32 @@ Backend-agnostic on purpose: ``nccl`` (= RCCL over xGMI) on the GPU node, ``gloo
 """
 from __future__ import annotations
 
+import os
 from typing import List, Sequence
 
 import torch
 import torch.distributed as dist
+
+
+def init_distributed(world: int, local_rank: int):
+    """One rank per GPU over RCCL (backend "nccl").  With fewer GPUs than ranks RCCL cannot run (two ranks on one device): the ranks
+    then share devices over gloo -- a functional run of the N > 1 control flow, reported as such in the JSON line and NEVER a
+    measurement.  AG_DIST_BACKEND forces either.  Returns (backend, local device index)."""
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    n_dev = torch.cuda.device_count()
+    backend = os.environ.get("AG_DIST_BACKEND") or ("nccl" if n_dev >= world else "gloo")
+    if backend == "nccl" and n_dev < world:
+        raise RuntimeError(f"--gpus {world} with {n_dev} visible GPU(s): RCCL needs one device per rank (AG_DIST_BACKEND=gloo for a functional run)")
+    local = local_rank % max(n_dev, 1)
+    torch.cuda.set_device(local)
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        dist.init_process_group(backend)
+    return backend, local
 
 
 def views_of_rank(n_views: int, rank: int, world: int) -> List[int]:
@@ -63,8 +85,10 @@ class BucketedGradSync:
     * xGMI is point-to-point (7 links x ~153 GB/s per GPU) and ring collectives are per-link bound, so buckets are few
       and large (default 128 MB: ~7 collectives per step) rather than DDP's 25 MB.
 
-    * A bucket's gradients can come from several HIP streams; each hook records an event on its own stream and the launch
-      waits for all of them (the collective itself only orders after the launching stream).
+    * A bucket's gradients can come from several HIP streams; each hook records an event on its own stream.  The collective is
+      issued under a dedicated COMMUNICATION stream that waits for those events: no compute stream is made to wait for the other
+      branches' gradients (round 2 made the stream of whichever hook fired last wait for all of them, which serialised that
+      backward branch behind the others exactly where the overlap was designed in).
     * One ``backward()`` per step.  A second gradient for the same parameter in one step raises (its bucket may already be
       reducing); ``defer_to_finish=True`` supports several backward calls per step by reducing everything in ``finish()``.
 
@@ -100,6 +124,7 @@ class BucketedGradSync:
         self.buckets.append((b_start, off))
         self._pending_init.append(b_count)
         self._world = dist.get_world_size() if dist.is_initialized() else 1
+        self._comm = torch.cuda.Stream(dev) if self._cuda else None      # collectives are ordered after the gradients' events HERE
         self._arm()
         self._handles = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
 
@@ -119,15 +144,19 @@ class BucketedGradSync:
 
     def _launch(self, b):
         """All-reduce bucket b.  Its gradients may have been accumulated on several HIP streams (the networks run their decoder
-        branches on side streams and autograd replays every node on its recording stream), while the collective only orders itself
-        after the CURRENT stream: wait for every gradient's own event first."""
+        branches on side streams and autograd replays every node on its recording stream).  The communication stream waits for every
+        gradient's own event and the collective is issued with that stream current, so RCCL orders itself after exactly the
+        producers of this bucket and nothing else waits."""
         s, e = self.buckets[b]
-        if self._cuda:
-            cur = torch.cuda.current_stream(self.flat.device)
-            for ev in self._events[b]:
-                cur.wait_event(ev)
-        self._events[b] = []
         self._launched[b] = True
+        if self._cuda:
+            for ev in self._events[b]:
+                self._comm.wait_event(ev)
+            self._events[b] = []
+            with torch.cuda.stream(self._comm):
+                self._works.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, async_op=True))
+            return
+        self._events[b] = []
         self._works.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, async_op=True))
 
     def _on_grad(self, p):
@@ -160,7 +189,9 @@ class BucketedGradSync:
                 if not self._launched[b]:
                     self._launch(b)
             for w in self._works:
-                w.wait()
+                w.wait()                                   # the CURRENT stream waits for the collective (and the host for gloo)
+            if self._cuda:
+                torch.cuda.current_stream(self.flat.device).wait_stream(self._comm)
             self._works = []
             if self.average:
                 self.flat /= self._world

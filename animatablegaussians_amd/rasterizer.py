@@ -368,6 +368,10 @@ class FusedRasterStep:
 
     def _binning(self, slot, cap):
         if slot["binning"] is None or slot["cap"] < cap:
+            old = slot["binning"]
+            if old is not None:
+                # allocated on the caller's stream, used only on the slot's: the previous view's backward may still be reading it
+                old.record_stream(slot["stream"])
             slot["binning"] = torch.empty((_scratch_bytes("binning", cap),), dtype=torch.uint8, device=self.dev)
             slot["cap"] = cap
         return slot["binning"]

@@ -86,15 +86,18 @@ _FLIPPED = {}
 
 
 def _flipped(kernel):
-    """FIR kernel flipped in both axes (the backward of an upfirdn2d), cached per kernel tensor and version: the network's three FIR
-    kernels are constants, and a flip is one more small launch per upfirdn2d backward otherwise."""
+    """FIR kernel flipped in both axes (the backward of an upfirdn2d), cached per kernel TENSOR and version: the network's three FIR
+    kernels are constants, and a flip is one more small launch per upfirdn2d backward otherwise.  The entry holds the source tensor
+    itself and is only used while it is that very object: a key made of the address alone would be handed to another kernel once the
+    first is freed and the allocator re-uses its block (a second model's blur kernel with another gain, a temporary passed to
+    ``upfirdn2d``) -- stale flipped taps, silently wrong gradients."""
     key = (kernel.data_ptr(), kernel._version, tuple(kernel.shape))
-    f = _FLIPPED.get(key)
-    if f is None:
+    e = _FLIPPED.get(key)
+    if e is None or e[0] is not kernel:
         if len(_FLIPPED) > 64:
             _FLIPPED.clear()
-        f = _FLIPPED[key] = torch.flip(kernel, [0, 1]).contiguous()
-    return f
+        e = _FLIPPED[key] = (kernel, torch.flip(kernel, [0, 1]).contiguous())
+    return e[1]
 
 
 def _empty(dev):

@@ -80,18 +80,10 @@ def main() -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = None
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        # one rank per GPU over RCCL ("nccl"); AG_DIST_BACKEND=gloo lets the N > 1 control flow be exercised on a box with
-        # fewer GPUs than ranks (ranks then share devices) -- a functional check only, never a measurement
-        backend = os.environ.get("AG_DIST_BACKEND", "nccl")
-        local_rank = local_rank % torch.cuda.device_count()
-        torch.cuda.set_device(local_rank)
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
+        from animatablegaussians_amd.parallel import init_distributed
+        backend, local_rank = init_distributed(world, local_rank)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
@@ -337,6 +329,8 @@ def main() -> None:
                            "through the library-owned step (ag_raster_forward_backward, one native call per view)"),
             "gaussians": P, "instances_per_view": int(R_mean), "tiles": T_tiles, "views": len(settings), "streams": args.streams,
             "parallelism": "1 process" if world == 1 else f"view-sharded x{world}, RCCL all-reduce of per-Gaussian grads (14 f32 each)",
+            "backend": None if world == 1 else (backend if backend == "nccl" else f"{backend}: fewer GPUs than ranks, ranks share devices -- a "
+                                                "functional run of the N > 1 control flow, NOT a measurement"),
         },
         "roofline": {
             "kernel": "blend_backward_wave_kernel" if os.environ.get("AG_BWD_KERNEL", "1") != "0" else "blend_backward_kernel",

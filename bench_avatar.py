@@ -296,18 +296,10 @@ def main() -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = None
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        # one rank per GPU over RCCL ("nccl"); AG_DIST_BACKEND=gloo lets the N > 1 control flow be exercised on a box with
-        # fewer GPUs than ranks (ranks then share devices) -- a functional check only, never a measurement
-        backend = os.environ.get("AG_DIST_BACKEND", "nccl")
-        local_rank = local_rank % torch.cuda.device_count()
-        torch.cuda.set_device(local_rank)
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
+        from animatablegaussians_amd.parallel import init_distributed
+        backend, local_rank = init_distributed(world, local_rank)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
@@ -342,6 +334,17 @@ def main() -> None:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    # N > 1: every rank must hold the same parameters after the run (identical averaged gradients -> identical Adam steps): compare a
+    # checksum and the largest element-wise difference to rank 0's copy
+    replicas_identical = None
+    if world > 1 and not args.infer:
+        flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+        ref = flat.clone()
+        dist.broadcast(ref, src=0)
+        diff = (flat - ref).abs().max().reshape(1)
+        dist.all_reduce(diff, op=dist.ReduceOp.MAX)
+        replicas_identical = bool(float(diff.item()) == 0.0)
+        del flat, ref
     if rank == 0:
         ms = 1e3 * elapsed / args.steps
         # conv FLOPs of a step: position + other nets once, colour net = shared 77 % once + 23 % per view
@@ -356,7 +359,10 @@ def main() -> None:
             "config": {"workload": f"SURVEY 8d config 3: {V} view(s) of one pose per step, whole render path"
                                    + (" (eval)" if args.infer else " + loss + backward + Adam"),
                        "gaussians": int(net.lbs.shape[0]), "parameters": int(n_params), "with_viewdirs": bool(net.with_viewdirs), "views_per_step": V, "lpips_loss_tail": lp is not None, "hip_graphs": bool(args.infer and args.graphs),
-                       "parallelism": "1 process" if world == 1 else f"view-sharded x{world}, bucketed RCCL all-reduce of {n_params * 4 >> 20} MB grads"},
+                       "parallelism": "1 process" if world == 1 else f"view-sharded x{world}, bucketed RCCL all-reduce of {n_params * 4 >> 20} MB grads",
+                       "backend": None if world == 1 else (backend if backend == "nccl" else f"{backend}: fewer GPUs than ranks, ranks share "
+                                                           "devices -- a functional run, NOT a measurement"),
+                       "replicas_identical_after_run": replicas_identical},
             "roofline": {"kernel": "gather_conv_kernel + wgrad_kernel (all StyleUNet convolutions of the step)", "bound": "mfma",
                          "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TF, 4),
                          "traffic": None, "note": "conv FLOPs of the step / WHOLE step time (lower bound on the kernels' own rate)"},

@@ -75,7 +75,9 @@ def test_bench_two_ranks_control_flow_on_one_gpu():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    env = dict(os.environ, AG_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    # no AG_DIST_BACKEND: with fewer GPUs than ranks the launch must pick the shared-device gloo run by itself (and say so), not hang in RCCL
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("AG_DIST_BACKEND", None)
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "30", "--warmup", "10"],
                        capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
@@ -85,6 +87,28 @@ def test_bench_two_ranks_control_flow_on_one_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 30 and d["scaling"] == "weak" and "view-sharded x2" in d["config"]["parallelism"]
     assert abs(d["value"] * d["ms_per_step"] - 2000.0) < 20.0                      # whole-job aggregate: 2 ranks x steps / time
-    assert "cpu_baseline" not in d and "full_step" not in d                        # N = 1 only
+    assert "cpu_baseline" not in d and "full_step" not in d and "stress_1m_2048" not in d      # N = 1 only
+    import torch
+    if torch.cuda.device_count() < 2:
+        assert d["config"]["backend"].startswith("gloo") and "NOT a measurement" in d["config"]["backend"]
     x = d["exchange_styleunet"]
     assert x["bytes"] == 4 * 223648936 and x["ms"] > 0 and x["bus_GBps"] > 0
+
+
+def test_training_replicas_stay_identical_over_two_adam_steps_two_ranks_one_gpu():
+    """`bench_avatar.py --gpus 2` as the driver would launch it, ranks sharing this box's GPU over gloo: two full training iterations
+    (view-sharded render, six-stream backward, bucketed all-reduce on the communication stream, fused Adam); afterwards every rank must
+    hold bit-identical parameters -- the property data parallelism rests on.  Functional only; no RCCL execution exists on this pool."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench_avatar.py"), "--gpus", "2", "--steps", "2", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["replicas_identical_after_run"] is True, d["config"]
