@@ -111,9 +111,10 @@ def test_concurrently_streamed_step_equals_the_serialised_step(net, monkeypatch)
     """Guard for the cross-wave packed-fp32 disturbance (profiles/r03_packed_fp32_hazard.md, stand-alone reproducer
     profiles/ub/pk_hazard.hip): the whole training iteration with the three networks on their HIP streams, run three times, against the
     same iteration with every kernel serialised on one stream (AG_SINGLE_STREAM=1).  Forward products are deterministic and must be
-    BIT-equal; the 224 M parameter gradients go through float atomics (split-K weight gradients, style / noise / bias reductions) whose
-    order differs between runs, so they are held to that noise: every element within 2e-5 of the tensor's largest gradient -- a product
-    term dropped by the disturbance changes an element by a multiple of that."""
+    BIT-equal (that is the check that caught the disturbance in round 2); the 224 M parameter gradients go through float atomics
+    (split-K weight gradients, style / noise / bias reductions) whose order differs from run to run, so each tensor is held to ITS OWN
+    noise, measured between two serialised runs (up to 3e-2 of the value for the noise-strength scalars: one number summed over a whole
+    feature map with mixed signs): concurrent-vs-serialised deviation <= 4 x that + 1e-5 of the tensor's largest gradient."""
     import torch
     items = _items(net)
     net.get_pose_map(items)
@@ -136,19 +137,20 @@ def test_concurrently_streamed_step_equals_the_serialised_step(net, monkeypatch)
     monkeypatch.delenv("AG_SINGLE_STREAM")
     for k in ref_maps:
         assert torch.equal(ref_maps[k], ref_maps2[k]), k
-    noise = max(float((a - b).abs().max() / a.abs().max().clamp_min(1e-30)) for a, b in zip(ref_grads, ref_grads2))
+    noise_t = [float((a - b).abs().max() / a.abs().max().clamp_min(1e-30)) for a, b in zip(ref_grads, ref_grads2)]
+    noise = max(noise_t)
     worst = 0.0
     for rep in range(3):
         maps, grads = step()
         for k in ref_maps:
             assert torch.equal(ref_maps[k], maps[k]), (rep, k, float((ref_maps[k] - maps[k]).abs().max()))
-        for (name, _), a, b in zip(params, ref_grads, grads):
+        for (name, _), a, b, nt in zip(params, ref_grads, grads, noise_t):
             rel = float((a - b).abs().max() / a.abs().max().clamp_min(1e-30))
-            worst = max(worst, rel)
-            assert rel <= 2e-5, (rep, name, rel, noise)
+            worst = max(worst, rel / (4 * nt + 1e-5))
+            assert rel <= 4 * nt + 1e-5, (rep, name, rel, nt)
         del maps, grads
-    print(f"concurrent vs serialised: {sum(p.numel() for _, p in params) / 1e6:.1f} M gradients, worst relative deviation {worst:.2e} "
-          f"(serialised run-to-run: {noise:.2e})")
+    print(f"concurrent vs serialised: {sum(p.numel() for _, p in params) / 1e6:.1f} M gradients, worst ratio to 4 x the tensor's own serialised "
+          f"run-to-run noise + 1e-5: {worst:.2f} (largest such noise: {noise:.2e})")
     net.zero_grad(set_to_none=True)
 
 
