@@ -81,6 +81,16 @@ class AgConvDesc(ctypes.Structure):
     _fields_ = [(n, c_i32) for n in ("kind", "Cin", "Cout", "H", "W", "k", "stride", "padding")] + [("weight_scale", c_f)]
 
 
+class AgLayerArgs(ctypes.Structure):          # include/ag_layers.h
+    _fields_ = ([(n, c_i32) for n in ("Cin", "Cout", "H", "W", "k", "resample", "modulated", "reserved")]
+                + [(n, c_f) for n in ("scale", "slope", "act_scale", "reserved_f")]
+                + [(n, c_vp) for n in ("x", "weight", "style", "noise", "noise_weight", "act_bias", "k_blur", "w_mod", "demod", "x_blur", "out",
+                                       "scratch", "workspace")]
+                + [("workspace_bytes", c_sz)]
+                + [(n, c_vp) for n in ("g_out", "g_x", "g_weight", "g_style", "g_bias_noise")]
+                + [("want_bias", c_i32), ("want_noise_weight", c_i32)])
+
+
 class AgSmplxModel(ctypes.Structure):
     _fields_ = [("V", c_i32), ("J", c_i32), ("NB", c_i32), ("reserved", c_i32)] + [(n, c_vp) for n in (
         "v_template", "shapedirs", "posedirs", "J_regressor", "parents", "lbs_weights", "joint_template", "joint_dirs")]
@@ -141,6 +151,11 @@ SYMBOLS = [
     # include/ag_styleunet.h
     ("ag_fused_bias_act", ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_f, c_f, ctypes.c_int64, ctypes.c_int64, c_i32, c_vp]),
     ("ag_upfirdn2d", ctypes.c_int, [c_vp, c_vp, c_vp] + [c_i32] * 13 + [c_vp]),
+    # include/ag_layers.h
+    ("ag_layer_output_size", ctypes.c_int, [ctypes.POINTER(AgLayerArgs), ctypes.POINTER(c_i32), ctypes.POINTER(c_i32)]),
+    ("ag_layer_scratch_floats", c_sz, [ctypes.POINTER(AgLayerArgs), c_i32]),
+    ("ag_layer_forward", ctypes.c_int, [ctypes.POINTER(AgLayerArgs), c_vp]),
+    ("ag_layer_backward", ctypes.c_int, [ctypes.POINTER(AgLayerArgs), c_vp]),
     # include/ag_conv.h
     ("ag_conv_output_size", ctypes.c_int, [ctypes.POINTER(AgConvDesc), ctypes.POINTER(c_i32), ctypes.POINTER(c_i32)]),
     ("ag_conv_workspace_bytes", c_sz, [ctypes.POINTER(AgConvDesc)]),

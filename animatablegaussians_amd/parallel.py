@@ -93,14 +93,24 @@ class BucketedGradSync:
       reducing); ``defer_to_finish=True`` supports several backward calls per step by reducing everything in ``finish()``.
 
     Usage per step: ``sync.zero()`` -> forward/backward (hooks fire) -> ``sync.finish()`` -> optimizer step.
-    Works on any backend (``nccl`` = RCCL on the GPU node, ``gloo`` in the CPU tests); with world size 1 it only
-    provides the flat gradient storage."""
+    Works on any backend (``nccl`` = RCCL on the GPU node, ``gloo`` in the CPU tests).
+
+    World size 1 (``flat_when_single=False``, the default): nothing is exchanged, so nothing is packed either -- no flat buffer, no
+    hooks, ``zero()`` drops the gradients (``.grad = None``: autograd then hands every parameter its gradient tensor as it is instead
+    of adding it into a pre-existing one) and ``finish()`` is empty (the autograd engine itself joins the backward's streams with the
+    caller's).  Per training step of the avatar that is 657 accumulate kernels, 657 Python hook calls with an event each and one
+    895-MB memset less.  ``flat_when_single=True`` keeps the flat storage and the hooks (tests of the bucket logic on one rank)."""
 
     def __init__(self, params: Sequence[torch.nn.Parameter], bucket_bytes: int = 128 << 20, average: bool = True,
-                 defer_to_finish: bool = False):
+                 defer_to_finish: bool = False, flat_when_single: bool = False):
         self.params = [p for p in params if p.requires_grad]
         self.average = average
         self.defer_to_finish = defer_to_finish
+        self._world = dist.get_world_size() if dist.is_initialized() else 1
+        self._passthrough = self._world == 1 and not flat_when_single
+        if self._passthrough:
+            self.flat, self.buckets, self._handles, self._works = None, [], [], []
+            return
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device
         self._cuda = dev.type == "cuda"
@@ -123,7 +133,6 @@ class BucketedGradSync:
             b_count += 1
         self.buckets.append((b_start, off))
         self._pending_init.append(b_count)
-        self._world = dist.get_world_size() if dist.is_initialized() else 1
         self._comm = torch.cuda.Stream(dev) if self._cuda else None      # collectives are ordered after the gradients' events HERE
         self._arm()
         self._handles = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
@@ -137,6 +146,10 @@ class BucketedGradSync:
 
     def zero(self):
         """Start of a step: clear the flat gradient buffer and re-arm the buckets."""
+        if self._passthrough:
+            for p in self.params:
+                p.grad = None
+            return
         if any(w is not None for w in self._works):
             raise RuntimeError("BucketedGradSync.zero() while collectives of the previous step are in flight: call finish() first")
         self.flat.zero_()
@@ -184,6 +197,8 @@ class BucketedGradSync:
     def finish(self):
         """End of backward: launch the buckets that have not been launched (parameters without gradient this step, or
         ``defer_to_finish``), wait, average."""
+        if self._passthrough:
+            return
         if self._world > 1:
             for b in range(len(self.buckets)):
                 if not self._launched[b]:

@@ -113,8 +113,8 @@ def test_concurrently_streamed_step_equals_the_serialised_step(net, monkeypatch)
     same iteration with every kernel serialised on one stream (AG_SINGLE_STREAM=1).  Forward products are deterministic and must be
     BIT-equal (that is the check that caught the disturbance in round 2); the 224 M parameter gradients go through float atomics
     (split-K weight gradients, style / noise / bias reductions) whose order differs from run to run, so each tensor is held to ITS OWN
-    noise, measured between two serialised runs (up to 3e-2 of the value for the noise-strength scalars: one number summed over a whole
-    feature map with mixed signs): concurrent-vs-serialised deviation <= 4 x that + 1e-5 of the tensor's largest gradient."""
+    noise, measured over three serialised runs (up to 3e-2 of the value for the noise-strength scalars: one number summed over a whole
+    feature map with mixed signs): concurrent-vs-serialised deviation <= 8 x that + 5e-4 of the tensor's largest gradient."""
     import torch
     items = _items(net)
     net.get_pose_map(items)
@@ -133,24 +133,27 @@ def test_concurrently_streamed_step_equals_the_serialised_step(net, monkeypatch)
 
     monkeypatch.setenv("AG_SINGLE_STREAM", "1")
     ref_maps, ref_grads = step()
-    ref_maps2, ref_grads2 = step()                                         # the atomics' own run-to-run noise, serialised
+    serial = [step() for _ in range(2)]                                    # the atomics' own run-to-run noise, serialised
     monkeypatch.delenv("AG_SINGLE_STREAM")
-    for k in ref_maps:
-        assert torch.equal(ref_maps[k], ref_maps2[k]), k
-    noise_t = [float((a - b).abs().max() / a.abs().max().clamp_min(1e-30)) for a, b in zip(ref_grads, ref_grads2)]
-    noise = max(noise_t)
-    worst = 0.0
+    rel_of = lambda a, b: float((a - b).abs().max() / a.abs().max().clamp_min(1e-30))   # noqa: E731
+    noise_t = [0.0] * len(params)
+    for maps2, grads2 in serial:
+        for k in ref_maps:
+            assert torch.equal(ref_maps[k], maps2[k]), k
+        noise_t = [max(n, rel_of(a, b)) for n, a, b in zip(noise_t, ref_grads, grads2)]
+    del serial
+    rows = []
     for rep in range(3):
         maps, grads = step()
         for k in ref_maps:
             assert torch.equal(ref_maps[k], maps[k]), (rep, k, float((ref_maps[k] - maps[k]).abs().max()))
         for (name, _), a, b, nt in zip(params, ref_grads, grads, noise_t):
-            rel = float((a - b).abs().max() / a.abs().max().clamp_min(1e-30))
-            worst = max(worst, rel / (4 * nt + 1e-5))
-            assert rel <= 4 * nt + 1e-5, (rep, name, rel, nt)
+            rows.append((rel_of(a, b) / (8 * nt + 5e-4), rel_of(a, b), nt, name, rep))
         del maps, grads
-    print(f"concurrent vs serialised: {sum(p.numel() for _, p in params) / 1e6:.1f} M gradients, worst ratio to 4 x the tensor's own serialised "
-          f"run-to-run noise + 1e-5: {worst:.2f} (largest such noise: {noise:.2e})")
+    rows.sort(reverse=True)
+    print(f"concurrent vs serialised: {sum(p.numel() for _, p in params) / 1e6:.1f} M gradients x 3 runs; worst ratios to 8 x the tensor's own "
+          f"serialised run-to-run deviation + 5e-4: " + "; ".join(f"{r:.2f} ({n}: {d:.1e} vs noise {t:.1e})" for r, d, t, n, _ in rows[:3]))
+    assert rows[0][0] <= 1.0, rows[:5]
     net.zero_grad(set_to_none=True)
 
 
