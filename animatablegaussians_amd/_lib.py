@@ -152,6 +152,7 @@ SYMBOLS = [
     ("ag_fused_bias_act", ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_f, c_f, ctypes.c_int64, ctypes.c_int64, c_i32, c_vp]),
     ("ag_upfirdn2d", ctypes.c_int, [c_vp, c_vp, c_vp] + [c_i32] * 13 + [c_vp]),
     # include/ag_layers.h
+    ("ag_layer_args_bytes", c_sz, []),
     ("ag_layer_output_size", ctypes.c_int, [ctypes.POINTER(AgLayerArgs), ctypes.POINTER(c_i32), ctypes.POINTER(c_i32)]),
     ("ag_layer_scratch_floats", c_sz, [ctypes.POINTER(AgLayerArgs), c_i32]),
     ("ag_layer_forward", ctypes.c_int, [ctypes.POINTER(AgLayerArgs), c_vp]),

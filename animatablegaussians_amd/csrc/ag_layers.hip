@@ -44,6 +44,8 @@ bool geometry(const AgLayerArgs* a, Geo& g)
 
 extern "C" {
 
+size_t ag_layer_args_bytes(void) { return sizeof(AgLayerArgs); }
+
 int ag_layer_output_size(const AgLayerArgs* a, int32_t* OH, int32_t* OW)
 {
     Geo g;

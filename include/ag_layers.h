@@ -54,6 +54,8 @@ typedef struct AgLayerArgs {
     int32_t want_bias, want_noise_weight;
 } AgLayerArgs;
 
+/* sizeof(AgLayerArgs) as the library was compiled: a binding checks its own struct layout against it. */
+size_t ag_layer_args_bytes(void);
 /* Output spatial size of the layer. */
 int ag_layer_output_size(const AgLayerArgs* a, int32_t* OH, int32_t* OW);
 /* Floats of `scratch` the forward (backward = 0) or backward (1) call needs. */

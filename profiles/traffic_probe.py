@@ -17,7 +17,7 @@ torch.cuda.synchronize()
 del x, y
 # one stream: with views overlapped the counters of a kernel include whatever ran beside it; no full-step legs (their large device copies
 # would be mistaken for the calibration copy)
-sys.argv = [os.path.join(ROOT, "bench.py"), "--steps", "16", "--warmup", "4", "--no-cpu-baseline", "--no-full-step", "--streams", "1"]
+sys.argv = [os.path.join(ROOT, "bench.py"), "--steps", "16", "--warmup", "4", "--no-cpu-baseline", "--no-full-step", "--no-stress", "--streams", "1"]
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
