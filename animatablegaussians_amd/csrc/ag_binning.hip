@@ -41,6 +41,8 @@ __global__ void __launch_bounds__(1024) tile_scan_kernel(int T, const uint32_t* 
     if (tid < 34) cls_hist[tid] = 0;
     __syncthreads();
     const uint4* count4 = reinterpret_cast<const uint4*>(tile_count);      // 256-byte aligned sub-array (ImageLayout)
+    const bool one_pass = T <= 4096;          // counts and segment starts of this thread's 4 tiles stay in registers for the ordering phase
+    uint32_t keep_c[4] = {0u, 0u, 0u, 0u}, keep_st[4] = {0u, 0u, 0u, 0u};
     for (int base = 0; base < T; base += 4096) {
         const int t0 = base + 4 * tid;
         uint32_t c[4] = {0u, 0u, 0u, 0u};
@@ -92,6 +94,8 @@ __global__ void __launch_bounds__(1024) tile_scan_kernel(int T, const uint32_t* 
                     tile_order[(uint32_t)(T - 1) - ((uint32_t)(t0 + k) - ne_before)] = make_uint4((uint32_t)(t0 + k), 0u, 0u, 0u);
                 }
             }
+#pragma unroll
+        for (int k = 0; k < 4; k++) { keep_c[k] = c[k]; keep_st[k] = start[k]; }
         __syncthreads();
         if (tid == 1023) { carry_s = start[4]; carry_ne = ne_before; }
         __syncthreads();
@@ -116,7 +120,10 @@ __global__ void __launch_bounds__(1024) tile_scan_kernel(int T, const uint32_t* 
         const int t0 = base + 4 * tid;
         if (t0 >= T) break;
         uint32_t c[4] = {0u, 0u, 0u, 0u}, st[4] = {0u, 0u, 0u, 0u};
-        if (t0 + 3 < T) {      // written above by this workgroup (barriers in between): one round trip for both
+        if (one_pass) {        // 1024^2: no second round trip to memory (the kernel is two dependent round trips deep otherwise)
+#pragma unroll
+            for (int k = 0; k < 4; k++) { c[k] = keep_c[k]; st[k] = keep_st[k]; }
+        } else if (t0 + 3 < T) {      // written above by this workgroup (barriers in between): one round trip for both
             const uint4 v4 = count4[t0 >> 2], s4 = reinterpret_cast<const uint4*>(cursor)[t0 >> 2];
             c[0] = v4.x; c[1] = v4.y; c[2] = v4.z; c[3] = v4.w;
             st[0] = s4.x; st[1] = s4.y; st[2] = s4.z; st[3] = s4.w;

@@ -29,17 +29,17 @@ CASES = [
     ("pw_torgb16_odd_channels", "conv", 70, 16, 144, 116, 1, 1, 0),
     ("pw_fromrgb", "conv", 3, 128, 32, 32, 1, 1, 0),
     ("pw_fromrgb_512", "conv", 3, 512, 16, 16, 1, 1, 0),
-    # stride-1 gathers the row-patch kernel takes in split mode (whole 16-channel blocks, row length a multiple of 4, patch inside
-    # the LDS budget): several rows per 256-pixel tile, one row per tile, a ragged last tile, parity classes 65 / 64 wide of a
-    # transposed convolution and of a stride-2 input gradient, one tap per patch (1 x 1), more than 128 output rows
-    ("rows_c3x3_64", "conv", 32, 48, 64, 64, 3, 1, 1),
-    ("rows_c3x3_wide", "conv", 16, 130, 24, 256, 3, 1, 1),
-    ("rows_c3x3_odd_h", "conv", 48, 40, 37, 128, 3, 1, 1),
-    ("rows_c3x3_512wide", "conv", 16, 24, 9, 512, 3, 1, 1),
-    ("rows_ct3x3", "convT", 32, 16, 64, 64, 3, 2, 0),
-    ("rows_c3x3_s2_dgrad", "conv", 16, 32, 129, 129, 3, 2, 0),
-    ("rows_c1x1", "conv", 64, 160, 64, 64, 1, 1, 0),
-    ("rows_c3x3_k_split", "conv", 256, 64, 32, 32, 3, 1, 1),
+    # tile-shape edge cases of the per-tap gather kernels: several image rows per 256-pixel N tile, one row per tile, a ragged last tile
+    # (odd height), rows wider than a tile, the 65 / 64-wide parity classes of a transposed convolution and of a stride-2 input gradient,
+    # one tap per K tile group (1 x 1), more than 128 output rows (two M tiles), and a K long enough for split-K
+    ("tiles_c3x3_64", "conv", 32, 48, 64, 64, 3, 1, 1),
+    ("tiles_c3x3_wide", "conv", 16, 130, 24, 256, 3, 1, 1),
+    ("tiles_c3x3_odd_h", "conv", 48, 40, 37, 128, 3, 1, 1),
+    ("tiles_c3x3_512wide", "conv", 16, 24, 9, 512, 3, 1, 1),
+    ("tiles_ct3x3", "convT", 32, 16, 64, 64, 3, 2, 0),
+    ("tiles_c3x3_s2_dgrad", "conv", 16, 32, 129, 129, 3, 2, 0),
+    ("tiles_c1x1", "conv", 64, 160, 64, 64, 1, 1, 0),
+    ("tiles_c3x3_k_split", "conv", 256, 64, 32, 32, 3, 1, 1),
 ]
 
 

@@ -222,3 +222,69 @@ def test_checkpoint_files_use_the_reference_layout(tmp_path):
     for k, v in checkpoint.avatar_state_dict(net).items():
         assert torch.equal(v, want[k]), k
     assert optm2.state_dict()['state'][0]['step'] == optm.state_dict()['state'][0]['step']
+
+
+def test_exr_writer_output_parses_byte_by_byte_per_the_file_layout_spec(tmp_path):
+    """The file `exr.imwrite` produces, walked with an independent parser written here from the OpenEXR file-layout document and the ZIP
+    codec of ImfZip.cpp (plain Python loops, nothing shared with exr.py): magic / version word, the attribute list with the types and
+    values OpenCV's writer emits for a float32 BGR image, the line-offset table, the 16-scan-line chunks `y | size | zlib(predicted,
+    de-interleaved bytes)`, channel-planar scan lines in alphabetical channel order.  OpenCV / OpenEXR are absent here, so this is the
+    most the format can be pinned: the writer against the specification rather than against its own reader."""
+    import struct
+    import zlib
+    from animatablegaussians_amd import exr
+    H, W = 40, 24                                             # 3 chunks: 16 + 16 + 8 scan lines
+    img = np.random.RandomState(5).standard_normal((H, W, 3)).astype(np.float32)
+    path = str(tmp_path / "m.exr")
+    exr.imwrite(path, img)
+    buf = open(path, "rb").read()
+    assert struct.unpack_from("<i", buf, 0)[0] == 20000630                        # magic 0x01312f76
+    ver = struct.unpack_from("<i", buf, 4)[0]
+    assert ver & 0xff == 2 and ver >> 8 == 0                                      # version 2, no tiled / long-name / deep / multipart flags
+    pos, attrs = 8, {}
+    while buf[pos] != 0:
+        e = buf.index(b"\0", pos); name = buf[pos:e].decode(); pos = e + 1
+        e = buf.index(b"\0", pos); typ = buf[pos:e].decode(); pos = e + 1
+        size = struct.unpack_from("<i", buf, pos)[0]; pos += 4
+        attrs[name] = (typ, buf[pos:pos + size]); pos += size
+    pos += 1                                                                      # end of header
+    for need in ("channels", "compression", "dataWindow", "displayWindow", "lineOrder", "pixelAspectRatio", "screenWindowCenter", "screenWindowWidth"):
+        assert need in attrs, need
+    typ, ch = attrs["channels"]
+    assert typ == "chlist"
+    names, p = [], 0
+    while ch[p] != 0:
+        e = ch.index(b"\0", p); names.append(ch[p:e].decode()); p = e + 1
+        ptype, plinear, xs, ys = struct.unpack_from("<iB3xii", ch, p); p += 16
+        assert ptype == 2 and xs == 1 and ys == 1                                 # FLOAT, sampling 1
+    assert names == ["B", "G", "R"] and p + 1 == len(ch)                          # alphabetical; OpenCV's channel 0 is stored as B
+    assert attrs["compression"] == ("compression", b"\x03")                       # ZIP_COMPRESSION: 16 scan lines per chunk
+    assert attrs["dataWindow"] == ("box2i", struct.pack("<4i", 0, 0, W - 1, H - 1)) and attrs["displayWindow"][1] == attrs["dataWindow"][1]
+    assert attrs["lineOrder"] == ("lineOrder", b"\0")                             # INCREASING_Y
+    assert attrs["pixelAspectRatio"] == ("float", struct.pack("<f", 1.0)) and attrs["screenWindowWidth"] == ("float", struct.pack("<f", 1.0))
+    assert attrs["screenWindowCenter"] == ("v2f", struct.pack("<2f", 0.0, 0.0))
+    n_chunks = (H + 15) // 16
+    offsets = struct.unpack_from(f"<{n_chunks}Q", buf, pos); pos += 8 * n_chunks
+    assert offsets[0] == pos                                                      # the first chunk follows the table
+    out = np.zeros((H, W, 3), np.float32)
+    for ci, off in enumerate(offsets):
+        y0, size = struct.unpack_from("<ii", buf, off)
+        assert y0 == 16 * ci
+        lines = min(16, H - y0)
+        raw_n = lines * W * 3 * 4
+        data = buf[off + 8: off + 8 + size]
+        if size < raw_n:                                                          # ImfZip.cpp: inflate, then undo predictor and interleave
+            t = bytearray(zlib.decompress(data))
+            assert len(t) == raw_n
+            for i in range(1, raw_n):
+                t[i] = (t[i - 1] + t[i] - 128) & 255
+            half = (raw_n + 1) // 2
+            raw = bytearray(raw_n)
+            raw[0::2] = t[:half]
+            raw[1::2] = t[half:]
+        else:
+            raw = data                                                            # a chunk that does not shrink is stored raw
+        blk = np.frombuffer(bytes(raw), "<f4").reshape(lines, 3, W)               # per scan line: the channels' rows in chlist order
+        out[y0:y0 + lines] = blk.transpose(0, 2, 1)
+        assert (offsets[ci + 1] if ci + 1 < n_chunks else len(buf)) == off + 8 + size     # chunks are back to back, the file ends with the last
+    np.testing.assert_array_equal(out, img)
