@@ -23,6 +23,8 @@ G = torch.randn(1, 6, 1024, 1024, device=dev)
 
 def run(backward):
     if backward:
+        net.zero_grad(set_to_none=True)       # as the training step does (no AccumulateGrad add kernels in the profile)
+        pose.grad = None
         images, _ = net([style], pose, randomize_noise=False)
         (images * G).sum().backward()
     else:
