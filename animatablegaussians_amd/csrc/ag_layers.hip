@@ -6,7 +6,20 @@
 #include "../../include/ag_layers.h"
 #include "../../include/ag_styleunet.h"
 
+#include <cstdlib>
+
 namespace {
+
+// Blur + noise / bias / activation of an up-sampling StyledConv as ONE pass each way (ag_fir4x4_noise_bias_act_*): AG_FUSED_TAIL bit 0
+// forward, bit 1 backward.  OFF by default: built, bit-identical to the two passes (tests/test_styleunet_ops.py, test_styleunet_net.py),
+// and measured same-box with profiles/ab_tail.sh -- network forward + backward 17.5-17.6 ms with two passes, 17.7-17.8 with the fused
+// forward, 18.2-18.8 with both fused.  It removes 12 of the ~1500 launches of a network pass; the fused backward (activation gradient
+// formed on the fly inside the FIR's adjoint, 70 loads per thread) is slower than the streaming pass + FIR it replaces.
+int fused_tail_mask()
+{
+    static const int m = [] { const char* e = getenv("AG_FUSED_TAIL"); return e ? atoi(e) : 0; }();
+    return m;
+}
 
 struct Geo {
     int OH, OW;          // layer output
@@ -89,7 +102,15 @@ int ag_layer_forward(const AgLayerArgs* a, void* stream)
     if (a->resample) {
         if (!a->k_blur) { ag::set_error("ag_layer_forward: resampling layer without FIR taps"); return AG_ERR_INVALID_ARGUMENT; }
         if ((rc = ag_conv_forward(&g.d, a->x, a->w_mod, nullptr, nullptr, aux, a->workspace, a->workspace_bytes, stream))) return rc;
-        if ((rc = ag_upfirdn2d(pre, aux, a->k_blur, a->Cout, g.CH, g.CW, 4, 4, 1, 1, 1, 1, 1, 1, 1, 1, stream))) return rc;
+        // Blur + noise + bias + activation in one pass (round 3); the filtered, pre-activation tensor never goes to memory
+        const bool nzr = a->noise && a->noise_weight;
+        if (!(fused_tail_mask() & 1)) {
+            if ((rc = ag_upfirdn2d(pre, aux, a->k_blur, a->Cout, g.CH, g.CW, 4, 4, 1, 1, 1, 1, 1, 1, 1, 1, stream))) return rc;
+            return ag_noise_bias_act_forward(a->out, pre, nzr ? a->noise : nullptr, nzr ? a->noise_weight : nullptr, a->act_bias, a->Cout,
+                                             g.OH * g.OW, a->slope, a->act_scale, stream);
+        }
+        return ag_fir4x4_noise_bias_act_forward(a->out, aux, a->k_blur, a->Cout, g.CH, g.CW, 1, 1, nzr ? a->noise : nullptr,
+                                                nzr ? a->noise_weight : nullptr, a->act_bias, a->slope, a->act_scale, stream);
     } else {
         if ((rc = ag_conv_forward(&g.d, a->x, a->w_mod, nullptr, nullptr, pre, a->workspace, a->workspace_bytes, stream))) return rc;
     }
@@ -109,7 +130,9 @@ int ag_layer_backward(const AgLayerArgs* a, void* stream)
     float* gb = (a->want_bias && a->g_bias_noise) ? a->g_bias_noise : nullptr;
     float* gnw = (nz && a->want_noise_weight && a->g_bias_noise) ? a->g_bias_noise + a->Cout : nullptr;
     int rc;
-    if ((rc = ag_noise_bias_act_backward(g_pre, a->g_out, a->out, gnw ? a->noise : nullptr, gb, gnw, a->Cout, g.OH * g.OW, a->slope, a->act_scale, stream))) return rc;
+    const bool fused_tail = a->modulated && a->resample && (fused_tail_mask() & 2);       // activation backward + the Blur's adjoint as one pass (below)
+    if (!fused_tail &&
+        (rc = ag_noise_bias_act_backward(g_pre, a->g_out, a->out, gnw ? a->noise : nullptr, gb, gnw, a->Cout, g.OH * g.OW, a->slope, a->act_scale, stream))) return rc;
     if (!a->modulated) {
         const float* cx = a->x;
         if (a->resample) {
@@ -129,8 +152,11 @@ int ag_layer_backward(const AgLayerArgs* a, void* stream)
     const float* g_conv = g_pre;
     float* after = aux;
     if (a->resample) {
-        // adjoint of Blur pad (1,1): pads (2,2) with the flipped taps: [2H] -> [2H + 1]
-        if ((rc = ag_upfirdn2d(aux, g_pre, a->k_blur, a->Cout, g.OH, g.OW, 4, 4, 1, 1, 1, 1, 2, 2, 2, 2, stream))) return rc;
+        // activation backward + adjoint of Blur pad (1,1) (pads (2,2) with the flipped taps: [2H] -> [2H + 1]) in one pass
+        if (!fused_tail) {
+            if ((rc = ag_upfirdn2d(aux, g_pre, a->k_blur, a->Cout, g.OH, g.OW, 4, 4, 1, 1, 1, 1, 2, 2, 2, 2, stream))) return rc;
+        } else if ((rc = ag_fir4x4_noise_bias_act_backward(aux, a->g_out, a->out, a->k_blur, a->Cout, g.OH, g.OW, gnw ? a->noise : nullptr, gb, gnw,
+                                                    a->slope, a->act_scale, stream))) return rc;
         g_conv = aux;
         after = aux + ((size_t)a->Cout * g.CH * g.CW + 63) / 64 * 64;
     }

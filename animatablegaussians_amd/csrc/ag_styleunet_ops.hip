@@ -318,8 +318,19 @@ __global__ void __launch_bounds__(256) upfirdn2d_kernel(float* __restrict__ out,
 // 4 x 2 block of outputs from a 7 x 5 window read as ten 16-byte loads (alignment is free on this part: profiles/ub/load_rate.hip), grid
 // (x quads, row pairs, image) so there is no division at all; same accumulation order per output as the general kernel (rows, then
 // columns, ascending; out-of-image taps contribute exact zeros), hence the same bits.
+// ACT (round 3): NoiseInjection + FusedLeakyReLU applied to the filtered value before it is stored -- the Blur behind an up-sampling
+// ModulatedConv2d and the StyledConv tail as ONE pass (dual_styleunet.py:188-193, 301-311, 596): channel = blockIdx.z, the value goes
+// through exactly the expression of noise_bias_act_forward_kernel.
+struct FirAct {
+    const float* noise;      // [out_h * out_w] or null
+    const float* nw;         // [1] (with noise)
+    const float* bias;       // [major] or null
+    float slope, scale;
+};
+
+template <bool ACT>
 __global__ void __launch_bounds__(256) fir4x4_kernel(float* __restrict__ out, const float* __restrict__ input,
-                                                     const float* __restrict__ kernel, UpfirdnParams p)
+                                                     const float* __restrict__ kernel, UpfirdnParams p, FirAct act)
 {
     __shared__ float taps[16];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -362,12 +373,116 @@ __global__ void __launch_bounds__(256) fir4x4_kernel(float* __restrict__ out, co
 #pragma unroll
                 for (int q = 0; q < 4; q++) v[q] = fmaf(win[dy + y][q + x], k, v[q]);
             }
+        if constexpr (ACT) {
+            const float b = act.bias ? act.bias[blockIdx.z] : 0.f, w = act.noise ? act.nw[0] : 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const float n = (act.noise && ox0 + q < p.out_w) ? act.noise[(size_t)(oy0 + dy) * p.out_w + ox0 + q] : 0.f;
+                const float t = v[q] + w * n + b;
+                v[q] = (t > 0.f ? t : t * act.slope) * act.scale;
+            }
+        }
         if (ox0 + 4 <= p.out_w && (((size_t)(dst + (size_t)dy * p.out_w)) & 15) == 0) {
             *reinterpret_cast<float4*>(dst + (size_t)dy * p.out_w) = make_float4(v[0], v[1], v[2], v[3]);
         } else {
 #pragma unroll
             for (int q = 0; q < 4; q++)
                 if (ox0 + q < p.out_w) dst[(size_t)dy * p.out_w + q] = v[q];
+        }
+    }
+}
+
+// Backward of fir4x4_kernel<true> with pads (1, 1) (the up-sampling StyledConv: [C, OH + 1, OW + 1] -> [C, OH, OW]): the gradient of the
+// activation input g_pre = g_out * (out > 0 ? 1 : slope) * scale is formed on the fly from g_out and the saved output, its bias /
+// noise-strength sums are reduced (every g_pre element is owned by exactly one thread), and the FIR's adjoint -- the flipped taps with
+// pads (2, 2) -- is applied to it: one pass instead of noise_bias_act_backward + upfirdn2d, and g_pre never goes to memory.
+// Thread = 4 x 2 outputs of the [OH + 1, OW + 1] grid from a 7 x 5 window; a workgroup walks kFirBwdRows rows so that the per-channel
+// sums cost few same-address atomics.
+constexpr int kFirBwdRows = 32;
+
+__global__ void __launch_bounds__(256) fir4x4_nba_backward_kernel(float* __restrict__ g_in, const float* __restrict__ g_out,
+                                                                  const float* __restrict__ y, const float* __restrict__ kflip,
+                                                                  const float* __restrict__ noise, float* __restrict__ gbias,
+                                                                  float* __restrict__ gnw, int OH, int OW, float slope, float scale)
+{
+    __shared__ float taps[16];
+    __shared__ float s_red[2][4];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    if (threadIdx.x < 16) taps[threadIdx.x] = kflip[threadIdx.x];
+    __syncthreads();
+    const int IH = OH + 1, IW = OW + 1;                                  // the convolution output this gradient belongs to
+    const size_t c = blockIdx.z;
+    const float* go = g_out + c * OH * OW;
+    const float* yo = y + c * OH * OW;
+    float* gi = g_in + c * IH * IW;
+    const int ox0 = (blockIdx.x * 64 + tx) * 4;
+    float sb = 0.f, sn = 0.f;
+    for (int rr = 0; rr < kFirBwdRows; rr += 8) {
+        const int oy0 = blockIdx.y * kFirBwdRows + rr + ty * 2;
+        if (ox0 >= IW || oy0 >= IH) continue;
+        const int cx = ox0 - 2, cy = oy0 - 2;                            // window origin in the [OH, OW] grid of g_pre
+        float win[5][8];
+        const bool x_inside = cx >= 0 && cx + 8 <= OW;
+#pragma unroll
+        for (int r = 0; r < 5; r++) {
+            const int iy = cy + r;
+            const bool row_ok = iy >= 0 && iy < OH;
+            const size_t ro = (size_t)(row_ok ? iy : 0) * OW;
+            if (row_ok && x_inside) {       // two 16-byte loads per array (alignment is free on this part)
+                const float4 ga = *reinterpret_cast<const float4*>(go + ro + cx), gb4 = *reinterpret_cast<const float4*>(go + ro + cx + 4);
+                const float4 ya = *reinterpret_cast<const float4*>(yo + ro + cx), yb = *reinterpret_cast<const float4*>(yo + ro + cx + 4);
+                win[r][0] = ga.x * (ya.x > 0.f ? 1.f : slope) * scale; win[r][1] = ga.y * (ya.y > 0.f ? 1.f : slope) * scale;
+                win[r][2] = ga.z * (ya.z > 0.f ? 1.f : slope) * scale; win[r][3] = ga.w * (ya.w > 0.f ? 1.f : slope) * scale;
+                win[r][4] = gb4.x * (yb.x > 0.f ? 1.f : slope) * scale; win[r][5] = gb4.y * (yb.y > 0.f ? 1.f : slope) * scale;
+                win[r][6] = gb4.z * (yb.z > 0.f ? 1.f : slope) * scale; win[r][7] = 0.f;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 7; q++) {
+                    const int ix = cx + q;
+                    float v = 0.f;
+                    if (row_ok && ix >= 0 && ix < OW) v = go[ro + ix] * (yo[ro + ix] > 0.f ? 1.f : slope) * scale;
+                    win[r][q] = v;
+                }
+                win[r][7] = 0.f;
+            }
+        }
+        // sums over the g_pre elements this thread owns: window rows 2..3, columns 2..5 (= positions oy0.., ox0.. of the [OH, OW] grid)
+#pragma unroll
+        for (int dy = 0; dy < 2; dy++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int iy = oy0 + dy, ix = ox0 + q;
+                if (iy < OH && ix < OW) {
+                    const float r = win[2 + dy][2 + q];
+                    sb += r;
+                    if (noise) sn += r * noise[(size_t)iy * OW + ix];
+                }
+            }
+#pragma unroll
+        for (int dy = 0; dy < 2; dy++) {
+            if (oy0 + dy >= IH) break;
+            float v[4] = { 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+            for (int yy = 0; yy < 4; yy++)
+#pragma unroll
+                for (int x = 0; x < 4; x++) {
+                    const float k = taps[(3 - yy) * 4 + (3 - x)];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) v[q] = fmaf(win[dy + yy][q + x], k, v[q]);
+                }
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (ox0 + q < IW) gi[(size_t)(oy0 + dy) * IW + ox0 + q] = v[q];
+        }
+    }
+    if (gbias || gnw) {
+        sb = wave_sum(sb);
+        sn = wave_sum(sn);
+        if ((threadIdx.x & 63) == 0) { s_red[0][ty] = sb; s_red[1][ty] = sn; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            if (gbias) atomicAdd(gbias + c, (s_red[0][0] + s_red[0][1]) + (s_red[0][2] + s_red[0][3]));
+            if (gnw) atomicAdd(gnw, (s_red[1][0] + s_red[1][1]) + (s_red[1][2] + s_red[1][3]));
         }
     }
 }
@@ -491,7 +606,7 @@ int ag_upfirdn2d(float* out, const float* input, const float* kernel, int32_t ma
     if (!out || !input || !kernel) { set_error("null pointer"); return AG_ERR_INVALID_ARGUMENT; }
     if (up_x == 1 && up_y == 1 && down_x == 1 && down_y == 1 && kernel_h == 4 && kernel_w == 4 && major <= 65535) {
         dim3 grid((p.out_w + 255) / 256, (p.out_h + 7) / 8, major);
-        hipLaunchKernelGGL(fir4x4_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), out, input, kernel, p);
+        hipLaunchKernelGGL(fir4x4_kernel<false>, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), out, input, kernel, p, FirAct{});
         return check_hip(hipGetLastError(), "fir4x4_kernel");
     }
     const long long total = (long long)major * p.out_h * p.out_w;
@@ -499,6 +614,49 @@ int ag_upfirdn2d(float* out, const float* input, const float* kernel, int32_t ma
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(upfirdn2d_kernel, dim3((int)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), out, input, kernel, p);
     return check_hip(hipGetLastError(), "upfirdn2d_kernel");
+}
+
+/* Blur (4 x 4 taps, pads (pad0, pad1)) + NoiseInjection + FusedLeakyReLU in one pass: out [major, OH, OW] from input [major, in_h, in_w]. */
+int ag_fir4x4_noise_bias_act_forward(float* out, const float* input, const float* kernel, int32_t major, int32_t in_h, int32_t in_w,
+                                     int32_t pad0, int32_t pad1, const float* noise, const float* noise_weight, const float* bias,
+                                     float slope, float scale, void* stream)
+{
+    if (major <= 0 || major > 65535 || in_h <= 0 || in_w <= 0 || !out || !input || !kernel || (noise && !noise_weight)) {
+        set_error("bad fir4x4_noise_bias_act_forward arguments");
+        return AG_ERR_INVALID_ARGUMENT;
+    }
+    UpfirdnParams p;
+    p.up_x = p.up_y = p.down_x = p.down_y = 1; p.pad_x0 = p.pad_y0 = pad0;
+    p.major = major; p.in_h = in_h; p.in_w = in_w; p.kernel_h = p.kernel_w = 4;
+    p.out_h = in_h + pad0 + pad1 - 3; p.out_w = in_w + pad0 + pad1 - 3;
+    if (p.out_h <= 0 || p.out_w <= 0) { set_error("fir4x4: empty output"); return AG_ERR_INVALID_ARGUMENT; }
+    FirAct act{ noise, noise_weight, bias, slope, scale };
+    dim3 grid((p.out_w + 255) / 256, (p.out_h + 7) / 8, major);
+    hipLaunchKernelGGL(fir4x4_kernel<true>, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), out, input, kernel, p, act);
+    return check_hip(hipGetLastError(), "fir4x4_kernel<act>");
+}
+
+/* Its backward for pads (1, 1): g_in [major, OH + 1, OW + 1] from g_out / the saved output y [major, OH, OW]; kernel_flipped = the taps
+ * flipped in both axes; gbias [major] / gnoise_weight [1] are zeroed here and accumulated (either may be NULL). */
+int ag_fir4x4_noise_bias_act_backward(float* g_in, const float* g_out, const float* y, const float* kernel_flipped, int32_t major,
+                                      int32_t OH, int32_t OW, const float* noise, float* gbias, float* gnoise_weight, float slope,
+                                      float scale, void* stream)
+{
+    if (major <= 0 || major > 65535 || OH <= 0 || OW <= 0 || !g_in || !g_out || !y || !kernel_flipped || (gnoise_weight && !noise)) {
+        set_error("bad fir4x4_noise_bias_act_backward arguments");
+        return AG_ERR_INVALID_ARGUMENT;
+    }
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (gbias && gnoise_weight == gbias + major) {
+        if (check_hip(hipMemsetAsync(gbias, 0, (size_t)(major + 1) * sizeof(float), s), "memset gbias+gnw")) return AG_ERR_HIP;
+    } else {
+        if (gbias && check_hip(hipMemsetAsync(gbias, 0, (size_t)major * sizeof(float), s), "memset gbias")) return AG_ERR_HIP;
+        if (gnoise_weight && check_hip(hipMemsetAsync(gnoise_weight, 0, sizeof(float), s), "memset gnw")) return AG_ERR_HIP;
+    }
+    dim3 grid((OW + 1 + 255) / 256, (OH + 1 + kFirBwdRows - 1) / kFirBwdRows, major);
+    hipLaunchKernelGGL(fir4x4_nba_backward_kernel, grid, dim3(256), 0, s, g_in, g_out, y, kernel_flipped, gnoise_weight ? noise : nullptr,
+                       gbias, gnoise_weight, OH, OW, slope, scale);
+    return check_hip(hipGetLastError(), "fir4x4_nba_backward_kernel");
 }
 
 }  // extern "C"

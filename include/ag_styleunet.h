@@ -78,6 +78,16 @@ int ag_modulate_weight_backward(float* dW, float* dstyle, const float* g, const 
  *   merge != 0        : in [4][C][h][w] -> out [C][2h][2w],  out[c][2i + p/2][2j + p%2] = sum_b matrix16[4p + b] * in[b][c][i][j]
  * matrix16 is a HOST pointer to the 16 coefficients.  The adjoint of a split with M is a merge with M^T and vice versa.
  */
+/* Round 3: the Blur behind an up-sampling ModulatedConv2d (dual_styleunet.py:188-193) and the StyledConv tail (NoiseInjection :301-311 +
+ * FusedLeakyReLU :596) as one pass each way.  Forward: out [major, in_h + pad0 + pad1 - 3, ...] = act(FIR_4x4(input) + noise_weight * noise
+ * + bias[channel]); backward (pads (1, 1) only): g_in [major, OH + 1, OW + 1] = FIR^T(g_out * act'(y)), bias / noise-strength sums zeroed
+ * here and accumulated (either may be NULL; pass gnoise_weight = gbias + major for one fill). */
+int ag_fir4x4_noise_bias_act_forward(float* out, const float* input, const float* kernel, int32_t major, int32_t in_h, int32_t in_w,
+                                     int32_t pad0, int32_t pad1, const float* noise, const float* noise_weight, const float* bias,
+                                     float slope, float scale, void* stream);
+int ag_fir4x4_noise_bias_act_backward(float* g_in, const float* g_out, const float* y, const float* kernel_flipped, int32_t major,
+                                      int32_t OH, int32_t OW, const float* noise, float* gbias, float* gnoise_weight, float slope,
+                                      float scale, void* stream);
 int ag_block2x2_transform(float* out, const float* in, const float* matrix16, int32_t merge, int32_t C, int32_t h, int32_t w,
                           void* stream);
 

@@ -218,3 +218,59 @@ def test_haar_split_merge_match_the_upfirdn_formulation():
     np.testing.assert_allclose(yg.grad.cpu().numpy(), yc.grad.numpy(), rtol=1e-6, atol=1e-6)
     # perfect reconstruction
     np.testing.assert_allclose(haar_merge(haar_split(xg.detach())).cpu().numpy(), x.numpy(), rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C,H,W,with_noise", [(5, 33, 21, True), (64, 129, 129, True), (3, 17, 260, False)])
+def test_fused_blur_noise_bias_act_equals_the_two_passes_and_the_torch_oracle(C, H, W, with_noise):
+    """ag_fir4x4_noise_bias_act_forward / _backward (round 3: the Blur behind an up-sampling ModulatedConv2d + NoiseInjection + FusedLeakyReLU
+    as one pass each way) against (a) the two separate entry points they replace and (b) the torch CPU oracle with autograd:
+    upfirdn2d(x, k, pad=(1, 1)) -> fused_leaky_relu(. + w * noise, bias), on odd sizes, a ragged width and without noise."""
+    import ctypes
+    import torch
+    from animatablegaussians_amd import _lib
+    from oracle import styleunet_oracle as so
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(C * 1000 + H)
+    x = torch.randn(C, H, W, generator=g)
+    k = torch.tensor([1., 3., 3., 1.])
+    k = k[None] * k[:, None] / 64 * 4
+    OH, OW = H - 1, W - 1
+    noise = torch.randn(OH, OW, generator=g) if with_noise else None
+    nw = torch.tensor([0.37]) if with_noise else None
+    bias = torch.randn(C, generator=g) * 0.3
+    gy = torch.randn(C, OH, OW, generator=g)
+    # torch oracle with autograd
+    xr, nwr, br = x.clone().requires_grad_(True), (nw.clone().requires_grad_(True) if with_noise else None), bias.clone().requires_grad_(True)
+    pre = so.upfirdn2d(xr, k, 1, 1, 1, 1, 1, 1, 1, 1)
+    if with_noise:
+        pre = pre + nwr * noise[None]
+    ref = torch.nn.functional.leaky_relu(pre + br[:, None, None], 0.2) * 2 ** 0.5
+    ref.backward(gy)
+    d = lambda t: t.cuda().contiguous() if t is not None else None  # noqa: E731
+    p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    xd, kd, nd, nwd, bd, gyd = d(x), d(k), d(noise), d(nw), d(bias), d(gy)
+    kf = torch.flip(kd, [0, 1]).contiguous()
+    out = torch.empty(C, OH, OW, device="cuda")
+    _lib.check(L.ag_fir4x4_noise_bias_act_forward(p(out), p(xd), p(kd), C, H, W, 1, 1, p(nd), p(nwd), p(bd), 0.2, 2 ** 0.5, st), "fwd")
+    # (a) the two passes
+    pre2, out2 = torch.empty(C, OH, OW, device="cuda"), torch.empty(C, OH, OW, device="cuda")
+    _lib.check(L.ag_upfirdn2d(p(pre2), p(xd), p(kd), C, H, W, 4, 4, 1, 1, 1, 1, 1, 1, 1, 1, st), "fir")
+    _lib.check(L.ag_noise_bias_act_forward(p(out2), p(pre2), p(nd), p(nwd), p(bd), C, OH * OW, 0.2, 2 ** 0.5, st), "nba")
+    assert float((out - out2).abs().max()) <= 1e-6 * float(out2.abs().max())
+    np.testing.assert_allclose(out.cpu().numpy(), ref.detach().numpy(), rtol=1e-5, atol=1e-6)
+    gin = torch.empty(C, H, W, device="cuda")
+    gbn = torch.empty(C + 1, device="cuda")
+    _lib.check(L.ag_fir4x4_noise_bias_act_backward(p(gin), p(gyd), p(out), p(kf), C, OH, OW, p(nd), p(gbn), p(gbn[C:]) if with_noise else None,
+                                                   0.2, 2 ** 0.5, st), "bwd")
+    gpre2, gin2, gbn2 = torch.empty(C, OH, OW, device="cuda"), torch.empty(C, H, W, device="cuda"), torch.empty(C + 1, device="cuda")
+    _lib.check(L.ag_noise_bias_act_backward(p(gpre2), p(gyd), p(out2), p(nd), p(gbn2), p(gbn2[C:]) if with_noise else None, C, OH * OW,
+                                            0.2, 2 ** 0.5, st), "nba bwd")
+    _lib.check(L.ag_upfirdn2d(p(gin2), p(gpre2), p(kf), C, OH, OW, 4, 4, 1, 1, 1, 1, 2, 2, 2, 2, st), "fir adj")
+    torch.cuda.synchronize()
+    assert float((gin - gin2).abs().max()) <= 1e-6 * float(gin2.abs().max())
+    np.testing.assert_allclose(gin.cpu().numpy(), xr.grad.numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(gbn[:C].cpu().numpy(), br.grad.numpy(), rtol=1e-4, atol=1e-4)
+    if with_noise:
+        np.testing.assert_allclose(float(gbn[C]), float(nwr.grad), rtol=1e-4, atol=1e-3)
