@@ -43,3 +43,23 @@ def test_patch_reference_routes_conv2d_gradfix_to_the_mfma_path():
         sys.path.remove(REF)
         for m in [m for m in sys.modules if m == "network" or m.startswith("network.")]:
             del sys.modules[m]
+
+
+def test_flipped_fir_kernel_cache_never_serves_a_recycled_address():
+    """styleunet_ops._flipped caches the flipped taps of an upfirdn2d kernel for its backward.  A key made of the address alone would be
+    handed to a DIFFERENT kernel once the first is freed and the allocator re-uses its block (round-2 advisor finding: 5 of 50 freshly
+    allocated 4 x 4 kernels got a stale result on the CPU allocator).  The entry now holds the source tensor and is used only for that
+    very object."""
+    import torch
+    from animatablegaussians_amd.styleunet_ops import _flipped
+    stale = 0
+    for i in range(200):
+        k = torch.full((4, 4), float(i)) + torch.arange(16.).reshape(4, 4)
+        f = _flipped(k)
+        stale += int(not torch.equal(f, torch.flip(k, [0, 1])))
+        del k, f
+    assert stale == 0
+    k = torch.arange(16.).reshape(4, 4)
+    assert _flipped(k) is _flipped(k)                                # still a cache for a kernel that stays alive
+    k.mul_(2.0)                                                      # in-place change bumps the version: recomputed
+    assert torch.equal(_flipped(k), torch.flip(k, [0, 1]))

@@ -288,3 +288,33 @@ def test_exr_writer_output_parses_byte_by_byte_per_the_file_layout_spec(tmp_path
         out[y0:y0 + lines] = blk.transpose(0, 2, 1)
         assert (offsets[ci + 1] if ci + 1 < n_chunks else len(buf)) == off + 8 + size     # chunks are back to back, the file ends with the last
     np.testing.assert_array_equal(out, img)
+
+
+def test_pre_round2_checkpoints_load_by_name_and_their_optimizer_file_is_refused(tmp_path):
+    """A `net.pt` written before the constant FIR / Haar buffers became part of the state (and with the old parameter order) still
+    loads -- by name, through `load_reference_state_dict` -- while its `optm.pt`, whose Adam moments are indexed by the OLD parameter
+    order, is skipped instead of being loaded onto the wrong parameters."""
+    import torch
+    from animatablegaussians_amd import checkpoint
+    from animatablegaussians_amd.avatar import AvatarNet
+    torch.manual_seed(1)
+    net = AvatarNet.synthetic({'with_viewdirs': True}, S=64, device='cpu')
+    optm = torch.optim.Adam(net.parameters(), lr=5e-4)
+    for p in net.parameters():
+        p.grad = torch.full_like(p, 1e-3)
+    optm.step()
+    const = ('.kernel', '.ll', '.lh', '.hl', '.hh')
+    want = {k: v.clone() for k, v in checkpoint.avatar_state_dict(net).items()}
+    legacy = {k: v.cpu() for k, v in want.items() if not k.endswith(const)}
+    assert len(legacy) < len(want)
+    os.makedirs(tmp_path / "old")
+    torch.save({'epoch_idx': 1, 'iter_idx': 7, 'avatar_net': legacy}, tmp_path / "old" / "net.pt")
+    torch.save({'avatar_net': optm.state_dict()}, tmp_path / "old" / "optm.pt")
+    with torch.no_grad():
+        for p in net.parameters():
+            p.add_(1.0)
+    optm2 = torch.optim.Adam(net.parameters(), lr=5e-4)
+    assert checkpoint.load_ckpt(str(tmp_path / "old"), net, optm2) == (1, 7)
+    for k, v in checkpoint.avatar_state_dict(net).items():
+        assert torch.equal(v, want[k]), k
+    assert len(optm2.state_dict()['state']) == 0                      # the optimizer file was not applied
