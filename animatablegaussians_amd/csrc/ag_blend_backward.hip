@@ -453,9 +453,15 @@ extern "C" int ag_debug_bwd_timeline(void* items, uint32_t capacity, uint32_t* c
 //   * waves never wait for each other: the start-up chain of one item hides behind the other five waves of its SIMD.
 constexpr int kBlk = 4;                                  // 4 x 4 pixels per wave
 constexpr int kBlocksPerTile = (kTileX / kBlk) * (kTileY / kBlk);
-constexpr int kWaveGrid = 8192;                          // single-wave workgroups; the hardware dispatcher balances them
+#ifndef AG_BWD_WAVE_GRID
+#define AG_BWD_WAVE_GRID 16384   /* one item per workgroup up to 1024 tiles x 16 blocks: 106.7 us against 108.3 with 8192 (profiles/ab_bwd.sh) */
+#endif
+#ifndef AG_BWD_WIN
+#define AG_BWD_WIN 16
+#endif
+constexpr int kWaveGrid = AG_BWD_WAVE_GRID;              // single-wave workgroups; the hardware dispatcher balances them
 constexpr int kRing = 96;                                // compacted records waiting to be blended (< 4 left over + <= 64 new)
-constexpr int kWin = 16;                                 // blended entries per atomic flush
+constexpr int kWin = AG_BWD_WIN;                         // blended entries per atomic flush
 
 struct WaveItemIter {
     uint32_t i, stride, x, n_active;
