@@ -88,7 +88,14 @@ __device__ __forceinline__ float row_read(float v, int lane, int k)   // value o
     return __shfl(v, (lane & 48) + k, 64);
 }
 
+#ifndef AG_FWD_WAVES_PER_SIMD
+#define AG_FWD_WAVES_PER_SIMD 8      // <= 64 VGPRs: four resident workgroups per CU (71 VGPRs without the bound: 58.8 us against 52.2, profiles/ab_fwd.sh)
+#endif
+#if AG_FWD_WAVES_PER_SIMD
+__global__ void __launch_bounds__(kBlendThreads, AG_FWD_WAVES_PER_SIMD) blend_forward_kernel(BlendFwdParams p)
+#else
 __global__ void __launch_bounds__(kBlendThreads) blend_forward_kernel(BlendFwdParams p)
+#endif
 {
     constexpr int NW = kBlendThreads / 64;
     __shared__ float4 s_rec[kChunk * 3];
@@ -144,17 +151,18 @@ __global__ void __launch_bounds__(kBlendThreads) blend_forward_kernel(BlendFwdPa
         bool done = !inside;                                                // row-uniform
 
         // staging pipeline: records one chunk ahead, list indices two chunks ahead
-        uint32_t id_next = 0;
-        float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
+        // Every load of the pipeline is UNCONDITIONAL (lanes past the end of the list read entry range.x / its record and are masked at
+        // the cull): a conditional load makes the compiler merge old and new registers right behind the load -- a wait for the data on
+        // the spot, i.e. no prefetch at all (round 3, found in the ISA of the wave backward kernel; this kernel had the same stall once
+        // per 512-entry chunk).
+        uint32_t id_next;
+        float4 r0, r1, r2;
         {
             const uint32_t k0 = range.x + tid, k1 = k0 + kChunk;
-            uint32_t id0 = 0;
-            if (k0 < range.y) id0 = p.point_list[k0];
-            if (k1 < range.y) id_next = p.point_list[k1];
-            if (k0 < range.y) {
-                const float4* src = reinterpret_cast<const float4*>(p.rec + id0);
-                r0 = src[0]; r1 = src[1]; r2 = src[2];
-            }
+            const uint32_t id0 = p.point_list[k0 < range.y ? k0 : range.x];
+            id_next = p.point_list[k1 < range.y ? k1 : range.x];
+            const float4* src = reinterpret_cast<const float4*>(p.rec + id0);
+            r0 = src[0]; r1 = src[1]; r2 = src[2];
         }
         // cull of chunk 0
         bool keep;
@@ -187,11 +195,11 @@ __global__ void __launch_bounds__(kBlendThreads) blend_forward_kernel(BlendFwdPa
             }
             // issue the gathers of chunk c+1 and the index loads of chunk c+2; both are consumed after the blend
             const uint32_t kn = k + kChunk, knn = kn + kChunk;
-            if (kn < range.y) {
+            {
                 const float4* src = reinterpret_cast<const float4*>(p.rec + id_next);
                 r0 = src[0]; r1 = src[1]; r2 = src[2];
             }
-            if (knn < range.y) id_next = p.point_list[knn];
+            id_next = p.point_list[knn < range.y ? knn : range.x];
             lds_barrier();
 
             // ---- second cull, per wave: a splat that reaches the 8x4 region reaches on average 40 % of its eight 2x2 blocks.
