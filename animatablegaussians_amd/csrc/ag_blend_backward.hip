@@ -460,7 +460,7 @@ constexpr int kBlocksPerTile = (kTileX / kBlk) * (kTileY / kBlk);
 #define AG_BWD_WIN 16
 #endif
 constexpr int kWaveGrid = AG_BWD_WAVE_GRID;              // single-wave workgroups; the hardware dispatcher balances them
-constexpr int kRing = 96;                                // compacted records waiting to be blended (< 4 left over + <= 64 new)
+constexpr int kRing = 128;                               // compacted records waiting to be blended (< 4 left over + <= 64 new); power of two: slot = position & 127
 constexpr int kWin = AG_BWD_WIN;                         // blended entries per atomic flush
 
 struct WaveItemIter {
@@ -517,6 +517,7 @@ __global__ void __launch_bounds__(64, AG_BWD_WAVE_OCC) blend_backward_wave_kerne
     const float nddelx = -ddelx_dx, nddely = -ddely_dy;
     const int vbase = (ry == 0) ? 0 : (ry == 1) ? 3 : (ry == 2) ? 5 : 8;
     const bool out_lane = qx < ((ry & 1) ? 2 : 3);           // this lane stores u[qx] as accumulator slot vbase + qx
+    const float bank0 = (e == 0) ? 1.0f : 0.0f;
 
     WaveItemIter it(blockIdx.x, gridDim.x, n_active);
     uint32_t tr, bk;
@@ -683,11 +684,14 @@ __global__ void __launch_bounds__(64, AG_BWD_WAVE_OCC) blend_backward_wave_kerne
                 }
                 // carry: T in front of entry 3 to all four lanes of the pixel; the state behind entry 3 to bank 0 (zero elsewhere)
                 T = from_entry3(Tin);
-                S_r = dpp_banks<AG_DPP_ROW_ROR(4), 0x1>(0.f, Br);
-                S_g = dpp_banks<AG_DPP_ROW_ROR(4), 0x1>(0.f, Bg);
-                S_b = dpp_banks<AG_DPP_ROW_ROR(4), 0x1>(0.f, Bb);
-                S_d = dpp_banks<AG_DPP_ROW_ROR(4), 0x1>(0.f, Bd);
-                S_a = dpp_banks<AG_DPP_ROW_ROR(4), 0x1>(0.f, Ba);
+                // (one v_mul_f32_dpp each: bank 3's value rotated into bank 0, times the lane constant 1 in bank 0 / 0 elsewhere)
+                asm volatile("v_mul_f32_dpp %0, %5, %10 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+                             "v_mul_f32_dpp %1, %6, %10 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+                             "v_mul_f32_dpp %2, %7, %10 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+                             "v_mul_f32_dpp %3, %8, %10 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+                             "v_mul_f32_dpp %4, %9, %10 row_ror:4 row_mask:0xf bank_mask:0xf"
+                             : "=&v"(S_r), "=&v"(S_g), "=&v"(S_b), "=&v"(S_d), "=&v"(S_a)
+                             : "v"(Br), "v"(Bg), "v"(Bb), "v"(Bd), "v"(Ba), "v"(bank0));
 
                 // sum over the block's 16 pixels per entry: rows (y) by register exchange 10 -> 5 -> 3, then x inside the quads
                 float s[6];
