@@ -549,8 +549,7 @@ __global__ void __launch_bounds__(64, AG_BWD_WAVE_OCC) blend_backward_wave_kerne
         const uint32_t rend = rbeg + wmax;                   // walk [rbeg, rend) from the back
 
         float T = T_final;
-        float S_r = 0.f, S_g = 0.f, S_b = 0.f, S_d = 0.f, S_a = 0.f;
-
+        float S = 0.f;               // g . (blended state behind the entries done so far), bank 0 only
         // staging pipeline: records one pass (64 entries) ahead, indices two passes ahead.  Every load is unconditional (lanes past the
         // end read entry rbeg / record 0 and are masked at the cull): a conditional load makes the compiler merge old and new
         // registers right behind the load, i.e. wait for it on the spot.
@@ -591,8 +590,7 @@ __global__ void __launch_bounds__(64, AG_BWD_WAVE_OCC) blend_backward_wave_kerne
             const unsigned long long mask = __ballot(keep);
             if (keep) {
                 const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-                int slot = cnt + rank;
-                slot = slot % kRing;
+                const int slot = (int)((uint32_t)(cnt + rank) & (uint32_t)(kRing - 1));
                 s_ring[slot * 3 + 0] = r0;
                 s_ring[slot * 3 + 1] = r1;
                 s_ring[slot * 3 + 2] = make_float4(r2.x, r2.y, __uint_as_float(wmax - o), __uint_as_float(id_cur));
@@ -617,7 +615,7 @@ __global__ void __launch_bounds__(64, AG_BWD_WAVE_OCC) blend_backward_wave_kerne
             while (cnt - head >= 4 || (last_pass && cnt > head)) {
                 const int idx = head + e;
                 const bool ev = idx < cnt;
-                const int slot = (ev ? idx : cnt - 1) % kRing;
+                const int slot = (int)((uint32_t)(ev ? idx : cnt - 1) & (uint32_t)(kRing - 1));
                 head += 4;
                 const float4 a = s_ring[slot * 3 + 0];   // x, y, conic a, conic b
                 const float4 b = s_ring[slot * 3 + 1];   // conic c, opacity, r, g
@@ -627,24 +625,22 @@ __global__ void __launch_bounds__(64, AG_BWD_WAVE_OCC) blend_backward_wave_kerne
                 const float G = __builtin_amdgcn_exp2f(power * 1.4426950408889634f);
                 const float alpha = fminf(0.99f, b.y * G);
                 const bool act = ev && (__float_as_uint(c.z) <= last_contributor) && (power <= 0.0f) && (alpha >= 1.0f / 255.0f);
-                if (!__any(act)) continue;
+                if (__ballot(act) == 0ull) continue;
                 const float al = act ? alpha : 0.f;
                 const float fac = 1.0f - al;
-                // affine maps g_e(S) = fac_e S + al_e c_e.  The state S behind the entries blended so far lives in BANK 0 only (0 in the
-                // other banks) and is folded into entry 0's map before the scan, so the inclusive scan yields the blended state behind
-                // each entry directly: no broadcast of the carry, no separate "A_exclusive * S" term.
+                // dL/dalpha_e needs the blended state behind entry e only through its dot product with the pixel's gradient
+                // g = (gr, gg, gb, gd, ga) (backward.cu:560-585 keeps five accum_rec channels and multiplies each by its dL_dchannel; g is
+                // the same for every entry of a pixel, so the five recurrences are one): affine maps m_e(S) = fac_e S + al_e w_e with
+                // w_e = g . (r, g, b, depth, 1)_e over the scalar S = g . state.  S lives in BANK 0 only (0 in the other banks) and
+                // is folded into entry 0's map before the scan, so the inclusive scan yields the state behind each entry directly.
+                const float w = fmaf(b.z, gr, fmaf(b.w, gg, fmaf(c.x, gb, fmaf(c.y, gd, ga))));
                 float A = fac;
-                float Br = fmaf(fac, S_r, al * b.z), Bg = fmaf(fac, S_g, al * b.w), Bb = fmaf(fac, S_b, al * c.x), Bd = fmaf(fac, S_d, al * c.y),
-                      Ba = fmaf(fac, S_a, al);
+                float B = fmaf(fac, S, al * w);
 #define AG_SCAN_STEP(N)                                                                                                        \
                 asm volatile("s_nop 1\n\t"                                                                                     \
-                             "v_fmac_f32_dpp %0, %0, %5 row_shr:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"             \
-                             "v_fmac_f32_dpp %1, %1, %5 row_shr:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"             \
-                             "v_fmac_f32_dpp %2, %2, %5 row_shr:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"             \
-                             "v_fmac_f32_dpp %3, %3, %5 row_shr:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"             \
-                             "v_fmac_f32_dpp %4, %4, %5 row_shr:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"             \
-                             "v_mul_f32_dpp %5, %5, %5 row_shr:" #N " row_mask:0xf bank_mask:0xf"                               \
-                             : "+v"(Br), "+v"(Bg), "+v"(Bb), "+v"(Bd), "+v"(Ba), "+v"(A));
+                             "v_fmac_f32_dpp %0, %0, %1 row_shr:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"             \
+                             "v_mul_f32_dpp %1, %1, %1 row_shr:" #N " row_mask:0xf bank_mask:0xf"                               \
+                             : "+v"(B), "+v"(A));
                 AG_SCAN_STEP(4) AG_SCAN_STEP(8)
 #undef AG_SCAN_STEP
                 // A = prod_{i<=e} fac_i: T in front of entry e;  state behind entry e = inclusive state of entry e-1 (bank 0: the carry).
@@ -653,17 +649,11 @@ __global__ void __launch_bounds__(64, AG_BWD_WAVE_OCC) blend_backward_wave_kerne
                 float rA = __builtin_amdgcn_rcpf(A);
                 rA = fmaf(fmaf(-A, rA, 1.0f), rA, rA);
                 const float Tin = T * rA;
-                const float beh_r = dpp_banks<AG_DPP_ROW_SHR(4), 0xf>(S_r, Br);
-                const float beh_g = dpp_banks<AG_DPP_ROW_SHR(4), 0xf>(S_g, Bg);
-                const float beh_b = dpp_banks<AG_DPP_ROW_SHR(4), 0xf>(S_b, Bb);
-                const float beh_d = dpp_banks<AG_DPP_ROW_SHR(4), 0xf>(S_d, Bd);
-                const float beh_a = dpp_banks<AG_DPP_ROW_SHR(4), 0xf>(S_a, Ba);
+                const float beh = dpp_banks<AG_DPP_ROW_SHR(4), 0xf>(S, B);
 
                 float v[10];
                 {
-                    float dL_dopa = (b.z - beh_r) * gr + (b.w - beh_g) * gg + (c.x - beh_b) * gb;
-                    dL_dopa += (c.y - beh_d) * gd;
-                    dL_dopa += (1.f - beh_a) * ga;
+                    float dL_dopa = w - beh;
                     dL_dopa = fmaf(dL_dopa, Tin, __builtin_amdgcn_rcpf(fac) * ntf_bg);
                     dL_dopa = act ? dL_dopa : 0.f;
                     const float wgt = al * Tin;
@@ -684,14 +674,8 @@ __global__ void __launch_bounds__(64, AG_BWD_WAVE_OCC) blend_backward_wave_kerne
                 }
                 // carry: T in front of entry 3 to all four lanes of the pixel; the state behind entry 3 to bank 0 (zero elsewhere)
                 T = from_entry3(Tin);
-                // (one v_mul_f32_dpp each: bank 3's value rotated into bank 0, times the lane constant 1 in bank 0 / 0 elsewhere)
-                asm volatile("v_mul_f32_dpp %0, %5, %10 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
-                             "v_mul_f32_dpp %1, %6, %10 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
-                             "v_mul_f32_dpp %2, %7, %10 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
-                             "v_mul_f32_dpp %3, %8, %10 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
-                             "v_mul_f32_dpp %4, %9, %10 row_ror:4 row_mask:0xf bank_mask:0xf"
-                             : "=&v"(S_r), "=&v"(S_g), "=&v"(S_b), "=&v"(S_d), "=&v"(S_a)
-                             : "v"(Br), "v"(Bg), "v"(Bb), "v"(Bd), "v"(Ba), "v"(bank0));
+                // (one v_mul_f32_dpp: bank 3's value rotated into bank 0, times the lane constant 1 in bank 0 / 0 elsewhere)
+                asm volatile("v_mul_f32_dpp %0, %1, %2 row_ror:4 row_mask:0xf bank_mask:0xf" : "=&v"(S) : "v"(B), "v"(bank0));
 
                 // sum over the block's 16 pixels per entry: rows (y) by register exchange 10 -> 5 -> 3, then x inside the quads
                 float s[6];
