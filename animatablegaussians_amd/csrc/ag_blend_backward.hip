@@ -4,21 +4,22 @@
 // T_final = 1 - alpha_out with T recovered by division, the depth and alpha-output gradient terms, the background
 // term, no gradient gate at the 0.99 alpha clamp, dL_dmean2D in NDC-scaled units (x 0.5 W, x 0.5 H).
 //
-// Same decomposition as the forward (ag_blend_forward.hip): persistent 8-wave workgroups own 8x4-pixel regions,
-// statically assigned longest-list-first; the tile list is culled 512 entries at a time against the region (rearmost
-// first, only up to the region's largest n_contrib) and compacted in processing order into LDS; inside a wave each
-// 16-lane DPP row is one pixel and its lanes are 16 consecutive entries of the back-to-front walk.  The reference's
-// three serial recurrences become row scans:
+// One independent WAVE per (tile, 4 x 4-pixel block): the wave culls the tile's depth-sorted list against its block (rearmost first,
+// only up to the block's largest n_contrib), compacts the survivors in processing order into a wave-private LDS ring and blends four
+// of them per step with lanes = 16 pixels x 4 entries.  The reference's serial recurrences become scans over the 4 entries of a step
+// (two DPP row shifts) with a carry in bank 0:
 //   T_e      = T / prod_{i<=e} (1 - alpha_i)                          inclusive product scan (the divisions of :534)
-//   behind_e = g_{e-1}( ... g_0(behind_0)),  g_i(S) = alpha_i c_i + (1 - alpha_i) S
-//                                                                      exclusive scan of affine maps (A, B[5]) for the
-//                                                                      colour / depth / alpha "accum_rec" of :541-565
-// after which the ten gradient terms of all 16 entries are independent.  The terms of the wave's 4 pixels are summed
-// with two register-exchange stages (v_permlane32_swap, v_permlane16_swap: 10 -> 5 -> 3 registers) and stored (plain
-// ds_write, no LDS atomics) into that wave's partial slab [10][kSub]; every kSub compacted entries the 8 slabs are summed
-// and flushed with one global atomic per (region, splat, component), laid out so that 16 adjacent lanes hit the 16 slots
-// of ONE 64-byte accumulator line (the atomic units work per line request: 409 -> 183 us).  The reference issues ten
-// atomics per (pixel, splat).
+//   behind_e = m_{e-1}( ... m_0(behind_0)),  m_i(S) = alpha_i w_i + (1 - alpha_i) S
+//                                                                      scan of affine maps over ONE scalar: the colour / depth / alpha
+//                                                                      "accum_rec" of :541-565 enter dL/dalpha only through their dot
+//                                                                      product with the pixel's gradient
+// after which the terms of the 4 entries are independent.  Per (pixel, entry) the kernel forms the six moments of q = G dL/dalpha
+// (ag_common.h AccumSlot) and the four colour / depth terms, sums them over the 16 pixels (v_permlane32_swap, v_permlane16_swap, two quad
+// butterflies: 10 -> 5 -> 3 registers) into a 1-KB window in LDS and flushes 16 entries at a time with one global atomic per (block,
+// splat, component), laid out so that 16 adjacent lanes hit the 16 slots of ONE 64-byte accumulator line (the atomic units work per
+// line request).  The reference issues ten atomics per (pixel, splat).  The round-2 design (8-wave workgroups on 8 x 4 regions, 16
+// entries per DPP row, per-wave partial slabs; 125 us on the bench view against 88) is commit 7b5ac22's version of this file;
+// profiles/r03_bwd_timeline.txt is its per-item timeline, which motivated this one.
 #include <cstdlib>
 #include "ag_common.h"
 
@@ -114,329 +115,7 @@ __device__ __forceinline__ float wave_reduce16_transposed(float (&v)[16], int la
     return x;
 }
 
-// Occupancy: 6 waves per SIMD (80 VGPRs, 4 of them spilled) and 48 KiB of LDS = 3 resident workgroups per CU.  Every item
-// starts with three dependent global round trips (n_contrib -> list indices -> records) and every flush ends in two workgroup
-// barriers; PMC shows the waves parked on barriers / waitcnt 60 % of their lifetime, and a third workgroup fills those holes.
-constexpr int kBwdWavesPerSimd = 6;
-// Compacted entries blended between two flushes of the per-wave partial sums.  With only two workgroups per CU resident
-// (512-workgroup grid) 64 -> 128 entries per flush measured 189 -> 172 us; with the 2048-workgroup grid the 21 KiB this
-// saves buy the third resident workgroup instead: 154 -> 135 us (same-box A/B).  (One shared slab filled with LDS float
-// atomics would need 5 KiB only, but measured 240-300 us.)
-// Round 2: the slabs are double-buffered, so ONE barrier per sub-chunk orders everything (compute k -> barrier -> flush k and, without
-// a second barrier, compute k+1 into the other slab: a wave can only write slab (k+1)&1 after every wave has passed barrier k, i.e.
-// after every wave finished flush k-1, the last reader of that slab) and the flush's LDS reads / atomics of the fast waves overlap
-// the blending of the slow ones.  Two 32-entry slabs cost the LDS of one 64-entry slab: still 3 workgroups per CU.
-constexpr int kSub = 32;
-constexpr int kPartStride = kSub + 2;     // == 2 (mod 32): the flush's (component, entry) lanes of a 32-lane LDS access hit 20 distinct banks
-
-// AG_BWD_TIMELINE (diagnostic build only: profiles/ub/build_timeline.sh, profiles/bwd_wg_times.py): thread 0 of every workgroup stamps
-// each (tile, region) item with the 100-MHz wall clock at its start, after the n_contrib round trip + reduction, after the first
-// records arrived and were culled, and at its end, together with the item's size figures.  Not compiled into the product.
-#ifdef AG_BWD_TIMELINE
-struct TlItem {
-    uint32_t wg, seq, tile, region, list_len, wmax, survivors, steps, skipped, active_pairs, chunks, pad;
-    unsigned long long t0, t_hdr, t_rec, t_end;
-};
-constexpr uint32_t kTlMax = 16384;
-__device__ TlItem g_tl[kTlMax];
-__device__ uint32_t g_tl_n;
-#define TL(stmt) do { if (threadIdx.x == 0) { stmt; } } while (0)
-#else
-#define TL(stmt) do { } while (0)
-#endif
-
-__global__ void __launch_bounds__(kBlendThreads, kBwdWavesPerSimd) blend_backward_kernel(BlendBwdParams p)
-{
-    constexpr int NW = kBlendThreads / 64;
-    __shared__ float4 s_rec[kChunk * 3];
-    __shared__ float s_part[2][kBlendThreads / 64][10][kPartStride];   // per-wave sums over its 4 pixels: plain stores, no LDS atomics
-    __shared__ uint32_t s_gid[kChunk];
-    __shared__ int s_wave_cnt[2][NW];
-    __shared__ uint32_t s_wave_max[NW];
-
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int row = lane >> 4, e = lane & 15;
-    const uint32_t n_active = p.counts[1];
-    const size_t HW = (size_t)p.W * p.H;
-    const float ddelx_dx = 0.5f * (float)p.W, ddely_dy = 0.5f * (float)p.H;
-    const float bg0 = p.bg[0], bg1 = p.bg[1], bg2 = p.bg[2];
-
-    int pb = 0;                                   // slab parity, toggled per sub-chunk for the whole kernel
-    ItemIter it(blockIdx.x, gridDim.x, n_active);
-    uint32_t tr, rg;
-    bool have = it.next(tr, rg);
-    uint4 hdr = make_uint4(0u, 0u, 0u, 0u);
-    if (have) { hdr = p.tile_order[tr]; hdr.w = rg; }
-    lds_barrier();
-
-#ifdef AG_BWD_TIMELINE
-    TlItem tl{};
-    uint32_t tl_seq = 0;
-#endif
-    while (have) {
-        TL(tl = TlItem{}; tl.t0 = wall_clock64(); tl.wg = blockIdx.x; tl.seq = tl_seq++; tl.tile = hdr.x; tl.region = hdr.w; tl.list_len = hdr.z - hdr.y);
-        uint32_t tr_n, rg_n;
-        const bool have_n = it.next(tr_n, rg_n);
-        uint4 hdr_n = make_uint4(0u, 0u, 0u, 0u);
-        if (have_n) { hdr_n = p.tile_order[tr_n]; hdr_n.w = rg_n; }
-
-        const int tile = (int)hdr.x, reg = (int)hdr.w;
-        const uint32_t rbeg = hdr.y;
-        const int tile_x = tile % p.gx, tile_y = tile / p.gx;
-        const int rx0 = tile_x * kTileX + (reg & 1) * kRegW, ry0 = tile_y * kTileY + (reg >> 1) * kRegH;
-        // the wave's 4 pixels form a 2x2 block (better coherence of the per-wave early-outs than a 4x1 strip)
-        const int px = rx0 + (wave & 3) * 2 + (row & 1), py = ry0 + (wave >> 2) * 2 + (row >> 1);
-        const bool inside = px < p.W && py < p.H;
-        const float pxf = (float)px, pyf = (float)py;
-        const float qx0f = (float)rx0, qy0f = (float)ry0, qx1f = (float)(rx0 + kRegW - 1), qy1f = (float)(ry0 + kRegH - 1);
-
-        // per-pixel constants (row-uniform)
-        const int pix = p.W * py + px;
-        uint32_t last_contributor = 0;
-        float T_final = 0.f, gr = 0.f, gg = 0.f, gb = 0.f, gd = 0.f, ga = 0.f;
-        if (inside) {
-            last_contributor = p.n_contrib[pix];
-            T_final = 1.0f - p.alphas[pix];
-            gr = p.dL_dpix[pix];
-            gg = p.dL_dpix[HW + pix];
-            gb = p.dL_dpix[2 * HW + pix];
-            gd = p.dL_ddepth[pix];
-            ga = p.dL_dalpha[pix];
-        }
-        const float bg_dot = bg0 * gr + bg1 * gg + bg2 * gb;
-
-        // nothing behind the region's largest n_contrib contributed to any of its pixels
-        uint32_t wmax = last_contributor;
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, d, 64));
-        if (lane == 0) s_wave_max[wave] = wmax;
-        lds_barrier();
-#pragma unroll
-        for (int w = 0; w < NW; w++) wmax = max(wmax, s_wave_max[w]);
-        const uint32_t rend = rbeg + wmax;   // walk [rbeg, rend) from the back
-        TL(tl.t_hdr = wall_clock64(); tl.wmax = wmax);
-
-        // row state of the back-to-front walk
-        float T = T_final;                                   // transmittance behind the entries processed so far
-        float S_r = 0.f, S_g = 0.f, S_b = 0.f, S_d = 0.f, S_a = 0.f;   // blended colour/depth/alpha behind them
-
-        // staging pipeline (records one chunk ahead, indices two chunks ahead); thread t takes entry rend-1-t-c*512
-        uint32_t id_cur = 0, id_next = 0;
-        float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
-        {
-            const uint32_t o0 = (uint32_t)tid, o1 = o0 + kChunk;
-            if (o0 < wmax) id_cur = p.point_list[rend - 1u - o0];
-            if (o1 < wmax) id_next = p.point_list[rend - 1u - o1];
-            if (o0 < wmax) {
-                const float4* src = reinterpret_cast<const float4*>(p.rec + id_cur);
-                r0 = src[0]; r1 = src[1]; r2 = src[2];
-            }
-        }
-        bool keep;
-        {
-            const float ddx = fmaxf(fmaxf(qx0f - r0.x, r0.x - qx1f), 0.f);
-            const float ddy = fmaxf(fmaxf(qy0f - r0.y, r0.y - qy1f), 0.f);
-            keep = ((uint32_t)tid < wmax) && ((ddx * ddx + ddy * ddy) <= r2.z);
-        }
-        unsigned long long mask = __ballot(keep);
-        if (lane == 0) s_wave_cnt[0][wave] = __popcll(mask);
-        lds_barrier();
-        TL(tl.t_rec = wall_clock64());
-
-        int cpar = 0;
-        for (uint32_t done_entries = 0; done_entries < wmax; done_entries += kChunk, cpar ^= 1) {
-            // ---- ordered compaction (processing order = back to front) ----
-            const uint32_t o = done_entries + (uint32_t)tid;        // offset from the back
-            const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-            int off = 0, K = 0;
-#pragma unroll
-            for (int w = 0; w < NW; w++) {
-                const int c = s_wave_cnt[cpar][w];
-                off += (w < wave) ? c : 0;
-                K += c;
-            }
-            if (keep) {
-                const int slot = off + rank;
-                s_rec[slot * 3 + 0] = r0;
-                s_rec[slot * 3 + 1] = r1;
-                s_rec[slot * 3 + 2] = make_float4(r2.x, r2.y, __uint_as_float(wmax - o), 0.f);   // b, depth, 1-based list position
-                s_gid[slot] = id_cur;
-            }
-            const uint32_t on = o + kChunk, onn = on + kChunk;
-            id_cur = id_next;
-            if (on < wmax) {
-                const float4* src = reinterpret_cast<const float4*>(p.rec + id_next);
-                r0 = src[0]; r1 = src[1]; r2 = src[2];
-            }
-            if (onn < wmax) id_next = p.point_list[rend - 1u - onn];
-            lds_barrier();
-            TL(tl.survivors += K; tl.chunks++);
-
-            // ---- kSub compacted entries at a time: 16 entries per step per pixel row, then flush ----
-            for (int sb = 0; sb < K; sb += kSub) {
-            const int sub_n = min(kSub, K - sb);
-            for (int s0 = sb; s0 < sb + sub_n; s0 += 16) {
-                const int idx = s0 + e;
-                const bool ev = idx < K;
-                const int ci = ev ? idx : (K - 1);
-                const float4 a = s_rec[ci * 3 + 0];   // x, y, conic a, conic b
-                const float4 b = s_rec[ci * 3 + 1];   // conic c, opacity, r, g
-                const float4 c = s_rec[ci * 3 + 2];   // b, depth, position
-                const float dx = a.x - pxf, dy = a.y - pyf;
-                const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
-                const float G = __builtin_amdgcn_exp2f(power * 1.4426950408889634f);
-                const float alpha = fminf(0.99f, b.y * G);
-                const bool act = ev && (__float_as_uint(c.z) <= last_contributor) && (power <= 0.0f) && (alpha >= 1.0f / 255.0f);
-                const int vbase = (row == 0) ? 0 : (row == 1) ? 3 : (row == 2) ? 5 : 8;
-                float* part = &s_part[pb][wave][vbase][idx - sb];
-                if (!__any(act)) {
-                    if (ev) { part[0] = 0.f; part[kPartStride] = 0.f; if (!(row & 1)) part[2 * kPartStride] = 0.f; }
-                    TL(tl.skipped++);
-                    continue;
-                }
-#ifdef AG_BWD_TIMELINE
-                { const unsigned long long am = __ballot(act); TL(tl.steps++; tl.active_pairs += __popcll(am)); }
-#endif
-                const float fac = act ? (1.0f - alpha) : 1.0f;
-                // affine maps g_e(S) = A S + B, A = fac, B = alpha * c (0 when inactive); inclusive row scan
-                const float al = act ? alpha : 0.f;
-                float A = fac, Br = al * b.z, Bg = al * b.w, Bb = al * c.x, Bd = al * c.y, Ba = al;
-                // One scan step = six DPP-operand VOP2 instructions.  The compiler does not fold these row shifts into the FMAs
-                // (it emits a v_mov_b32_dpp per operand: 30 of the 168 VALU instructions of a step), so the step is spelled out:
-                //   B  <- B + row_shr(B) * A      v_fmac_f32_dpp with bound_ctrl: lanes shifted in from outside the row read 0
-                //   A  <- row_shr(A) * A          v_mul_f32_dpp WITHOUT bound_ctrl: those lanes are not written and keep A (x 1)
-                // s_nop 1: a DPP read needs two wait states after the VALU write of its source; inside the block the five
-                // accumulators alternate, so only the first read needs the explicit gap.  Measured 139 -> 128 us.
-#define AG_SCAN_STEP(N)                                                                                                        \
-                asm volatile("s_nop 1\n\t"                                                                                     \
-                             "v_fmac_f32_dpp %0, %0, %5 row_shr:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"             \
-                             "v_fmac_f32_dpp %1, %1, %5 row_shr:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"             \
-                             "v_fmac_f32_dpp %2, %2, %5 row_shr:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"             \
-                             "v_fmac_f32_dpp %3, %3, %5 row_shr:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"             \
-                             "v_fmac_f32_dpp %4, %4, %5 row_shr:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"             \
-                             "v_mul_f32_dpp %5, %5, %5 row_shr:" #N " row_mask:0xf bank_mask:0xf"                               \
-                             : "+v"(Br), "+v"(Bg), "+v"(Bb), "+v"(Bd), "+v"(Ba), "+v"(A));
-                AG_SCAN_STEP(1) AG_SCAN_STEP(2) AG_SCAN_STEP(4) AG_SCAN_STEP(8)
-#undef AG_SCAN_STEP
-                // A is now prod_{i<=e} fac_i: T in front of entry e; exclusive maps give the blend behind entry e
-                const float Tin = T * __builtin_amdgcn_rcpf(A);
-                const float Aex = row_shr<1>(A, 1.0f);
-                const float beh_r = fmaf(Aex, S_r, row_shr0<1>(Br));
-                const float beh_g = fmaf(Aex, S_g, row_shr0<1>(Bg));
-                const float beh_b = fmaf(Aex, S_b, row_shr0<1>(Bb));
-                const float beh_d = fmaf(Aex, S_d, row_shr0<1>(Bd));
-                const float beh_a = fmaf(Aex, S_a, row_shr0<1>(Ba));
-
-                // the ten per-(pixel, entry) terms; inactive lanes contribute exact zeros through `m`
-                float v[10];
-                {
-                    const float m = act ? 1.f : 0.f;
-                    float dL_dopa = (b.z - beh_r) * gr + (b.w - beh_g) * gg + (c.x - beh_b) * gb;
-                    dL_dopa += (c.y - beh_d) * gd;
-                    dL_dopa += (1.f - beh_a) * ga;
-                    dL_dopa *= Tin;
-                    dL_dopa += (-T_final * __builtin_amdgcn_rcpf(fac)) * bg_dot;
-                    dL_dopa *= m;
-                    const float wgt = al * Tin;            // al is 0 on inactive lanes
-                    const float dL_dG = b.y * dL_dopa;
-                    const float gdx = G * dx, gdy = G * dy;
-                    const float dG_ddelx = -gdx * a.z - gdy * a.w;
-                    const float dG_ddely = -gdy * b.x - gdx * a.w;
-                    v[A_M2X] = dL_dG * dG_ddelx * ddelx_dx;
-                    v[A_M2Y] = dL_dG * dG_ddely * ddely_dy;
-                    v[A_CONX] = -0.5f * gdx * dx * dL_dG;
-                    v[A_CONY] = -0.5f * gdx * dy * dL_dG;
-                    v[A_CONW] = -0.5f * gdy * dy * dL_dG;
-                    v[A_OPAC] = G * dL_dopa;
-                    v[A_COLR] = wgt * gr;
-                    v[A_COLG] = wgt * gg;
-                    v[A_COLB] = wgt * gb;
-                    v[A_DEPTH] = wgt * gd;
-                }
-                // carry for the next step: state behind entry 15 of this step
-                T = row_read(Tin, lane, 15);
-                const float A15 = row_read(A, lane, 15);
-                S_r = fmaf(A15, S_r, row_read(Br, lane, 15));
-                S_g = fmaf(A15, S_g, row_read(Bg, lane, 15));
-                S_b = fmaf(A15, S_b, row_read(Bb, lane, 15));
-                S_d = fmaf(A15, S_d, row_read(Bd, lane, 15));
-                S_a = fmaf(A15, S_a, row_read(Ba, lane, 15));
-
-                // sum the 4 pixels (rows) of this wave per entry column: 10 -> 5 -> 3 registers
-                float s[6];
-#pragma unroll
-                for (int i = 0; i < 5; i++) {
-                    swap32(v[i], v[i + 5]);
-                    s[i] = v[i] + v[i + 5];      // rows 0,1: value i ; rows 2,3: value i+5
-                }
-                s[5] = 0.f;
-                float u[3];
-#pragma unroll
-                for (int i = 0; i < 3; i++) {
-                    swap16(s[i], s[i + 3]);
-                    u[i] = s[i] + s[i + 3];      // row 0: value i, row 1: value i+3, row 2: value i+5, row 3: value i+8
-                }
-                if (ev) { part[0] = u[0]; part[kPartStride] = u[1]; if (!(row & 1)) part[2 * kPartStride] = u[2]; }
-            }
-            lds_barrier();   // partial sums of this sub-chunk complete
-            // flush: lane = (entry, component) with the 16 accumulator slots of one splat in 16 ADJACENT lanes, so one wave
-            // instruction touches 4 whole 64-byte accumulator lines instead of 64 different ones (the atomic units work
-            // per line request); 512 threads cover 32 entries per pass.  Exact zeros are skipped.
-#pragma unroll
-            for (int pass = 0; pass < kSub / 32; pass++) {
-                const int ent = pass * 32 + (tid >> 4), comp = tid & 15;
-                if (ent < sub_n && comp < 10) {
-                    float acc = 0.f;
-#pragma unroll
-                    for (int w = 0; w < NW; w++) acc += s_part[pb][w][comp][ent];
-                    if (acc != 0.f) atomicAdd(p.accum + (size_t)s_gid[sb + ent] * kAccumFloats + comp, acc);
-                }
-            }
-            pb ^= 1;         // no second barrier: the next sub-chunk goes to the other slab
-            }
-
-            // ---- cull of the next chunk ----
-            {
-                const float ddx = fmaxf(fmaxf(qx0f - r0.x, r0.x - qx1f), 0.f);
-                const float ddy = fmaxf(fmaxf(qy0f - r0.y, r0.y - qy1f), 0.f);
-                keep = (on < wmax) && ((ddx * ddx + ddy * ddy) <= r2.z);
-            }
-            mask = __ballot(keep);
-            if (lane == 0) s_wave_cnt[cpar ^ 1][wave] = __popcll(mask);
-            lds_barrier();   // s_rec / s_gid reusable, next counts visible
-        }
-#ifdef AG_BWD_TIMELINE
-        if (threadIdx.x == 0) {
-            tl.t_end = wall_clock64();
-            const uint32_t slot = atomicAdd(&g_tl_n, 1u);
-            if (slot < kTlMax) g_tl[slot] = tl;
-        }
-#endif
-        hdr = hdr_n;
-        have = have_n;
-    }
-}
-
-#ifdef AG_BWD_TIMELINE
-// copies the records of the launches since the last call to the host and resets the log
-extern "C" int ag_debug_bwd_timeline(void* items, uint32_t capacity, uint32_t* count)
-{
-    uint32_t n = 0;
-    if (hipDeviceSynchronize() != hipSuccess) return AG_ERR_HIP;
-    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_tl_n), sizeof(n)) != hipSuccess) return AG_ERR_HIP;
-    const uint32_t m = n < capacity ? n : capacity;
-    if (m && hipMemcpyFromSymbol(items, HIP_SYMBOL(g_tl), (size_t)(m < kTlMax ? m : kTlMax) * sizeof(TlItem)) != hipSuccess) return AG_ERR_HIP;
-    const uint32_t zero = 0;
-    if (hipMemcpyToSymbol(HIP_SYMBOL(g_tl_n), &zero, sizeof(zero)) != hipSuccess) return AG_ERR_HIP;
-    *count = m < kTlMax ? m : kTlMax;
-    return AG_OK;
-}
-#endif
-
-// ------------------------------------------------------------------------------------------------------------------------------------
-// Round 3: one independent WAVE per (tile, 4x4-pixel block).  No workgroup barriers, no cross-wave partial slabs.
-// ------------------------------------------------------------------------------------------------------------------------------------
-// What the per-item timeline of the kernel above showed (profiles/r03_bwd_timeline.txt, bench view): its body runs at the rate six
+// What the per-item timeline of the round-2 region kernel showed (profiles/r03_bwd_timeline.txt, bench view): its body runs at the rate six
 // waves sharing a SIMD's VALU allow (1.8 us per 32-entry sub-chunk = the ~180 VALU instructions of each of the six), so the kernel is
 // bound by instruction count, and 84 % of its (pixel, entry) lane slots are dead: a wave walks ALL survivors of the 8x4 region cull
 // (134 per item) for its 2x2 pixels although only 44 reach them, more than half of its 16-entry steps are skipped after paying
@@ -512,9 +191,7 @@ __global__ void __launch_bounds__(64, AG_BWD_WAVE_OCC) blend_backward_wave_kerne
     const int ry = lane >> 4, e = (lane >> 2) & 3, qx = lane & 3;
     const uint32_t n_active = p.counts[1];
     const size_t HW = (size_t)p.W * p.H;
-    const float ddelx_dx = 0.5f * (float)p.W, ddely_dy = 0.5f * (float)p.H;
     const float bg0 = p.bg[0], bg1 = p.bg[1], bg2 = p.bg[2];
-    const float nddelx = -ddelx_dx, nddely = -ddely_dy;
     const int vbase = (ry == 0) ? 0 : (ry == 1) ? 3 : (ry == 2) ? 5 : 8;
     const bool out_lane = qx < ((ry & 1) ? 2 : 3);           // this lane stores u[qx] as accumulator slot vbase + qx
     const float bank0 = (e == 0) ? 1.0f : 0.0f;
@@ -655,18 +332,17 @@ __global__ void __launch_bounds__(64, AG_BWD_WAVE_OCC) blend_backward_wave_kerne
                 {
                     float dL_dopa = w - beh;
                     dL_dopa = fmaf(dL_dopa, Tin, __builtin_amdgcn_rcpf(fac) * ntf_bg);
-                    dL_dopa = act ? dL_dopa : 0.f;
+                    // q = G dL/dalpha; the geometric gradients of the entry are q times monomials of (dx, dy) times constants of
+                    // the Gaussian (opacity, conic, viewport scale), which the preprocess backward applies once per Gaussian
+                    const float q = act ? G * dL_dopa : 0.f;
                     const float wgt = al * Tin;
-                    const float dL_dG = b.y * dL_dopa;
-                    const float gdx = G * dx, gdy = G * dy;
-                    const float tx = fmaf(gdx, a.z, gdy * a.w), ty = fmaf(gdy, b.x, gdx * a.w);     // -dG/ddelx, -dG/ddely
-                    const float hG = -0.5f * dL_dG, hx = hG * gdx;
-                    v[A_M2X] = (dL_dG * nddelx) * tx;
-                    v[A_M2Y] = (dL_dG * nddely) * ty;
-                    v[A_CONX] = hx * dx;
-                    v[A_CONY] = hx * dy;
-                    v[A_CONW] = (hG * gdy) * dy;
-                    v[A_OPAC] = G * dL_dopa;
+                    const float qdx = q * dx, qdy = q * dy;
+                    v[A_QDX] = qdx;
+                    v[A_QDY] = qdy;
+                    v[A_QXX] = qdx * dx;
+                    v[A_QXY] = qdx * dy;
+                    v[A_QYY] = qdy * dy;
+                    v[A_Q] = q;
                     v[A_COLR] = wgt * gr;
                     v[A_COLG] = wgt * gg;
                     v[A_COLB] = wgt * gb;
@@ -763,18 +439,10 @@ int launch_blend_backward(const AgRasterBackwardArgs& a, hipStream_t s)
     p.accum = reinterpret_cast<float*>(aligned_base(a.accum_buffer));
     if (check_hip(hipMemsetAsync(p.accum, 0, (size_t)a.P * kAccumFloats * sizeof(float), s), "memset accum")) return AG_ERR_HIP;
     if (a.num_rendered <= 0) return AG_OK;
-    // the wave kernel is the product path since round 3; AG_BWD_KERNEL=0 selects the round-2 region kernel (same-box A/B in profiles/)
-    static const int variant = [] { const char* e = getenv("AG_BWD_KERNEL"); return e ? atoi(e) : 1; }();
-    if (variant == 1) {
-        const long long items = (long long)p.T * kBlocksPerTile;
-        const int grid = (int)(items < kWaveGrid ? items : kWaveGrid);
-        { ProfScope ps(AG_K_BLEND_BACKWARD, s); hipLaunchKernelGGL(blend_backward_wave_kernel, dim3(grid), dim3(64), 0, s, p); }
-        return check_hip(hipGetLastError(), "blend_backward_wave_kernel");
-    }
-    const long long items = (long long)p.T * kRegionsPerTile;
-    const int grid = (int)(items < kBlendGrid ? items : kBlendGrid);   // 3 resident workgroups of 8 waves per CU (48 KiB of LDS each), 2.7x oversubscribed
-    { ProfScope ps(AG_K_BLEND_BACKWARD, s); hipLaunchKernelGGL(blend_backward_kernel, dim3(grid), dim3(kBlendThreads), 0, s, p); }
-    return check_hip(hipGetLastError(), "blend_backward_kernel");
+    const long long items = (long long)p.T * kBlocksPerTile;
+    const int grid = (int)(items < kWaveGrid ? items : kWaveGrid);
+    { ProfScope ps(AG_K_BLEND_BACKWARD, s); hipLaunchKernelGGL(blend_backward_wave_kernel, dim3(grid), dim3(64), 0, s, p); }
+    return check_hip(hipGetLastError(), "blend_backward_wave_kernel");
 }
 
 }  // namespace ag

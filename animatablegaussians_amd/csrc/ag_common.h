@@ -26,9 +26,13 @@ struct __attribute__((aligned(16))) GaussRec {
 };
 static_assert(sizeof(GaussRec) == 48, "GaussRec must be 48 bytes");
 
-// Per-Gaussian accumulator row of the blend backward: one 64-byte line.
+// Per-Gaussian accumulator row of the blend backward: one 64-byte line.  With q = G * dL/dalpha of a (pixel, entry) pair and
+// (dx, dy) = mean2D - pixel, the blend backward sums the six MOMENTS q, q dx, q dy, q dx^2, q dx dy, q dy^2 over the pixels; every
+// geometric gradient of backward.cu:560-600 is a per-Gaussian linear map of those (opacity, conic and the viewport scale are constants
+// of the Gaussian), applied once per Gaussian by the preprocess backward (accum_to_gradients) instead of once per (pixel, entry):
+//   dL/dopacity = Q;  dL/dconic = -0.5 op (QXX, QXY, QYY);  dL/dmean2D = -0.5 op (W (ca QDX + cb QDY), H (cc QDY + cb QDX))
 constexpr int kAccumFloats = 16;
-enum AccumSlot { A_M2X = 0, A_M2Y, A_CONX, A_CONY, A_CONW, A_OPAC, A_COLR, A_COLG, A_COLB, A_DEPTH };
+enum AccumSlot { A_QDX = 0, A_QDY, A_QXX, A_QXY, A_QYY, A_Q, A_COLR, A_COLG, A_COLB, A_DEPTH };
 
 // Blend kernels: a workgroup of 8 waves owns an 8x4 pixel region (8 regions per 16x16 tile); each wave blends
 // 4 pixels (one per 16-lane DPP row) x 16 list entries per step.

@@ -58,6 +58,8 @@ struct PreBwdParams {
     const float* __restrict__ view;
     const float* __restrict__ proj;
     const float* __restrict__ accum;
+    const GaussRec* __restrict__ rec;       // forward records: conic + opacity of the moment -> gradient map
+    float half_w, half_h;                   // d(ndc -> pixel)/d(ndc): 0.5 W, 0.5 H (backward.cu:463-464)
     const float* __restrict__ shs;          // NULL on the colors_precomp path
     const float* __restrict__ campos;
     const uint8_t* __restrict__ clamped;
@@ -88,8 +90,13 @@ __global__ void __launch_bounds__(256) preprocess_backward_kernel(PreBwdParams p
         for (int i = 0; i < 16; i++) { V[i] = p.view[i]; Pm[i] = p.proj[i]; }
         const float4* arow = reinterpret_cast<const float4*>(p.accum + (size_t)idx * kAccumFloats);
         const float4 a0 = arow[0], a1 = arow[1], a2 = arow[2];
-        g_m2[0] = a0.x; g_m2[1] = a0.y;
-        const float dcon_x = a0.z, dcon_y = a0.w, dcon_w = a1.x;
+        // moments of q = G dL/dalpha over the Gaussian's pixels -> the gradients backward.cu:560-600 accumulates per (pixel, entry)
+        // (ag_common.h AccumSlot): dG/ddelx = -G (ca dx + cb dy), dL/dG = op dL/dalpha, dL/dconic = -0.5 G d d^T dL/dG
+        const GaussRec gr = p.rec[idx];
+        const float nhop = -0.5f * gr.op;
+        g_m2[0] = (2.0f * nhop * p.half_w) * fmaf(gr.ca, a0.x, gr.cb * a0.y);
+        g_m2[1] = (2.0f * nhop * p.half_h) * fmaf(gr.cc, a0.y, gr.cb * a0.x);
+        const float dcon_x = nhop * a0.z, dcon_y = nhop * a0.w, dcon_w = nhop * a1.x;
         g_op = a1.y;
         g_col[0] = a1.z; g_col[1] = a1.w; g_col[2] = a2.x;
         const float g_depth = a2.y;
@@ -268,6 +275,8 @@ int launch_preprocess_backward(const AgRasterBackwardArgs& a, hipStream_t s)
     p.cov3Ds = a.cov3D_precomp ? a.cov3D_precomp : reinterpret_cast<const float*>(gb + gl.cov3d);
     p.view = a.viewmatrix; p.proj = a.projmatrix;
     p.accum = reinterpret_cast<const float*>(aligned_base(a.accum_buffer));
+    p.rec = reinterpret_cast<const GaussRec*>(gb + gl.rec);
+    p.half_w = 0.5f * (float)a.W; p.half_h = 0.5f * (float)a.H;
     p.shs = a.colors_precomp ? nullptr : a.shs; p.campos = a.campos; p.sh_degree = a.sh_degree; p.sh_coeffs = a.sh_coeffs;
     p.clamped = reinterpret_cast<const uint8_t*>(gb + gl.clamped); p.dL_dsh = a.dL_dsh;
     p.dL_dmeans2D = a.dL_dmeans2D; p.dL_dcolors = a.dL_dcolors; p.dL_dopacity = a.dL_dopacity;

@@ -336,7 +336,7 @@ def main() -> None:
                                                 "functional run of the N > 1 control flow, NOT a measurement"),
         },
         "roofline": {
-            "kernel": "blend_backward_wave_kernel" if os.environ.get("AG_BWD_KERNEL", "1") != "0" else "blend_backward_kernel",
+            "kernel": "blend_backward_wave_kernel",
             "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": int(alg_dom), "avg_launch_us": round(dom_us, 2), "launches_timed": n_dom,

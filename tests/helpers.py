@@ -124,7 +124,10 @@ def gpu_native_backward(fw, grads, alphas=None):
     names = ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations")
     res = {n: o.cpu().numpy() for n, o in zip(names, out)}
     acc = _scratch_view(accum, 0, P * 64, np.float32).reshape(P, 16)
-    res["dL_dconic"] = np.stack([acc[:, 2], acc[:, 3], np.zeros(P, np.float32), acc[:, 4]], 1)
+    # the accumulator row holds the MOMENTS of q = G dL/dalpha (csrc/ag_common.h AccumSlot); dL/dconic = -0.5 * opacity * (q dx^2, q dx dy,
+    # q dy^2) is applied by the preprocess backward and restated here in float64 for the comparison with the oracle's dL_dconic
+    nhop = -0.5 * inp["opacities"].detach().cpu().numpy().astype(np.float64).reshape(P)
+    res["dL_dconic"] = np.stack([nhop * acc[:, 2], nhop * acc[:, 3], np.zeros(P), nhop * acc[:, 4]], 1)
     res["dL_ddepths"] = acc[:, 9:10].copy()
     return res
 
