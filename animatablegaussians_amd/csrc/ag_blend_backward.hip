@@ -178,6 +178,24 @@ __device__ __forceinline__ float from_entry3(float v)
     return dpp_banks<AG_DPP_ROW_SHL(8), 0x3>(v, v);
 }
 
+// AG_BWD_STATS (diagnostic build only: profiles/ub/build_variant.sh stats ag_blend_backward -DAG_BWD_STATS, profiles/bwd_step_stats.py): lane 0
+// of every wave adds its work figures to global counters.  Not compiled into the product.
+#ifdef AG_BWD_STATS
+enum { ST_ITEMS = 0, ST_WALKED, ST_SURVIVORS, ST_STEPS, ST_SKIPPED, ST_ACTIVE_PAIRS, ST_ACTIVE_ENTRIES, ST_STEPS_BY_ACTIVE_ENTRIES /* 5 slots */, ST_N = 12 };
+__device__ unsigned long long g_bwd_stats[ST_N];
+#define ST(k, v) do { if (lane == 0) atomicAdd(&g_bwd_stats[k], (unsigned long long)(v)); } while (0)
+extern "C" int ag_debug_bwd_stats(unsigned long long* out)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return AG_ERR_HIP;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bwd_stats), sizeof(g_bwd_stats)) != hipSuccess) return AG_ERR_HIP;
+    unsigned long long zero[ST_N] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_bwd_stats), zero, sizeof(zero)) != hipSuccess) return AG_ERR_HIP;
+    return AG_OK;
+}
+#else
+#define ST(k, v) do { } while (0)
+#endif
+
 #ifndef AG_BWD_WAVE_OCC
 #define AG_BWD_WAVE_OCC 6       // waves per SIMD the register budget is cut for
 #endif
@@ -224,6 +242,7 @@ __global__ void __launch_bounds__(64, AG_BWD_WAVE_OCC) blend_backward_wave_kerne
         const uint32_t wmax = wave_umax(last_contributor);
         if (wmax == 0) continue;
         const uint32_t rend = rbeg + wmax;                   // walk [rbeg, rend) from the back
+        ST(ST_ITEMS, 1); ST(ST_WALKED, wmax);
 
         float T = T_final;
         float S = 0.f;               // g . (blended state behind the entries done so far), bank 0 only
@@ -273,6 +292,7 @@ __global__ void __launch_bounds__(64, AG_BWD_WAVE_OCC) blend_backward_wave_kerne
                 s_ring[slot * 3 + 2] = make_float4(r2.x, r2.y, __uint_as_float(wmax - o), __uint_as_float(id_cur));
             }
             cnt += __popcll(mask);
+            ST(ST_SURVIVORS, __popcll(mask));
             // ---- next pass's records, the indices of the one after ----
             const uint32_t on = o + 64u, onn = on + 64u;
             id_cur = id_next;
@@ -302,6 +322,16 @@ __global__ void __launch_bounds__(64, AG_BWD_WAVE_OCC) blend_backward_wave_kerne
                 const float G = __builtin_amdgcn_exp2f(power * 1.4426950408889634f);
                 const float alpha = fminf(0.99f, b.y * G);
                 const bool act = ev && (__float_as_uint(c.z) <= last_contributor) && (power <= 0.0f) && (alpha >= 1.0f / 255.0f);
+#ifdef AG_BWD_STATS
+                {
+                    const unsigned long long am = __ballot(act);
+                    unsigned long long em = am | (am >> 32); em |= em >> 16;            // fold the 4 rows: bit (e * 4 + x)
+                    int ne = 0;
+                    for (int q = 0; q < 4; q++) ne += ((em >> (4 * q)) & 0xfull) ? 1 : 0;
+                    ST(ST_STEPS, 1); ST(ST_SKIPPED, am == 0ull); ST(ST_ACTIVE_PAIRS, __popcll(am)); ST(ST_ACTIVE_ENTRIES, ne);
+                    ST(ST_STEPS_BY_ACTIVE_ENTRIES + ne, 1);
+                }
+#endif
                 if (__ballot(act) == 0ull) continue;
                 const float al = act ? alpha : 0.f;
                 const float fac = 1.0f - al;
