@@ -210,8 +210,9 @@ __global__ void __launch_bounds__(64, AG_BWD_WAVE_OCC) blend_backward_wave_kerne
     const uint32_t n_active = p.counts[1];
     const size_t HW = (size_t)p.W * p.H;
     const float bg0 = p.bg[0], bg1 = p.bg[1], bg2 = p.bg[2];
-    const int vbase = (ry == 0) ? 0 : (ry == 1) ? 3 : (ry == 2) ? 5 : 8;
-    const bool out_lane = qx < ((ry & 1) ? 2 : 3);           // this lane stores u[qx] as accumulator slot vbase + qx
+    // flush lane (entry, component): component -> window slot [row][4]: rows hold the values (0, 1, 2) (3, 4, -) (5, 6, 7) (8, 9, -)
+    const int out_comp = lane & 15;
+    const int out_slot = out_comp < 3 ? out_comp : out_comp < 5 ? out_comp + 1 : out_comp < 8 ? out_comp + 3 : out_comp < 10 ? out_comp + 4 : 15;
     const float bank0 = (e == 0) ? 1.0f : 0.0f;
 
     WaveItemIter it(blockIdx.x, gridDim.x, n_active);
@@ -244,7 +245,7 @@ __global__ void __launch_bounds__(64, AG_BWD_WAVE_OCC) blend_backward_wave_kerne
         const uint32_t rend = rbeg + wmax;                   // walk [rbeg, rend) from the back
         ST(ST_ITEMS, 1); ST(ST_WALKED, wmax);
 
-        float T = T_final;
+        float P = 1.0f;              // prod (1 - alpha) over the entries done so far (all four lanes of the pixel)
         float S = 0.f;               // g . (blended state behind the entries done so far), bank 0 only
         // staging pipeline: records one pass (64 entries) ahead, indices two passes ahead.  Every load is unconditional (lanes past the
         // end read entry rbeg / record 0 and are masked at the cull): a conditional load makes the compiler merge old and new
@@ -266,7 +267,7 @@ __global__ void __launch_bounds__(64, AG_BWD_WAVE_OCC) blend_backward_wave_kerne
             uint32_t gid[kWin / 4];
 #pragma unroll
             for (int pass = 0; pass < kWin / 4; pass++) {
-                val[pass] = s_out[(pass * 4 + (lane >> 4)) * 16 + (lane & 15)];
+                val[pass] = s_out[(pass * 4 + (lane >> 4)) * 16 + out_slot];
                 gid[pass] = s_wgid[pass * 4 + (lane >> 4)];
             }
 #pragma unroll
@@ -320,8 +321,10 @@ __global__ void __launch_bounds__(64, AG_BWD_WAVE_OCC) blend_backward_wave_kerne
                 const float dx = a.x - pxf, dy = a.y - pyf;
                 const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
                 const float G = __builtin_amdgcn_exp2f(power * 1.4426950408889634f);
-                const float alpha = fminf(0.99f, b.y * G);
-                const bool act = ev && (__float_as_uint(c.z) <= last_contributor) && (power <= 0.0f) && (alpha >= 1.0f / 255.0f);
+                // (the alpha threshold is the LAST test so that the wave vote below reads the compare's own lane mask)
+                const bool pre = (int)ev & (int)(__float_as_uint(c.z) <= last_contributor) & (int)(power <= 0.0f);   // no short circuit: a branch here drags an LDS read behind the exp
+                const float al0 = pre ? fminf(0.99f, b.y * G) : 0.f;
+                const bool act = al0 >= 1.0f / 255.0f;
 #ifdef AG_BWD_STATS
                 {
                     const unsigned long long am = __ballot(act);
@@ -333,7 +336,7 @@ __global__ void __launch_bounds__(64, AG_BWD_WAVE_OCC) blend_backward_wave_kerne
                 }
 #endif
                 if (__ballot(act) == 0ull) continue;
-                const float al = act ? alpha : 0.f;
+                const float al = act ? al0 : 0.f;
                 const float fac = 1.0f - al;
                 // dL/dalpha_e needs the blended state behind entry e only through its dot product with the pixel's gradient
                 // g = (gr, gg, gb, gd, ga) (backward.cu:560-585 keeps five accum_rec channels and multiplies each by its dL_dchannel; g is
@@ -350,12 +353,12 @@ __global__ void __launch_bounds__(64, AG_BWD_WAVE_OCC) blend_backward_wave_kerne
                              : "+v"(B), "+v"(A));
                 AG_SCAN_STEP(4) AG_SCAN_STEP(8)
 #undef AG_SCAN_STEP
-                // A = prod_{i<=e} fac_i: T in front of entry e;  state behind entry e = inclusive state of entry e-1 (bank 0: the carry).
-                // T is carried through list_length / 4 of these divisions (the reference divides once per entry, backward.cu:534): one
-                // Newton step on v_rcp_f32 (1 ulp) keeps the chain at the rounding of an exact division.
-                float rA = __builtin_amdgcn_rcpf(A);
-                rA = fmaf(fmaf(-A, rA, 1.0f), rA, rA);
-                const float Tin = T * rA;
+                // A = prod_{i<=e} fac_i over the step; P = the same product over all earlier steps (carried in every lane of the pixel);
+                // T in front of entry e = T_final / (P A).  The reference divides T by (1 - alpha) once per entry (backward.cu:534); here
+                // the chain carried from step to step is the PRODUCT (multiplications only, as in the forward) and every T is one
+                // v_rcp_f32 (1 ulp) + one multiplication away from it, so reciprocal errors do not accumulate along the list.
+                const float Pe = P * A;
+                const float Tin = T_final * __builtin_amdgcn_rcpf(Pe);
                 const float beh = dpp_banks<AG_DPP_ROW_SHR(4), 0xf>(S, B);
 
                 float v[10];
@@ -378,8 +381,8 @@ __global__ void __launch_bounds__(64, AG_BWD_WAVE_OCC) blend_backward_wave_kerne
                     v[A_COLB] = wgt * gb;
                     v[A_DEPTH] = wgt * gd;
                 }
-                // carry: T in front of entry 3 to all four lanes of the pixel; the state behind entry 3 to bank 0 (zero elsewhere)
-                T = from_entry3(Tin);
+                // carry: the product up to entry 3 to all four lanes of the pixel; the state behind entry 3 to bank 0 (zero elsewhere)
+                P = from_entry3(Pe);
                 // (one v_mul_f32_dpp: bank 3's value rotated into bank 0, times the lane constant 1 in bank 0 / 0 elsewhere)
                 asm volatile("v_mul_f32_dpp %0, %1, %2 row_ror:4 row_mask:0xf bank_mask:0xf" : "=&v"(S) : "v"(B), "v"(bank0));
 
@@ -395,13 +398,24 @@ __global__ void __launch_bounds__(64, AG_BWD_WAVE_OCC) blend_backward_wave_kerne
 #pragma unroll
                 for (int i = 0; i < 3; i++) {
                     swap16(s[i], s[i + 3]);
-                    u[i] = s[i] + s[i + 3];      // row 0: value i, row 1: value i+3, row 2: value i+5, row 3: value i+8
-                    u[i] += dpp<AG_DPP_QUAD_PERM(1, 0, 3, 2)>(u[i]);
-                    u[i] += dpp<AG_DPP_QUAD_PERM(2, 3, 0, 1)>(u[i]);
+                    u[i] = s[i] + s[i + 3];      // row 0: value i, row 1: value i+3, row 2: value i+5, row 3: value i+8 (odd rows: u[2] = 0)
                 }
-                const float mine = (qx == 0) ? u[0] : (qx == 1) ? u[1] : u[2];
-                if (out_lane) s_out[(win + e) * 16 + vbase + qx] = ev ? mine : 0.f;
-                if (ry == 0 && qx == 0) s_wgid[win + e] = __float_as_uint(c.w);
+                // x inside the quads: two butterflies as DPP operands of the additions (spelled out: the compiler sinks the second
+                // addition into the store's exec region and leaves a v_mov_b32_dpp per value behind)
+                asm volatile("s_nop 1\n\t"
+                             "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                             "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                             "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                             "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                             "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                             "v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+                             : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]));
+                // window: [entry][row][4]; lanes of entries past the end of the ring hold exact zeros (act is false there)
+                if (qx == 0) {
+                    float* dst = s_out + (win + e) * 16 + ry * 4;
+                    dst[0] = u[0]; dst[1] = u[1]; dst[2] = u[2];
+                    if (ry == 0) s_wgid[win + e] = __float_as_uint(c.w);
+                }
                 win += 4;
                 if (win == kWin) flush();
             }
