@@ -57,6 +57,11 @@ __device__ __forceinline__ float row_shr(float v, float fill)
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), AG_ROW_SHR(N), 0xf, 0xf, false));
 }
 
+__device__ __forceinline__ float row_lane15(float v)   // row_newbcast:15: every lane receives lane 15 of its 16-lane row
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x15f, 0xf, 0xf, true));
+}
+
 __device__ __forceinline__ float row_inclusive_product(float x)
 {
     // x <- row_shr(x) * x with the shift as the DPP operand of the multiply: without bound_ctrl the lanes whose source falls
@@ -241,6 +246,21 @@ __global__ void __launch_bounds__(kBlendThreads) blend_forward_kernel(BlendFwdPa
                 const float pin = row_inclusive_product(fac);
                 const float Tb = T * row_shr<1>(pin, 1.0f);          // transmittance in front of entry e
                 const float testT = T * pin;                         // ... and behind it
+                // A pixel stops once in its life, a step happens dozens of times: when no entry of the wave's four rows stops (the vote reads
+                // the compare's own lane mask), every valid entry blends and the row's next T is lane 15's -- one row_newbcast instead of
+                // the ballot / first-stop / ds_bpermute ladder below.
+                const float stop_t = valid ? testT : 1.0f;
+                if (__ballot(stop_t < 0.0001f) == 0ull) {
+                    const float w = valid ? alpha * Tb : 0.f;
+                    Cr += b.z * w;
+                    Cg += b.w * w;
+                    Cb += c.x * w;
+                    Dd += c.y * w;
+                    Ws += w;
+                    last = valid ? __float_as_uint(c.z) : last;
+                    T = row_lane15(testT);
+                    continue;
+                }
                 const bool stop = valid && (testT < 0.0001f);
                 const uint32_t rowbits = (uint32_t)(__ballot(stop) >> (lane & 48)) & 0xffffu;
                 const int f = rowbits ? __builtin_ctz(rowbits) : 16; // first stopping entry of this pixel
