@@ -139,7 +139,10 @@ constexpr int kBlocksPerTile = (kTileX / kBlk) * (kTileY / kBlk);
 #define AG_BWD_WIN 16
 #endif
 constexpr int kWaveGrid = AG_BWD_WAVE_GRID;              // single-wave workgroups; the hardware dispatcher balances them
-constexpr int kRing = 128;                               // compacted records waiting to be blended (< 4 left over + <= 64 new); power of two: slot = position & 127
+#ifndef AG_BWD_RING
+#define AG_BWD_RING 128
+#endif
+constexpr int kRing = AG_BWD_RING;                               // compacted records waiting to be blended (< 4 left over + <= 64 new); power of two: slot = position & 127
 constexpr int kWin = AG_BWD_WIN;                         // blended entries per atomic flush
 
 struct WaveItemIter {
@@ -287,7 +290,7 @@ __global__ void __launch_bounds__(64, AG_BWD_WAVE_OCC) blend_backward_wave_kerne
             const unsigned long long mask = __ballot(keep);
             if (keep) {
                 const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-                const int slot = (int)((uint32_t)(cnt + rank) & (uint32_t)(kRing - 1));
+                const int slot = (kRing & (kRing - 1)) ? (cnt + rank) % kRing : (int)((uint32_t)(cnt + rank) & (uint32_t)(kRing - 1));
                 s_ring[slot * 3 + 0] = r0;
                 s_ring[slot * 3 + 1] = r1;
                 s_ring[slot * 3 + 2] = make_float4(r2.x, r2.y, __uint_as_float(wmax - o), __uint_as_float(id_cur));
@@ -313,7 +316,7 @@ __global__ void __launch_bounds__(64, AG_BWD_WAVE_OCC) blend_backward_wave_kerne
             while (cnt - head >= 4 || (last_pass && cnt > head)) {
                 const int idx = head + e;
                 const bool ev = idx < cnt;
-                const int slot = (int)((uint32_t)(ev ? idx : cnt - 1) & (uint32_t)(kRing - 1));
+                const int slot = (kRing & (kRing - 1)) ? (ev ? idx : cnt - 1) % kRing : (int)((uint32_t)(ev ? idx : cnt - 1) & (uint32_t)(kRing - 1));
                 head += 4;
                 const float4 a = s_ring[slot * 3 + 0];   // x, y, conic a, conic b
                 const float4 b = s_ring[slot * 3 + 1];   // conic c, opacity, r, g
