@@ -272,6 +272,72 @@ template <> __device__ __forceinline__ void sort_regs<8>(uint64_t (&v)[8]) { sor
 template <> __device__ __forceinline__ void sort_regs<4>(uint64_t (&v)[4]) { sort4(v); }
 
 constexpr uint64_t kKeyInf = ~0ull;
+
+// ---- wave-level bitonic network: 64 lanes x 4 keys in registers -> one ascending run of 256 (round 3) ----
+// The first six merge rounds of a tile's sort (runs of 4 -> 256) used to go through LDS like the later ones: a merge-path binary search and
+// four dependent LDS reads per thread and round, ~1.6 us each on the bench view's ~1000-entry tiles whatever the run length.  Inside a
+// wave the same merges are 33 compare-exchange stages on registers: element i = lane * 4 + r, partner i ^ j; j = 1, 2 are in the lane's own
+// registers, j = 4 .. 128 are lane ^ 1, 2 (DPP quad_perm), ^ 4, 8, 16 (ds_swizzle bit mode: the LDS crossbar, no memory) and ^ 32 (bpermute).
+// (Round 2 measured a FULL register-held bitonic sort of long tiles slower than the merge sort: its n log^2 n exchanges lose beyond a few
+// hundred keys.  Here the network stops at the wave's 256 keys and the merge-path rounds take over at L = 256.)
+template <int D>
+__device__ __forceinline__ uint32_t lane_xor32(uint32_t v)
+{
+    if constexpr (D == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true);        // quad_perm [1,0,3,2]
+    else if constexpr (D == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
+    else if constexpr (D == 4) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x101f);                     // and 0x1f, xor 4
+    else if constexpr (D == 8) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x201f);
+    else if constexpr (D == 16) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x401f);
+    else return (uint32_t)__shfl_xor((int)v, 32, 64);
+}
+
+template <int D>
+__device__ __forceinline__ uint64_t lane_xor64(uint64_t v)
+{
+    return ((uint64_t)lane_xor32<D>((uint32_t)(v >> 32)) << 32) | lane_xor32<D>((uint32_t)v);
+}
+
+__device__ __forceinline__ void cswap_dir(uint64_t& a, uint64_t& b, bool asc)   // asc: a <= b afterwards, else a >= b
+{
+    const bool sw = (a > b) == asc;
+    const uint64_t x = sw ? b : a, y = sw ? a : b;
+    a = x; b = y;
+}
+
+template <int K, int J>
+__device__ __forceinline__ void bitonic_stage(uint64_t (&v)[4], int lane)
+{
+    const bool asc = (lane & (K / 4)) == 0;        // direction of the run of K this element's merge builds (K = 256: always ascending)
+    if constexpr (J >= 4) {
+        const bool want_min = ((lane & (J / 4)) == 0) == asc;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const uint64_t o = lane_xor64<J / 4>(v[r]);
+            v[r] = ((v[r] < o) == want_min) ? v[r] : o;
+        }
+    } else if constexpr (J == 2) {
+        cswap_dir(v[0], v[2], asc); cswap_dir(v[1], v[3], asc);
+    } else {
+        cswap_dir(v[0], v[1], asc); cswap_dir(v[2], v[3], asc);
+    }
+    if constexpr (J > 1) bitonic_stage<K, J / 2>(v, lane);
+}
+
+// v[0..3] of every lane: any keys -> lane l holds elements 4l .. 4l+3 of the wave's 256 keys in ascending order
+__device__ __forceinline__ void wave_sort256(uint64_t (&v)[4], int lane)
+{
+    sort4(v);
+    if (lane & 1) { uint64_t t = v[0]; v[0] = v[3]; v[3] = t; t = v[1]; v[1] = v[2]; v[2] = t; }   // runs of 4: ascending in even lanes, descending in odd ones
+    bitonic_stage<8, 4>(v, lane);
+    bitonic_stage<16, 8>(v, lane);
+    bitonic_stage<32, 16>(v, lane);
+    bitonic_stage<64, 32>(v, lane);
+    bitonic_stage<128, 64>(v, lane);
+    bitonic_stage<256, 128>(v, lane);
+}
+#ifndef AG_SORT_WAVE_NETWORK
+#define AG_SORT_WAVE_NETWORK 1
+#endif
 constexpr int kSortSmallCap = 2048;   // 512 threads x 4 keys (half the sequential merge steps per round of 256 x 8)
 constexpr int kSortLargeCap = 8192;   // 1024 threads x 8 keys
 
@@ -312,7 +378,10 @@ __device__ __forceinline__ void sort_segment_lds(uint64_t* __restrict__ sk, cons
     const uint32_t base = (uint32_t)tid * (uint32_t)KPT;
 #pragma unroll
     for (int i = 0; i < KPT; i++) v[i] = (base + i < n) ? seg[base + i] : kKeyInf;
-    if (!PRESORTED) sort_regs<KPT>(v);
+    constexpr bool WAVE_RUNS = !PRESORTED && KPT == 4 && AG_SORT_WAVE_NETWORK;   // runs of 256 from the wave network instead of runs of KPT
+    if constexpr (WAVE_RUNS) {
+        if constexpr (KPT == 4) wave_sort256(v, tid & 63);
+    } else if (!PRESORTED) sort_regs<KPT>(v);
     if (base < n) {
 #pragma unroll
         for (int i = 0; i < KPT; i++) bufA[base + i] = v[i];
@@ -320,7 +389,7 @@ __device__ __forceinline__ void sort_segment_lds(uint64_t* __restrict__ sk, cons
     __syncthreads();
     // 2. merge rounds over the first n8 = ceil(n / KPT) * KPT slots
     const uint32_t n8 = (n + (uint32_t)KPT - 1u) & ~((uint32_t)KPT - 1u);
-    for (uint32_t L = PRESORTED ? run0 : (uint32_t)KPT; L < n8; L <<= 1) {
+    for (uint32_t L = PRESORTED ? run0 : (WAVE_RUNS ? 256u : (uint32_t)KPT); L < n8; L <<= 1) {
         if (base < n8) {
             const uint32_t ps = base & ~(2u * L - 1u);          // start of this thread's run pair
             const uint32_t o = base - ps;                        // first output index inside the merged pair
