@@ -93,6 +93,24 @@ __device__ __forceinline__ float row_read(float v, int lane, int k)   // value o
     return __shfl(v, (lane & 48) + k, 64);
 }
 
+// AG_FWD_STATS (diagnostic build only: profiles/ub/build_variant.sh fstats ag_blend_forward -DAG_FWD_STATS, profiles/fwd_step_stats.py): lane 0 of
+// every wave adds its work figures to global counters.  Not compiled into the product.
+#ifdef AG_FWD_STATS
+enum { FS_ITEMS = 0, FS_CHUNKS, FS_LIST, FS_REGION_SURV, FS_SUBCULL_PASSES, FS_WAVE_SURV, FS_STEPS, FS_FAST_STEPS, FS_ACTIVE_PAIRS, FS_BREAKS, FS_N = 12 };
+__device__ unsigned long long g_fwd_stats[FS_N];
+#define FST(k, v) do { if (lane == 0) atomicAdd(&g_fwd_stats[k], (unsigned long long)(v)); } while (0)
+extern "C" int ag_debug_fwd_stats(unsigned long long* out)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return AG_ERR_HIP;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fwd_stats), sizeof(g_fwd_stats)) != hipSuccess) return AG_ERR_HIP;
+    unsigned long long zero[FS_N] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_fwd_stats), zero, sizeof(zero)) != hipSuccess) return AG_ERR_HIP;
+    return AG_OK;
+}
+#else
+#define FST(k, v) do { } while (0)
+#endif
+
 #ifndef AG_FWD_WAVES_PER_SIMD
 #define AG_FWD_WAVES_PER_SIMD 8      // <= 64 VGPRs: four resident workgroups per CU (71 VGPRs without the bound: 58.8 us against 52.2, profiles/ab_fwd.sh)
 #endif
@@ -180,8 +198,10 @@ __global__ void __launch_bounds__(kBlendThreads) blend_forward_kernel(BlendFwdPa
         if (lane == 0) { s_wave_cnt[0][wave] = __popcll(mask); s_wave_done[wave] = 0; }
         lds_barrier();
 
+        if (wave == 0) { FST(FS_ITEMS, 1); FST(FS_LIST, range.y - range.x); }
         int cpar = 0;
         for (uint32_t base = range.x; base < range.y; base += kChunk, cpar ^= 1) {
+            if (wave == 0) FST(FS_CHUNKS, 1);
             // ---- ordered compaction of the survivors into LDS ----
             const uint32_t k = base + tid;
             const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
@@ -211,7 +231,7 @@ __global__ void __launch_bounds__(kBlendThreads) blend_forward_kernel(BlendFwdPa
             // Each wave keeps the indices of the entries whose cut-off disc touches ITS block (same conservative test, so the
             // dropped entries contribute exactly nothing) and blends only those: half the steps of walking the region's list.
             int cntw = 0;
-            {
+            if (!__all(done)) {     // a wave whose four pixels are finished has nothing to pick from this chunk
                 const float bx0 = (float)(rx0 + (wave & 3) * 2), by0 = (float)(ry0 + (wave >> 2) * 2);
                 for (int i0 = 0; i0 < K; i0 += 64) {
                     const int i = i0 + lane;
@@ -229,9 +249,12 @@ __global__ void __launch_bounds__(kBlendThreads) blend_forward_kernel(BlendFwdPa
                 }
             }
 
+            if (wave == 0) FST(FS_REGION_SURV, K);
+            FST(FS_SUBCULL_PASSES, (K + 63) / 64); FST(FS_WAVE_SURV, cntw);
             // ---- blend: 16 entries per step per pixel row ----
             for (int s0 = 0; s0 < cntw; s0 += 16) {
-                if (__all(done)) break;
+                if (__all(done)) { FST(FS_BREAKS, 1); break; }
+                FST(FS_STEPS, 1);
                 const int li = s0 + e;
                 const bool ev = li < cntw;
                 const int ci = s_widx[wave][ev ? li : (cntw - 1)];
@@ -250,7 +273,9 @@ __global__ void __launch_bounds__(kBlendThreads) blend_forward_kernel(BlendFwdPa
                 // the compare's own lane mask), every valid entry blends and the row's next T is lane 15's -- one row_newbcast instead of
                 // the ballot / first-stop / ds_bpermute ladder below.
                 const float stop_t = valid ? testT : 1.0f;
+                FST(FS_ACTIVE_PAIRS, __popcll(__ballot(valid)));
                 if (__ballot(stop_t < 0.0001f) == 0ull) {
+                    FST(FS_FAST_STEPS, 1);
                     const float w = valid ? alpha * Tb : 0.f;
                     Cr += b.z * w;
                     Cg += b.w * w;
