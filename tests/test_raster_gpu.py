@@ -126,6 +126,32 @@ def test_forward_oversized_tile_uses_global_sort():
     h.assert_image_parity(gpu, ref, max_fragile_frac=0.05)
 
 
+def test_tile_sort_every_size_class_is_bit_exact():
+    """One scene whose tile lists span every path of the tile sort -- shorter than one thread's 4 keys, inside one wave's 256-key
+    network, several waves' runs merged through LDS (257 .. 2048), the chunked large class (2049 .. 8192) and the global network
+    beyond -- with a block of exact depth ties (order falls back to the Gaussian index).  Sorted lists and ranges bit-exact against the oracle."""
+    rs = np.random.RandomState(11)
+    P, n_halo = 50000, 400
+    scene = synth.random_gaussians(P=P, img=256)
+    # a dense core (tiles beyond 8192 entries), a wider cloud around it (hundreds to thousands) and a sparse halo (a handful per tile)
+    n1 = P // 3
+    n2 = P - n1 - n_halo
+    halo = np.stack([rs.uniform(-0.5, 0.5, n_halo), rs.uniform(-0.5, 0.5, n_halo), rs.uniform(-0.1, 0.1, n_halo)], 1)
+    scene["means3D"] = np.concatenate([rs.normal(0, 0.025, (n1, 3)), rs.normal(0, 0.12, (n2, 3)), halo]).astype(np.float32)
+    scene["means3D"][: P // 8, 2] = 0.0          # exact depth ties inside the long tiles
+    scene["scales"] = np.full((P, 3), 0.0015, np.float32)
+    scene["opacities"] = np.full((P, 1), 0.05, np.float32)
+    cam = h.cam_of(scene)
+    ref = h.oracle_forward(scene, cam)
+    n = (ref["ranges"][:, 1] - ref["ranges"][:, 0]).astype(np.int64)
+    classes = [(1, 4), (5, 256), (257, 512), (513, 1024), (1025, 2048), (2049, 8192), (8193, 10 ** 9)]
+    have = [int(((n >= lo) & (n <= hi)).sum()) for lo, hi in classes]
+    assert all(have), f"tile-length classes {classes} -> counts {have}: the scene must reach every path"
+    print(f"\n[sort] tiles per length class {dict(zip([c[1] for c in classes], have))}, longest {int(n.max())}")
+    gpu = h.gpu_native_forward(scene, cam)
+    _bitexact(gpu, ref)
+
+
 def _run_autograd(scene, cam, grads):
     import torch
     from animatablegaussians_amd.rasterizer import GaussianRasterizer
