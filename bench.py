@@ -141,12 +141,19 @@ def main() -> None:
             torch.cat(grads, dim=1, out=grad_pack)
             dist.all_reduce(grad_pack)
 
+    # the cameras of a capture rig are fixed: one prepared handle (argument structures + output images) per (camera, stream slot), built
+    # on first use -- inside the warm-up -- as a multi-view trainer would build them once at start-up
+    handles = {}
+
     def step_fused(i: int, slot=None):
         v = (i * world + rank) % len(settings)                     # this rank's view of the step
         k = (i % len(fused.slots)) if slot is None else slot
         if world > 1:
             fused.slots[k]["stream"].wait_stream(comm_stream)       # the slot's gradient arrays are still being packed for step i - n
-        _, _, _, _, g = fused.view(settings[v], det[0], det[1], det[2], det[3], det[4], g_color, g_depth, g_alpha, slot=k)
+        h = handles.get((v, k))
+        if h is None:
+            h = handles[(v, k)] = fused.prepare(settings[v], g_color, g_depth, g_alpha, k)
+        _, _, _, _, g = fused.run(h, det[0], det[1], det[2], det[3], det[4], inputs_outlive_join=True)
         if world > 1:
             exchange([g["dL_dmeans3D"], g["dL_dscales"], g["dL_drotations"], g["dL_dopacity"], g["dL_dcolors"]], fused.slots[k]["stream"])
 

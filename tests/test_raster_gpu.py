@@ -573,6 +573,29 @@ def test_fused_forward_backward_step_equals_the_operator_path():
     ref = one.join()
     assert float((last["dL_dmeans3D"] - ref["dL_dmeans3D"]).abs().max()) <= 2e-5 * float(ref["dL_dmeans3D"].abs().max())
     del g
+    # prepared handles (one per camera and slot, reused over iterations): same images and sums as view(); a second iteration with NEW
+    # input arrays and new image gradients through the same handles picks the new pointers up
+    step = FusedRasterStep(6000, 256, 256, "cuda", n_streams=2)
+    ins = [det[k] for k in ("means3D", "colors", "opacities", "scales", "rotations")]
+    gs = [[t(up["dL_dcolor"]), t(up["dL_ddepth"]), t(up["dL_dalpha"])] for up in ups]
+    handles = [step.prepare(rs, *gs[v], v % 2) for v, rs in enumerate(settings)]
+    for it in range(2):
+        if it == 1:
+            ins = [x.clone() for x in ins]
+            gs = [[x.clone() for x in g3] for g3 in gs]
+        for v, hd in enumerate(handles):
+            color, depth, alpha, radii, _ = step.run(hd, *ins, image_grads=gs[v] if it == 1 else None, accumulate=True,
+                                                     inputs_outlive_join=(it == 1))
+            torch.cuda.synchronize()
+            for a, b, nm in zip((color, depth, alpha, radii), want_img[v], ("color", "depth", "alpha", "radii")):
+                assert torch.equal(a, b), f"prepared view {v}, iteration {it}: {nm} differs from the operator path"
+        got = step.join()
+        torch.cuda.synchronize()
+        for k, w in want.items():
+            scale = float(w.abs().max())
+            assert float((got[k] - w.reshape(got[k].shape)).abs().max()) <= 2e-5 * scale + 1e-9, (k, it)
+    with pytest.raises(RuntimeError):
+        step.run(handles[0], ins[0][:10], *ins[1:])
 
 
 def test_optimistic_forward_is_bit_identical_and_survives_overflow():
