@@ -205,12 +205,19 @@ __global__ void __launch_bounds__(kBlendThreads) blend_forward_kernel(BlendFwdPa
             // ---- ordered compaction of the survivors into LDS ----
             const uint32_t k = base + tid;
             const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-            int off = 0, K = 0;
-#pragma unroll
-            for (int w = 0; w < NW; w++) {
-                const int c = s_wave_cnt[cpar][w];
-                off += (w < wave) ? c : 0;
-                K += c;
+            // offsets of the waves' survivors: lane w reads wave w's count, a three-step DPP prefix sum over the 8 counts, two lane reads
+            // (one LDS read and 7 instructions instead of 8 reads and a 16-instruction scalar loop)
+            int off, K;
+            {
+                static_assert(NW == 8, "the prefix below covers 8 waves");
+                const int c = s_wave_cnt[cpar][lane & 7];
+                int x = c;
+                x += __builtin_amdgcn_update_dpp(0, x, AG_ROW_SHR(1), 0xf, 0xf, true);
+                x += __builtin_amdgcn_update_dpp(0, x, AG_ROW_SHR(2), 0xf, 0xf, true);
+                x += __builtin_amdgcn_update_dpp(0, x, AG_ROW_SHR(4), 0xf, 0xf, true);      // lanes 0..7: inclusive prefix
+                const int wv = __builtin_amdgcn_readfirstlane(wave);
+                off = __builtin_amdgcn_readlane(x, wv) - __builtin_amdgcn_readlane(c, wv);
+                K = __builtin_amdgcn_readlane(x, 7);
             }
             if (keep) {
                 const int slot = off + rank;
@@ -320,10 +327,20 @@ __global__ void __launch_bounds__(kBlendThreads) blend_forward_kernel(BlendFwdPa
         }
 
         // ---- per-pixel totals (lane 15 of each row) and output ----
-        Cr = row_total(Cr); Cg = row_total(Cg); Cb = row_total(Cb); Dd = row_total(Dd); Ws = row_total(Ws);
-        uint32_t lm = last;   // positions grow with e and with the step: the row maximum is the last contributor
-#pragma unroll
-        for (int d = 1; d < 16; d <<= 1) lm = max(lm, (uint32_t)__shfl_up((int)lm, d, 16));
+        // row sums (valid in lane 15) with the shift as the DPP operand of the addition: 4 instructions per value (the compiler's form of
+        // `x += row_shr(x)` is a v_mov_b32_dpp and the add); positions grow with e and with the step, so the row maximum is the last contributor
+        uint32_t lm = last;
+#define AG_ROW_SUM_STEP(N)                                                                                                        \
+        asm volatile("s_nop 1\n\t"                                                                                               \
+                     "v_add_f32_dpp %0, %0, %0 row_shr:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                        \
+                     "v_add_f32_dpp %1, %1, %1 row_shr:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                        \
+                     "v_add_f32_dpp %2, %2, %2 row_shr:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                        \
+                     "v_add_f32_dpp %3, %3, %3 row_shr:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                        \
+                     "v_add_f32_dpp %4, %4, %4 row_shr:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                        \
+                     "v_max_u32_dpp %5, %5, %5 row_shr:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1"                              \
+                     : "+v"(Cr), "+v"(Cg), "+v"(Cb), "+v"(Dd), "+v"(Ws), "+v"(lm));
+        AG_ROW_SUM_STEP(1) AG_ROW_SUM_STEP(2) AG_ROW_SUM_STEP(4) AG_ROW_SUM_STEP(8)
+#undef AG_ROW_SUM_STEP
         if (inside && e == 15) {
             const int pix = p.W * py + px;
             const size_t HW = (size_t)p.W * p.H;
