@@ -124,8 +124,9 @@ __device__ __forceinline__ float wave_reduce16_transposed(float (&v)[16], int la
 //   * lanes = 16 pixels (4 x 4 block) x 4 list entries; lane = y * 16 + e * 4 + x, so a pixel's 4 entries sit in the 4 banks of a DPP
 //     row: the affine-map scan is TWO row_shr steps (4, 8) instead of four, the carry to the next step is a bank-masked row_shl pair,
 //     and the sum over the 16 pixels is the same permlane32/16 swap pair (over y) plus two quad butterflies (over x);
-//   * the wave culls the tile list against ITS 4 x 4 pixels (83 survivors of 363 walked per block on the bench view, against 134 of 446
-//     for the 8x4 region) and blends exactly those: 21 dense steps per block;
+//   * the wave culls the tile list against ITS 4 x 4 pixels (108 survivors of 475 walked per block on bench view 0 -- profiles/
+//     r03_bwd_step_stats.txt -- against 134 of 446 for the 8x4 region) and blends exactly those: 27 dense steps per block, 27 % of their
+//     (pixel, entry) lanes active;
 //   * sums of 16 blended entries collect in a 1-KB wave-private LDS slab and leave as line-coalesced atomics (16 adjacent lanes = one
 //     64-byte accumulator line, as before); line requests: one per (block, survivor) = 0.85 M against 0.68 M -- still far inside
 //     the 20 lines / ns the memory side retires;
@@ -142,7 +143,7 @@ constexpr int kWaveGrid = AG_BWD_WAVE_GRID;              // single-wave workgrou
 #ifndef AG_BWD_RING
 #define AG_BWD_RING 128
 #endif
-constexpr int kRing = AG_BWD_RING;                               // compacted records waiting to be blended (< 4 left over + <= 64 new); power of two: slot = position & 127
+constexpr int kRing = AG_BWD_RING;                       // compacted records waiting to be blended (< 4 left over + <= 64 new); power of two: slot = position & 127
 constexpr int kWin = AG_BWD_WIN;                         // blended entries per atomic flush
 
 struct WaveItemIter {
