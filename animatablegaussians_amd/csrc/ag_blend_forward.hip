@@ -111,6 +111,9 @@ extern "C" int ag_debug_fwd_stats(unsigned long long* out)
 #define FST(k, v) do { } while (0)
 #endif
 
+#ifndef AG_FWD_LDS_PAD
+#define AG_FWD_LDS_PAD 0
+#endif
 #ifndef AG_FWD_WAVES_PER_SIMD
 #define AG_FWD_WAVES_PER_SIMD 8      // <= 64 VGPRs: four resident workgroups per CU (71 VGPRs without the bound: 58.8 us against 52.2, profiles/ab_fwd.sh)
 #endif
@@ -125,6 +128,11 @@ __global__ void __launch_bounds__(kBlendThreads) blend_forward_kernel(BlendFwdPa
     __shared__ int s_wave_cnt[2][NW];
     __shared__ int s_wave_done[NW];
     __shared__ uint16_t s_widx[NW][kChunk];   // per wave: the compacted entries that can reach ITS 2x2 pixels, in list order
+#if AG_FWD_LDS_PAD          /* diagnostic: fewer resident workgroups per CU (profiles/r03_bwd_step_stats.txt: the forward's time against occupancy) */
+    __shared__ uint32_t s_pad[AG_FWD_LDS_PAD / 4];
+    if (threadIdx.x == 0 && blockIdx.x == 0xffffffffu) s_pad[0] = 1u;
+    asm volatile("" :: "v"(s_pad[threadIdx.x & 7]));
+#endif
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int row = lane >> 4, e = lane & 15;
