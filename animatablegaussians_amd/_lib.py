@@ -128,6 +128,8 @@ SYMBOLS = [
     ("ag_fir4x4_noise_bias_act_forward", ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_f, c_f, c_vp]),
     ("ag_fir4x4_noise_bias_act_backward", ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_f, c_f, c_vp]),
     ("ag_block2x2_transform", ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_vp]),
+    ("ag_skip_chain_forward", ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    ("ag_skip_chain_backward", ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
     # include/ag_lpips.h
     ("ag_maxpool2x2_forward", ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_vp]),
     ("ag_maxpool2x2_backward", ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_vp]),

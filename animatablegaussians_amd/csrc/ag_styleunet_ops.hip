@@ -266,6 +266,91 @@ __global__ void __launch_bounds__(256) block2x2_merge_kernel(float* __restrict__
     }
 }
 
+// ToRGB's wavelet-domain skip (dual_styleunet.py:607-633: InverseHaarTransform -> Upsample -> HaarTransform, then added to the layer's output)
+// as ONE linear map [4C, h, w] -> [4C, 2h, 2w].  Each of the three stages is local (a 2 x 2 block transform, a 4-tap FIR after zero
+// stuffing, a 2 x 2 block transform), so the 4 x (2 x 2) outputs of site (i, j) -- sub-band s', parity (py, px) -- depend on the 4 sub-bands
+// of the 3 x 3 sites around it: out[s'][2i+py][2j+px] (+)= sum_{s,a,b} taps[s'][py][px][s][a][b] * skip[s][i+a-1][j+b-1], zero outside (the
+// FIR's zero padding).  The 576 coefficients are derived on the host from the two Haar matrices and the FIR kernel (styleunet_ops.py).
+// One pass over 4 + 16 floats per site instead of four kernels moving 108.
+constexpr int kSkipTaps = 4 * 2 * 2 * 4 * 3 * 3;
+
+struct SkipTaps { float v[kSkipTaps]; };   // by value: the kernel-argument segment, read with scalar loads at compile-time offsets
+
+__global__ void __launch_bounds__(256) skip_chain_forward_kernel(float* __restrict__ out, const float* __restrict__ skip,
+                                                                 const SkipTaps taps, int C, int h, int w, int accumulate)
+{
+    const float* s_t = taps.v;
+    const long long plane = (long long)h * w, total = (long long)C * plane;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int j = (int)(idx % w);
+        const long long r = idx / w;
+        const int i = (int)(r % h), c = (int)(r / h);
+        float in[4][3][3];
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+#pragma unroll
+            for (int a = 0; a < 3; a++)
+#pragma unroll
+                for (int b = 0; b < 3; b++) {
+                    const int ii = i + a - 1, jj = j + b - 1;
+                    in[s][a][b] = (ii >= 0 && ii < h && jj >= 0 && jj < w) ? skip[((size_t)s * C + c) * plane + (size_t)ii * w + jj] : 0.f;
+                }
+#pragma unroll
+        for (int so = 0; so < 4; so++)
+#pragma unroll
+            for (int py = 0; py < 2; py++) {
+                float acc[2] = { 0.f, 0.f };
+#pragma unroll
+                for (int px = 0; px < 2; px++) {
+                    const float* t = s_t + ((so * 2 + py) * 2 + px) * 36;
+#pragma unroll
+                    for (int s = 0; s < 4; s++)
+#pragma unroll
+                        for (int a = 0; a < 3; a++)
+#pragma unroll
+                            for (int b = 0; b < 3; b++) acc[px] = fmaf(t[(s * 3 + a) * 3 + b], in[s][a][b], acc[px]);
+                }
+                float2* dst = reinterpret_cast<float2*>(out + (((size_t)so * C + c) * 2 * h + 2 * i + py) * (2 * (size_t)w) + 2 * j);
+                float2 v = make_float2(acc[0], acc[1]);
+                if (accumulate) { const float2 o = *dst; v.x += o.x; v.y += o.y; }
+                *dst = v;
+            }
+    }
+}
+
+// adjoint: gskip[s][i][j] = sum over the sites (I, J) = (i - a + 1, j - b + 1) that read it, of taps[s'][py][px][s][a][b] * g[s'][2I+py][2J+px]
+__global__ void __launch_bounds__(256) skip_chain_backward_kernel(float* __restrict__ gskip, const float* __restrict__ g,
+                                                                  const SkipTaps taps, int C, int h, int w)
+{
+    const float* s_t = taps.v;
+    const long long plane = (long long)h * w, total = (long long)C * plane;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int j = (int)(idx % w);
+        const long long r = idx / w;
+        const int i = (int)(r % h), c = (int)(r / h);
+        float acc[4] = { 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int b = 0; b < 3; b++) {
+                const int I = i - a + 1, J = j - b + 1;
+                if (I < 0 || I >= h || J < 0 || J >= w) continue;
+#pragma unroll
+                for (int so = 0; so < 4; so++)
+#pragma unroll
+                    for (int py = 0; py < 2; py++) {
+                        const float2 gv = *reinterpret_cast<const float2*>(g + (((size_t)so * C + c) * 2 * h + 2 * I + py) * (2 * (size_t)w) + 2 * J);
+                        const float* t0 = s_t + ((so * 2 + py) * 2 + 0) * 36, *t1 = t0 + 36;
+#pragma unroll
+                        for (int s = 0; s < 4; s++)
+                            acc[s] = fmaf(t0[(s * 3 + a) * 3 + b], gv.x, fmaf(t1[(s * 3 + a) * 3 + b], gv.y, acc[s]));
+                    }
+            }
+#pragma unroll
+        for (int s = 0; s < 4; s++) gskip[((size_t)s * C + c) * plane + (size_t)i * w + j] = acc[s];
+    }
+}
+
 __device__ __forceinline__ int floor_div(int a, int b)
 {
     int c = a / b;
@@ -585,6 +670,35 @@ int ag_block2x2_transform(float* out, const float* in, const float* matrix16, in
     if (merge) hipLaunchKernelGGL(block2x2_merge_kernel, dim3((int)blocks), dim3(256), 0, s, out, in, M, C, h, w);
     else       hipLaunchKernelGGL(block2x2_split_kernel, dim3((int)blocks), dim3(256), 0, s, out, in, M, C, h, w);
     return check_hip(hipGetLastError(), "block2x2 kernel");
+}
+
+int ag_skip_chain_forward(float* out, const float* skip, const float* taps, int32_t C, int32_t h, int32_t w, int32_t accumulate, void* stream)
+{
+    if (C < 0 || h < 0 || w < 0) { set_error("bad skip chain sizes"); return AG_ERR_INVALID_ARGUMENT; }
+    const long long total = (long long)C * h * w;
+    if (total == 0) return AG_OK;
+    if (!out || !skip || !taps) { set_error("null pointer"); return AG_ERR_INVALID_ARGUMENT; }
+    long long blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    SkipTaps t;
+    for (int i = 0; i < kSkipTaps; i++) t.v[i] = taps[i];      // host pointer: passed to the kernel by value
+    hipLaunchKernelGGL(skip_chain_forward_kernel, dim3((int)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), out, skip, t, C, h, w,
+                       accumulate);
+    return check_hip(hipGetLastError(), "skip_chain_forward_kernel");
+}
+
+int ag_skip_chain_backward(float* gskip, const float* gout, const float* taps, int32_t C, int32_t h, int32_t w, void* stream)
+{
+    if (C < 0 || h < 0 || w < 0) { set_error("bad skip chain sizes"); return AG_ERR_INVALID_ARGUMENT; }
+    const long long total = (long long)C * h * w;
+    if (total == 0) return AG_OK;
+    if (!gskip || !gout || !taps) { set_error("null pointer"); return AG_ERR_INVALID_ARGUMENT; }
+    long long blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    SkipTaps t;
+    for (int i = 0; i < kSkipTaps; i++) t.v[i] = taps[i];
+    hipLaunchKernelGGL(skip_chain_backward_kernel, dim3((int)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), gskip, gout, t, C, h, w);
+    return check_hip(hipGetLastError(), "skip_chain_backward_kernel");
 }
 
 int ag_upfirdn2d(float* out, const float* input, const float* kernel, int32_t major, int32_t in_h, int32_t in_w,

@@ -12,7 +12,19 @@ from __future__ import annotations
 import torch
 
 from . import conv as agc
-from .styleunet_ops import (_HAAR_ANALYSIS, _HAAR_SYNTHESIS, _Block2x2, _ModulateWeight, _NoiseBiasAct, _transpose4, _UpFirDn2d)
+import os
+
+from .styleunet_ops import (_HAAR_ANALYSIS, _HAAR_SYNTHESIS, _Block2x2, _ModulateWeight, _NoiseBiasAct, _transpose4, _UpFirDn2d,
+                            skip_chain_backward, skip_chain_forward_)
+
+# ToRGB's iwt -> Upsample -> dwt skip path as one kernel (AG_SKIP_CHAIN=0: the three kernels + the addition, for the A/B and the equality test)
+_SKIP_CHAIN = os.environ.get("AG_SKIP_CHAIN") != "0"
+
+
+def set_skip_chain(on: bool) -> bool:
+    global _SKIP_CHAIN
+    prev, _SKIP_CHAIN = _SKIP_CHAIN, bool(on)
+    return prev
 
 _SQRT2 = 2 ** 0.5
 
@@ -149,12 +161,17 @@ class _ToRGB(torch.autograd.Function):
         s_conv = _Sub()
         out = agc._Conv.forward(s_conv, x, wm, bias, None, agc.AG_CONV, 1, 0, 1.0)
         s_up = None
+        ctx.skip_k = None
         if skip is not None:
-            s_m, s_u, s_s = _Sub(), _Sub(), _Sub()
-            t = _Block2x2.forward(s_m, skip, _HAAR_SYNTHESIS, True)
-            t = _UpFirDn2d.forward(s_u, t, k_blur_up, (2, 2), (1, 1), (2, 1, 2, 1))
-            out.add_(_Block2x2.forward(s_s, t, _HAAR_ANALYSIS, False))
-            s_up = s_u
+            if _SKIP_CHAIN:                                   # one kernel: the composed linear map, accumulated into the layer's output
+                skip_chain_forward_(out, skip, k_blur_up, accumulate=True)
+                ctx.skip_k = k_blur_up                        # a module buffer, not an output of this node: a plain attribute is safe
+            else:
+                s_m, s_u, s_s = _Sub(), _Sub(), _Sub()
+                t = _Block2x2.forward(s_m, skip, _HAAR_SYNTHESIS, True)
+                t = _UpFirDn2d.forward(s_u, t, k_blur_up, (2, 2), (1, 1), (2, 1, 2, 1))
+                out.add_(_Block2x2.forward(s_s, t, _HAAR_ANALYSIS, False))
+                s_up = s_u
         _stash(ctx, (s_mod, s_conv, s_up))
         return out
 
@@ -165,7 +182,9 @@ class _ToRGB(torch.autograd.Function):
         nx, nw, ns, nb, nskip = ctx.needs_input_grad[:5]
         g = g.contiguous()
         gskip = None
-        if s_up is not None and nskip:
+        if ctx.skip_k is not None and nskip:                 # the fused skip path: one adjoint kernel
+            gskip = skip_chain_backward(g, ctx.skip_k)
+        elif s_up is not None and nskip:
             # adjoints of the two fixed 2 x 2 block transforms: the other transform with the transposed matrix
             t = _Block2x2.forward(_Sub(), g, _transpose4(_HAAR_ANALYSIS), True)
             t = _UpFirDn2d.backward(s_up, t)[0]

@@ -26,7 +26,7 @@ import torch.nn.functional as F
 
 from . import conv as agc
 from . import fused_layers
-from .styleunet_ops import fused_leaky_relu, haar_merge, haar_split, modulate_weight, noise_bias_act, upfirdn2d_nchw
+from .styleunet_ops import fused_leaky_relu, haar_merge, haar_split, modulate_weight, noise_bias_act, skip_chain, upfirdn2d_nchw
 
 _SQRT2 = 2 ** 0.5
 # ConvLayer / StyledConv / ToRGB as one autograd node each (fused_layers.py: same kernels, same order, bit-identical results, a third of
@@ -273,9 +273,12 @@ class DualStyleUNet(torch.nn.Module):
         weight = self._modulated_weight(f"{prefix}.conv", w_latent, False)
         out = agc.conv2d(x, weight, bias=self._p(f"{prefix}.bias").reshape(-1), stride=1, padding=0)   # bias in the conv epilogue
         if skip is not None:
-            s = self._haar_merge(skip)
-            s = upfirdn2d_nchw(s, self._k_blur_up, up=2, pad=(2, 1))     # Upsample (:32-50)
-            out = out + self._haar_split(s)
+            if fused_layers._SKIP_CHAIN:
+                out = out + skip_chain(skip, self._k_blur_up)            # iwt -> Upsample -> dwt as one kernel
+            else:
+                s = self._haar_merge(skip)
+                s = upfirdn2d_nchw(s, self._k_blur_up, up=2, pad=(2, 1))     # Upsample (:32-50)
+                out = out + self._haar_split(s)
         return out
 
     def get_latent(self, z):

@@ -319,3 +319,109 @@ def haar_split(x):
 def haar_merge(y):
     """InverseHaarTransform (dual_styleunet.py:406-425): [1, 4C, h, w] -> [1, C, 2h, 2w]."""
     return _Block2x2.apply(y, _HAAR_SYNTHESIS, True)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# ToRGB's skip path as one kernel (round 3): InverseHaarTransform -> Upsample -> HaarTransform (dual_styleunet.py:607-633) is a linear,
+# local map; its coefficients follow from the two 4 x 4 Haar matrices above and the FIR kernel by pushing unit impulses through the
+# three stages on a 5 x 5 grid of sites (numpy on the host, once per FIR kernel).
+# ---------------------------------------------------------------------------------------------------------------------------------
+def skip_chain_taps(k_up) -> "list[float]":
+    """Coefficients [s'][py][px][s][a][b] (4 x 2 x 2 x 4 x 3 x 3) with out[s'][2i+py][2j+px] = sum taps * skip[s][i+a-1][j+b-1].
+    ``k_up``: the 4 x 4 Upsample kernel incl. its gain (``upfirdn2d(x, k_up, up=2, pad=(2, 1))``, dual_styleunet.py:32-50).  Stage
+    semantics: merge / split = the 2 x 2 block transforms above; upfirdn2d = zero stuffing, zero padding (2 before, 1 after),
+    correlation with the flipped kernel (upfirdn2d.py:167-183)."""
+    import numpy as np
+    k = np.asarray(k_up, np.float64).reshape(4, 4)
+    A = np.asarray(_HAAR_ANALYSIS, np.float64).reshape(4, 4)
+    B = np.asarray(_HAAR_SYNTHESIS, np.float64).reshape(4, 4)
+    n = 5
+    taps = np.zeros((4, 2, 2, 4, 3, 3))
+    kf = k[::-1, ::-1]
+    for s in range(4):
+        skip = np.zeros((4, n, n))
+        skip[s, 2, 2] = 1.0
+        M = np.zeros((2 * n, 2 * n))
+        for i in range(n):
+            for j in range(n):
+                o = B @ skip[:, i, j]
+                M[2 * i, 2 * j], M[2 * i, 2 * j + 1], M[2 * i + 1, 2 * j], M[2 * i + 1, 2 * j + 1] = o
+        Z = np.zeros((4 * n, 4 * n))
+        Z[::2, ::2] = M
+        Zp = np.pad(Z, ((2, 1), (2, 1)))
+        U = np.zeros((4 * n, 4 * n))
+        for ky in range(4):
+            for kx in range(4):
+                U += kf[ky, kx] * Zp[ky:ky + 4 * n, kx:kx + 4 * n]
+        O = np.zeros((4, 2 * n, 2 * n))
+        for i in range(2 * n):
+            for j in range(2 * n):
+                O[:, i, j] = A @ np.array([U[2 * i, 2 * j], U[2 * i, 2 * j + 1], U[2 * i + 1, 2 * j], U[2 * i + 1, 2 * j + 1]])
+        inside = np.zeros_like(O, dtype=bool)
+        for a in range(3):
+            for b in range(3):
+                I, J = 2 - (a - 1), 2 - (b - 1)          # the site that reads the impulse at offset (a - 1, b - 1)
+                for py in range(2):
+                    for px in range(2):
+                        taps[:, py, px, s, a, b] = O[:, 2 * I + py, 2 * J + px]
+                        inside[:, 2 * I + py, 2 * J + px] = True
+        if np.abs(O[~inside]).max() != 0.0:
+            raise RuntimeError("skip_chain_taps: the composed map reaches beyond the 3 x 3 neighbourhood (unexpected FIR kernel)")
+    return [float(v) for v in taps.astype(np.float32).reshape(-1)]
+
+
+_SKIP_TAPS = {}
+
+
+def _skip_taps_host(k_up: torch.Tensor):
+    """The 576 coefficients as a ctypes float array (host memory: the library passes them to its kernels by value), cached per kernel
+    tensor -- one read-back of 16 floats the first time."""
+    key = (k_up.device, k_up.data_ptr(), k_up._version)
+    t = _SKIP_TAPS.get(key)
+    if t is None:
+        t = _SKIP_TAPS[key] = (ctypes.c_float * 576)(*skip_chain_taps(k_up.detach().cpu().numpy()))
+    return ctypes.cast(t, ctypes.c_void_p)
+
+
+def skip_chain_forward_(out: torch.Tensor, skip: torch.Tensor, k_up: torch.Tensor, accumulate: bool = True) -> torch.Tensor:
+    """out [1, 4C, 2h, 2w] (+)= HaarTransform(Upsample(InverseHaarTransform(skip [1, 4C, h, w]))) in place; returns ``out``."""
+    if skip.dim() != 4 or skip.shape[0] != 1 or skip.shape[1] % 4 or not skip.is_cuda or skip.dtype != torch.float32:
+        raise RuntimeError("skip_chain: float32 GPU tensor [1, 4C, h, w]")
+    C, h, w = int(skip.shape[1]) // 4, int(skip.shape[2]), int(skip.shape[3])
+    if tuple(out.shape) != (1, 4 * C, 2 * h, 2 * w) or not out.is_contiguous() or out.dtype != torch.float32:
+        raise RuntimeError("skip_chain: out must be a contiguous float32 [1, 4C, 2h, 2w]")
+    skip = skip.contiguous()
+    taps = _skip_taps_host(k_up)
+    with _lib.on_device(skip.device):
+        _lib.check(_lib.lib().ag_skip_chain_forward(_p(out), _p(skip), taps, C, h, w, int(bool(accumulate)), _stream(skip.device)),
+                   "ag_skip_chain_forward")
+    return out
+
+
+def skip_chain_backward(g: torch.Tensor, k_up: torch.Tensor) -> torch.Tensor:
+    """Adjoint of the skip path: g [1, 4C, 2h, 2w] -> gskip [1, 4C, h, w]."""
+    g = g.contiguous()
+    C, h, w = int(g.shape[1]) // 4, int(g.shape[2]) // 2, int(g.shape[3]) // 2
+    gskip = torch.empty((1, 4 * C, h, w), dtype=torch.float32, device=g.device)
+    taps = _skip_taps_host(k_up)
+    with _lib.on_device(g.device):
+        _lib.check(_lib.lib().ag_skip_chain_backward(_p(gskip), _p(g), taps, C, h, w, _stream(g.device)), "ag_skip_chain_backward")
+    return gskip
+
+
+class _SkipChain(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, skip, k_up):
+        C, h, w = int(skip.shape[1]) // 4, int(skip.shape[2]), int(skip.shape[3])
+        out = torch.empty((1, 4 * C, 2 * h, 2 * w), dtype=torch.float32, device=skip.device)
+        ctx.k_up = k_up
+        return skip_chain_forward_(out, skip, k_up, accumulate=False)
+
+    @staticmethod
+    def backward(ctx, g):
+        return skip_chain_backward(g, ctx.k_up), None
+
+
+def skip_chain(skip: torch.Tensor, k_up: torch.Tensor) -> torch.Tensor:
+    """HaarTransform(Upsample(InverseHaarTransform(skip))) as one kernel, differentiable w.r.t. ``skip``."""
+    return _SkipChain.apply(skip, k_up)

@@ -274,3 +274,63 @@ def test_fused_blur_noise_bias_act_equals_the_two_passes_and_the_torch_oracle(C,
     np.testing.assert_allclose(gbn[:C].cpu().numpy(), br.grad.numpy(), rtol=1e-4, atol=1e-4)
     if with_noise:
         np.testing.assert_allclose(float(gbn[C]), float(nwr.grad), rtol=1e-4, atol=1e-3)
+
+
+def test_skip_chain_taps_reproduce_the_reference_chain_on_the_cpu():
+    """The 576 coefficients of ToRGB's composed skip map (styleunet_ops.skip_chain_taps: InverseHaarTransform -> Upsample -> HaarTransform,
+    dual_styleunet.py:607-633) against the three stages run one after the other by the oracle (the reference's own upfirdn2d CPU path
+    restated), float64, odd sizes, every border."""
+    import torch
+    from animatablegaussians_amd.styleunet_ops import skip_chain_taps
+    from oracle import dual_styleunet_oracle as do
+    k = do._fir(gain=4.0, dtype=torch.float64)
+    taps = np.array(skip_chain_taps(k.numpy()), np.float64).reshape(4, 2, 2, 4, 3, 3)
+    assert int((taps != 0).sum()) == 256                      # two of the three row (column) offsets per parity: 4 x 4 x 4 x (2 x 2)
+    rs = np.random.RandomState(0)
+    for C, h, w in ((3, 7, 6), (1, 1, 1), (2, 2, 9)):
+        x = torch.from_numpy(rs.normal(size=(1, 4 * C, h, w)))
+        ref = do.haar_split(do.upfirdn2d(do.haar_merge(x), k, up=2, pad=(2, 1))).numpy()
+        xp = np.pad(x.numpy()[0].reshape(4, C, h, w), ((0, 0), (0, 0), (1, 1), (1, 1)))
+        out = np.zeros((4, C, 2 * h, 2 * w))
+        for so in range(4):
+            for py in range(2):
+                for px in range(2):
+                    acc = np.zeros((C, h, w))
+                    for s in range(4):
+                        for a in range(3):
+                            for b in range(3):
+                                acc += taps[so, py, px, s, a, b] * xp[s, :, a:a + h, b:b + w]
+                    out[so, :, py::2, px::2] = acc
+        assert np.abs(out.reshape(ref.shape) - ref).max() <= 1e-6 * max(1.0, np.abs(ref).max())     # taps are stored as float32
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C,h,w", [(3, 8, 8), (3, 33, 17), (1, 1, 1), (3, 256, 256)])
+def test_skip_chain_kernel_equals_the_three_kernel_path_and_the_oracle(C, h, w):
+    """ag_skip_chain_forward / _backward against (a) the three kernels they replace (block merge, upfirdn2d up = 2, block split) with
+    their autograd, (b) the float64 oracle chain; accumulate mode adds into an existing output."""
+    import torch
+    from animatablegaussians_amd import styleunet_ops as so
+    from oracle import dual_styleunet_oracle as do
+    rs = np.random.RandomState(C * 1000 + h)
+    x_np = rs.normal(size=(1, 4 * C, h, w)).astype(np.float32)
+    g_np = rs.normal(size=(1, 4 * C, 2 * h, 2 * w)).astype(np.float32)
+    k_up = do._fir(gain=4.0).cuda()
+    x1 = torch.from_numpy(x_np).cuda().requires_grad_(True)
+    y1 = so.skip_chain(x1, k_up)
+    y1.backward(torch.from_numpy(g_np).cuda())
+    x2 = torch.from_numpy(x_np).cuda().requires_grad_(True)
+    y2 = so.haar_split(so.upfirdn2d_nchw(so.haar_merge(x2), k_up, up=2, pad=(2, 1)))
+    y2.backward(torch.from_numpy(g_np).cuda())
+    x3 = torch.from_numpy(x_np).double().requires_grad_(True)
+    y3 = do.haar_split(do.upfirdn2d(do.haar_merge(x3), do._fir(gain=4.0, dtype=torch.float64), up=2, pad=(2, 1)))
+    y3.backward(torch.from_numpy(g_np).double())
+    torch.cuda.synchronize()
+    for got, three, ref, nm in ((y1, y2, y3, "forward"), (x1.grad, x2.grad, x3.grad, "gradient")):
+        ref = ref.detach().numpy()
+        scale = max(1.0, float(np.abs(ref).max()))
+        assert float(np.abs(got.detach().cpu().numpy() - ref).max()) <= 2e-6 * scale, nm
+        assert float((got.detach() - three.detach()).abs().max()) <= 2e-6 * scale, nm + " vs the three kernels"
+    base = torch.from_numpy(g_np).cuda().clone()
+    so.skip_chain_forward_(base, x1.detach(), k_up, accumulate=True)
+    assert float((base - (torch.from_numpy(g_np).cuda() + y1.detach())).abs().max()) <= 1e-6 * max(1.0, float(y1.abs().max()))
