@@ -6,6 +6,7 @@
 //   upfirdn2d     : one output element per thread, x-fastest so a wave writes 256 contiguous bytes and its <= 16 taps
 //                   read overlapping contiguous spans that stay in L1/L2 (each input element feeds <= kh*kw/(up^2)
 //                   outputs); the <= 4x4 FIR taps sit in LDS.
+#include <cstring>
 #include "ag_common.h"
 #include "../../include/ag_styleunet.h"
 
@@ -268,86 +269,111 @@ __global__ void __launch_bounds__(256) block2x2_merge_kernel(float* __restrict__
 
 // ToRGB's wavelet-domain skip (dual_styleunet.py:607-633: InverseHaarTransform -> Upsample -> HaarTransform, then added to the layer's output)
 // as ONE linear map [4C, h, w] -> [4C, 2h, 2w].  Each of the three stages is local (a 2 x 2 block transform, a 4-tap FIR after zero
-// stuffing, a 2 x 2 block transform), so the 4 x (2 x 2) outputs of site (i, j) -- sub-band s', parity (py, px) -- depend on the 4 sub-bands
-// of the 3 x 3 sites around it: out[s'][2i+py][2j+px] (+)= sum_{s,a,b} taps[s'][py][px][s][a][b] * skip[s][i+a-1][j+b-1], zero outside (the
-// FIR's zero padding).  The 576 coefficients are derived on the host from the two Haar matrices and the FIR kernel (styleunet_ops.py).
-// One pass over 4 + 16 floats per site instead of four kernels moving 108.
-constexpr int kSkipTaps = 4 * 2 * 2 * 4 * 3 * 3;
-
-struct SkipTaps { float v[kSkipTaps]; };   // by value: the kernel-argument segment, read with scalar loads at compile-time offsets
+// stuffing, a 2 x 2 block transform) and separable, so the 4 x (2 x 2) outputs of site (i, j) -- sub-band s' = (u'y, u'x), parity (py, px) --
+// depend on the 4 sub-bands s = (uy, ux) of the 3 x 3 sites around it through two 1-D maps:
+//   out[(u'y, u'x)][2i+py][2j+px] (+)= sum_{uy,a} wy[u'y][py][uy][a] * sum_{ux,b} wx[u'x][px][ux][b] * skip[(uy, ux)][i+a-1][j+b-1]
+// (zero outside: the FIR's zero padding; sub-band index = uy + 2 ux for the reference's order ll, lh, hl, hh).  The 2 x 24 coefficients
+// are derived on the host from the Haar matrices and the FIR kernel (styleunet_ops.py) and passed by value (48 scalar registers).
+// One pass over 4 + 32 floats per site instead of four kernels moving 108; 240 FMAs per site.
+struct SkipTaps { float wy[2][2][2][3], wx[2][2][2][3]; };
 
 __global__ void __launch_bounds__(256) skip_chain_forward_kernel(float* __restrict__ out, const float* __restrict__ skip,
-                                                                 const SkipTaps taps, int C, int h, int w, int accumulate)
+                                                                 const SkipTaps t, int C, int h, int w, int accumulate)
 {
-    const float* s_t = taps.v;
     const long long plane = (long long)h * w, total = (long long)C * plane;
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
         const int j = (int)(idx % w);
         const long long r = idx / w;
         const int i = (int)(r % h), c = (int)(r / h);
-        float in[4][3][3];
+        float xs[2][3][2][2];                      // [uy][a][u'x][px]: the x stage
 #pragma unroll
-        for (int s = 0; s < 4; s++)
+        for (int uy = 0; uy < 2; uy++)
 #pragma unroll
-            for (int a = 0; a < 3; a++)
+            for (int a = 0; a < 3; a++) {
+                const int ii = i + a - 1;
+                float in[2][3];
 #pragma unroll
-                for (int b = 0; b < 3; b++) {
-                    const int ii = i + a - 1, jj = j + b - 1;
-                    in[s][a][b] = (ii >= 0 && ii < h && jj >= 0 && jj < w) ? skip[((size_t)s * C + c) * plane + (size_t)ii * w + jj] : 0.f;
-                }
+                for (int ux = 0; ux < 2; ux++)
 #pragma unroll
-        for (int so = 0; so < 4; so++)
+                    for (int b = 0; b < 3; b++) {
+                        const int jj = j + b - 1;
+                        in[ux][b] = (ii >= 0 && ii < h && jj >= 0 && jj < w) ? skip[((size_t)(uy + 2 * ux) * C + c) * plane + (size_t)ii * w + jj] : 0.f;
+                    }
 #pragma unroll
-            for (int py = 0; py < 2; py++) {
-                float acc[2] = { 0.f, 0.f };
+                for (int vx = 0; vx < 2; vx++)
 #pragma unroll
-                for (int px = 0; px < 2; px++) {
-                    const float* t = s_t + ((so * 2 + py) * 2 + px) * 36;
+                    for (int px = 0; px < 2; px++) {
+                        float acc = 0.f;
 #pragma unroll
-                    for (int s = 0; s < 4; s++)
+                        for (int ux = 0; ux < 2; ux++)
 #pragma unroll
-                        for (int a = 0; a < 3; a++)
-#pragma unroll
-                            for (int b = 0; b < 3; b++) acc[px] = fmaf(t[(s * 3 + a) * 3 + b], in[s][a][b], acc[px]);
-                }
-                float2* dst = reinterpret_cast<float2*>(out + (((size_t)so * C + c) * 2 * h + 2 * i + py) * (2 * (size_t)w) + 2 * j);
-                float2 v = make_float2(acc[0], acc[1]);
-                if (accumulate) { const float2 o = *dst; v.x += o.x; v.y += o.y; }
-                *dst = v;
-            }
-    }
-}
-
-// adjoint: gskip[s][i][j] = sum over the sites (I, J) = (i - a + 1, j - b + 1) that read it, of taps[s'][py][px][s][a][b] * g[s'][2I+py][2J+px]
-__global__ void __launch_bounds__(256) skip_chain_backward_kernel(float* __restrict__ gskip, const float* __restrict__ g,
-                                                                  const SkipTaps taps, int C, int h, int w)
-{
-    const float* s_t = taps.v;
-    const long long plane = (long long)h * w, total = (long long)C * plane;
-    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
-        const int j = (int)(idx % w);
-        const long long r = idx / w;
-        const int i = (int)(r % h), c = (int)(r / h);
-        float acc[4] = { 0.f, 0.f, 0.f, 0.f };
-#pragma unroll
-        for (int a = 0; a < 3; a++)
-#pragma unroll
-            for (int b = 0; b < 3; b++) {
-                const int I = i - a + 1, J = j - b + 1;
-                if (I < 0 || I >= h || J < 0 || J >= w) continue;
-#pragma unroll
-                for (int so = 0; so < 4; so++)
-#pragma unroll
-                    for (int py = 0; py < 2; py++) {
-                        const float2 gv = *reinterpret_cast<const float2*>(g + (((size_t)so * C + c) * 2 * h + 2 * I + py) * (2 * (size_t)w) + 2 * J);
-                        const float* t0 = s_t + ((so * 2 + py) * 2 + 0) * 36, *t1 = t0 + 36;
-#pragma unroll
-                        for (int s = 0; s < 4; s++)
-                            acc[s] = fmaf(t0[(s * 3 + a) * 3 + b], gv.x, fmaf(t1[(s * 3 + a) * 3 + b], gv.y, acc[s]));
+                            for (int b = 0; b < 3; b++) acc = fmaf(t.wx[vx][px][ux][b], in[ux][b], acc);
+                        xs[uy][a][vx][px] = acc;
                     }
             }
 #pragma unroll
-        for (int s = 0; s < 4; s++) gskip[((size_t)s * C + c) * plane + (size_t)i * w + j] = acc[s];
+        for (int vy = 0; vy < 2; vy++)
+#pragma unroll
+            for (int vx = 0; vx < 2; vx++)
+#pragma unroll
+                for (int py = 0; py < 2; py++) {
+                    float acc[2] = { 0.f, 0.f };
+#pragma unroll
+                    for (int px = 0; px < 2; px++)
+#pragma unroll
+                        for (int uy = 0; uy < 2; uy++)
+#pragma unroll
+                            for (int a = 0; a < 3; a++) acc[px] = fmaf(t.wy[vy][py][uy][a], xs[uy][a][vx][px], acc[px]);
+                    float2* dst = reinterpret_cast<float2*>(out + (((size_t)(vy + 2 * vx) * C + c) * 2 * h + 2 * i + py) * (2 * (size_t)w) + 2 * j);
+                    float2 v = make_float2(acc[0], acc[1]);
+                    if (accumulate) { const float2 o = *dst; v.x += o.x; v.y += o.y; }
+                    *dst = v;
+                }
+    }
+}
+
+// adjoint: gskip[(uy, ux)][i][j] = sum over the sites (I, J) = (i - a + 1, j - b + 1) that read it of
+//          wy[u'y][py][uy][a] * wx[u'x][px][ux][b] * g[(u'y, u'x)][2I+py][2J+px]
+__global__ void __launch_bounds__(256) skip_chain_backward_kernel(float* __restrict__ gskip, const float* __restrict__ g,
+                                                                  const SkipTaps t, int C, int h, int w)
+{
+    const long long plane = (long long)h * w, total = (long long)C * plane;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int j = (int)(idx % w);
+        const long long r = idx / w;
+        const int i = (int)(r % h), c = (int)(r / h);
+        float acc[2][2] = { { 0.f, 0.f }, { 0.f, 0.f } };      // [uy][ux]
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            const int I = i - a + 1;
+            if (I < 0 || I >= h) continue;
+#pragma unroll
+            for (int vy = 0; vy < 2; vy++)
+#pragma unroll
+                for (int py = 0; py < 2; py++) {
+                    float rx[2] = { 0.f, 0.f };                  // [ux]: the x stage of row (I, u'y, py)
+#pragma unroll
+                    for (int b = 0; b < 3; b++) {
+                        const int J = j - b + 1;
+                        if (J < 0 || J >= w) continue;
+#pragma unroll
+                        for (int vx = 0; vx < 2; vx++) {
+                            const float2 gv = *reinterpret_cast<const float2*>(g + (((size_t)(vy + 2 * vx) * C + c) * 2 * h + 2 * I + py) * (2 * (size_t)w) + 2 * J);
+#pragma unroll
+                            for (int ux = 0; ux < 2; ux++)
+                                rx[ux] = fmaf(t.wx[vx][0][ux][b], gv.x, fmaf(t.wx[vx][1][ux][b], gv.y, rx[ux]));
+                        }
+                    }
+#pragma unroll
+                    for (int uy = 0; uy < 2; uy++)
+#pragma unroll
+                        for (int ux = 0; ux < 2; ux++) acc[uy][ux] = fmaf(t.wy[vy][py][uy][a], rx[ux], acc[uy][ux]);
+                }
+        }
+#pragma unroll
+        for (int uy = 0; uy < 2; uy++)
+#pragma unroll
+            for (int ux = 0; ux < 2; ux++) gskip[((size_t)(uy + 2 * ux) * C + c) * plane + (size_t)i * w + j] = acc[uy][ux];
     }
 }
 
@@ -681,7 +707,7 @@ int ag_skip_chain_forward(float* out, const float* skip, const float* taps, int3
     long long blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     SkipTaps t;
-    for (int i = 0; i < kSkipTaps; i++) t.v[i] = taps[i];      // host pointer: passed to the kernel by value
+    memcpy(&t, taps, sizeof(t));                                // host pointer: wy[24] then wx[24], passed to the kernel by value
     hipLaunchKernelGGL(skip_chain_forward_kernel, dim3((int)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), out, skip, t, C, h, w,
                        accumulate);
     return check_hip(hipGetLastError(), "skip_chain_forward_kernel");
@@ -696,7 +722,7 @@ int ag_skip_chain_backward(float* gskip, const float* gout, const float* taps, i
     long long blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     SkipTaps t;
-    for (int i = 0; i < kSkipTaps; i++) t.v[i] = taps[i];
+    memcpy(&t, taps, sizeof(t));
     hipLaunchKernelGGL(skip_chain_backward_kernel, dim3((int)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), gskip, gout, t, C, h, w);
     return check_hip(hipGetLastError(), "skip_chain_backward_kernel");
 }

@@ -370,16 +370,39 @@ def skip_chain_taps(k_up) -> "list[float]":
     return [float(v) for v in taps.astype(np.float32).reshape(-1)]
 
 
+def skip_chain_taps_1d(k_up) -> "list[float]":
+    """The composed map as two 1-D factors: ``wy[u'][p][u][a]`` (24 floats) then ``wx[u'][p][u][b]`` (24), with
+    taps[(u'y, u'x)][py][px][(uy, ux)][a][b] = wy[u'y][py][uy][a] * wx[u'x][px][ux][b] and sub-band index uy + 2 ux (the reference's order
+    ll, lh, hl, hh: 'lh' is high-pass along y).  Every stage is an outer product of 1-D maps when the FIR kernel is (the reference's is:
+    outer([1, 3, 3, 1]), dual_styleunet.py:21-29); a kernel for which the factorisation does not reproduce the 2-D taps is rejected."""
+    import numpy as np
+    W = np.asarray(skip_chain_taps(k_up), np.float64).reshape(4, 2, 2, 4, 3, 3)
+    a0, b0 = np.unravel_index(np.argmax(np.abs(W[0, 0, 0, 0])), (3, 3))
+    ref = W[0, 0, 0, 0, a0, b0]
+    wy = np.zeros((2, 2, 2, 3))
+    wx = np.zeros((2, 2, 2, 3))
+    for v in range(2):
+        for p in range(2):
+            for u in range(2):
+                wy[v, p, u, :] = W[v, p, 0, u, :, b0]                 # x indices fixed at (low, parity 0, low, b0)
+                wx[v, p, u, :] = W[2 * v, 0, p, 2 * u, a0, :] / ref
+    R = np.einsum("vpua,wqxb->vwpquxab", wy, wx)                       # [u'y][u'x][py][px][uy][ux][a][b]
+    R = R.transpose(1, 0, 2, 3, 5, 4, 6, 7).reshape(4, 2, 2, 4, 3, 3)      # sub-band index = uy + 2 ux: ux is the slow index
+    if np.abs(R - W).max() > 1e-6 * np.abs(W).max():
+        raise RuntimeError("skip_chain_taps_1d: the Upsample kernel is not an outer product of 1-D kernels")
+    return [float(x) for x in np.concatenate([wy.reshape(-1), wx.reshape(-1)]).astype(np.float32)]
+
+
 _SKIP_TAPS = {}
 
 
 def _skip_taps_host(k_up: torch.Tensor):
-    """The 576 coefficients as a ctypes float array (host memory: the library passes them to its kernels by value), cached per kernel
+    """The 48 coefficients as a ctypes float array (host memory: the library passes them to its kernels by value), cached per kernel
     tensor -- one read-back of 16 floats the first time."""
     key = (k_up.device, k_up.data_ptr(), k_up._version)
     t = _SKIP_TAPS.get(key)
     if t is None:
-        t = _SKIP_TAPS[key] = (ctypes.c_float * 576)(*skip_chain_taps(k_up.detach().cpu().numpy()))
+        t = _SKIP_TAPS[key] = (ctypes.c_float * 48)(*skip_chain_taps_1d(k_up.detach().cpu().numpy()))
     return ctypes.cast(t, ctypes.c_void_p)
 
 

@@ -92,9 +92,10 @@ int ag_block2x2_transform(float* out, const float* in, const float* matrix16, in
                           void* stream);
 /* Round 3: ToRGB's wavelet-domain skip path (dual_styleunet.py:607-633: InverseHaarTransform :406-425 -> Upsample :32-50 -> HaarTransform
  * :387-403, added to the layer's output) as one linear pass.  skip [4C, h, w] (sub-band-major channels, as torch.cat builds them) ->
- * out [4C, 2h, 2w]; taps: HOST pointer to the 576 coefficients [s'][py][px][s][a][b] of the composed map (passed to the kernel by value; derived from the
- * two Haar matrices and the FIR kernel: styleunet_ops.skip_chain_taps); accumulate != 0 adds into out.  backward: the adjoint, gskip
- * [4C, h, w] from gout [4C, 2h, 2w]. */
+ * out [4C, 2h, 2w]; taps: HOST pointer to the 48 coefficients of the two 1-D factors of the composed map, wy[u'][p][u][a] then
+ * wx[u'][p][u][b] (2 x 2 x 2 x 3 each: output sub-band, output parity, input sub-band, site offset + 1; sub-band index of a channel group =
+ * uy + 2 ux; derived from the Haar matrices and the FIR kernel by styleunet_ops.skip_chain_taps_1d; passed to the kernel by value);
+ * accumulate != 0 adds into out.  backward: the adjoint, gskip [4C, h, w] from gout [4C, 2h, 2w]. */
 int ag_skip_chain_forward(float* out, const float* skip, const float* taps, int32_t C, int32_t h, int32_t w, int32_t accumulate, void* stream);
 int ag_skip_chain_backward(float* gskip, const float* gout, const float* taps, int32_t C, int32_t h, int32_t w, void* stream);
 

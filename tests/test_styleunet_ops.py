@@ -302,6 +302,17 @@ def test_skip_chain_taps_reproduce_the_reference_chain_on_the_cpu():
                                 acc += taps[so, py, px, s, a, b] * xp[s, :, a:a + h, b:b + w]
                     out[so, :, py::2, px::2] = acc
         assert np.abs(out.reshape(ref.shape) - ref).max() <= 1e-6 * max(1.0, np.abs(ref).max())     # taps are stored as float32
+    # the two 1-D factors the kernels take reproduce the 2-D coefficients; a kernel that is not an outer product is refused
+    from animatablegaussians_amd.styleunet_ops import skip_chain_taps_1d
+    f = np.array(skip_chain_taps_1d(k.numpy()), np.float64)
+    wy, wx = f[:24].reshape(2, 2, 2, 3), f[24:].reshape(2, 2, 2, 3)
+    for so in range(4):
+        for s in range(4):
+            want = taps[so, :, :, s]
+            got = np.einsum("pa,qb->pqab", wy[so & 1, :, s & 1, :], wx[so >> 1, :, s >> 1, :])
+            assert np.abs(got - want).max() <= 1e-6
+    with pytest.raises(RuntimeError):
+        skip_chain_taps_1d(np.arange(16.0).reshape(4, 4) + np.eye(4))
 
 
 @pytest.mark.gpu
