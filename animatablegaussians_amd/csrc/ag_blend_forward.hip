@@ -389,9 +389,9 @@ int launch_blend_forward(const AgRasterForwardArgs& a, int R, hipStream_t s)
     p.bg = a.bg;
     p.out_color = a.out_color; p.out_depth = a.out_depth; p.out_alpha = a.out_alpha;
     p.n_contrib = reinterpret_cast<uint32_t*>(ib + il.n_contrib);
-    // 2048 workgroups, of which 1024 (4 per CU) are resident: each takes 2-3 items of the longest-first order by the static
-    // rule, and the hardware dispatcher starts the second half wherever a slot frees up first -- load balancing without
-    // atomics (see kBlendGrid in ag_common.h for the measurements).
+    // up to kBlendGrid (6144) workgroups, of which 1024 (4 per CU) are resident: one item each on avatar views (~5000 region items), the
+    // longest lists first, and the hardware dispatcher starts the rest wherever a slot frees up first -- load balancing without atomics
+    // (see kBlendGrid in ag_common.h for the measurements); beyond that the static rule deals several items per workgroup.
     const long long items = (long long)p.T * kRegionsPerTile;
     const int grid = (int)(items < kBlendGrid ? items : kBlendGrid);
     { ProfScope ps(AG_K_BLEND_FORWARD, s); hipLaunchKernelGGL(blend_forward_kernel, dim3(grid), dim3(kBlendThreads), 0, s, p); }

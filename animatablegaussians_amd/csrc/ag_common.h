@@ -55,9 +55,14 @@ constexpr int kQueues = 8;    // XCDs: the static work assignment keeps all regi
 // and the whole step 10 % SLOWER: device-scope returning atomics take microseconds under the flush traffic).  The hardware
 // dispatcher does it for free: with kBlendGrid = 2048 workgroups each takes 2-3 items by the same static rule and late
 // workgroups start on whichever CU frees a slot first: forward 67 -> 59 us, backward 166 -> 152 us, step +14-20 %.
-// (4096-8192 workgroups: same kernel times, but two concurrent streams then starve each other; 32768: dispatch of empty
-// workgroups costs more than it saves.)
-constexpr int kBlendGrid = 2048;
+// (Rounds 1-2: 4096-8192 workgroups gave the same kernel times and two concurrent streams then starved each other.  Round 3, with the
+// backward on 16384 single-wave workgroups and the leaner forward: 2048 / 4096 / 6144 / 8192 / 16384 workgroups = 50.2 / 47.1 / 46.1 /
+// 46.3 / 48.4 us forward, 7423 / 7501 / 7534 / 7475 / 7375 views/s with three views in flight, 1793 -> 1844 views/s at 2048^2 --
+// profiles/ab_kernels.sh.  One item per workgroup up to 768 active tiles.)
+#ifndef AG_BLEND_GRID
+#define AG_BLEND_GRID 6144
+#endif
+constexpr int kBlendGrid = AG_BLEND_GRID;
 
 struct ItemIter {
     uint32_t i, stride, x, n_active;
