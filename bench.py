@@ -336,7 +336,8 @@ def main() -> None:
         "config": {
             "workload": "BASELINE configs[1]: avatar front|back map, 1 view @1024x1024 per step, rasterizer fwd+bwd "
                         + ("through GaussianRasterizer + torch.autograd" if args.operator_path else
-                           "through the library-owned step (ag_raster_forward_backward, one native call per view)"),
+                           "through the library-owned step (ag_raster_forward_backward, one native call per view; per-camera argument structures and "
+                           "output images prepared once, FusedRasterStep.prepare / run)"),
             "gaussians": P, "instances_per_view": int(R_mean), "tiles": T_tiles, "views": len(settings), "streams": args.streams,
             "parallelism": "1 process" if world == 1 else f"view-sharded x{world}, RCCL all-reduce of per-Gaussian grads (14 f32 each)",
             "backend": None if world == 1 else (backend if backend == "nccl" else f"{backend}: fewer GPUs than ranks, ranks share devices -- a "
