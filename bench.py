@@ -141,9 +141,13 @@ def main() -> None:
             torch.cat(grads, dim=1, out=grad_pack)
             dist.all_reduce(grad_pack)
 
-    # the cameras of a capture rig are fixed: one prepared handle (argument structures + output images) per (camera, stream slot), built
-    # on first use -- inside the warm-up -- as a multi-view trainer would build them once at start-up
+    # the cameras of a capture rig are fixed: one prepared handle (argument structures + output images) per (camera, stream slot), all
+    # built here, before the warm-up, as a multi-view trainer builds them once at start-up (allocation only: no kernel runs)
     handles = {}
+    if not args.operator_path:
+        for v in range(len(settings)):
+            for k in range(len(fused.slots)):
+                handles[(v, k)] = fused.prepare(settings[v], g_color, g_depth, g_alpha, k)
 
     def step_fused(i: int, slot=None):
         v = (i * world + rank) % len(settings)                     # this rank's view of the step
