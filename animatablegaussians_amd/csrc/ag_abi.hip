@@ -252,11 +252,41 @@ int ag_raster_backward(const AgRasterBackwardArgs* a, void* stream)
     return launch_preprocess_backward(*a, s);
 }
 
-int ag_raster_forward_backward(const AgRasterForwardArgs* f, AgRasterBackwardArgs* b, int32_t capacity, void* stream,
-                               int32_t* num_rendered_host)
+// Tickets of views whose instance count has not been read yet (ag_raster_forward_backward_enqueue / ag_raster_collect): a pinned
+// 3-word landing zone and an event each, per device, reused.
+namespace {
+struct Ticket { int32_t* w = nullptr; hipEvent_t ev = nullptr; int dev = -1; int32_t capacity = 0; bool busy = false; };
+constexpr int kTickets = 64;
+Ticket g_tk[kTickets];
+std::mutex g_tk_mu;
+
+int ticket_acquire(int32_t capacity)
 {
-    if (!f || !b || !num_rendered_host) { set_error("null args"); return AG_ERR_INVALID_ARGUMENT; }
-    *num_rendered_host = 0;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(g_tk_mu);
+    for (int pass = 0; pass < 2; pass++)
+        for (int i = 0; i < kTickets; i++) {
+            Ticket& t = g_tk[i];
+            if (t.busy) continue;
+            if (pass == 0 && t.dev != dev) continue;          // first a free ticket of this device, then an unused one
+            if (pass == 1 && t.dev != -1) continue;
+            if (t.dev == -1) {
+                if (hipHostMalloc(reinterpret_cast<void**>(&t.w), 64, hipHostMallocDefault) != hipSuccess) { t.w = nullptr; return -1; }
+                if (hipEventCreateWithFlags(&t.ev, hipEventDisableTiming) != hipSuccess) { (void)hipHostFree(t.w); t.w = nullptr; t.ev = nullptr; return -1; }
+                t.dev = dev;
+            }
+            t.busy = true; t.capacity = capacity;
+            return i;
+        }
+    return -1;
+}
+}  // namespace
+
+int ag_raster_forward_backward_enqueue(const AgRasterForwardArgs* f, AgRasterBackwardArgs* b, int32_t capacity, void* stream, int32_t* ticket)
+{
+    if (!f || !b || !ticket) { set_error("null args"); return AG_ERR_INVALID_ARGUMENT; }
+    *ticket = -1;
     if (capacity <= 0) { set_error("capacity must be positive"); return AG_ERR_INVALID_ARGUMENT; }
     if (f->shs && !f->colors_precomp) { set_error("ag_raster_forward_backward: colours-precomp path only"); return AG_ERR_UNSUPPORTED; }
     // complete the backward arguments from the forward's
@@ -269,28 +299,53 @@ int ag_raster_forward_backward(const AgRasterForwardArgs* f, AgRasterBackwardArg
     int rc = validate_forward(f, true, capacity);
     if (rc) return rc;
     if ((rc = validate_backward(b))) return rc;
-    if (f->P == 0) return ag_raster_forward_render(f, 0, stream);
+    if (f->P == 0) return ag_raster_forward_render(f, 0, stream);           // nothing to count: no ticket (*ticket stays -1)
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    int32_t* w = pinned_word();
-    hipEvent_t ev = plan_event();
-    if (!w || !ev) { set_error("hipHostMalloc / hipEventCreate failed"); return AG_ERR_HIP; }
-    if ((rc = launch_preprocess(*f, s))) return rc;
-    if ((rc = launch_tile_scan(*f, s, (uint32_t)capacity))) return rc;
+    const int tk = ticket_acquire(capacity);
+    if (tk < 0) { set_error("no free read-back ticket (64 views pending) or hipHostMalloc / hipEventCreate failed"); return AG_ERR_HIP; }
+    Ticket& t = g_tk[tk];
+    auto fail = [&](int code) { std::lock_guard<std::mutex> lk(g_tk_mu); t.busy = false; return code; };
+    if ((rc = launch_preprocess(*f, s))) return fail(rc);
+    if ((rc = launch_tile_scan(*f, s, (uint32_t)capacity))) return fail(rc);
     ImageLayout il((size_t)f->W, (size_t)f->H);
     const char* ib = aligned_base(f->image_buffer);
-    if ((rc = check_hip(hipMemcpyAsync(w, ib + il.num_rendered, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, s), "read num_rendered"))) return rc;
-    if ((rc = check_hip(hipEventRecord(ev, s), "record plan event"))) return rc;
-    if ((rc = launch_bin_sort(*f, capacity, s))) return rc;
-    if ((rc = launch_blend_forward(*f, capacity, s))) return rc;
-    if ((rc = launch_blend_backward(*b, s))) return rc;
-    if ((rc = launch_preprocess_backward(*b, s))) return rc;
-    if ((rc = check_hip(hipEventSynchronize(ev), "wait for the instance count"))) return rc;
-    *num_rendered_host = w[0];
-    if (w[2]) {
-        set_error("forward+backward: %d instances exceed the capacity of %d; redo the view with a larger capacity", w[0], capacity);
+    if ((rc = check_hip(hipMemcpyAsync(t.w, ib + il.num_rendered, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, s), "read num_rendered"))) return fail(rc);
+    if ((rc = check_hip(hipEventRecord(t.ev, s), "record plan event"))) return fail(rc);
+    if ((rc = launch_bin_sort(*f, capacity, s))) return fail(rc);
+    if ((rc = launch_blend_forward(*f, capacity, s))) return fail(rc);
+    if ((rc = launch_blend_backward(*b, s))) return fail(rc);
+    if ((rc = launch_preprocess_backward(*b, s))) return fail(rc);
+    *ticket = tk;
+    return AG_OK;
+}
+
+int ag_raster_collect(int32_t ticket, int32_t* num_rendered_host)
+{
+    if (!num_rendered_host) { set_error("null num_rendered_host"); return AG_ERR_INVALID_ARGUMENT; }
+    *num_rendered_host = 0;
+    if (ticket < 0 || ticket >= kTickets || !g_tk[ticket].busy) { set_error("ag_raster_collect: no such pending view (%d)", ticket); return AG_ERR_INVALID_ARGUMENT; }
+    Ticket& t = g_tk[ticket];
+    const int rc = check_hip(hipEventSynchronize(t.ev), "wait for the instance count");
+    const int32_t n = t.w[0], over = t.w[2], cap = t.capacity;
+    { std::lock_guard<std::mutex> lk(g_tk_mu); t.busy = false; }
+    if (rc) return rc;
+    *num_rendered_host = n;
+    if (over) {
+        set_error("forward+backward: %d instances exceed the capacity of %d; redo the view with a larger capacity", n, cap);
         return AG_ERR_SCRATCH_TOO_SMALL;
     }
     return AG_OK;
+}
+
+int ag_raster_forward_backward(const AgRasterForwardArgs* f, AgRasterBackwardArgs* b, int32_t capacity, void* stream,
+                               int32_t* num_rendered_host)
+{
+    if (!num_rendered_host) { set_error("null args"); return AG_ERR_INVALID_ARGUMENT; }
+    *num_rendered_host = 0;
+    int32_t ticket = -1;
+    const int rc = ag_raster_forward_backward_enqueue(f, b, capacity, stream, &ticket);
+    if (rc || ticket < 0) return rc;
+    return ag_raster_collect(ticket, num_rendered_host);
 }
 
 const char* ag_prof_kernel_name(int32_t id)

@@ -368,7 +368,7 @@ class FusedRasterStep:
             self.slots.append(dict(stream=torch.cuda.Stream(self.dev), grads=grads, used=False,
                                    geom=torch.empty((_scratch_bytes("geom", self.P),), **byte),
                                    img=torch.empty((_scratch_bytes("image", self.W, self.H),), **byte),
-                                   accum=torch.empty((_scratch_bytes("accum", self.P),), **byte), binning=None, cap=0))
+                                   accum=torch.empty((_scratch_bytes("accum", self.P),), **byte), binning=None, cap=0, pending=None))
         self._next = 0
 
     def _binning(self, slot, cap):
@@ -427,10 +427,16 @@ class FusedRasterStep:
         """Enqueue forward + backward of a prepared view on its slot's stream.  ``image_grads``: new ``(g_color, g_depth, g_alpha)`` of this
         iteration (None = the ones the handle holds).  ``inputs_outlive_join``: the caller keeps the five input arrays and the image
         gradients alive until :meth:`join` (then their ``record_stream`` bookkeeping, ~1 us each, is skipped).
-        Returns ``(color, depth, alpha, radii, grads)`` like :meth:`view`."""
+        Returns ``(color, depth, alpha, radii, grads)`` like :meth:`view`.
+
+        The host does not wait for the view's instance count here (``ag_raster_forward_backward_enqueue``): it is read when the slot is
+        used next or at :meth:`join` (``ag_raster_collect``).  Should the view turn out to have more instances than the slot's binning
+        buffer holds (first frames of a configuration), it is redone at that point -- until then its images are not valid; the
+        gradient sums are never touched by a view that does not fit."""
         L = _lib.lib()
         P, dev = self.P, self.dev
         sl = self.slots[h.slot]
+        self._collect(sl)                                         # the slot's previous view: its count is known by now (or soon)
         ins = (means3D, colors, opacities, scales, rotations)
         if h.inputs is None or any(x is not y for x, y in zip(ins, h.inputs)) or any(t.data_ptr() != q for t, q in zip(ins, h.in_ptrs)):
             if int(means3D.size(0)) != P:
@@ -445,25 +451,42 @@ class FusedRasterStep:
         b.accumulate = int(bool(accumulate and sl["used"]))       # the slot's first view of a step writes, later ones add
         st = sl["stream"]
         st.wait_stream(torch.cuda.current_stream(dev))            # inputs were produced on the caller's stream
-        R = ctypes.c_int32(0)
         with _on_device(dev):
             cap = _capacity.get(self.key) or (4 * P + 4096)
-            while True:
-                binning = self._binning(sl, cap)
-                a.binning_buffer = binning.data_ptr(); a.binning_bytes = binning.numel()
-                rc = L.ag_raster_forward_backward(ctypes.byref(a), ctypes.byref(b), cap, ctypes.c_void_p(st.cuda_stream), ctypes.byref(R))
-                if rc != _lib.AG_ERR_SCRATCH_TOO_SMALL:
-                    _lib.check(rc, "ag_raster_forward_backward")
-                    break
-                cap = int(R.value) + int(R.value) // 4 + 1024     # outgrown: the sums are untouched, redo the view
-        want = int(R.value) + int(R.value) // 4 + 1024
-        if want > _capacity.get(self.key, 0):
-            _capacity[self.key] = want
+            binning = self._binning(sl, cap)
+            a.binning_buffer = binning.data_ptr(); a.binning_bytes = binning.numel()
+            tk = ctypes.c_int32(-1)
+            _lib.check(L.ag_raster_forward_backward_enqueue(ctypes.byref(a), ctypes.byref(b), cap, ctypes.c_void_p(st.cuda_stream), ctypes.byref(tk)),
+                       "ag_raster_forward_backward_enqueue")
+        if tk.value >= 0:
+            sl["pending"] = (tk.value, h, cap)
         sl["used"] = True
         if not inputs_outlive_join:
             for t in h.checked + h.image_grads:
                 t.record_stream(st)                               # allocator: still in use on the internal stream
         return h.color, h.depth, h.alpha, h.radii, sl["grads"]
+
+    def _collect(self, sl):
+        """Read the instance count of the slot's pending view (waits for its preprocess + scan only).  More instances than the binning
+        buffer was sized for: the view did not touch its outputs or the sums; it is redone here, synchronously, with a larger buffer."""
+        pend = sl.get("pending")
+        if pend is None:
+            return
+        sl["pending"] = None
+        tk, h, cap = pend
+        L = _lib.lib()
+        R = ctypes.c_int32(0)
+        with _on_device(self.dev):
+            rc = L.ag_raster_collect(tk, ctypes.byref(R))
+            while rc == _lib.AG_ERR_SCRATCH_TOO_SMALL:
+                cap = int(R.value) + int(R.value) // 4 + 1024
+                binning = self._binning(sl, cap)
+                h.a.binning_buffer = binning.data_ptr(); h.a.binning_bytes = binning.numel()
+                rc = L.ag_raster_forward_backward(ctypes.byref(h.a), ctypes.byref(h.b), cap, ctypes.c_void_p(sl["stream"].cuda_stream), ctypes.byref(R))
+            _lib.check(rc, "ag_raster_forward_backward")
+        want = int(R.value) + int(R.value) // 4 + 1024
+        if want > _capacity.get(self.key, 0):
+            _capacity[self.key] = want
 
     def view(self, rs: GaussianRasterizationSettings, means3D, colors, opacities, scales, rotations, g_color, g_depth, g_alpha,
              accumulate: bool = False, slot: Optional[int] = None):
@@ -481,6 +504,7 @@ class FusedRasterStep:
                     torch.empty((0,), dtype=torch.int32, device=dev), self.slots[k]["grads"])
         h = self.prepare(rs, g_color, g_depth, g_alpha, k)
         out = self.run(h, means3D, colors, opacities, scales, rotations, accumulate=accumulate)
+        self._collect(self.slots[k])                              # one-off form: the count (and a redo, if needed) before returning
         st = self.slots[k]["stream"]
         for t in h.keep + [h.color, h.depth, h.alpha, h.radii]:
             t.record_stream(st)
@@ -491,6 +515,7 @@ class FusedRasterStep:
         the last ``join()`` (``{name: [P, c] tensor}``; the tensors belong to slot 0 and are overwritten by its next view)."""
         cur = torch.cuda.current_stream(self.dev)
         for sl in self.slots:
+            self._collect(sl)
             cur.wait_stream(sl["stream"])
         used = [sl for sl in self.slots if sl["used"]]
         for sl in self.slots:

@@ -184,6 +184,16 @@ int ag_raster_backward(const AgRasterBackwardArgs* args, void* stream);
 int ag_raster_forward_backward(const AgRasterForwardArgs* fwd, AgRasterBackwardArgs* bwd, int32_t capacity, void* stream,
                                int32_t* num_rendered_host);
 
+/*
+ * The same in two halves, so that the host does not block once per view (round 3): _enqueue issues every kernel of the view and returns a
+ * ticket; ag_raster_collect(ticket) waits for the view's instance count (its preprocess + scan, not its blend kernels), returns it and
+ * reports AG_ERR_SCRATCH_TOO_SMALL exactly as above (the view then did not touch its outputs / sums and has to be redone).  Collect every
+ * ticket (at the latest before the scratch buffers of the view are reused); up to 64 views may be pending.  P == 0: no ticket (-1).
+ */
+int ag_raster_forward_backward_enqueue(const AgRasterForwardArgs* fwd, AgRasterBackwardArgs* bwd, int32_t capacity, void* stream,
+                                       int32_t* ticket);
+int ag_raster_collect(int32_t ticket, int32_t* num_rendered_host);
+
 /* mark_visible (rasterize_points.cu:210-229, rasterizer_impl.cu:54-66,141-152): present[i] = view-space z > 0.2 */
 int ag_raster_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,
                            uint8_t* present, void* stream);
