@@ -239,21 +239,39 @@ def full_step_probe(dev, block=4, blocks=5):
     """bench.py's ``full_step`` leg: BASELINE configs[2] -- the whole training iteration (3 StyleUNets + assembly + LBS + raster,
     loss, backward, fused Adam) at 1 view per step (the reference's own batch shape) and at 4 views of one pose per step, in the product's
     convolution arithmetic; the same two numbers in the other two modes of include/ag_conv.h beside them.  Per mode and batch shape:
-    ``blocks`` blocks of ``block`` pipelined steps (device-synchronised at the block ends), interleaved between the modes so that clock
-    and temperature history are shared; reported = the MEDIAN block (20 steps per figure), with the fastest and slowest beside it."""
+    ``blocks`` blocks of ``block`` pipelined steps (device-synchronised at the block ends), back to back after an allocator reset and
+    three settling steps; reported = the MEDIAN block (20 steps per figure), with the fastest and slowest beside it."""
     from animatablegaussians_amd import conv as agc
     import numpy as np
     step = TrainingStep(dev)
     mode0 = agc.get_math()
     modes = [mode0] + [m for m in ("fp32", "split_bf16x3") if m != mode0]
-    t1 = {m: [] for m in modes}
-    t4 = {m: [] for m in modes}
+    def measure(first_pass):
+        # Per arithmetic mode (the product's first) and batch shape: reset the caching allocator, let it settle for three untimed steps, then
+        # time the blocks back to back.  (Interleaving the modes, as rounds 1-2 did to share clock history, makes the allocator regrow its
+        # pool inside timed blocks -- every mode / shape has its own workspace and activation sizes: reserved memory went 11 -> 31 GiB over
+        # two interleaved passes at 4.5 GiB allocated, with single blocks 2-8x slow.)
+        import torch
+        a1 = {m: [] for m in modes}
+        a4 = {m: [] for m in modes}
+        for m in modes:
+            agc.set_math(m)
+            for V, acc in ((1, a1), (4, a4)):
+                torch.cuda.empty_cache()
+                timed(lambda i: step(i, V), 1, 2, dev)
+                for _rep in range(blocks):
+                    acc[m].append(timed(lambda i: step(i, V), block, 0, dev))
+        return a1, a4
+
+    # A block of the product mode more than 3x slower than its fastest one means the pass was disturbed (seen once in ~12 fresh-box runs: the
+    # first process on a box, every block of the leg 8x slow while the legs before it were normal).  The pass is then repeated once and
+    # the disturbed one is reported beside the result instead of inside it.
+    discarded = None
     try:
-        for _rep in range(blocks):
-            for m in modes:
-                agc.set_math(m)
-                t1[m].append(timed(lambda i: step(i, 1), block, 1 if _rep else 2, dev))
-                t4[m].append(timed(lambda i: step(i, 4), block, 1 if _rep else 2, dev))
+        t1, t4 = measure(True)
+        if os.environ.get("AG_BENCH_FORCE_REMEASURE") == "1" or max(t1[mode0]) > 3.0 * min(t1[mode0]) or max(t4[mode0]) > 3.0 * min(t4[mode0]):
+            discarded = {"ms_per_step_1view": [round(float(x), 2) for x in t1[mode0]], "ms_per_step_4views": [round(float(x), 2) for x in t4[mode0]]}
+            t1, t4 = measure(False)
     finally:
         agc.set_math(mode0)
 
@@ -268,7 +286,9 @@ def full_step_probe(dev, block=4, blocks=5):
            "conv_math": mode0}
     out.update(rec(mode0))
     out.update({"steps_timed": [block * blocks, block * blocks], "parameters": step.n_params,
-                "note": f"{blocks} blocks of {block} pipelined steps per arithmetic mode and batch shape, interleaved; the median block"})
+                "note": f"{blocks} blocks of {block} pipelined steps per arithmetic mode and batch shape, back to back after an allocator reset and 3 settling steps; the median block"})
+    if discarded is not None:
+        out["discarded_first_pass"] = dict(discarded, reason="a block more than 3x slower than the fastest of its pass: the pass was repeated once")
     keys = {"fp32": "conv_math_fp32", "split_bf16x3": "conv_math_split_bf16x3_opt_in_not_fp32_grade", "split_bf16": "conv_math_split_bf16"}
     for m in modes[1:]:
         out[keys[m]] = rec(m)
