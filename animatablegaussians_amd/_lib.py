@@ -91,6 +91,29 @@ class AgLayerArgs(ctypes.Structure):          # include/ag_layers.h
                 + [("want_bias", c_i32), ("want_noise_weight", c_i32)])
 
 
+AG_MAX_GROUPS = 16
+_PTRS = c_vp * AG_MAX_GROUPS
+
+
+class AgGroupedLayerArgs(ctypes.Structure):   # include/ag_layers.h
+    _fields_ = ([(n, c_i32) for n in ("G", "Cin", "Cout", "H", "W", "k", "resample", "modulated")]
+                + [(n, c_f) for n in ("scale", "slope", "act_scale", "reserved_f")]
+                + [("x", c_vp), ("x_group_stride", ctypes.c_int64)]
+                + [(n, _PTRS) for n in ("weight", "style", "noise", "noise_weight", "act_bias")]
+                + [(n, c_vp) for n in ("k_blur", "w_mod", "demod", "x_blur", "out", "scratch", "workspace")]
+                + [("workspace_bytes", c_sz)]
+                + [(n, c_vp) for n in ("g_out", "g_x", "g_weight", "g_style", "g_bias_noise")]
+                + [("want_bias", c_i32), ("want_noise_weight", c_i32)])
+
+
+class AgGroupedToRgbArgs(ctypes.Structure):   # include/ag_layers.h
+    _fields_ = ([(n, c_i32) for n in ("G", "Cin", "Cout", "H", "W")] + [("scale", c_f), ("x", c_vp)]
+                + [(n, _PTRS) for n in ("weight", "style", "bias")]
+                + [(n, c_vp) for n in ("skip", "skip_taps", "w_mod", "out", "scratch", "workspace")]
+                + [("workspace_bytes", c_sz)]
+                + [(n, c_vp) for n in ("g_out", "g_x", "g_weight", "g_style", "g_skip")])
+
+
 class AgSmplxModel(ctypes.Structure):
     _fields_ = [("V", c_i32), ("J", c_i32), ("NB", c_i32), ("reserved", c_i32)] + [(n, c_vp) for n in (
         "v_template", "shapedirs", "posedirs", "J_regressor", "parents", "lbs_weights", "joint_template", "joint_dirs")]
@@ -122,14 +145,14 @@ SYMBOLS = [
     ("ag_debug_atomic_rate", ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
     ("ag_noise_bias_act_forward", ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_float,
                                                ctypes.c_float, c_vp]),
-    ("ag_noise_bias_act_backward", ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_int32, ctypes.c_int32,
+    ("ag_noise_bias_act_partial_floats", c_sz, [c_i32, c_i32]),
+    ("ag_noise_bias_act_backward", ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_int32, ctypes.c_int32,
                                                 ctypes.c_float, ctypes.c_float, c_vp]),
     ("ag_modulate_weight_forward", ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, ctypes.c_float, ctypes.c_int32, ctypes.c_int32,
                                                 ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_vp]),
-    ("ag_modulate_weight_backward", ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_float, ctypes.c_int32,
+    ("ag_modulate_weight_partial_floats", c_sz, [c_i32, c_i32]),
+    ("ag_modulate_weight_backward", ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_float, ctypes.c_int32,
                                                  ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_vp]),
-    ("ag_fir4x4_noise_bias_act_forward", ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_f, c_f, c_vp]),
-    ("ag_fir4x4_noise_bias_act_backward", ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_f, c_f, c_vp]),
     ("ag_block2x2_transform", ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_vp]),
     ("ag_skip_chain_forward", ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
     ("ag_skip_chain_backward", ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
@@ -164,6 +187,18 @@ SYMBOLS = [
     ("ag_layer_scratch_floats", c_sz, [ctypes.POINTER(AgLayerArgs), c_i32]),
     ("ag_layer_forward", ctypes.c_int, [ctypes.POINTER(AgLayerArgs), c_vp]),
     ("ag_layer_backward", ctypes.c_int, [ctypes.POINTER(AgLayerArgs), c_vp]),
+    ("ag_grouped_layer_args_bytes", c_sz, []),
+    ("ag_grouped_layer_output_size", ctypes.c_int, [ctypes.POINTER(AgGroupedLayerArgs), ctypes.POINTER(c_i32), ctypes.POINTER(c_i32)]),
+    ("ag_grouped_layer_scratch_floats", c_sz, [ctypes.POINTER(AgGroupedLayerArgs), c_i32]),
+    ("ag_grouped_layer_workspace_bytes", c_sz, [ctypes.POINTER(AgGroupedLayerArgs)]),
+    ("ag_grouped_layer_forward", ctypes.c_int, [ctypes.POINTER(AgGroupedLayerArgs), c_vp]),
+    ("ag_grouped_layer_backward", ctypes.c_int, [ctypes.POINTER(AgGroupedLayerArgs), c_vp]),
+    ("ag_grouped_to_rgb_args_bytes", c_sz, []),
+    ("ag_grouped_to_rgb_scratch_floats", c_sz, [ctypes.POINTER(AgGroupedToRgbArgs), c_i32]),
+    ("ag_grouped_to_rgb_workspace_bytes", c_sz, [ctypes.POINTER(AgGroupedToRgbArgs)]),
+    ("ag_grouped_to_rgb_forward", ctypes.c_int, [ctypes.POINTER(AgGroupedToRgbArgs), c_vp]),
+    ("ag_grouped_to_rgb_backward", ctypes.c_int, [ctypes.POINTER(AgGroupedToRgbArgs), c_vp]),
+    ("ag_grouped_block2x2", ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     # include/ag_conv.h
     ("ag_conv_output_size", ctypes.c_int, [ctypes.POINTER(AgConvDesc), ctypes.POINTER(c_i32), ctypes.POINTER(c_i32)]),
     ("ag_conv_workspace_bytes", c_sz, [ctypes.POINTER(AgConvDesc)]),

@@ -399,9 +399,32 @@ class AvatarNet(nn.Module):
             g = self._graphs[key] = _Graphed(fn, inputs)
         return g(*inputs)
 
+    def _grouped_nets(self):
+        """The grouped executor over (position, colour, other) -- networks with equal ToRGB widths next to each other -- or None when
+        AG_GROUPED=0 / ``set_grouped(False)`` selects the one-network-at-a-time path (A/B measurements, the equality test)."""
+        if not getattr(self, "_use_grouped", os.environ.get("AG_GROUPED") != "0"):
+            return None
+        g = getattr(self, "_grouped", None)
+        if g is None:
+            from .grouped import GroupedStyleUNets
+            nets = [self.position_net, self.color_net, self.other_net]
+            g = self._grouped = GroupedStyleUNets(nets) if GroupedStyleUNets.supported(nets) else False
+        return g or None
+
+    def set_grouped(self, on: bool) -> bool:
+        prev = getattr(self, "_use_grouped", os.environ.get("AG_GROUPED") != "0")
+        self._use_grouped = bool(on)
+        return prev
+
     def get_maps(self, pose_map, front_viewdirs=None, back_viewdirs=None):
         """The three StyleUNet evaluations of ``get_positions`` / ``get_others`` / ``get_colors``  (:93-124), raw maps."""
         x = pose_map[None].contiguous()
+        if self._graphs_active() and self._grouped_nets() is not None:        # ONE capture of the grouped chain of all three networks
+            def all_fn(p, f, b):
+                pm, cm, om = self._grouped_nets().forward([self.position_style, self.color_style, self.other_style], p,
+                                                          {1: (f, b)} if f is not None else None)
+                return pm, om, cm
+            return tuple(self._graphed(("grouped", front_viewdirs is not None), all_fn, [x, front_viewdirs, back_viewdirs]))
         if self._graphs_active():
             (position_map,) = self._graphed("position", lambda p: self.position_net([self.position_style], p, randomize_noise=False)[0], [x])
             (other_map,) = self._graphed("other", lambda p: self.other_net([self.other_style], p, randomize_noise=False)[0], [x])
@@ -411,6 +434,11 @@ class AvatarNet(nn.Module):
                 [x, front_viewdirs, back_viewdirs])
             return position_map, other_map, color_map
         color_style = torch.rand_like(self.color_style) if self.random_style and self.training else self.color_style
+        grouped = self._grouped_nets()
+        if grouped is not None:                      # the three networks as ONE launch chain (grouped.py): G = 3 encoders, G = 6 decoders
+            vf = {1: (front_viewdirs, back_viewdirs)} if front_viewdirs is not None else None
+            position_map, color_map, other_map = grouped.forward([self.position_style, color_style, self.other_style], x, vf)
+            return position_map, other_map, color_map
         position_map, other_map, color_map = self._concurrently([
             lambda: self.position_net([self.position_style], x, randomize_noise=False)[0],
             lambda: self.other_net([self.other_style], x, randomize_noise=False)[0],
@@ -514,7 +542,16 @@ class AvatarNet(nn.Module):
         pose_map = items['smpl_pos_map'][:3]
         x = pose_map[None].contiguous()
         feats = [self.get_viewdir_feat({**items, **v}) if self.with_viewdirs else (None, None) for v in views]
-        if self._graphs_active():
+        if self._graphs_active() and self._grouped_nets() is not None:        # one capture per view count: shared stages once, the tail per view
+            nv = len(views)
+
+            def views_fn(p, *fb):
+                vf = {1: [(fb[2 * i], fb[2 * i + 1]) for i in range(nv)]}
+                pm, cms, om = self._grouped_nets().forward([self.position_style, self.color_style, self.other_style], p, vf)
+                return (pm, om, *cms)
+            outs = self._graphed(("grouped_views", nv, self.with_viewdirs), views_fn, [x] + [t for fb in feats for t in fb])
+            position_map, other_map, color_maps = outs[0], outs[1], [c.clone() for c in outs[2:]]
+        elif self._graphs_active():
             (position_map,) = self._graphed("position", lambda p: self.position_net([self.position_style], p, randomize_noise=False)[0], [x])
             (other_map,) = self._graphed("other", lambda p: self.other_net([self.other_style], p, randomize_noise=False)[0], [x])
             cn = self.color_net
@@ -537,6 +574,10 @@ class AvatarNet(nn.Module):
             for f, b in feats:
                 (cm,) = self._graphed(("color_view", f is not None), view_fn, [f, b])
                 color_maps.append(cm.clone())     # the capture's output buffer is reused by the next view
+        elif self._grouped_nets() is not None:
+            color_style = torch.rand_like(self.color_style) if self.random_style and self.training else self.color_style
+            vf = {1: [fb for fb in feats]} if self.with_viewdirs else {1: [(None, None)] * len(feats)}
+            position_map, color_maps, other_map = self._grouped_nets().forward([self.position_style, color_style, self.other_style], x, vf)
         else:
             color_style = torch.rand_like(self.color_style) if self.random_style and self.training else self.color_style
             position_map, other_map, color_maps = self._concurrently([

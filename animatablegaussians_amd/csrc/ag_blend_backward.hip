@@ -411,7 +411,10 @@ __global__ void __launch_bounds__(64, AG_BWD_WAVE_OCC) blend_backward_wave_kerne
                 // carry: the product up to entry 3 to all four lanes of the pixel; the state behind entry 3 to bank 0 (zero elsewhere)
                 P = from_entry3(Pe);
                 // (one v_mul_f32_dpp: bank 3's value rotated into bank 0, times the lane constant 1 in bank 0 / 0 elsewhere)
-                asm volatile("v_mul_f32_dpp %0, %1, %2 row_ror:4 row_mask:0xf bank_mask:0xf" : "=&v"(S) : "v"(B), "v"(bank0));
+                // s_nop 1: B was written by the inline-asm scan above, which the compiler's hazard recogniser does not see -- a VALU write needs two
+                // wait states before a DPP read of the same register (as the other DPP blocks of this kernel do)
+                asm volatile("s_nop 1\n\t"
+                             "v_mul_f32_dpp %0, %1, %2 row_ror:4 row_mask:0xf bank_mask:0xf" : "=&v"(S) : "v"(B), "v"(bank0));
 
 #if AG_BWD_KNOCKOUT & 4     /* diagnostic: no sum over the pixels, no window */
                 { float acc = 0.f; for (int i = 0; i < 10; i++) acc += v[i]; asm volatile("" :: "v"(acc)); win = 0; continue; }

@@ -29,6 +29,7 @@
 #include <cstdlib>
 
 #include "ag_common.h"
+#include "ag_groups.h"
 #include "../../include/ag_conv.h"
 #include "../../include/ag_raster.h"   // AgKernelId (timing hooks)
 
@@ -36,10 +37,12 @@ namespace ag {
 
 // ag_conv_pointwise.hip: 1 x 1 convolutions with <= 32 output rows or <= 4 input channels as streaming VALU kernels.
 // Return 1 when they handled the call, 0 when it is not theirs (the MFMA path below runs), < 0 on error.
-int pointwise_forward(const AgConvDesc* d, const float* x, const float* w, const float* out_scale, const float* bias, float* y, hipStream_t s);
-int pointwise_backward_input(const AgConvDesc* d, const float* dy, const float* w, float* dx, hipStream_t s);
-int pointwise_backward_weight(const AgConvDesc* d, const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes,
-                              hipStream_t s);
+// Grouped (ag_groups.h): G instances, activations at the given float strides, weights / biases from pointer tables, dw stacked.
+int pointwise_forward(const AgConvDesc* d, int G, const float* x, long long x_gs, const PtrTable& w, const float* out_scale, const PtrTable& bias,
+                      float* y, long long y_gs, hipStream_t s);
+int pointwise_backward_input(const AgConvDesc* d, int G, const float* dy, long long dy_gs, const PtrTable& w, float* dx, long long dx_gs, hipStream_t s);
+int pointwise_backward_weight(const AgConvDesc* d, int G, const float* x, long long x_gs, const float* dy, long long dy_gs, float* dw, long long dw_gs,
+                              void* workspace, size_t workspace_bytes, hipStream_t s);
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: HIP's float4 struct in arrays defeats SROA (scratch spills)
@@ -129,8 +132,7 @@ struct GatherProblem {
     const float* xin;      // [Cg][Hg][Wg]
     const float* At;       // per class: tile-blocked packed weights [Mpad / BM][nkt][BM][16]
     float* yout;           // [M][OHf][OWf]
-    const float* out_scale;
-    const float* bias;
+    const float* out_scale;  // [M] or null (G = 1 only)
     int Cg, Cpad, Hg, Wg;  // Cpad = channels rounded up to BK: every K tile lies inside one tap
     int M, Mpad, OHf, OWf;
     int os;                // output stride of the class grids (1: plain gather, 2: parity classes)
@@ -138,18 +140,44 @@ struct GatherProblem {
     int nclasses, Ncols;   // Ncols = sum over classes of gh * gw
     int kt_per_split;      // K tiles per blockIdx.z slice (gridDim.z == 1: all of them)
     float* partial;        // gridDim.z > 1: raw accumulators go to partial[z][Mpad][Ncols] and reduce_splits_kernel finishes
+    // grouped launch (ag_groups.h): gridDim.y = G * mtiles, instance = blockIdx.y / mtiles
+    int G, mtiles;
+    long long x_gs, y_gs;  // floats between the instances' inputs (0: one shared input) / outputs
+    long long at_gs;       // packed-weight elements (the unit of GatherClass::at_off) between the instances' packed weights
+    long long part_gs;     // floats between the instances' split-K partial images (= splits * Mpad * Ncols)
+    PtrTable bias_t;       // per-instance bias (replaces `bias`, which is kept for the epilogue's signature and set per workgroup)
     GatherClass cls[kMaxClasses];
 };
 
+// what a workgroup of a grouped launch works on
+struct GroupView {
+    int grp, my;                 // instance, M tile inside the instance
+    const float* xin;
+    float* yout;
+    float* partial;
+    const float* bias;
+};
+__device__ __forceinline__ GroupView group_view(const GatherProblem& p)
+{
+    GroupView v;
+    v.grp = (int)blockIdx.y / p.mtiles;
+    v.my = (int)blockIdx.y - v.grp * p.mtiles;
+    v.xin = p.xin + (size_t)v.grp * p.x_gs;
+    v.yout = p.yout + (size_t)v.grp * p.y_gs;
+    v.partial = p.partial ? p.partial + (size_t)v.grp * p.part_gs : nullptr;
+    v.bias = p.bias_t.p[v.grp];
+    return v;
+}
+
 // Epilogue shared by the gather kernels.  C/D layout of the 32 x 32 MFMAs: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
 template <int WMB, int WNB>
-__device__ __forceinline__ void gather_epilogue(const GatherProblem& p, const GatherClass& cl, f32x16 (&acc)[WMB][WNB], int m0, int n0,
-                                                int N, int wm, int wn, int lane)
+__device__ __forceinline__ void gather_epilogue(const GatherProblem& p, const GroupView& gv, const GatherClass& cl, f32x16 (&acc)[WMB][WNB], int m0,
+                                                int n0, int N, int wm, int wn, int lane)
 {
     const int gw = cl.gw;
     const int col = lane & 31, rbase = 4 * (lane >> 5);
     if (gridDim.z > 1) {
-        float* part = p.partial + (size_t)blockIdx.z * p.Mpad * p.Ncols + cl.col_begin;
+        float* part = gv.partial + (size_t)blockIdx.z * p.Mpad * p.Ncols + cl.col_begin;
 #pragma unroll
         for (int i = 0; i < WMB; i++)
 #pragma unroll
@@ -173,15 +201,15 @@ __device__ __forceinline__ void gather_epilogue(const GatherProblem& p, const Ga
         const int oy = q / gw, ox = q - oy * gw;
         opix[j] = (size_t)(cl.y0 + oy * p.os) * p.OWf + (cl.x0 + ox * p.os);
     }
-    const bool has_scale = p.out_scale != nullptr, has_bias = p.bias != nullptr;
+    const bool has_scale = p.out_scale != nullptr, has_bias = gv.bias != nullptr;
 #pragma unroll
     for (int i = 0; i < WMB; i++)
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int m = m0 + (wm * WMB + i) * 32 + (r & 3) + 8 * (r >> 2) + rbase;
             if (m >= p.M) continue;
-            const float sc = has_scale ? p.out_scale[m] : 1.f, bi = has_bias ? p.bias[m] : 0.f;
-            float* row = p.yout + (size_t)m * p.OHf * p.OWf;
+            const float sc = has_scale ? p.out_scale[m] : 1.f, bi = has_bias ? gv.bias[m] : 0.f;
+            float* row = gv.yout + (size_t)m * p.OHf * p.OWf;
 #pragma unroll
             for (int j = 0; j < WNB; j++)
                 if (nn[j] < N) row[opix[j]] = acc[i][j][r] * sc + bi;
@@ -219,7 +247,8 @@ __global__ void __launch_bounds__(64 * WVM * WVN, AG_CONV_WAVES_PER_SIMD) gather
     const GatherClass& cl = p.cls[ci];
     const int gw = cl.gw, ntaps = cl.ntaps;
     const int N = cl.gh * gw;
-    const int m0 = blockIdx.y * BM, n0 = ((int)blockIdx.x - cl.tile_begin) * BN;
+    const GroupView gv = group_view(p);
+    const int m0 = gv.my * BM, n0 = ((int)blockIdx.x - cl.tile_begin) * BN;
 
     const int n_loc = tid % BN, g = (wave * 64) / BN;   // g is wave-uniform (BN >= 64)
     const int n = n0 + n_loc;
@@ -250,9 +279,9 @@ __global__ void __launch_bounds__(64 * WVM * WVN, AG_CONV_WAVES_PER_SIMD) gather
     int t_cur = kt_beg % ntaps;
     int c_cur = (kt_beg / ntaps) * BK + g * KG;
     const size_t plane_b = (size_t)p.Hg * p.Wg * sizeof(float);
-    const char* const xin_b = reinterpret_cast<const char*>(p.xin);
+    const char* const xin_b = reinterpret_cast<const char*>(gv.xin);
     const int c_last = p.Cg - 1;
-    const char* a_ptr = reinterpret_cast<const char*>(p.At + cl.at_off + ((size_t)blockIdx.y * nkt_all + kt_beg) * (BM * BK));
+    const char* a_ptr = reinterpret_cast<const char*>(p.At + (size_t)gv.grp * p.at_gs + cl.at_off + ((size_t)gv.my * nkt_all + kt_beg) * (BM * BK));
     const uint32_t a_voff = (uint32_t)min(tid, AF - 1) * 16u;       // threads past the tile re-read its last float4
 
     // Three-stage software pipeline.  While the MFMAs of tile k run from operand registers, tile k+1 moves
@@ -341,7 +370,7 @@ __global__ void __launch_bounds__(64 * WVM * WVN, AG_CONV_WAVES_PER_SIMD) gather
     }
     // (the gather kernel above and the wgrad kernel below share this loop shape)
 
-    gather_epilogue<WMB, WNB>(p, cl, acc, m0, n0, N, wm, wn, lane);
+    gather_epilogue<WMB, WNB>(p, gv, cl, acc, m0, n0, N, wm, wn, lane);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -462,7 +491,8 @@ __global__ void __launch_bounds__(64 * WVM * WVN, AG_CONV_WAVES_PER_SIMD) gather
     const GatherClass& cl = p.cls[ci];
     const int gw = cl.gw, ntaps = cl.ntaps;
     const int N = cl.gh * gw;
-    const int m0 = blockIdx.y * BM, n0 = ((int)blockIdx.x - cl.tile_begin) * BN;
+    const GroupView gv = group_view(p);
+    const int m0 = gv.my * BM, n0 = ((int)blockIdx.x - cl.tile_begin) * BN;
 
     const int n_loc = tid % BN, g = (wave * 64) / BN;
     const int n = n0 + n_loc;
@@ -492,10 +522,10 @@ __global__ void __launch_bounds__(64 * WVM * WVN, AG_CONV_WAVES_PER_SIMD) gather
     int t_cur = kt_beg % ntaps;
     int c_cur = (kt_beg / ntaps) * BK + g * KG;
     const size_t plane_b = (size_t)p.Hg * p.Wg * sizeof(float);
-    const char* const xin_b = reinterpret_cast<const char*>(p.xin);
+    const char* const xin_b = reinterpret_cast<const char*>(gv.xin);
     const int c_last = p.Cg - 1;
     // packed weights: cl.at_off counts fp32-tile floats (BM * 16 per tile); a split tile has a_bytes = 6 bytes per element
-    const char* a_ptr = reinterpret_cast<const char*>(p.At) + (size_t)cl.at_off * 6 + ((size_t)blockIdx.y * nkt_all + kt_beg) * T::a_bytes;
+    const char* a_ptr = reinterpret_cast<const char*>(p.At) + ((size_t)gv.grp * p.at_gs + (size_t)cl.at_off) * 6 + ((size_t)gv.my * nkt_all + kt_beg) * T::a_bytes;
     const uint32_t a_voff0 = (uint32_t)min(tid, AC - 1) * 16u;
     const uint32_t a_voff1 = (uint32_t)min(NT + tid, AC - 1) * 16u;
     const bool a_thread0 = tid < AC;                  // wave-uniform (AC is a multiple of 64)
@@ -647,7 +677,7 @@ __global__ void __launch_bounds__(64 * WVM * WVN, AG_CONV_WAVES_PER_SIMD) gather
             step_tail(kt, S[1], false);
         }
     }
-    gather_epilogue<WMB, WNB>(p, cl, acc, m0, n0, N, wm, wn, lane);
+    gather_epilogue<WMB, WNB>(p, gv, cl, acc, m0, n0, N, wm, wn, lane);
 }
 
 // split-K finish: y = (sum_z partial[z][m][col]) * out_scale[m] + bias[m], in a fixed order (deterministic)
@@ -656,19 +686,23 @@ __global__ void __launch_bounds__(256) reduce_splits_kernel(GatherProblem p, int
     const int Nc = p.Ncols;
     const long long total = (long long)p.M * Nc;
     const size_t zstride = (size_t)p.Mpad * Nc;
+    const int grp = blockIdx.y;                                   // grouped launch: one grid row per instance
+    const float* __restrict__ partial = p.partial + (size_t)grp * p.part_gs;
+    const float* __restrict__ bias = p.bias_t.p[grp];
+    float* __restrict__ yout = p.yout + (size_t)grp * p.y_gs;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int m = (int)(i / Nc), colg = (int)(i - (long long)m * Nc);
         float v = 0.f;
-        for (int z = 0; z < splits; z++) v += p.partial[z * zstride + i];
+        for (int z = 0; z < splits; z++) v += partial[z * zstride + i];
         if (p.out_scale) v *= p.out_scale[m];
-        if (p.bias) v += p.bias[m];
+        if (bias) v += bias[m];
         int ci = 0;
 #pragma unroll
         for (int c = 1; c < kMaxClasses; c++)
             if (c < p.nclasses && colg >= p.cls[c].col_begin) ci = c;
         const int nn = colg - p.cls[ci].col_begin;
         const int oy = nn / p.cls[ci].gw, ox = nn - oy * p.cls[ci].gw;
-        p.yout[(size_t)m * p.OHf * p.OWf + (size_t)(p.cls[ci].y0 + oy * p.os) * p.OWf + (p.cls[ci].x0 + ox * p.os)] = v;
+        yout[(size_t)m * p.OHf * p.OWf + (size_t)(p.cls[ci].y0 + oy * p.os) * p.OWf + (p.cls[ci].x0 + ox * p.os)] = v;
     }
 }
 
@@ -680,7 +714,8 @@ __global__ void __launch_bounds__(256) reduce_splits_kernel(GatherProblem p, int
 // (16 * k*k floats per row of the other index: coalesced reads), in the destination every (class, tap) is one 1-KB run [16 m][16 c]
 // (coalesced writes) -- 38 MB for the 1024 -> 512 layer in ~15 us instead of 90 with a gather per element.
 struct PackProblem {
-    const float* w;
+    PtrTable w_t;            // weights of the instances (blockIdx.z)
+    long long at_gs;         // packed elements between the instances' images
     float* At;
     int C, Cpad, M, Mpad, BM, nclasses, k2;
     long long stride_c, stride_m;
@@ -701,7 +736,7 @@ __device__ __forceinline__ void load_weight_block(float (&blk)[16][16 * kMaxTaps
     const int o = tid >> 4, inner = tid & 15, k2 = p.k2;
     const int c = cb * 16 + (m_inner ? o : inner), m = m16 * 16 + (m_inner ? inner : o);
     const bool ok = c < p.C && m < p.M;
-    const float* src = p.w + (ok ? (long long)c * p.stride_c + (long long)m * p.stride_m : 0);
+    const float* src = p.w_t.p[blockIdx.z] + (ok ? (long long)c * p.stride_c + (long long)m * p.stride_m : 0);
     float v[kMaxTaps];
 #pragma unroll
     for (int t = 0; t < kMaxTaps; t++) v[t] = (ok && t < k2) ? src[t] : 0.f;
@@ -729,7 +764,7 @@ __global__ void __launch_bounds__(256) pack_weights_kernel(PackProblem p)
     for (int ci = 0; ci < p.nclasses; ci++) {
         const int ntaps = p.ntaps[ci];
         const long long nkt = (long long)ntaps * ctiles;
-        float* dst = p.At + p.begin[ci] + ((mt * nkt + (long long)cb * ntaps) * p.BM + mrow) * 16 + kl;
+        float* dst = p.At + (size_t)blockIdx.z * p.at_gs + p.begin[ci] + ((mt * nkt + (long long)cb * ntaps) * p.BM + mrow) * 16 + kl;
         const bool zero = p.zero[ci] != 0;
         for (int t = 0; t < ntaps; t++) dst[(long long)t * p.BM * 16] = zero ? 0.f : blk[o][inner * k2 + p.tapoff[ci][t]];
     }
@@ -757,7 +792,7 @@ __global__ void __launch_bounds__(256) pack_weights_split_kernel(PackProblem p)
     for (int ci = 0; ci < p.nclasses; ci++) {
         const int ntaps = p.ntaps[ci];
         const long long nkt = (long long)ntaps * ctiles;
-        char* base = reinterpret_cast<char*>(p.At) + (size_t)p.begin[ci] * 6 + (size_t)(mt * nkt + (long long)cb * ntaps) * (kPlanes * plane)
+        char* base = reinterpret_cast<char*>(p.At) + ((size_t)blockIdx.z * p.at_gs + (size_t)p.begin[ci]) * 6 + (size_t)(mt * nkt + (long long)cb * ntaps) * (kPlanes * plane)
                      + chunk_off(mrow, kp >> 2) + (kp & 3) * 4;
         const bool zero = p.zero[ci] != 0;
         for (int t = th; t < ntaps; t += 2) {
@@ -782,6 +817,8 @@ struct WgradProblem {
     int Mw, Cg, Hg, Wg, gh, gw, sy, sx, ntaps;
     int ksplit_len;        // pixels per split (multiple of BK)
     float wscale;          // the forward convolved with w * wscale: dL/dw = wscale * dL/d(w * wscale)
+    int G, mtiles;         // grouped launch: gridDim.y = G * mtiles
+    long long a_gs, xin_gs, c_gs;     // floats between the instances' operands / outputs
     int dy[kMaxTaps], dx[kMaxTaps];
 };
 
@@ -803,14 +840,17 @@ __global__ void __launch_bounds__(64 * WVM * WVN, AG_CONV_WAVES_PER_SIMD) wgrad_
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WVN, wn = wave % WVN;
     const int Kp = p.gh * p.gw, Nw = p.Cg * p.ntaps;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int grp = (int)blockIdx.y / p.mtiles, my = (int)blockIdx.y - grp * p.mtiles;      // grouped launch (ag_groups.h)
+    const float* __restrict__ xin_g = p.xin + (size_t)grp * p.xin_gs;
+    float* __restrict__ c_g = p.c + (size_t)grp * p.c_gs;
+    const int m0 = my * BM, n0 = blockIdx.x * BN;
     const int kbeg = blockIdx.z * p.ksplit_len, kend = min(Kp, kbeg + p.ksplit_len);
     if (kbeg >= kend) return;
 
     // A loader: row am, 4 consecutive pixels aq..aq+3 (A is pixel-contiguous) -> one dwordx4 load, one b128 LDS write
     const int am = tid >> 2, aq = (tid & 3) * 4;
     const bool a_thread = am < BM && (m0 + am) < p.Mw;
-    const float* a_row = p.a + (size_t)min(m0 + am, p.Mw - 1) * Kp;
+    const float* a_row = p.a + (size_t)grp * p.a_gs + (size_t)min(m0 + am, p.Mw - 1) * Kp;
     // B loader: pixel bk of the tile (lanes run along pixels), columns bn, bn + BSTEP, ...; a column = (channel, tap) is fixed per
     // thread for the whole kernel: its plane + tap offset and its tap displacement live in registers
     const int bk = tid & 15, bn = tid >> 4;
@@ -865,7 +905,7 @@ __global__ void __launch_bounds__(64 * WVM * WVN, AG_CONV_WAVES_PER_SIMD) wgrad_
 #pragma unroll
         for (int j = 0; j < BC; j++) {
             const bool in = k_ok & ((unsigned)(iy0 + col_dy[j]) < (unsigned)p.Hg) & ((unsigned)(ix0 + col_dx[j]) < (unsigned)p.Wg);
-            st.rb[j] = p.xin[in ? col_off[j] + pixoff : 0];
+            st.rb[j] = xin_g[in ? col_off[j] + pixoff : 0];
             ok |= in ? (1u << j) : 0u;
         }
         st.ok = ok;
@@ -942,7 +982,7 @@ __global__ void __launch_bounds__(64 * WVM * WVN, AG_CONV_WAVES_PER_SIMD) wgrad_
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int m = m0 + (wm * WMB + i) * 32 + (r & 3) + 8 * (r >> 2) + rbase;
-                if (m < p.Mw) atomicAdd(p.c + (size_t)m * Nw + nn, acc[i][j][r] * p.wscale);   // 32 lanes = 128 contiguous bytes
+                if (m < p.Mw) atomicAdd(c_g + (size_t)m * Nw + nn, acc[i][j][r] * p.wscale);   // 32 lanes = 128 contiguous bytes
             }
         }
 }
@@ -966,13 +1006,16 @@ __global__ void __launch_bounds__(64 * WVM * WVN, AG_CONV_WAVES_PER_SIMD) wgrad_
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WVN, wn = wave % WVN;
     const int Kp = p.gh * p.gw, Nw = p.Cg * p.ntaps;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int grp = (int)blockIdx.y / p.mtiles, my = (int)blockIdx.y - grp * p.mtiles;      // grouped launch (ag_groups.h)
+    const float* __restrict__ xin_g = p.xin + (size_t)grp * p.xin_gs;
+    float* __restrict__ c_g = p.c + (size_t)grp * p.c_gs;
+    const int m0 = my * BM, n0 = blockIdx.x * BN;
     const int kbeg = blockIdx.z * p.ksplit_len, kend = min(Kp, kbeg + p.ksplit_len);
     if (kbeg >= kend) return;
 
     const int am = tid >> 2, aq = (tid & 3) * 4;
     const bool a_thread = am < BM && (m0 + am) < p.Mw;
-    const float* a_row = p.a + (size_t)min(m0 + am, p.Mw - 1) * Kp;
+    const float* a_row = p.a + (size_t)grp * p.a_gs + (size_t)min(m0 + am, p.Mw - 1) * Kp;
     const int a_woff = chunk_off(min(am, BM - 1), aq >> 3) + (aq & 7) * 2;
     const int bk = tid & 15, bn = tid >> 4;
     const int plane = p.Hg * p.Wg;
@@ -1033,7 +1076,7 @@ __global__ void __launch_bounds__(64 * WVM * WVN, AG_CONV_WAVES_PER_SIMD) wgrad_
 #pragma unroll
         for (int j = 0; j < BC; j++) {
             const bool in = k_ok & ((unsigned)(iy0 + col_dy[j]) < (unsigned)p.Hg) & ((unsigned)(ix0 + col_dx[j]) < (unsigned)p.Wg);
-            st.rb[j] = p.xin[in ? col_off[j] + pixoff : 0];
+            st.rb[j] = xin_g[in ? col_off[j] + pixoff : 0];
             ok |= in ? (1u << j) : 0u;
         }
         st.ok = ok;
@@ -1123,7 +1166,7 @@ __global__ void __launch_bounds__(64 * WVM * WVN, AG_CONV_WAVES_PER_SIMD) wgrad_
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int m = m0 + (wm * WMB + i) * 32 + (r & 3) + 8 * (r >> 2) + rbase;
-                if (m < p.Mw) atomicAdd(p.c + (size_t)m * Nw + nn, acc[i][j][r] * p.wscale);
+                if (m < p.Mw) atomicAdd(c_g + (size_t)m * Nw + nn, acc[i][j][r] * p.wscale);
             }
         }
 }
@@ -1241,14 +1284,14 @@ static double lanes_cost(long long W, int per, double fixed)
     const long long r = (W + kCUs - 1) / kCUs;
     return per * (r <= 1 ? 1.0 : 0.9 * r) + fixed * r;
 }
-static int choose_splits(long long tiles, int Mpad, int Ncols, int nkt)
+static int choose_splits(long long tiles, int Mpad, int Ncols, int nkt, int G = 1)
 {
     if (nkt < 8) return 1;
-    const long long cap = (long long)(kMaxPartialBytes / ((size_t)Mpad * Ncols * sizeof(float)));
+    const long long cap = (long long)(kMaxPartialBytes / ((size_t)Mpad * Ncols * sizeof(float) * G));
     const int smax = (int)std::min<long long>(std::min<long long>(nkt / 4, cap), 96);
     // unit = the time of one K tile in a workgroup (~0.45 us).  Splitting adds the finish launch (~6 units) and, per split, one
     // write + one read of the fp32 output at ~6 TB/s (L2 / Infinity Cache resident for these sizes)
-    const double per_split = 8.0 * (double)Mpad * Ncols / 6e12 / 0.45e-6;
+    const double per_split = 8.0 * (double)Mpad * Ncols * G / 6e12 / 0.45e-6;
     int best = 1;
     double best_cost = 1e30;
     for (int sp = 1; sp <= std::max(1, smax); sp++) {
@@ -1261,13 +1304,14 @@ static int choose_splits(long long tiles, int Mpad, int Ncols, int nkt)
 
 // Fills tile_begin / col_begin / at_off / nkt of the classes (dy, dx, gh, gw, y0, x0, ntaps set by the caller), packs the
 // weights of all classes with one launch and runs them with one launch (+ one split-K finish).
-static int pack_and_launch(GatherProblem& gp, const TapSet* taps, int bm, const float* w, long long stride_c, long long stride_m,
+static int pack_and_launch(GatherProblem& gp, const TapSet* taps, int bm, const PtrTable& w, long long stride_c, long long stride_m,
                            float wscale, int k, float* At, float* partial, hipStream_t s)
 {
     const bool split = split_math();
     const int BN = bn_of(bm);
+    const int G = gp.G;
     PackProblem pp;
-    pp.w = w; pp.At = At; pp.C = gp.Cg; pp.Cpad = gp.Cpad; pp.M = gp.M; pp.Mpad = gp.Mpad; pp.BM = bm; pp.nclasses = gp.nclasses;
+    pp.w_t = w; pp.At = At; pp.C = gp.Cg; pp.Cpad = gp.Cpad; pp.M = gp.M; pp.Mpad = gp.Mpad; pp.BM = bm; pp.nclasses = gp.nclasses;
     pp.stride_c = stride_c; pp.stride_m = stride_m; pp.wscale = wscale; pp.has_wscale = wscale != 1.f;
     long long tiles = 0, at = 0;
     int cols = 0, nkt_max = 0;
@@ -1284,29 +1328,33 @@ static int pack_and_launch(GatherProblem& gp, const TapSet* taps, int bm, const 
         if (cl.nkt > nkt_max) nkt_max = cl.nkt;
     }
     pp.begin[gp.nclasses] = at;
+    pp.at_gs = at;
+    gp.at_gs = at;
+    gp.mtiles = gp.Mpad / bm;
     gp.Ncols = cols;
     if (tiles == 0) return AG_OK;
     pp.k2 = k * k;
     if ((stride_c != pp.k2 && stride_m != pp.k2) || pp.k2 > kMaxTaps) { set_error("pack: unexpected weight strides"); return AG_ERR_INVALID_ARGUMENT; }
-    if (split) hipLaunchKernelGGL(pack_weights_split_kernel, dim3(gp.Cpad / BK, gp.Mpad / 16), dim3(256), 0, s, pp);
-    else       hipLaunchKernelGGL(pack_weights_kernel, dim3(gp.Cpad / BK, gp.Mpad / 16), dim3(256), 0, s, pp);
+    if (split) hipLaunchKernelGGL(pack_weights_split_kernel, dim3(gp.Cpad / BK, gp.Mpad / 16, G), dim3(256), 0, s, pp);
+    else       hipLaunchKernelGGL(pack_weights_kernel, dim3(gp.Cpad / BK, gp.Mpad / 16, G), dim3(256), 0, s, pp);
     int rc = check_hip(hipGetLastError(), "pack_weights_kernel");
     if (rc) return rc;
 
-    int splits = choose_splits(tiles * (gp.Mpad / bm), gp.Mpad, cols, nkt_max);
+    int splits = choose_splits(tiles * (gp.Mpad / bm) * G, gp.Mpad, cols, nkt_max, G);
     if (const char* forced = getenv("AG_CONV_SPLITS")) {       // measurement hook (profiles/conv_split_sweep.py)
         const int f = atoi(forced);
-        const long long cap = (long long)(kMaxPartialBytes / ((size_t)gp.Mpad * cols * sizeof(float)));
+        const long long cap = (long long)(kMaxPartialBytes / ((size_t)gp.Mpad * cols * sizeof(float) * G));
         if (f >= 1) splits = (int)std::min<long long>(std::min(f, std::max(1, nkt_max)), std::max<long long>(1, cap));
     }
     gp.kt_per_split = (nkt_max + splits - 1) / splits;
     splits = (nkt_max + gp.kt_per_split - 1) / gp.kt_per_split;
     gp.partial = splits > 1 ? partial : nullptr;
+    gp.part_gs = (long long)splits * gp.Mpad * cols;
     gp.At = At;
-    dim3 grid((unsigned)tiles, gp.Mpad / bm, splits);
+    dim3 grid((unsigned)tiles, (gp.Mpad / bm) * G, splits);
     double flops = 0.0;
     for (int c = 0; c < gp.nclasses; c++)
-        if (!gp.cls[c].zero_weights) flops += 2.0 * gp.M * (double)gp.cls[c].gh * gp.cls[c].gw * gp.cls[c].ntaps * gp.Cg;
+        if (!gp.cls[c].zero_weights) flops += 2.0 * G * gp.M * (double)gp.cls[c].gh * gp.cls[c].gw * gp.cls[c].ntaps * gp.Cg;
     ProfScope ps(AG_K_GATHER_CONV, s, flops);      // covers the split-K finish too
     if (split) {
         const bool cexact = gp.Cg % BK == 0 && (size_t)gp.Cg * gp.Hg * gp.Wg * sizeof(float) < (size_t(1) << 32);
@@ -1329,7 +1377,7 @@ static int pack_and_launch(GatherProblem& gp, const TapSet* taps, int bm, const 
     const long long total = (long long)gp.M * cols;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(reduce_splits_kernel, dim3(blocks), dim3(256), 0, s, gp, splits);
+    hipLaunchKernelGGL(reduce_splits_kernel, dim3(blocks, G), dim3(256), 0, s, gp, splits);
     return check_hip(hipGetLastError(), "reduce_splits_kernel");
 }
 
@@ -1364,21 +1412,36 @@ size_t ag_conv_workspace_bytes(const AgConvDesc* d)
     return packed_bytes(d) + kMaxPartialBytes + 512;
 }
 
+}  // extern "C"
+
+namespace ag {
+size_t conv_workspace_bytes_g(const AgConvDesc* d, int G)
+{
+    if (validate(d) || G < 1 || G > kMaxGroups) return 0;
+    return (size_t)G * packed_bytes(d) + kMaxPartialBytes + 512;
+}
+}  // namespace ag
+
+extern "C" {
+
 // Shared by forward / backward-input: which GEMM to run.
 //   plain gather with all taps (sy = sx = stride_in), tap offset = sign * k - pad_off, one class
 //   or the 4 output-parity classes of a stride-2 "scatter" (transposed conv forward, input gradient of a stride-2 conv)
-static int run_gather_family(const AgConvDesc* d, bool backward_input, const float* xin, const float* w, const float* out_scale,
-                             const float* bias, float* yout, void* workspace, size_t workspace_bytes, hipStream_t s)
+static int run_gather_family(const AgConvDesc* d, bool backward_input, int G, const float* xin, long long x_gs, const PtrTable& w,
+                             const float* out_scale, const PtrTable& bias, float* yout, long long y_gs, void* workspace, size_t workspace_bytes,
+                             hipStream_t s)
 {
     int OH, OW;
     out_size(d, OH, OW);
     const int k = d->k, k2 = k * k;
-    if (workspace_bytes < ag_conv_workspace_bytes(d) || !workspace) { set_error("conv workspace too small"); return AG_ERR_SCRATCH_TOO_SMALL; }
+    if (workspace_bytes < conv_workspace_bytes_g(d, G) || !workspace) { set_error("conv workspace too small"); return AG_ERR_SCRATCH_TOO_SMALL; }
+    if (G > 1 && out_scale) { set_error("grouped convolution: out_scale is a single-instance option"); return AG_ERR_UNSUPPORTED; }
     float* At = reinterpret_cast<float*>(aligned_base(workspace));
-    float* partial = reinterpret_cast<float*>(aligned_base(workspace) + packed_bytes(d));
+    float* partial = reinterpret_cast<float*>(aligned_base(workspace) + (size_t)G * packed_bytes(d));
 
     GatherProblem gp;
-    gp.out_scale = out_scale; gp.bias = bias; gp.yout = yout; gp.xin = xin;
+    gp.out_scale = out_scale; gp.bias_t = bias; gp.yout = yout; gp.xin = xin;
+    gp.G = G; gp.x_gs = x_gs; gp.y_gs = y_gs;
     const bool conv = d->kind == AG_CONV;
     // input of the GEMM / output of the GEMM in tensor terms
     int Cg, Hg, Wg, M, OHf, OWf;
@@ -1454,51 +1517,56 @@ static int run_gather_family(const AgConvDesc* d, bool backward_input, const flo
     return pack_and_launch(gp, taps, bm, w, stride_c, stride_m, wscale_of(d), k, At, partial, s);
 }
 
-int ag_conv_forward(const AgConvDesc* d, const float* x, const float* w, const float* out_scale, const float* bias, float* y,
-                    void* workspace, size_t workspace_bytes, void* stream)
+}  // extern "C"
+
+namespace ag {
+
+int conv_forward_g(const AgConvDesc* d, int G, const float* x, long long x_gs, const PtrTable& w, const float* out_scale, const PtrTable& bias,
+                   float* y, long long y_gs, void* workspace, size_t workspace_bytes, hipStream_t s)
 {
     int rc = validate(d);
     if (rc) return rc;
-    if (!x || !w || !y) { set_error("null conv tensor"); return AG_ERR_INVALID_ARGUMENT; }
-    if ((rc = pointwise_forward(d, x, w, out_scale, bias, y, reinterpret_cast<hipStream_t>(stream))) != 0) return rc < 0 ? rc : AG_OK;
-    return run_gather_family(d, false, x, w, out_scale, bias, y, workspace, workspace_bytes, reinterpret_cast<hipStream_t>(stream));
+    if (G < 1 || G > kMaxGroups || !x || !table_complete(w, G) || !y) { set_error("null conv tensor / bad group count"); return AG_ERR_INVALID_ARGUMENT; }
+    if ((rc = pointwise_forward(d, G, x, x_gs, w, out_scale, bias, y, y_gs, s)) != 0) return rc < 0 ? rc : AG_OK;
+    return run_gather_family(d, false, G, x, x_gs, w, out_scale, bias, y, y_gs, workspace, workspace_bytes, s);
 }
 
-int ag_conv_backward_input(const AgConvDesc* d, const float* dy, const float* w, float* dx, void* workspace,
-                           size_t workspace_bytes, void* stream)
+int conv_backward_input_g(const AgConvDesc* d, int G, const float* dy, long long dy_gs, const PtrTable& w, float* dx, long long dx_gs,
+                          void* workspace, size_t workspace_bytes, hipStream_t s)
 {
     int rc = validate(d);
     if (rc) return rc;
-    if (!dy || !w || !dx) { set_error("null conv tensor"); return AG_ERR_INVALID_ARGUMENT; }
-    if ((rc = pointwise_backward_input(d, dy, w, dx, reinterpret_cast<hipStream_t>(stream))) != 0) return rc < 0 ? rc : AG_OK;
-    return run_gather_family(d, true, dy, w, nullptr, nullptr, dx, workspace, workspace_bytes, reinterpret_cast<hipStream_t>(stream));
+    if (G < 1 || G > kMaxGroups || !dy || !table_complete(w, G) || !dx) { set_error("null conv tensor / bad group count"); return AG_ERR_INVALID_ARGUMENT; }
+    if ((rc = pointwise_backward_input(d, G, dy, dy_gs, w, dx, dx_gs, s)) != 0) return rc < 0 ? rc : AG_OK;
+    return run_gather_family(d, true, G, dy, dy_gs, w, nullptr, PtrTable{}, dx, dx_gs, workspace, workspace_bytes, s);
 }
 
-int ag_conv_backward_weight(const AgConvDesc* d, const float* x, const float* dy, float* dw, void* workspace,
-                            size_t workspace_bytes, void* stream)
+// dw: G gradients stacked at dw_gs floats (each the shape of one weight); overwritten
+int conv_backward_weight_g(const AgConvDesc* d, int G, const float* x, long long x_gs, const float* dy, long long dy_gs, float* dw, long long dw_gs,
+                           void* workspace, size_t workspace_bytes, hipStream_t s)
 {
     int rc = validate(d);
     if (rc) return rc;
-    if (!x || !dy || !dw) { set_error("null conv tensor"); return AG_ERR_INVALID_ARGUMENT; }
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if ((rc = pointwise_backward_weight(d, x, dy, dw, workspace, workspace_bytes, s)) != 0) return rc < 0 ? rc : AG_OK;
+    if (G < 1 || G > kMaxGroups || !x || !dy || !dw) { set_error("null conv tensor / bad group count"); return AG_ERR_INVALID_ARGUMENT; }
+    if ((rc = pointwise_backward_weight(d, G, x, x_gs, dy, dy_gs, dw, dw_gs, workspace, workspace_bytes, s)) != 0) return rc < 0 ? rc : AG_OK;
     int OH, OW;
     out_size(d, OH, OW);
     const int k = d->k, k2 = k * k;
     WgradProblem wp;
     if (d->kind == AG_CONV) {      // dw[co][(ci,t)] = sum_o dy[co][o] * x[ci][o*s - p + k]
-        wp.a = dy; wp.xin = x; wp.Mw = d->Cout; wp.Cg = d->Cin; wp.Hg = d->H; wp.Wg = d->W; wp.gh = OH; wp.gw = OW;
+        wp.a = dy; wp.xin = x; wp.a_gs = dy_gs; wp.xin_gs = x_gs; wp.Mw = d->Cout; wp.Cg = d->Cin; wp.Hg = d->H; wp.Wg = d->W; wp.gh = OH; wp.gw = OW;
         wp.sy = wp.sx = d->stride;
         for (int t = 0; t < k2; t++) { wp.dy[t] = t / k - d->padding; wp.dx[t] = t % k - d->padding; }
     } else {                       // dw[ci][(co,t)] = sum_i x[ci][i] * dy[co][2 i + k]
-        wp.a = x; wp.xin = dy; wp.Mw = d->Cin; wp.Cg = d->Cout; wp.Hg = OH; wp.Wg = OW; wp.gh = d->H; wp.gw = d->W;
+        wp.a = x; wp.xin = dy; wp.a_gs = x_gs; wp.xin_gs = dy_gs; wp.Mw = d->Cin; wp.Cg = d->Cout; wp.Hg = OH; wp.Wg = OW; wp.gh = d->H; wp.gw = d->W;
         wp.sy = wp.sx = 2;
         for (int t = 0; t < k2; t++) { wp.dy[t] = t / k; wp.dx[t] = t % k; }
     }
-    wp.c = dw; wp.ntaps = k2; wp.wscale = wscale_of(d);
+    wp.c = dw; wp.c_gs = dw_gs; wp.G = G; wp.ntaps = k2; wp.wscale = wscale_of(d);
     const int Kp = wp.gh * wp.gw, Nw = wp.Cg * k2;
     const int bm = pick_bm(wp.Mw), BN = bn_of(bm);
-    const int tiles = ((Nw + BN - 1) / BN) * ((wp.Mw + bm - 1) / bm);
+    const int tiles = ((Nw + BN - 1) / BN) * ((wp.Mw + bm - 1) / bm) * G;
+    wp.mtiles = (wp.Mw + bm - 1) / bm;
     // pixel slices: same CU-share model as the gather kernel; a workgroup's fixed cost is its prologue plus the 16 K float atomics of
     // its epilogue (~6 K-tile-times); at least 8 K tiles per slice
     const int nkt_all = (Kp + BK - 1) / BK;
@@ -1517,9 +1585,14 @@ int ag_conv_backward_weight(const AgConvDesc* d, const float* x, const float* dy
     }
     wp.ksplit_len = round_up((Kp + splits - 1) / splits, BK);
     splits = (Kp + wp.ksplit_len - 1) / wp.ksplit_len;
-    if ((rc = check_hip(hipMemsetAsync(dw, 0, (size_t)wp.Mw * Nw * sizeof(float), s), "memset dw"))) return rc;
-    dim3 grid((Nw + BN - 1) / BN, (wp.Mw + bm - 1) / bm, splits);
-    ProfScope ps(AG_K_WGRAD, s, 2.0 * wp.Mw * (double)Kp * Nw);
+    if (dw_gs == (long long)wp.Mw * Nw || G == 1) {
+        if ((rc = check_hip(hipMemsetAsync(dw, 0, (size_t)G * wp.Mw * Nw * sizeof(float), s), "memset dw"))) return rc;
+    } else {
+        for (int g = 0; g < G; g++)
+            if ((rc = check_hip(hipMemsetAsync(dw + (size_t)g * dw_gs, 0, (size_t)wp.Mw * Nw * sizeof(float), s), "memset dw"))) return rc;
+    }
+    dim3 grid((Nw + BN - 1) / BN, wp.mtiles * G, splits);
+    ProfScope ps(AG_K_WGRAD, s, 2.0 * G * wp.Mw * (double)Kp * Nw);
     const bool avec = (Kp & 3) == 0;      // rows of A 16-byte aligned
     if (split_math()) {
         const bool six = split_terms() == 6;
@@ -1540,6 +1613,28 @@ int ag_conv_backward_weight(const AgConvDesc* d, const float* x, const float* dy
         else      hipLaunchKernelGGL((wgrad_kernel<2, 1, 2, 4, false>), grid, dim3(512), 0, s, wp);
     }
     return check_hip(hipGetLastError(), "wgrad_kernel");
+}
+
+}  // namespace ag
+
+extern "C" {
+
+int ag_conv_forward(const AgConvDesc* d, const float* x, const float* w, const float* out_scale, const float* bias, float* y,
+                    void* workspace, size_t workspace_bytes, void* stream)
+{
+    return conv_forward_g(d, 1, x, 0, table_of(w), out_scale, table_of(bias), y, 0, workspace, workspace_bytes, reinterpret_cast<hipStream_t>(stream));
+}
+
+int ag_conv_backward_input(const AgConvDesc* d, const float* dy, const float* w, float* dx, void* workspace,
+                           size_t workspace_bytes, void* stream)
+{
+    return conv_backward_input_g(d, 1, dy, 0, table_of(w), dx, 0, workspace, workspace_bytes, reinterpret_cast<hipStream_t>(stream));
+}
+
+int ag_conv_backward_weight(const AgConvDesc* d, const float* x, const float* dy, float* dw, void* workspace,
+                            size_t workspace_bytes, void* stream)
+{
+    return conv_backward_weight_g(d, 1, x, 0, dy, 0, dw, 0, workspace, workspace_bytes, reinterpret_cast<hipStream_t>(stream));
 }
 
 int ag_conv_set_math(int mode)

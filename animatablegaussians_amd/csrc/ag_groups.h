@@ -1,0 +1,79 @@
+// Grouped ("batched, per-sample weights") execution of the StyleUNet layers (gfx950).
+//
+// The avatar evaluates three DualStyleUNets of identical layer shapes on the same pose map (network/avatar.py:34-36,93-124) and each
+// of them runs two decoders of identical shapes (dual_styleunet.py:869-905): up to G = 6 (more with several camera views of a pose)
+// instances of every layer that differ only in their parameter tensors.  A grouped launch runs the G instances of one layer as ONE
+// kernel: activations are stacked [G][C][H][W] (a group stride between instances; stride 0 = one input shared by all), parameters stay
+// the reference's separate tensors and reach the kernel as a table of G pointers inside the kernel-argument structure (uniform per
+// workgroup: a scalar load from the kernarg segment).  G = 1 is the plain single-instance call: the per-kernel ABI of
+// include/ag_styleunet.h / ag_conv.h is the G = 1 case of these launchers, there is one implementation of every kernel.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstddef>
+#include <cstdint>
+
+namespace ag {
+
+constexpr int kMaxGroups = 16;
+
+struct PtrTable {
+    const float* p[kMaxGroups];
+};
+
+inline PtrTable table_of(const float* one)
+{
+    PtrTable t{};
+    t.p[0] = one;
+    return t;
+}
+
+inline PtrTable table_of(const float* const* list, int G)
+{
+    PtrTable t{};
+    for (int g = 0; g < G && g < kMaxGroups; g++) t.p[g] = list ? list[g] : nullptr;
+    return t;
+}
+
+inline bool table_complete(const PtrTable& t, int G)
+{
+    for (int g = 0; g < G; g++)
+        if (!t.p[g]) return false;
+    return true;
+}
+
+// ---- ag_styleunet_ops.hip --------------------------------------------------------------------------------------------------------
+// y [G][C][HW] = lrelu(x + nw_g[0] * noise_g[pix] + bias_g[c]) * scale; a null table entry = no noise / no bias for that instance
+int noise_bias_act_forward_g(float* y, const float* x, int G, const PtrTable& noise, const PtrTable& nw, const PtrTable& bias, int C, int HW,
+                             float slope, float scale, hipStream_t s);
+// floats of `partials` the backward needs
+size_t noise_bias_act_partial_floats(int G, int C, int HW);
+// gbias: instance g writes C sums at gbias + g * gb_stride (null: not wanted); gnw: one sum at gnw + g * gnw_stride (null: not wanted).
+// Deterministic: per-workgroup partial sums + a fixed-order finish (no float atomics).
+int noise_bias_act_backward_g(float* gx, const float* gy, const float* y, int G, const PtrTable& noise, float* gbias, long long gb_stride,
+                              float* gnw, long long gnw_stride, float* partials, int C, int HW, float slope, float scale, hipStream_t s);
+// out [G][Co][Ci][K2] (or [G][Ci][Co][K2] transposed), dcoef [G][Co] (may be null)
+int modulate_weight_forward_g(float* out, float* dcoef, int G, const PtrTable& W, const PtrTable& style, float scale, int demod, int Co, int Ci,
+                              int K2, int transposed, hipStream_t s);
+size_t modulate_weight_partial_floats(int G, int Co, int Ci);
+// dW [G][Co][Ci][K2], dstyle [G][Ci], g = dL/dout stacked like out; deterministic (partials [G][Co][Ci] + fixed-order finish)
+int modulate_weight_backward_g(float* dW, float* dstyle, float* partials, const float* g, int G, const PtrTable& W, const PtrTable& style,
+                               const float* dcoef, float scale, int demod, int Co, int Ci, int K2, int transposed, hipStream_t s);
+int skip_chain_forward_g(float* out, const float* skip, const float* taps_host, int G, int C, int h, int w, int accumulate, hipStream_t s);
+int skip_chain_backward_g(float* gskip, const float* gout, const float* taps_host, int G, int C, int h, int w, hipStream_t s);
+int block2x2_transform_g(float* out, const float* in, const float* matrix16_host, int merge, int G, int C, int h, int w, hipStream_t s);
+
+// ---- ag_conv.hip -----------------------------------------------------------------------------------------------------------------
+// Strides in floats between the instances' tensors; x_gs = 0 shares one input among all instances.  Weights (and the forward's bias) come
+// from pointer tables; the G weight gradients are written stacked at dw_gs floats.  out_scale is a single-instance option.
+}  // namespace ag
+struct AgConvDesc;
+namespace ag {
+size_t conv_workspace_bytes_g(const AgConvDesc* d, int G);
+int conv_forward_g(const AgConvDesc* d, int G, const float* x, long long x_gs, const PtrTable& w, const float* out_scale, const PtrTable& bias,
+                   float* y, long long y_gs, void* workspace, size_t workspace_bytes, hipStream_t s);
+int conv_backward_input_g(const AgConvDesc* d, int G, const float* dy, long long dy_gs, const PtrTable& w, float* dx, long long dx_gs,
+                          void* workspace, size_t workspace_bytes, hipStream_t s);
+int conv_backward_weight_g(const AgConvDesc* d, int G, const float* x, long long x_gs, const float* dy, long long dy_gs, float* dw, long long dw_gs,
+                           void* workspace, size_t workspace_bytes, hipStream_t s);
+
+}  // namespace ag

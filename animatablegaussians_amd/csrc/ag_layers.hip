@@ -1,25 +1,19 @@
-// Layer-level entry points (include/ag_layers.h): one native call per ConvLayer / StyledConv, forward and backward.  Pure composition of
-// the per-kernel entry points -- same kernels, same order, same results -- so that the host pays one Python -> C transition per layer
-// instead of three to five.
+// Layer-level entry points (include/ag_layers.h): one native call per ConvLayer / StyledConv / ToRGB, forward and backward, for G
+// instances of the layer at once (ag_groups.h; G = 1 is the single-layer call).  Pure composition of the grouped kernel launchers -- same
+// kernels, same order as the per-kernel calls -- so that the host pays one Python -> C transition per layer (and per GROUP of layers)
+// instead of three to five per layer.
 #include "ag_common.h"
+#include "ag_groups.h"
 #include "../../include/ag_conv.h"
 #include "../../include/ag_layers.h"
 #include "../../include/ag_styleunet.h"
 
 #include <cstdlib>
+#include <cstring>
+
+using namespace ag;
 
 namespace {
-
-// Blur + noise / bias / activation of an up-sampling StyledConv as ONE pass each way (ag_fir4x4_noise_bias_act_*): AG_FUSED_TAIL bit 0
-// forward, bit 1 backward.  OFF by default: built, bit-identical to the two passes (tests/test_styleunet_ops.py, test_styleunet_net.py),
-// and measured same-box with profiles/ab_tail.sh -- network forward + backward 17.5-17.6 ms with two passes, 17.7-17.8 with the fused
-// forward, 18.2-18.8 with both fused.  It removes 12 of the ~1500 launches of a network pass; the fused backward (activation gradient
-// formed on the fly inside the FIR's adjoint, 70 loads per thread) is slower than the streaming pass + FIR it replaces.
-int fused_tail_mask()
-{
-    static const int m = [] { const char* e = getenv("AG_FUSED_TAIL"); return e ? atoi(e) : 0; }();
-    return m;
-}
 
 struct Geo {
     int OH, OW;          // layer output
@@ -28,9 +22,9 @@ struct Geo {
     AgConvDesc d;
 };
 
-bool geometry(const AgLayerArgs* a, Geo& g)
+bool geometry(const AgGroupedLayerArgs* a, Geo& g)
 {
-    if (!a || a->Cin <= 0 || a->Cout <= 0 || a->H <= 0 || a->W <= 0 || a->k <= 0) return false;
+    if (!a || a->G < 1 || a->G > AG_MAX_GROUPS || a->Cin <= 0 || a->Cout <= 0 || a->H <= 0 || a->W <= 0 || a->k <= 0) return false;
     g.BH = a->H; g.BW = a->W;
     g.d = AgConvDesc{};
     g.d.Cin = a->Cin; g.d.Cout = a->Cout; g.d.k = a->k;
@@ -53,122 +47,303 @@ bool geometry(const AgLayerArgs* a, Geo& g)
     return g.OH > 0 && g.OW > 0;
 }
 
+size_t pad64(size_t n) { return (n + 63) / 64 * 64; }
+
+// float offsets of the regions inside `scratch`
+struct Scratch {
+    size_t pre, aux, g_blur, g_wm, nba_part, mod_part, total;
+};
+
+Scratch scratch_layout(const AgGroupedLayerArgs* a, const Geo& g, bool backward)
+{
+    const size_t G = a->G;
+    Scratch s{};
+    size_t o = 0;
+    s.pre = o;  o += pad64(G * a->Cout * g.OH * g.OW);                                           // activation input / its gradient
+    s.aux = o;
+    if (a->modulated && a->resample) o += pad64(G * a->Cout * g.CH * g.CW);                        // transposed-convolution output / its gradient
+    s.g_blur = o;
+    if (!a->modulated && a->resample && backward) o += pad64(G * a->Cin * g.BH * g.BW);            // gradient of the blurred input
+    s.g_wm = o;
+    if (backward && a->modulated) o += pad64(G * (size_t)a->Cout * a->Cin * a->k * a->k);          // gradient of the modulated weight
+    s.nba_part = o;
+    if (backward) o += pad64(noise_bias_act_partial_floats(a->G, a->Cout, g.OH * g.OW));
+    s.mod_part = o;
+    if (backward && a->modulated) o += pad64(modulate_weight_partial_floats(a->G, a->Cout, a->Cin));
+    s.total = o + 64;
+    return s;
+}
+
+void to_grouped(const AgLayerArgs* a, AgGroupedLayerArgs& g)
+{
+    memset(&g, 0, sizeof(g));
+    g.G = 1;
+    g.Cin = a->Cin; g.Cout = a->Cout; g.H = a->H; g.W = a->W; g.k = a->k; g.resample = a->resample; g.modulated = a->modulated;
+    g.scale = a->scale; g.slope = a->slope; g.act_scale = a->act_scale;
+    g.x = a->x; g.x_group_stride = 0;
+    g.weight[0] = a->weight; g.style[0] = a->style; g.noise[0] = a->noise; g.noise_weight[0] = a->noise_weight; g.act_bias[0] = a->act_bias;
+    g.k_blur = a->k_blur; g.w_mod = a->w_mod; g.demod = a->demod; g.x_blur = a->x_blur; g.out = a->out;
+    g.scratch = a->scratch; g.workspace = a->workspace; g.workspace_bytes = a->workspace_bytes;
+    g.g_out = a->g_out; g.g_x = a->g_x; g.g_weight = a->g_weight; g.g_style = a->g_style; g.g_bias_noise = a->g_bias_noise;
+    g.want_bias = a->want_bias; g.want_noise_weight = a->want_noise_weight;
+}
+
 }  // namespace
 
 extern "C" {
 
 size_t ag_layer_args_bytes(void) { return sizeof(AgLayerArgs); }
+size_t ag_grouped_layer_args_bytes(void) { return sizeof(AgGroupedLayerArgs); }
+size_t ag_grouped_to_rgb_args_bytes(void) { return sizeof(AgGroupedToRgbArgs); }
 
-int ag_layer_output_size(const AgLayerArgs* a, int32_t* OH, int32_t* OW)
+int ag_grouped_layer_output_size(const AgGroupedLayerArgs* a, int32_t* OH, int32_t* OW)
 {
     Geo g;
-    if (!geometry(a, g) || !OH || !OW) { ag::set_error("ag_layer_output_size: bad layer description"); return AG_ERR_INVALID_ARGUMENT; }
+    if (!geometry(a, g) || !OH || !OW) { set_error("ag_layer_output_size: bad layer description"); return AG_ERR_INVALID_ARGUMENT; }
     *OH = g.OH; *OW = g.OW;
     return AG_OK;
 }
 
-size_t ag_layer_scratch_floats(const AgLayerArgs* a, int32_t backward)
+size_t ag_grouped_layer_scratch_floats(const AgGroupedLayerArgs* a, int32_t backward)
 {
     Geo g;
     if (!geometry(a, g)) return 0;
-    const size_t pre = (size_t)a->Cout * g.OH * g.OW;                         // activation input / its gradient
-    size_t n = pre + 64;
-    if (a->modulated && a->resample) n += (size_t)a->Cout * g.CH * g.CW + 64;   // transposed-convolution output / its gradient
-    if (!a->modulated && a->resample && backward) n += (size_t)a->Cin * g.BH * g.BW + 64;   // gradient of the blurred input
-    if (backward && a->modulated) n += (size_t)a->Cout * a->Cin * a->k * a->k + 64;   // gradient of the modulated weight
-    return n;
+    return scratch_layout(a, g, backward != 0).total;
+}
+
+size_t ag_grouped_layer_workspace_bytes(const AgGroupedLayerArgs* a)
+{
+    Geo g;
+    if (!geometry(a, g)) return 0;
+    return conv_workspace_bytes_g(&g.d, a->G);
+}
+
+int ag_grouped_layer_forward(const AgGroupedLayerArgs* a, void* stream)
+{
+    Geo g;
+    if (!geometry(a, g) || !a->x || !a->out || !a->scratch) { set_error("ag_layer_forward: bad arguments"); return AG_ERR_INVALID_ARGUMENT; }
+    const int G = a->G;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const PtrTable w_t = table_of(a->weight, G), bias_t = table_of(a->act_bias, G);
+    if (!table_complete(w_t, G)) { set_error("ag_layer_forward: null weight"); return AG_ERR_INVALID_ARGUMENT; }
+    const Scratch L = scratch_layout(a, g, false);
+    float* pre = a->scratch + L.pre;
+    float* aux = a->scratch + L.aux;
+    const long long x_gs = G > 1 ? a->x_group_stride : 0;
+    const long long pre_gs = (long long)a->Cout * g.OH * g.OW;
+    int rc;
+    if (!a->modulated) {
+        const float* cx = a->x;
+        long long cx_gs = x_gs;
+        if (a->resample) {
+            if (!a->k_blur || !a->x_blur) { set_error("ag_layer_forward: down-sampling layer without FIR taps / x_blur"); return AG_ERR_INVALID_ARGUMENT; }
+            const int n_in = (G > 1 && x_gs == 0) ? 1 : G;                    // a shared input is blurred once
+            if ((rc = ag_upfirdn2d(a->x_blur, a->x, a->k_blur, n_in * a->Cin, a->H, a->W, 4, 4, 1, 1, 1, 1, 2, 2, 2, 2, stream))) return rc;
+            cx = a->x_blur;
+            cx_gs = n_in == 1 ? 0 : (long long)a->Cin * g.BH * g.BW;
+        }
+        if ((rc = conv_forward_g(&g.d, G, cx, cx_gs, w_t, nullptr, PtrTable{}, pre, pre_gs, a->workspace, a->workspace_bytes, s))) return rc;
+        return noise_bias_act_forward_g(a->out, pre, G, PtrTable{}, PtrTable{}, bias_t, a->Cout, g.OH * g.OW, a->slope, a->act_scale, s);
+    }
+    const PtrTable style_t = table_of(a->style, G);
+    if (!table_complete(style_t, G) || !a->w_mod || !a->demod) { set_error("ag_layer_forward: StyledConv needs style, w_mod and demod"); return AG_ERR_INVALID_ARGUMENT; }
+    if ((rc = modulate_weight_forward_g(a->w_mod, a->demod, G, w_t, style_t, a->scale, 1, a->Cout, a->Cin, a->k * a->k, a->resample ? 1 : 0, s))) return rc;
+    // the modulated weights of the instances, stacked
+    PtrTable wm_t{};
+    const size_t wn = (size_t)a->Cout * a->Cin * a->k * a->k;
+    for (int i = 0; i < G; i++) wm_t.p[i] = a->w_mod + i * wn;
+    PtrTable noise_t{}, nw_t{};
+    for (int i = 0; i < G; i++)
+        if (a->noise[i] && a->noise_weight[i]) { noise_t.p[i] = a->noise[i]; nw_t.p[i] = a->noise_weight[i]; }
+    if (a->resample) {
+        if (!a->k_blur) { set_error("ag_layer_forward: resampling layer without FIR taps"); return AG_ERR_INVALID_ARGUMENT; }
+        if ((rc = conv_forward_g(&g.d, G, a->x, x_gs, wm_t, nullptr, PtrTable{}, aux, (long long)a->Cout * g.CH * g.CW, a->workspace, a->workspace_bytes, s))) return rc;
+        if ((rc = ag_upfirdn2d(pre, aux, a->k_blur, G * a->Cout, g.CH, g.CW, 4, 4, 1, 1, 1, 1, 1, 1, 1, 1, stream))) return rc;
+    } else {
+        if ((rc = conv_forward_g(&g.d, G, a->x, x_gs, wm_t, nullptr, PtrTable{}, pre, pre_gs, a->workspace, a->workspace_bytes, s))) return rc;
+    }
+    return noise_bias_act_forward_g(a->out, pre, G, noise_t, nw_t, bias_t, a->Cout, g.OH * g.OW, a->slope, a->act_scale, s);
+}
+
+int ag_grouped_layer_backward(const AgGroupedLayerArgs* a, void* stream)
+{
+    Geo g;
+    if (!geometry(a, g) || !a->x || !a->out || !a->scratch || !a->g_out) { set_error("ag_layer_backward: bad arguments"); return AG_ERR_INVALID_ARGUMENT; }
+    const int G = a->G;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const PtrTable w_t = table_of(a->weight, G);
+    if (!table_complete(w_t, G)) { set_error("ag_layer_backward: null weight"); return AG_ERR_INVALID_ARGUMENT; }
+    const long long x_gs = G > 1 ? a->x_group_stride : 0;
+    if (G > 1 && x_gs == 0 && a->g_x) { set_error("ag_layer_backward: an input shared by the instances has no per-instance gradient"); return AG_ERR_INVALID_ARGUMENT; }
+    const Scratch L = scratch_layout(a, g, true);
+    float* g_pre = a->scratch + L.pre;
+    float* aux = a->scratch + L.aux;
+    const long long pre_gs = (long long)a->Cout * g.OH * g.OW;
+    PtrTable noise_t{};
+    bool all_noise = a->modulated != 0;
+    for (int i = 0; i < G; i++) {
+        if (a->modulated && a->noise[i] && a->noise_weight[i]) noise_t.p[i] = a->noise[i];
+        else all_noise = false;
+    }
+    float* gb = (a->want_bias && a->g_bias_noise) ? a->g_bias_noise : nullptr;
+    float* gnw = (all_noise && a->want_noise_weight && a->g_bias_noise) ? a->g_bias_noise + a->Cout : nullptr;
+    int rc;
+    if ((rc = noise_bias_act_backward_g(g_pre, a->g_out, a->out, G, noise_t, gb, a->Cout + 1, gnw, a->Cout + 1, a->scratch + L.nba_part, a->Cout,
+                                        g.OH * g.OW, a->slope, a->act_scale, s))) return rc;
+    if (!a->modulated) {
+        if (a->resample) {
+            if (!a->x_blur || !a->k_blur) { set_error("ag_layer_backward: down-sampling layer without x_blur / FIR taps"); return AG_ERR_INVALID_ARGUMENT; }
+            const int n_in = (G > 1 && x_gs == 0) ? 1 : G;
+            const long long xb_gs = n_in == 1 ? 0 : (long long)a->Cin * g.BH * g.BW;
+            if (a->g_x) {     // gradient w.r.t. the blurred input, then the FIR's adjoint (flipped taps, pads (1,1): [H + 1] -> [H])
+                float* g_blur = a->scratch + L.g_blur;
+                if ((rc = conv_backward_input_g(&g.d, G, g_pre, pre_gs, w_t, g_blur, (long long)a->Cin * g.BH * g.BW, a->workspace, a->workspace_bytes, s))) return rc;
+                if ((rc = ag_upfirdn2d(a->g_x, g_blur, a->k_blur, G * a->Cin, g.BH, g.BW, 4, 4, 1, 1, 1, 1, 1, 1, 1, 1, stream))) return rc;
+            }
+            if (a->g_weight && (rc = conv_backward_weight_g(&g.d, G, a->x_blur, xb_gs, g_pre, pre_gs, a->g_weight, (long long)a->Cout * a->Cin * a->k * a->k,
+                                                            a->workspace, a->workspace_bytes, s))) return rc;
+            return AG_OK;
+        }
+        if (a->g_x && (rc = conv_backward_input_g(&g.d, G, g_pre, pre_gs, w_t, a->g_x, (long long)a->Cin * a->H * a->W, a->workspace, a->workspace_bytes, s))) return rc;
+        if (a->g_weight && (rc = conv_backward_weight_g(&g.d, G, a->x, x_gs, g_pre, pre_gs, a->g_weight, (long long)a->Cout * a->Cin * a->k * a->k, a->workspace,
+                                                        a->workspace_bytes, s))) return rc;
+        return AG_OK;
+    }
+    const PtrTable style_t = table_of(a->style, G);
+    if (!table_complete(style_t, G) || !a->w_mod || !a->demod) { set_error("ag_layer_backward: StyledConv needs style, w_mod and demod"); return AG_ERR_INVALID_ARGUMENT; }
+    PtrTable wm_t{};
+    const size_t wn = (size_t)a->Cout * a->Cin * a->k * a->k;
+    for (int i = 0; i < G; i++) wm_t.p[i] = a->w_mod + i * wn;
+    const float* g_conv = g_pre;
+    long long gconv_gs = pre_gs;
+    if (a->resample) {
+        // adjoint of Blur pad (1,1): pads (2,2) with the flipped taps, [2H] -> [2H + 1]
+        if ((rc = ag_upfirdn2d(aux, g_pre, a->k_blur, G * a->Cout, g.OH, g.OW, 4, 4, 1, 1, 1, 1, 2, 2, 2, 2, stream))) return rc;
+        g_conv = aux;
+        gconv_gs = (long long)a->Cout * g.CH * g.CW;
+    }
+    if (a->g_x && (rc = conv_backward_input_g(&g.d, G, g_conv, gconv_gs, wm_t, a->g_x, (long long)a->Cin * a->H * a->W, a->workspace, a->workspace_bytes, s))) return rc;
+    if (a->g_weight) {
+        if (!a->g_style) { set_error("ag_layer_backward: g_weight without g_style"); return AG_ERR_INVALID_ARGUMENT; }
+        float* g_wm = a->scratch + L.g_wm;
+        if ((rc = conv_backward_weight_g(&g.d, G, a->x, x_gs, g_conv, gconv_gs, g_wm, (long long)wn, a->workspace, a->workspace_bytes, s))) return rc;
+        if ((rc = modulate_weight_backward_g(a->g_weight, a->g_style, a->scratch + L.mod_part, g_wm, G, w_t, style_t, a->demod, a->scale, 1, a->Cout, a->Cin,
+                                             a->k * a->k, a->resample ? 1 : 0, s))) return rc;
+    }
+    return AG_OK;
+}
+
+// ---- single-layer calls = G = 1 ---------------------------------------------------------------------------------------------------
+int ag_layer_output_size(const AgLayerArgs* a, int32_t* OH, int32_t* OW)
+{
+    if (!a) { set_error("ag_layer_output_size: null"); return AG_ERR_INVALID_ARGUMENT; }
+    AgGroupedLayerArgs g;
+    to_grouped(a, g);
+    return ag_grouped_layer_output_size(&g, OH, OW);
+}
+
+size_t ag_layer_scratch_floats(const AgLayerArgs* a, int32_t backward)
+{
+    if (!a) return 0;
+    AgGroupedLayerArgs g;
+    to_grouped(a, g);
+    return ag_grouped_layer_scratch_floats(&g, backward);
 }
 
 int ag_layer_forward(const AgLayerArgs* a, void* stream)
 {
-    Geo g;
-    if (!geometry(a, g) || !a->x || !a->weight || !a->out || !a->scratch) { ag::set_error("ag_layer_forward: bad arguments"); return AG_ERR_INVALID_ARGUMENT; }
-    const size_t pre_n = ((size_t)a->Cout * g.OH * g.OW + 63) / 64 * 64;
-    float* pre = a->scratch;
-    float* aux = a->scratch + pre_n;
-    int rc;
-    if (!a->modulated) {
-        const float* cx = a->x;
-        if (a->resample) {
-            if (!a->k_blur || !a->x_blur) { ag::set_error("ag_layer_forward: down-sampling layer without FIR taps / x_blur"); return AG_ERR_INVALID_ARGUMENT; }
-            if ((rc = ag_upfirdn2d(a->x_blur, a->x, a->k_blur, a->Cin, a->H, a->W, 4, 4, 1, 1, 1, 1, 2, 2, 2, 2, stream))) return rc;
-            cx = a->x_blur;
-        }
-        if ((rc = ag_conv_forward(&g.d, cx, a->weight, nullptr, nullptr, pre, a->workspace, a->workspace_bytes, stream))) return rc;
-        return ag_noise_bias_act_forward(a->out, pre, nullptr, nullptr, a->act_bias, a->Cout, g.OH * g.OW, a->slope, a->act_scale, stream);
-    }
-    if (!a->style || !a->w_mod || !a->demod) { ag::set_error("ag_layer_forward: StyledConv needs style, w_mod and demod"); return AG_ERR_INVALID_ARGUMENT; }
-    if ((rc = ag_modulate_weight_forward(a->w_mod, a->demod, a->weight, a->style, a->scale, 1, a->Cout, a->Cin, a->k * a->k, a->resample ? 1 : 0, stream))) return rc;
-    if (a->resample) {
-        if (!a->k_blur) { ag::set_error("ag_layer_forward: resampling layer without FIR taps"); return AG_ERR_INVALID_ARGUMENT; }
-        if ((rc = ag_conv_forward(&g.d, a->x, a->w_mod, nullptr, nullptr, aux, a->workspace, a->workspace_bytes, stream))) return rc;
-        // Blur + noise + bias + activation in one pass (round 3); the filtered, pre-activation tensor never goes to memory
-        const bool nzr = a->noise && a->noise_weight;
-        if (!(fused_tail_mask() & 1)) {
-            if ((rc = ag_upfirdn2d(pre, aux, a->k_blur, a->Cout, g.CH, g.CW, 4, 4, 1, 1, 1, 1, 1, 1, 1, 1, stream))) return rc;
-            return ag_noise_bias_act_forward(a->out, pre, nzr ? a->noise : nullptr, nzr ? a->noise_weight : nullptr, a->act_bias, a->Cout,
-                                             g.OH * g.OW, a->slope, a->act_scale, stream);
-        }
-        return ag_fir4x4_noise_bias_act_forward(a->out, aux, a->k_blur, a->Cout, g.CH, g.CW, 1, 1, nzr ? a->noise : nullptr,
-                                                nzr ? a->noise_weight : nullptr, a->act_bias, a->slope, a->act_scale, stream);
-    } else {
-        if ((rc = ag_conv_forward(&g.d, a->x, a->w_mod, nullptr, nullptr, pre, a->workspace, a->workspace_bytes, stream))) return rc;
-    }
-    const bool nz = a->noise && a->noise_weight;
-    return ag_noise_bias_act_forward(a->out, pre, nz ? a->noise : nullptr, nz ? a->noise_weight : nullptr, a->act_bias, a->Cout, g.OH * g.OW,
-                                     a->slope, a->act_scale, stream);
+    if (!a) { set_error("ag_layer_forward: null"); return AG_ERR_INVALID_ARGUMENT; }
+    AgGroupedLayerArgs g;
+    to_grouped(a, g);
+    return ag_grouped_layer_forward(&g, stream);
 }
 
 int ag_layer_backward(const AgLayerArgs* a, void* stream)
 {
-    Geo g;
-    if (!geometry(a, g) || !a->x || !a->weight || !a->out || !a->scratch || !a->g_out) { ag::set_error("ag_layer_backward: bad arguments"); return AG_ERR_INVALID_ARGUMENT; }
-    const size_t pre_n = ((size_t)a->Cout * g.OH * g.OW + 63) / 64 * 64;
-    float* g_pre = a->scratch;
-    float* aux = a->scratch + pre_n;
-    const bool nz = a->modulated && a->noise && a->noise_weight;
-    float* gb = (a->want_bias && a->g_bias_noise) ? a->g_bias_noise : nullptr;
-    float* gnw = (nz && a->want_noise_weight && a->g_bias_noise) ? a->g_bias_noise + a->Cout : nullptr;
+    if (!a) { set_error("ag_layer_backward: null"); return AG_ERR_INVALID_ARGUMENT; }
+    AgGroupedLayerArgs g;
+    to_grouped(a, g);
+    return ag_grouped_layer_backward(&g, stream);
+}
+
+// ---- ToRGB (dual_styleunet.py:607-633) for G instances ------------------------------------------------------------------------------
+// out = conv1x1(x, (scale * W) * style) + bias [+ HaarTransform(Upsample(InverseHaarTransform(skip)))]
+static bool rgb_ok(const AgGroupedToRgbArgs* a)
+{
+    return a && a->G >= 1 && a->G <= AG_MAX_GROUPS && a->Cin > 0 && a->Cout > 0 && a->H > 0 && a->W > 0;
+}
+
+static AgConvDesc rgb_desc(const AgGroupedToRgbArgs* a)
+{
+    AgConvDesc d{};
+    d.kind = AG_CONV; d.Cin = a->Cin; d.Cout = a->Cout; d.H = a->H; d.W = a->W; d.k = 1; d.stride = 1; d.padding = 0; d.weight_scale = 1.0f;
+    return d;
+}
+
+size_t ag_grouped_to_rgb_workspace_bytes(const AgGroupedToRgbArgs* a)
+{
+    if (!rgb_ok(a)) return 0;
+    const AgConvDesc d = rgb_desc(a);
+    return conv_workspace_bytes_g(&d, a->G);
+}
+
+size_t ag_grouped_to_rgb_scratch_floats(const AgGroupedToRgbArgs* a, int32_t backward)
+{
+    if (!rgb_ok(a)) return 0;
+    if (!backward) return 64;
+    return pad64((size_t)a->G * a->Cout * a->Cin) + pad64(modulate_weight_partial_floats(a->G, a->Cout, a->Cin)) + 64;
+}
+
+int ag_grouped_to_rgb_forward(const AgGroupedToRgbArgs* a, void* stream)
+{
+    if (!rgb_ok(a) || !a->x || !a->out || !a->w_mod) { set_error("ag_to_rgb_forward: bad arguments"); return AG_ERR_INVALID_ARGUMENT; }
+    const int G = a->G;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const PtrTable w_t = table_of(a->weight, G), style_t = table_of(a->style, G), bias_t = table_of(a->bias, G);
     int rc;
-    const bool fused_tail = a->modulated && a->resample && (fused_tail_mask() & 2);       // activation backward + the Blur's adjoint as one pass (below)
-    if (!fused_tail &&
-        (rc = ag_noise_bias_act_backward(g_pre, a->g_out, a->out, gnw ? a->noise : nullptr, gb, gnw, a->Cout, g.OH * g.OW, a->slope, a->act_scale, stream))) return rc;
-    if (!a->modulated) {
-        const float* cx = a->x;
-        if (a->resample) {
-            if (!a->x_blur || !a->k_blur) { ag::set_error("ag_layer_backward: down-sampling layer without x_blur / FIR taps"); return AG_ERR_INVALID_ARGUMENT; }
-            if (a->g_x) {     // gradient w.r.t. the blurred input, then the FIR's adjoint (flipped taps, pads (1,1): [H + 1] -> [H])
-                if ((rc = ag_conv_backward_input(&g.d, g_pre, a->weight, aux, a->workspace, a->workspace_bytes, stream))) return rc;
-                if ((rc = ag_upfirdn2d(a->g_x, aux, a->k_blur, a->Cin, g.BH, g.BW, 4, 4, 1, 1, 1, 1, 1, 1, 1, 1, stream))) return rc;
-            }
-            if (a->g_weight && (rc = ag_conv_backward_weight(&g.d, a->x_blur, g_pre, a->g_weight, a->workspace, a->workspace_bytes, stream))) return rc;
-            return AG_OK;
-        }
-        if (a->g_x && (rc = ag_conv_backward_input(&g.d, g_pre, a->weight, a->g_x, a->workspace, a->workspace_bytes, stream))) return rc;
-        if (a->g_weight && (rc = ag_conv_backward_weight(&g.d, cx, g_pre, a->g_weight, a->workspace, a->workspace_bytes, stream))) return rc;
-        return AG_OK;
-    }
-    if (!a->style || !a->w_mod || !a->demod) { ag::set_error("ag_layer_backward: StyledConv needs style, w_mod and demod"); return AG_ERR_INVALID_ARGUMENT; }
-    const float* g_conv = g_pre;
-    float* after = aux;
-    if (a->resample) {
-        // activation backward + adjoint of Blur pad (1,1) (pads (2,2) with the flipped taps: [2H] -> [2H + 1]) in one pass
-        if (!fused_tail) {
-            if ((rc = ag_upfirdn2d(aux, g_pre, a->k_blur, a->Cout, g.OH, g.OW, 4, 4, 1, 1, 1, 1, 2, 2, 2, 2, stream))) return rc;
-        } else if ((rc = ag_fir4x4_noise_bias_act_backward(aux, a->g_out, a->out, a->k_blur, a->Cout, g.OH, g.OW, gnw ? a->noise : nullptr, gb, gnw,
-                                                    a->slope, a->act_scale, stream))) return rc;
-        g_conv = aux;
-        after = aux + ((size_t)a->Cout * g.CH * g.CW + 63) / 64 * 64;
-    }
-    if (a->g_x && (rc = ag_conv_backward_input(&g.d, g_conv, a->w_mod, a->g_x, a->workspace, a->workspace_bytes, stream))) return rc;
-    if (a->g_weight) {
-        if (!a->g_style) { ag::set_error("ag_layer_backward: g_weight without g_style"); return AG_ERR_INVALID_ARGUMENT; }
-        float* g_wm = after;
-        if ((rc = ag_conv_backward_weight(&g.d, a->x, g_conv, g_wm, a->workspace, a->workspace_bytes, stream))) return rc;
-        if ((rc = ag_modulate_weight_backward(a->g_weight, a->g_style, g_wm, a->weight, a->style, a->demod, a->scale, 1, a->Cout, a->Cin, a->k * a->k,
-                                              a->resample ? 1 : 0, stream))) return rc;
+    if ((rc = modulate_weight_forward_g(a->w_mod, nullptr, G, w_t, style_t, a->scale, 0, a->Cout, a->Cin, 1, 0, s))) return rc;
+    PtrTable wm_t{};
+    for (int i = 0; i < G; i++) wm_t.p[i] = a->w_mod + (size_t)i * a->Cout * a->Cin;
+    const AgConvDesc d = rgb_desc(a);
+    const long long hw = (long long)a->H * a->W;
+    if ((rc = conv_forward_g(&d, G, a->x, a->Cin * hw, wm_t, nullptr, bias_t, a->out, a->Cout * hw, a->workspace, a->workspace_bytes, s))) return rc;
+    if (a->skip) {
+        if (!a->skip_taps || (a->Cout & 3) || (a->H & 1) || (a->W & 1)) { set_error("ag_to_rgb_forward: skip path needs taps, 4C channels, even size"); return AG_ERR_INVALID_ARGUMENT; }
+        return skip_chain_forward_g(a->out, a->skip, a->skip_taps, G, a->Cout / 4, a->H / 2, a->W / 2, 1, s);
     }
     return AG_OK;
+}
+
+int ag_grouped_to_rgb_backward(const AgGroupedToRgbArgs* a, void* stream)
+{
+    if (!rgb_ok(a) || !a->x || !a->g_out || !a->w_mod || !a->scratch) { set_error("ag_to_rgb_backward: bad arguments"); return AG_ERR_INVALID_ARGUMENT; }
+    const int G = a->G;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const PtrTable w_t = table_of(a->weight, G), style_t = table_of(a->style, G);
+    PtrTable wm_t{};
+    for (int i = 0; i < G; i++) wm_t.p[i] = a->w_mod + (size_t)i * a->Cout * a->Cin;
+    const AgConvDesc d = rgb_desc(a);
+    const long long hw = (long long)a->H * a->W;
+    int rc;
+    if (a->g_skip) {
+        if (!a->skip_taps) { set_error("ag_to_rgb_backward: skip gradient without taps"); return AG_ERR_INVALID_ARGUMENT; }
+        if ((rc = skip_chain_backward_g(a->g_skip, a->g_out, a->skip_taps, G, a->Cout / 4, a->H / 2, a->W / 2, s))) return rc;
+    }
+    if (a->g_x && (rc = conv_backward_input_g(&d, G, a->g_out, a->Cout * hw, wm_t, a->g_x, a->Cin * hw, a->workspace, a->workspace_bytes, s))) return rc;
+    if (a->g_weight) {
+        if (!a->g_style) { set_error("ag_to_rgb_backward: g_weight without g_style"); return AG_ERR_INVALID_ARGUMENT; }
+        float* g_wm = a->scratch;
+        float* part = a->scratch + pad64((size_t)G * a->Cout * a->Cin);
+        if ((rc = conv_backward_weight_g(&d, G, a->x, a->Cin * hw, a->g_out, a->Cout * hw, g_wm, (long long)a->Cout * a->Cin, a->workspace, a->workspace_bytes, s))) return rc;
+        if ((rc = modulate_weight_backward_g(a->g_weight, a->g_style, part, g_wm, G, w_t, style_t, nullptr, a->scale, 0, a->Cout, a->Cin, 1, 0, s))) return rc;
+    }
+    return AG_OK;
+}
+
+/* Stacked copies of the per-instance helpers the grouped network needs between layers. */
+int ag_grouped_block2x2(float* out, const float* in, const float* matrix16, int32_t merge, int32_t G, int32_t C, int32_t h, int32_t w, void* stream)
+{
+    return block2x2_transform_g(out, in, matrix16, merge, G, C, h, w, reinterpret_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

@@ -8,6 +8,7 @@
 //                   outputs); the <= 4x4 FIR taps sit in LDS.
 #include <cstring>
 #include "ag_common.h"
+#include "ag_groups.h"
 #include "../../include/ag_styleunet.h"
 
 namespace ag {
@@ -56,20 +57,25 @@ __global__ void __launch_bounds__(256) fused_bias_act_kernel(float* __restrict__
 // ------------------------------------------------------------------------------------------------------------------
 // StyledConv tail in one pass (dual_styleunet.py:598-604): y = lrelu(x + nw * noise[pix] + bias[c], slope) * scale
 // and its backward with the two reductions folded in: gx = gy * (y > 0 ? 1 : slope) * scale,
-// gbias[c] += sum_pix gx, gnw += sum_{c,pix} gx * noise[pix].  One workgroup owns a run of pixels of ONE channel, so
-// the bias is a scalar and both sums are a workgroup reduction + one atomic each.
+// gbias[c] = sum_pix gx, gnw = sum_{c,pix} gx * noise[pix].  One workgroup owns a run of pixels of ONE channel, so the bias is a scalar
+// and both sums are a workgroup reduction.  The reductions are DETERMINISTIC (round 4): every workgroup stores its two partial sums,
+// nba_finish_kernel adds them in a fixed order -- the noise-strength gradient is ONE number summed over a whole feature map with mixed
+// signs, and float atomics in arrival order moved it by up to 3e-2 of its value from run to run.
+// Grouped (ag_groups.h): x, y are [G][C][HW]; noise / noise weight / bias come from per-instance pointer tables.
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int kNbaChunk = 4096;   // pixels per workgroup (16 per thread)
 
 __global__ void __launch_bounds__(256) noise_bias_act_forward_kernel(float* __restrict__ y, const float* __restrict__ x,
-                                                                    const float* __restrict__ noise, const float* __restrict__ nw,
-                                                                    const float* __restrict__ bias, int C, int HW, int chunks,
-                                                                    float slope, float scale)
+                                                                    const PtrTable noise_t, const PtrTable nw_t, const PtrTable bias_t,
+                                                                    int C, int HW, int chunks, float slope, float scale)
 {
-    const int c = blockIdx.x / chunks, p0 = (blockIdx.x - c * chunks) * kNbaChunk;
-    const float b = bias ? bias[c] : 0.f, w = noise ? nw[0] : 0.f;
-    const float* xr = x + (size_t)c * HW;
-    float* yr = y + (size_t)c * HW;
+    const int cg = blockIdx.x / chunks, p0 = (blockIdx.x - cg * chunks) * kNbaChunk;      // cg: channel index over all instances
+    const int grp = cg / C, c = cg - grp * C;
+    const float* __restrict__ noise = noise_t.p[grp];
+    const float* __restrict__ bias = bias_t.p[grp];
+    const float b = bias ? bias[c] : 0.f, w = noise ? nw_t.p[grp][0] : 0.f;
+    const float* xr = x + (size_t)cg * HW;
+    float* yr = y + (size_t)cg * HW;
     const int pend = min(HW, p0 + kNbaChunk);
     if ((HW & 3) == 0) {
         for (int p = p0 + threadIdx.x * 4; p < pend; p += 1024) {
@@ -99,16 +105,18 @@ __device__ __forceinline__ float wave_sum(float v)
     return v;
 }
 
+// partials: [G * C * chunks][2] = (sum gx, sum gx * noise) of every workgroup
 __global__ void __launch_bounds__(256) noise_bias_act_backward_kernel(float* __restrict__ gx, const float* __restrict__ gy,
-                                                                     const float* __restrict__ y, const float* __restrict__ noise,
-                                                                     float* __restrict__ gbias, float* __restrict__ gnw, int C,
-                                                                     int HW, int chunks, float slope, float scale)
+                                                                     const float* __restrict__ y, const PtrTable noise_t,
+                                                                     float* __restrict__ partials, int C, int HW, int chunks, float slope,
+                                                                     float scale)
 {
     __shared__ float s_red[2][4];
-    const int c = blockIdx.x / chunks, p0 = (blockIdx.x - c * chunks) * kNbaChunk;
-    const float* gyr = gy + (size_t)c * HW;
-    const float* yr = y + (size_t)c * HW;
-    float* gxr = gx + (size_t)c * HW;
+    const int cg = blockIdx.x / chunks, p0 = (blockIdx.x - cg * chunks) * kNbaChunk;
+    const float* __restrict__ noise = noise_t.p[cg / C];
+    const float* gyr = gy + (size_t)cg * HW;
+    const float* yr = y + (size_t)cg * HW;
+    float* gxr = gx + (size_t)cg * HW;
     const int pend = min(HW, p0 + kNbaChunk);
     float sb = 0.f, sn = 0.f;
     if ((HW & 3) == 0) {
@@ -134,22 +142,18 @@ __global__ void __launch_bounds__(256) noise_bias_act_backward_kernel(float* __r
             if (noise) sn += r * noise[p];
         }
     }
+    if (!partials) return;
     sb = wave_sum(sb);
     sn = wave_sum(sn);
     const int wave = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) { s_red[0][wave] = sb; s_red[1][wave] = sn; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        if (gbias) atomicAdd(gbias + c, (s_red[0][0] + s_red[0][1]) + (s_red[0][2] + s_red[0][3]));
-        if (gnw) atomicAdd(gnw, (s_red[1][0] + s_red[1][1]) + (s_red[1][2] + s_red[1][3]));
+        partials[2 * (size_t)blockIdx.x] = (s_red[0][0] + s_red[0][1]) + (s_red[0][2] + s_red[0][3]);
+        partials[2 * (size_t)blockIdx.x + 1] = (s_red[1][0] + s_red[1][1]) + (s_red[1][2] + s_red[1][3]);
     }
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// Weight modulation + demodulation of ModulatedConv2d's fused branch (dual_styleunet.py:254-259), one workgroup per
-// output channel:  w'[co][ci][k] = (scale * W[co][ci][k]) * style[ci];  d[co] = rsqrt(sum w'^2 + 1e-8);  out = w' * d.
-// `transposed` writes out[ci][co][k] (the layout conv_transpose2d takes, :268-272).
-// ------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float block_sum_256(float v, float* s_red)
 {
     v = wave_sum(v);
@@ -160,13 +164,42 @@ __device__ __forceinline__ float block_sum_256(float v, float* s_red)
     return r;
 }
 
+// One workgroup per instance: gbias[c] = the channel's chunk sums in chunk order; gnw = all C * chunks sums of the instance, each thread a
+// strided subsequence in order, then the fixed butterfly of block_sum_256.  Same bits on every run.
+__global__ void __launch_bounds__(256) nba_finish_kernel(const float* __restrict__ partials, float* __restrict__ gbias, long long gb_stride,
+                                                         float* __restrict__ gnw, long long gnw_stride, int C, int per_channel)
+{
+    __shared__ float s_red[4];
+    const int grp = blockIdx.x;
+    const float* part = partials + 2 * (size_t)grp * C * per_channel;
+    if (gbias)
+        for (int c = threadIdx.x; c < C; c += 256) {
+            float s = 0.f;
+            for (int k = 0; k < per_channel; k++) s += part[2 * ((size_t)c * per_channel + k)];
+            gbias[(size_t)grp * gb_stride + c] = s;
+        }
+    if (gnw) {
+        float t = 0.f;
+        for (int i = threadIdx.x; i < C * per_channel; i += 256) t += part[2 * (size_t)i + 1];
+        t = block_sum_256(t, s_red);
+        if (threadIdx.x == 0) gnw[(size_t)grp * gnw_stride] = t;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Weight modulation + demodulation of ModulatedConv2d's fused branch (dual_styleunet.py:254-259), one workgroup per
+// output channel:  w'[co][ci][k] = (scale * W[co][ci][k]) * style[ci];  d[co] = rsqrt(sum w'^2 + 1e-8);  out = w' * d.
+// `transposed` writes out[ci][co][k] (the layout conv_transpose2d takes, :268-272).  Grouped: blockIdx.x = instance * Co + co.
+// ------------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) modulate_weight_forward_kernel(float* __restrict__ out, float* __restrict__ dcoef,
-                                                                     const float* __restrict__ W, const float* __restrict__ style,
+                                                                     const PtrTable W_t, const PtrTable style_t,
                                                                      float scale, int demod, int Co, int Ci, int K2, int transposed)
 {
     __shared__ float s_red[4];
-    const int co = blockIdx.x, n = Ci * K2;
-    const float* w = W + (size_t)co * n;
+    const int grp = blockIdx.x / Co, co = blockIdx.x - grp * Co, n = Ci * K2;
+    const float* __restrict__ style = style_t.p[grp];
+    const float* w = W_t.p[grp] + (size_t)co * n;
+    out += (size_t)grp * Co * n;
     float q = 0.f;
     if (demod) {
         for (int i = threadIdx.x; i < n; i += 256) {
@@ -176,7 +209,7 @@ __global__ void __launch_bounds__(256) modulate_weight_forward_kernel(float* __r
         q = block_sum_256(q, s_red);
     }
     const float d = demod ? rsqrtf(q + 1e-8f) : 1.0f;
-    if (threadIdx.x == 0 && dcoef) dcoef[co] = d;
+    if (threadIdx.x == 0 && dcoef) dcoef[blockIdx.x] = d;
     for (int i = threadIdx.x; i < n; i += 256) {
         const int ci = i / K2, k = i - ci * K2;
         const float v = (scale * w[i]) * style[ci];
@@ -186,17 +219,21 @@ __global__ void __launch_bounds__(256) modulate_weight_forward_kernel(float* __r
 }
 
 // g = dL/dout.  dL/dw' = g * d - d^3 * (sum g w') * w'   (g when there is no demodulation);
-// dW = dL/dw' * scale * style[ci];  dstyle[ci] += sum_{co, k} dL/dw' * scale * W     (float atomics over co)
-__global__ void __launch_bounds__(256) modulate_weight_backward_kernel(float* __restrict__ dW, float* __restrict__ dstyle,
-                                                                      const float* __restrict__ g, const float* __restrict__ W,
-                                                                      const float* __restrict__ style, const float* __restrict__ dcoef,
+// dW = dL/dw' * scale * style[ci];  dstyle[ci] = sum_{co, k} dL/dw' * scale * W: every (co, ci) pair's sum over the taps goes to
+// partials[grp][co][ci], modulate_finish_kernel adds them over co in a fixed order (deterministic; float atomics over co before round 4)
+__global__ void __launch_bounds__(256) modulate_weight_backward_kernel(float* __restrict__ dW, float* __restrict__ partials,
+                                                                      const float* __restrict__ g, const PtrTable W_t,
+                                                                      const PtrTable style_t, const float* __restrict__ dcoef,
                                                                       float scale, int demod, int Co, int Ci, int K2, int transposed)
 {
     __shared__ float s_red[4];
-    const int co = blockIdx.x, n = Ci * K2;
-    const float* w = W + (size_t)co * n;
+    const int grp = blockIdx.x / Co, co = blockIdx.x - grp * Co, n = Ci * K2;
+    const float* __restrict__ style = style_t.p[grp];
+    const float* w = W_t.p[grp] + (size_t)co * n;
+    g += (size_t)grp * Co * n;
+    dW += (size_t)grp * Co * n;
     float gw = 0.f;
-    const float d = demod ? dcoef[co] : 1.0f;
+    const float d = demod ? dcoef[blockIdx.x] : 1.0f;
     if (demod) {
         for (int i = threadIdx.x; i < n; i += 256) {
             const int ci = i / K2, k = i - ci * K2;
@@ -206,7 +243,7 @@ __global__ void __launch_bounds__(256) modulate_weight_backward_kernel(float* __
         gw = block_sum_256(gw, s_red);
     }
     const float c3 = d * d * d * gw;
-    // one thread per input channel keeps the K2 taps of that channel together: a single atomic per (co, ci)
+    // one thread per input channel keeps the K2 taps of that channel together
     for (int ci = threadIdx.x; ci < Ci; ci += 256) {
         const float sc = scale * style[ci];
         float ds = 0.f;
@@ -218,8 +255,24 @@ __global__ void __launch_bounds__(256) modulate_weight_backward_kernel(float* __
             dW[(size_t)co * n + i] = gp * sc;
             ds += gp * sw;
         }
-        atomicAdd(dstyle + ci, ds);
+        partials[(size_t)blockIdx.x * Ci + ci] = ds;
     }
+}
+
+// dstyle[grp][ci] = sum_co partials[grp][co][ci]: a workgroup owns 64 channels, its four waves a quarter of the rows each, in order
+__global__ void __launch_bounds__(256) modulate_finish_kernel(float* __restrict__ dstyle, const float* __restrict__ partials, int Co, int Ci)
+{
+    __shared__ float s_q[4][64];
+    const int grp = blockIdx.y, lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int ci = blockIdx.x * 64 + lane;
+    const float* part = partials + (size_t)grp * Co * Ci;
+    const int per = (Co + 3) / 4, r0 = q * per, r1 = min(Co, r0 + per);
+    float s = 0.f;
+    if (ci < Ci)
+        for (int co = r0; co < r1; co++) s += part[(size_t)co * Ci + ci];
+    s_q[q][lane] = s;
+    __syncthreads();
+    if (q == 0 && ci < Ci) dstyle[(size_t)grp * Ci + ci] = (s_q[0][lane] + s_q[1][lane]) + (s_q[2][lane] + s_q[3][lane]);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -230,38 +283,44 @@ __global__ void __launch_bounds__(256) modulate_weight_backward_kernel(float* __
 // ------------------------------------------------------------------------------------------------------------------
 struct Block2x2 { float m[16]; };
 
-__global__ void __launch_bounds__(256) block2x2_split_kernel(float* __restrict__ y, const float* __restrict__ x, Block2x2 M, int C,
+__global__ void __launch_bounds__(256) block2x2_split_kernel(float* __restrict__ y, const float* __restrict__ x, Block2x2 M, int G, int C,
                                                             int h, int w)
 {
-    const long long total = (long long)C * h * w;
+    const long long per = (long long)C * h * w, total = per * G;          // grouped: x [G][C][2h][2w] -> y [G][4][C][h][w]
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int jx = (int)(i % w);
         const long long r = i / w;
-        const int iy = (int)(r % h), c = (int)(r / h);
-        const float* src = x + ((size_t)c * 2 * h + 2 * iy) * (2 * w) + 2 * jx;
+        const int iy = (int)(r % h);
+        const long long cg = r / h;                                       // channel over all instances
+        const long long grp = cg / C, il = i - grp * per;
+        const float* src = x + ((size_t)cg * 2 * h + 2 * iy) * (2 * w) + 2 * jx;
         const float2 t = *reinterpret_cast<const float2*>(src), b = *reinterpret_cast<const float2*>(src + 2 * w);
         const float v[4] = { t.x, t.y, b.x, b.y };
+        float* dst = y + (size_t)grp * 4 * per + il;
 #pragma unroll
         for (int band = 0; band < 4; band++)
-            y[(size_t)band * total + i] = M.m[4 * band + 0] * v[0] + M.m[4 * band + 1] * v[1] + M.m[4 * band + 2] * v[2] + M.m[4 * band + 3] * v[3];
+            dst[(size_t)band * per] = M.m[4 * band + 0] * v[0] + M.m[4 * band + 1] * v[1] + M.m[4 * band + 2] * v[2] + M.m[4 * band + 3] * v[3];
     }
 }
 
-__global__ void __launch_bounds__(256) block2x2_merge_kernel(float* __restrict__ x, const float* __restrict__ y, Block2x2 M, int C,
+__global__ void __launch_bounds__(256) block2x2_merge_kernel(float* __restrict__ x, const float* __restrict__ y, Block2x2 M, int G, int C,
                                                             int h, int w)
 {
-    const long long total = (long long)C * h * w;
+    const long long per = (long long)C * h * w, total = per * G;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int jx = (int)(i % w);
         const long long r = i / w;
-        const int iy = (int)(r % h), c = (int)(r / h);
+        const int iy = (int)(r % h);
+        const long long cg = r / h;
+        const long long grp = cg / C, il = i - grp * per;
+        const float* src = y + (size_t)grp * 4 * per + il;
         float v[4];
 #pragma unroll
-        for (int band = 0; band < 4; band++) v[band] = y[(size_t)band * total + i];
+        for (int band = 0; band < 4; band++) v[band] = src[(size_t)band * per];
         float o[4];
 #pragma unroll
         for (int p = 0; p < 4; p++) o[p] = M.m[4 * p + 0] * v[0] + M.m[4 * p + 1] * v[1] + M.m[4 * p + 2] * v[2] + M.m[4 * p + 3] * v[3];
-        float* dst = x + ((size_t)c * 2 * h + 2 * iy) * (2 * w) + 2 * jx;
+        float* dst = x + ((size_t)cg * 2 * h + 2 * iy) * (2 * w) + 2 * jx;
         *reinterpret_cast<float2*>(dst) = make_float2(o[0], o[1]);
         *reinterpret_cast<float2*>(dst + 2 * w) = make_float2(o[2], o[3]);
     }
@@ -277,14 +336,17 @@ __global__ void __launch_bounds__(256) block2x2_merge_kernel(float* __restrict__
 // One pass over 4 + 32 floats per site instead of four kernels moving 108; 240 FMAs per site.
 struct SkipTaps { float wy[2][2][2][3], wx[2][2][2][3]; };
 
-__global__ void __launch_bounds__(256) skip_chain_forward_kernel(float* __restrict__ out, const float* __restrict__ skip,
-                                                                 const SkipTaps t, int C, int h, int w, int accumulate)
+__global__ void __launch_bounds__(256) skip_chain_forward_kernel(float* __restrict__ out_all, const float* __restrict__ skip_all,
+                                                                 const SkipTaps t, int G, int C, int h, int w, int accumulate)
 {
-    const long long plane = (long long)h * w, total = (long long)C * plane;
+    const long long plane = (long long)h * w, total = (long long)G * C * plane;       // grouped: skip [G][4C][h][w] -> out [G][4C][2h][2w]
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
         const int j = (int)(idx % w);
         const long long r = idx / w;
-        const int i = (int)(r % h), c = (int)(r / h);
+        const int i = (int)(r % h);
+        const int cg = (int)(r / h), grp = cg / C, c = cg - grp * C;
+        const float* __restrict__ skip = skip_all + (size_t)grp * 4 * C * plane;
+        float* __restrict__ out = out_all + (size_t)grp * 16 * C * plane;
         float xs[2][3][2][2];                      // [uy][a][u'x][px]: the x stage
 #pragma unroll
         for (int uy = 0; uy < 2; uy++)
@@ -334,14 +396,17 @@ __global__ void __launch_bounds__(256) skip_chain_forward_kernel(float* __restri
 
 // adjoint: gskip[(uy, ux)][i][j] = sum over the sites (I, J) = (i - a + 1, j - b + 1) that read it of
 //          wy[u'y][py][uy][a] * wx[u'x][px][ux][b] * g[(u'y, u'x)][2I+py][2J+px]
-__global__ void __launch_bounds__(256) skip_chain_backward_kernel(float* __restrict__ gskip, const float* __restrict__ g,
-                                                                  const SkipTaps t, int C, int h, int w)
+__global__ void __launch_bounds__(256) skip_chain_backward_kernel(float* __restrict__ gskip_all, const float* __restrict__ g_all,
+                                                                  const SkipTaps t, int G, int C, int h, int w)
 {
-    const long long plane = (long long)h * w, total = (long long)C * plane;
+    const long long plane = (long long)h * w, total = (long long)G * C * plane;
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
         const int j = (int)(idx % w);
         const long long r = idx / w;
-        const int i = (int)(r % h), c = (int)(r / h);
+        const int i = (int)(r % h);
+        const int cg = (int)(r / h), grp = cg / C, c = cg - grp * C;
+        float* __restrict__ gskip = gskip_all + (size_t)grp * 4 * C * plane;
+        const float* __restrict__ g = g_all + (size_t)grp * 16 * C * plane;
         float acc[2][2] = { { 0.f, 0.f }, { 0.f, 0.f } };      // [uy][ux]
 #pragma unroll
         for (int a = 0; a < 3; a++) {
@@ -429,19 +494,10 @@ __global__ void __launch_bounds__(256) upfirdn2d_kernel(float* __restrict__ out,
 // 4 x 2 block of outputs from a 7 x 5 window read as ten 16-byte loads (alignment is free on this part: profiles/ub/load_rate.hip), grid
 // (x quads, row pairs, image) so there is no division at all; same accumulation order per output as the general kernel (rows, then
 // columns, ascending; out-of-image taps contribute exact zeros), hence the same bits.
-// ACT (round 3): NoiseInjection + FusedLeakyReLU applied to the filtered value before it is stored -- the Blur behind an up-sampling
-// ModulatedConv2d and the StyledConv tail as ONE pass (dual_styleunet.py:188-193, 301-311, 596): channel = blockIdx.z, the value goes
-// through exactly the expression of noise_bias_act_forward_kernel.
-struct FirAct {
-    const float* noise;      // [out_h * out_w] or null
-    const float* nw;         // [1] (with noise)
-    const float* bias;       // [major] or null
-    float slope, scale;
-};
-
-template <bool ACT>
+// (A variant that also applied NoiseInjection + FusedLeakyReLU to the filtered value, and its fused backward, existed in round 3: bit-identical,
+// no gain -- 12 of ~1500 launches of a network pass, slower backward -- and removed in round 4: profiles/r03_fused_tail_ab.txt.)
 __global__ void __launch_bounds__(256) fir4x4_kernel(float* __restrict__ out, const float* __restrict__ input,
-                                                     const float* __restrict__ kernel, UpfirdnParams p, FirAct act)
+                                                     const float* __restrict__ kernel, UpfirdnParams p)
 {
     __shared__ float taps[16];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -484,15 +540,6 @@ __global__ void __launch_bounds__(256) fir4x4_kernel(float* __restrict__ out, co
 #pragma unroll
                 for (int q = 0; q < 4; q++) v[q] = fmaf(win[dy + y][q + x], k, v[q]);
             }
-        if constexpr (ACT) {
-            const float b = act.bias ? act.bias[blockIdx.z] : 0.f, w = act.noise ? act.nw[0] : 0.f;
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const float n = (act.noise && ox0 + q < p.out_w) ? act.noise[(size_t)(oy0 + dy) * p.out_w + ox0 + q] : 0.f;
-                const float t = v[q] + w * n + b;
-                v[q] = (t > 0.f ? t : t * act.slope) * act.scale;
-            }
-        }
         if (ox0 + 4 <= p.out_w && (((size_t)(dst + (size_t)dy * p.out_w)) & 15) == 0) {
             *reinterpret_cast<float4*>(dst + (size_t)dy * p.out_w) = make_float4(v[0], v[1], v[2], v[3]);
         } else {
@@ -503,99 +550,129 @@ __global__ void __launch_bounds__(256) fir4x4_kernel(float* __restrict__ out, co
     }
 }
 
-// Backward of fir4x4_kernel<true> with pads (1, 1) (the up-sampling StyledConv: [C, OH + 1, OW + 1] -> [C, OH, OW]): the gradient of the
-// activation input g_pre = g_out * (out > 0 ? 1 : slope) * scale is formed on the fly from g_out and the saved output, its bias /
-// noise-strength sums are reduced (every g_pre element is owned by exactly one thread), and the FIR's adjoint -- the flipped taps with
-// pads (2, 2) -- is applied to it: one pass instead of noise_bias_act_backward + upfirdn2d, and g_pre never goes to memory.
-// Thread = 4 x 2 outputs of the [OH + 1, OW + 1] grid from a 7 x 5 window; a workgroup walks kFirBwdRows rows so that the per-channel
-// sums cost few same-address atomics.
-constexpr int kFirBwdRows = 32;
+// ------------------------------------------------------------------------------------------------------------------
+// grouped launchers (ag_groups.h); G = 1 is the per-kernel C ABI below
+// ------------------------------------------------------------------------------------------------------------------
+static bool bad_groups(int G) { return G < 1 || G > kMaxGroups; }
 
-__global__ void __launch_bounds__(256) fir4x4_nba_backward_kernel(float* __restrict__ g_in, const float* __restrict__ g_out,
-                                                                  const float* __restrict__ y, const float* __restrict__ kflip,
-                                                                  const float* __restrict__ noise, float* __restrict__ gbias,
-                                                                  float* __restrict__ gnw, int OH, int OW, float slope, float scale)
+int noise_bias_act_forward_g(float* y, const float* x, int G, const PtrTable& noise, const PtrTable& nw, const PtrTable& bias, int C, int HW,
+                             float slope, float scale, hipStream_t s)
 {
-    __shared__ float taps[16];
-    __shared__ float s_red[2][4];
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    if (threadIdx.x < 16) taps[threadIdx.x] = kflip[threadIdx.x];
-    __syncthreads();
-    const int IH = OH + 1, IW = OW + 1;                                  // the convolution output this gradient belongs to
-    const size_t c = blockIdx.z;
-    const float* go = g_out + c * OH * OW;
-    const float* yo = y + c * OH * OW;
-    float* gi = g_in + c * IH * IW;
-    const int ox0 = (blockIdx.x * 64 + tx) * 4;
-    float sb = 0.f, sn = 0.f;
-    for (int rr = 0; rr < kFirBwdRows; rr += 8) {
-        const int oy0 = blockIdx.y * kFirBwdRows + rr + ty * 2;
-        if (ox0 >= IW || oy0 >= IH) continue;
-        const int cx = ox0 - 2, cy = oy0 - 2;                            // window origin in the [OH, OW] grid of g_pre
-        float win[5][8];
-        const bool x_inside = cx >= 0 && cx + 8 <= OW;
-#pragma unroll
-        for (int r = 0; r < 5; r++) {
-            const int iy = cy + r;
-            const bool row_ok = iy >= 0 && iy < OH;
-            const size_t ro = (size_t)(row_ok ? iy : 0) * OW;
-            if (row_ok && x_inside) {       // two 16-byte loads per array (alignment is free on this part)
-                const float4 ga = *reinterpret_cast<const float4*>(go + ro + cx), gb4 = *reinterpret_cast<const float4*>(go + ro + cx + 4);
-                const float4 ya = *reinterpret_cast<const float4*>(yo + ro + cx), yb = *reinterpret_cast<const float4*>(yo + ro + cx + 4);
-                win[r][0] = ga.x * (ya.x > 0.f ? 1.f : slope) * scale; win[r][1] = ga.y * (ya.y > 0.f ? 1.f : slope) * scale;
-                win[r][2] = ga.z * (ya.z > 0.f ? 1.f : slope) * scale; win[r][3] = ga.w * (ya.w > 0.f ? 1.f : slope) * scale;
-                win[r][4] = gb4.x * (yb.x > 0.f ? 1.f : slope) * scale; win[r][5] = gb4.y * (yb.y > 0.f ? 1.f : slope) * scale;
-                win[r][6] = gb4.z * (yb.z > 0.f ? 1.f : slope) * scale; win[r][7] = 0.f;
-            } else {
-#pragma unroll
-                for (int q = 0; q < 7; q++) {
-                    const int ix = cx + q;
-                    float v = 0.f;
-                    if (row_ok && ix >= 0 && ix < OW) v = go[ro + ix] * (yo[ro + ix] > 0.f ? 1.f : slope) * scale;
-                    win[r][q] = v;
-                }
-                win[r][7] = 0.f;
-            }
-        }
-        // sums over the g_pre elements this thread owns: window rows 2..3, columns 2..5 (= positions oy0.., ox0.. of the [OH, OW] grid)
-#pragma unroll
-        for (int dy = 0; dy < 2; dy++)
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int iy = oy0 + dy, ix = ox0 + q;
-                if (iy < OH && ix < OW) {
-                    const float r = win[2 + dy][2 + q];
-                    sb += r;
-                    if (noise) sn += r * noise[(size_t)iy * OW + ix];
-                }
-            }
-#pragma unroll
-        for (int dy = 0; dy < 2; dy++) {
-            if (oy0 + dy >= IH) break;
-            float v[4] = { 0.f, 0.f, 0.f, 0.f };
-#pragma unroll
-            for (int yy = 0; yy < 4; yy++)
-#pragma unroll
-                for (int x = 0; x < 4; x++) {
-                    const float k = taps[(3 - yy) * 4 + (3 - x)];
-#pragma unroll
-                    for (int q = 0; q < 4; q++) v[q] = fmaf(win[dy + yy][q + x], k, v[q]);
-                }
-#pragma unroll
-            for (int q = 0; q < 4; q++)
-                if (ox0 + q < IW) gi[(size_t)(oy0 + dy) * IW + ox0 + q] = v[q];
-        }
+    if (bad_groups(G) || C < 0 || HW < 0 || ((C > 0 && HW > 0) && (!y || !x))) { set_error("bad noise_bias_act arguments"); return AG_ERR_INVALID_ARGUMENT; }
+    for (int g = 0; g < G; g++)
+        if (noise.p[g] && !nw.p[g]) { set_error("noise_bias_act: noise without a noise weight"); return AG_ERR_INVALID_ARGUMENT; }
+    if (C == 0 || HW == 0) return AG_OK;
+    const int chunks = (HW + kNbaChunk - 1) / kNbaChunk;
+    hipLaunchKernelGGL(noise_bias_act_forward_kernel, dim3(G * C * chunks), dim3(256), 0, s, y, x, noise, nw, bias, C, HW, chunks, slope, scale);
+    return check_hip(hipGetLastError(), "noise_bias_act_forward_kernel");
+}
+
+size_t noise_bias_act_partial_floats(int G, int C, int HW)
+{
+    if (G <= 0 || C <= 0 || HW <= 0) return 0;
+    return (size_t)2 * G * C * ((HW + kNbaChunk - 1) / kNbaChunk);
+}
+
+int noise_bias_act_backward_g(float* gx, const float* gy, const float* y, int G, const PtrTable& noise, float* gbias, long long gb_stride,
+                              float* gnw, long long gnw_stride, float* partials, int C, int HW, float slope, float scale, hipStream_t s)
+{
+    if (bad_groups(G) || C < 0 || HW < 0 || ((C > 0 && HW > 0) && (!gx || !gy || !y)) || ((gbias || gnw) && !partials)) {
+        set_error("bad noise_bias_act_backward arguments (the parameter sums need the `partials` scratch)");
+        return AG_ERR_INVALID_ARGUMENT;
     }
-    if (gbias || gnw) {
-        sb = wave_sum(sb);
-        sn = wave_sum(sn);
-        if ((threadIdx.x & 63) == 0) { s_red[0][ty] = sb; s_red[1][ty] = sn; }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            if (gbias) atomicAdd(gbias + c, (s_red[0][0] + s_red[0][1]) + (s_red[0][2] + s_red[0][3]));
-            if (gnw) atomicAdd(gnw, (s_red[1][0] + s_red[1][1]) + (s_red[1][2] + s_red[1][3]));
+    if (gnw)
+        for (int g = 0; g < G; g++)
+            if (!noise.p[g]) { set_error("noise_bias_act_backward: noise-strength gradient without noise"); return AG_ERR_INVALID_ARGUMENT; }
+    if (C == 0 || HW == 0) {
+        for (int g = 0; g < G; g++) {
+            if (gbias && C > 0 && check_hip(hipMemsetAsync(gbias + g * gb_stride, 0, (size_t)C * sizeof(float), s), "memset gbias")) return AG_ERR_HIP;
+            if (gnw && check_hip(hipMemsetAsync(gnw + g * gnw_stride, 0, sizeof(float), s), "memset gnw")) return AG_ERR_HIP;
         }
+        return AG_OK;
     }
+    const int chunks = (HW + kNbaChunk - 1) / kNbaChunk;
+    const bool sums = gbias || gnw;
+    hipLaunchKernelGGL(noise_bias_act_backward_kernel, dim3(G * C * chunks), dim3(256), 0, s, gx, gy, y, gnw ? noise : PtrTable{},
+                       sums ? partials : nullptr, C, HW, chunks, slope, scale);
+    if (check_hip(hipGetLastError(), "noise_bias_act_backward_kernel")) return AG_ERR_HIP;
+    if (!sums) return AG_OK;
+    hipLaunchKernelGGL(nba_finish_kernel, dim3(G), dim3(256), 0, s, partials, gbias, gb_stride, gnw, gnw_stride, C, chunks);
+    return check_hip(hipGetLastError(), "nba_finish_kernel");
+}
+
+int modulate_weight_forward_g(float* out, float* dcoef, int G, const PtrTable& W, const PtrTable& style, float scale, int demod, int Co, int Ci,
+                              int K2, int transposed, hipStream_t s)
+{
+    if (bad_groups(G) || Co <= 0 || Ci <= 0 || K2 <= 0 || !out || !table_complete(W, G) || !table_complete(style, G)) {
+        set_error("bad modulate_weight arguments");
+        return AG_ERR_INVALID_ARGUMENT;
+    }
+    hipLaunchKernelGGL(modulate_weight_forward_kernel, dim3(G * Co), dim3(256), 0, s, out, dcoef, W, style, scale, demod, Co, Ci, K2, transposed);
+    return check_hip(hipGetLastError(), "modulate_weight_forward_kernel");
+}
+
+size_t modulate_weight_partial_floats(int G, int Co, int Ci)
+{
+    if (G <= 0 || Co <= 0 || Ci <= 0) return 0;
+    return (size_t)G * Co * Ci;
+}
+
+int modulate_weight_backward_g(float* dW, float* dstyle, float* partials, const float* g, int G, const PtrTable& W, const PtrTable& style,
+                               const float* dcoef, float scale, int demod, int Co, int Ci, int K2, int transposed, hipStream_t s)
+{
+    if (bad_groups(G) || Co <= 0 || Ci <= 0 || K2 <= 0 || !dW || !dstyle || !partials || !g || !table_complete(W, G) || !table_complete(style, G) ||
+        (demod && !dcoef)) {
+        set_error("bad modulate_weight_backward arguments");
+        return AG_ERR_INVALID_ARGUMENT;
+    }
+    hipLaunchKernelGGL(modulate_weight_backward_kernel, dim3(G * Co), dim3(256), 0, s, dW, partials, g, W, style, dcoef, scale, demod, Co, Ci, K2,
+                       transposed);
+    if (check_hip(hipGetLastError(), "modulate_weight_backward_kernel")) return AG_ERR_HIP;
+    hipLaunchKernelGGL(modulate_finish_kernel, dim3((Ci + 63) / 64, G), dim3(256), 0, s, dstyle, partials, Co, Ci);
+    return check_hip(hipGetLastError(), "modulate_finish_kernel");
+}
+
+int block2x2_transform_g(float* out, const float* in, const float* matrix16, int merge, int G, int C, int h, int w, hipStream_t s)
+{
+    if (bad_groups(G) || C < 0 || h < 0 || w < 0 || !matrix16) { set_error("bad block2x2 arguments"); return AG_ERR_INVALID_ARGUMENT; }
+    const long long total = (long long)G * C * h * w;
+    if (total == 0) return AG_OK;
+    if (!out || !in) { set_error("null pointer"); return AG_ERR_INVALID_ARGUMENT; }
+    Block2x2 M;
+    for (int i = 0; i < 16; i++) M.m[i] = matrix16[i];       // host pointer: 16 coefficients passed by value to the kernel
+    long long blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    if (merge) hipLaunchKernelGGL(block2x2_merge_kernel, dim3((int)blocks), dim3(256), 0, s, out, in, M, G, C, h, w);
+    else       hipLaunchKernelGGL(block2x2_split_kernel, dim3((int)blocks), dim3(256), 0, s, out, in, M, G, C, h, w);
+    return check_hip(hipGetLastError(), "block2x2 kernel");
+}
+
+int skip_chain_forward_g(float* out, const float* skip, const float* taps, int G, int C, int h, int w, int accumulate, hipStream_t s)
+{
+    if (bad_groups(G) || C < 0 || h < 0 || w < 0) { set_error("bad skip chain sizes"); return AG_ERR_INVALID_ARGUMENT; }
+    const long long total = (long long)G * C * h * w;
+    if (total == 0) return AG_OK;
+    if (!out || !skip || !taps) { set_error("null pointer"); return AG_ERR_INVALID_ARGUMENT; }
+    long long blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    SkipTaps t;
+    memcpy(&t, taps, sizeof(t));                                // host pointer: wy[24] then wx[24], passed to the kernel by value
+    hipLaunchKernelGGL(skip_chain_forward_kernel, dim3((int)blocks), dim3(256), 0, s, out, skip, t, G, C, h, w, accumulate);
+    return check_hip(hipGetLastError(), "skip_chain_forward_kernel");
+}
+
+int skip_chain_backward_g(float* gskip, const float* gout, const float* taps, int G, int C, int h, int w, hipStream_t s)
+{
+    if (bad_groups(G) || C < 0 || h < 0 || w < 0) { set_error("bad skip chain sizes"); return AG_ERR_INVALID_ARGUMENT; }
+    const long long total = (long long)G * C * h * w;
+    if (total == 0) return AG_OK;
+    if (!gskip || !gout || !taps) { set_error("null pointer"); return AG_ERR_INVALID_ARGUMENT; }
+    long long blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    SkipTaps t;
+    memcpy(&t, taps, sizeof(t));
+    hipLaunchKernelGGL(skip_chain_backward_kernel, dim3((int)blocks), dim3(256), 0, s, gskip, gout, t, G, C, h, w);
+    return check_hip(hipGetLastError(), "skip_chain_backward_kernel");
 }
 
 }  // namespace ag
@@ -626,105 +703,52 @@ int ag_fused_bias_act(float* out, const float* x, const float* bias, const float
 int ag_noise_bias_act_forward(float* y, const float* x, const float* noise, const float* noise_weight, const float* bias,
                               int32_t C, int32_t HW, float slope, float scale, void* stream)
 {
-    if (C < 0 || HW < 0 || ((C > 0 && HW > 0) && (!y || !x)) || (noise && !noise_weight)) {
-        set_error("bad noise_bias_act arguments");
-        return AG_ERR_INVALID_ARGUMENT;
-    }
-    if (C == 0 || HW == 0) return AG_OK;
-    const int chunks = (HW + kNbaChunk - 1) / kNbaChunk;
-    hipLaunchKernelGGL(noise_bias_act_forward_kernel, dim3(C * chunks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), y, x,
-                       noise, noise_weight, bias, C, HW, chunks, slope, scale);
-    return check_hip(hipGetLastError(), "noise_bias_act_forward_kernel");
+    if (noise && !noise_weight) { set_error("bad noise_bias_act arguments"); return AG_ERR_INVALID_ARGUMENT; }
+    return noise_bias_act_forward_g(y, x, 1, table_of(noise), table_of(noise_weight), table_of(bias), C, HW, slope, scale,
+                                    reinterpret_cast<hipStream_t>(stream));
 }
 
+size_t ag_noise_bias_act_partial_floats(int32_t C, int32_t HW) { return noise_bias_act_partial_floats(1, C, HW); }
+
 int ag_noise_bias_act_backward(float* gx, const float* gy, const float* y, const float* noise, float* gbias, float* gnoise_weight,
-                               int32_t C, int32_t HW, float slope, float scale, void* stream)
+                               float* partials, int32_t C, int32_t HW, float slope, float scale, void* stream)
 {
-    if (C < 0 || HW < 0 || ((C > 0 && HW > 0) && (!gx || !gy || !y)) || (gnoise_weight && !noise)) {
-        set_error("bad noise_bias_act_backward arguments");
-        return AG_ERR_INVALID_ARGUMENT;
-    }
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (gbias && gnoise_weight == gbias + C) {       // the caller put the scalar right behind the C bias sums: one fill for both
-        if (check_hip(hipMemsetAsync(gbias, 0, (size_t)(C + 1) * sizeof(float), s), "memset gbias+gnw")) return AG_ERR_HIP;
-    } else {
-        if (gbias && check_hip(hipMemsetAsync(gbias, 0, (size_t)C * sizeof(float), s), "memset gbias")) return AG_ERR_HIP;
-        if (gnoise_weight && check_hip(hipMemsetAsync(gnoise_weight, 0, sizeof(float), s), "memset gnw")) return AG_ERR_HIP;
-    }
-    if (C == 0 || HW == 0) return AG_OK;
-    const int chunks = (HW + kNbaChunk - 1) / kNbaChunk;
-    hipLaunchKernelGGL(noise_bias_act_backward_kernel, dim3(C * chunks), dim3(256), 0, s, gx, gy, y, noise, gbias, gnoise_weight, C,
-                       HW, chunks, slope, scale);
-    return check_hip(hipGetLastError(), "noise_bias_act_backward_kernel");
+    if (gnoise_weight && !noise) { set_error("bad noise_bias_act_backward arguments"); return AG_ERR_INVALID_ARGUMENT; }
+    return noise_bias_act_backward_g(gx, gy, y, 1, table_of(gnoise_weight ? noise : nullptr), gbias, 0, gnoise_weight, 0, partials, C, HW, slope,
+                                     scale, reinterpret_cast<hipStream_t>(stream));
 }
 
 int ag_modulate_weight_forward(float* out, float* dcoef, const float* W, const float* style, float scale, int32_t demodulate,
                                int32_t Co, int32_t Ci, int32_t K2, int32_t transposed, void* stream)
 {
-    if (Co <= 0 || Ci <= 0 || K2 <= 0 || !out || !W || !style) { set_error("bad modulate_weight arguments"); return AG_ERR_INVALID_ARGUMENT; }
-    hipLaunchKernelGGL(modulate_weight_forward_kernel, dim3(Co), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), out, dcoef, W,
-                       style, scale, demodulate, Co, Ci, K2, transposed);
-    return check_hip(hipGetLastError(), "modulate_weight_forward_kernel");
+    return modulate_weight_forward_g(out, dcoef, 1, table_of(W), table_of(style), scale, demodulate, Co, Ci, K2, transposed,
+                                     reinterpret_cast<hipStream_t>(stream));
 }
 
-int ag_modulate_weight_backward(float* dW, float* dstyle, const float* g, const float* W, const float* style, const float* dcoef,
-                                float scale, int32_t demodulate, int32_t Co, int32_t Ci, int32_t K2, int32_t transposed, void* stream)
+size_t ag_modulate_weight_partial_floats(int32_t Co, int32_t Ci) { return modulate_weight_partial_floats(1, Co, Ci); }
+
+int ag_modulate_weight_backward(float* dW, float* dstyle, float* partials, const float* g, const float* W, const float* style,
+                                const float* dcoef, float scale, int32_t demodulate, int32_t Co, int32_t Ci, int32_t K2, int32_t transposed,
+                                void* stream)
 {
-    if (Co <= 0 || Ci <= 0 || K2 <= 0 || !dW || !dstyle || !g || !W || !style || (demodulate && !dcoef)) {
-        set_error("bad modulate_weight_backward arguments");
-        return AG_ERR_INVALID_ARGUMENT;
-    }
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (check_hip(hipMemsetAsync(dstyle, 0, (size_t)Ci * sizeof(float), s), "memset dstyle")) return AG_ERR_HIP;
-    hipLaunchKernelGGL(modulate_weight_backward_kernel, dim3(Co), dim3(256), 0, s, dW, dstyle, g, W, style, dcoef, scale, demodulate,
-                       Co, Ci, K2, transposed);
-    return check_hip(hipGetLastError(), "modulate_weight_backward_kernel");
+    return modulate_weight_backward_g(dW, dstyle, partials, g, 1, table_of(W), table_of(style), dcoef, scale, demodulate, Co, Ci, K2, transposed,
+                                      reinterpret_cast<hipStream_t>(stream));
 }
 
 int ag_block2x2_transform(float* out, const float* in, const float* matrix16, int32_t merge, int32_t C, int32_t h, int32_t w,
                           void* stream)
 {
-    if (C < 0 || h < 0 || w < 0 || !matrix16) { set_error("bad block2x2 arguments"); return AG_ERR_INVALID_ARGUMENT; }
-    const long long total = (long long)C * h * w;
-    if (total == 0) return AG_OK;
-    if (!out || !in) { set_error("null pointer"); return AG_ERR_INVALID_ARGUMENT; }
-    Block2x2 M;
-    for (int i = 0; i < 16; i++) M.m[i] = matrix16[i];       // host pointer: 16 coefficients passed by value to the kernel
-    long long blocks = (total + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (merge) hipLaunchKernelGGL(block2x2_merge_kernel, dim3((int)blocks), dim3(256), 0, s, out, in, M, C, h, w);
-    else       hipLaunchKernelGGL(block2x2_split_kernel, dim3((int)blocks), dim3(256), 0, s, out, in, M, C, h, w);
-    return check_hip(hipGetLastError(), "block2x2 kernel");
+    return block2x2_transform_g(out, in, matrix16, merge, 1, C, h, w, reinterpret_cast<hipStream_t>(stream));
 }
 
 int ag_skip_chain_forward(float* out, const float* skip, const float* taps, int32_t C, int32_t h, int32_t w, int32_t accumulate, void* stream)
 {
-    if (C < 0 || h < 0 || w < 0) { set_error("bad skip chain sizes"); return AG_ERR_INVALID_ARGUMENT; }
-    const long long total = (long long)C * h * w;
-    if (total == 0) return AG_OK;
-    if (!out || !skip || !taps) { set_error("null pointer"); return AG_ERR_INVALID_ARGUMENT; }
-    long long blocks = (total + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
-    SkipTaps t;
-    memcpy(&t, taps, sizeof(t));                                // host pointer: wy[24] then wx[24], passed to the kernel by value
-    hipLaunchKernelGGL(skip_chain_forward_kernel, dim3((int)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), out, skip, t, C, h, w,
-                       accumulate);
-    return check_hip(hipGetLastError(), "skip_chain_forward_kernel");
+    return skip_chain_forward_g(out, skip, taps, 1, C, h, w, accumulate, reinterpret_cast<hipStream_t>(stream));
 }
 
 int ag_skip_chain_backward(float* gskip, const float* gout, const float* taps, int32_t C, int32_t h, int32_t w, void* stream)
 {
-    if (C < 0 || h < 0 || w < 0) { set_error("bad skip chain sizes"); return AG_ERR_INVALID_ARGUMENT; }
-    const long long total = (long long)C * h * w;
-    if (total == 0) return AG_OK;
-    if (!gskip || !gout || !taps) { set_error("null pointer"); return AG_ERR_INVALID_ARGUMENT; }
-    long long blocks = (total + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
-    SkipTaps t;
-    memcpy(&t, taps, sizeof(t));
-    hipLaunchKernelGGL(skip_chain_backward_kernel, dim3((int)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), gskip, gout, t, C, h, w);
-    return check_hip(hipGetLastError(), "skip_chain_backward_kernel");
+    return skip_chain_backward_g(gskip, gout, taps, 1, C, h, w, reinterpret_cast<hipStream_t>(stream));
 }
 
 int ag_upfirdn2d(float* out, const float* input, const float* kernel, int32_t major, int32_t in_h, int32_t in_w,
@@ -746,7 +770,7 @@ int ag_upfirdn2d(float* out, const float* input, const float* kernel, int32_t ma
     if (!out || !input || !kernel) { set_error("null pointer"); return AG_ERR_INVALID_ARGUMENT; }
     if (up_x == 1 && up_y == 1 && down_x == 1 && down_y == 1 && kernel_h == 4 && kernel_w == 4 && major <= 65535) {
         dim3 grid((p.out_w + 255) / 256, (p.out_h + 7) / 8, major);
-        hipLaunchKernelGGL(fir4x4_kernel<false>, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), out, input, kernel, p, FirAct{});
+        hipLaunchKernelGGL(fir4x4_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), out, input, kernel, p);
         return check_hip(hipGetLastError(), "fir4x4_kernel");
     }
     const long long total = (long long)major * p.out_h * p.out_w;
@@ -754,49 +778,6 @@ int ag_upfirdn2d(float* out, const float* input, const float* kernel, int32_t ma
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(upfirdn2d_kernel, dim3((int)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), out, input, kernel, p);
     return check_hip(hipGetLastError(), "upfirdn2d_kernel");
-}
-
-/* Blur (4 x 4 taps, pads (pad0, pad1)) + NoiseInjection + FusedLeakyReLU in one pass: out [major, OH, OW] from input [major, in_h, in_w]. */
-int ag_fir4x4_noise_bias_act_forward(float* out, const float* input, const float* kernel, int32_t major, int32_t in_h, int32_t in_w,
-                                     int32_t pad0, int32_t pad1, const float* noise, const float* noise_weight, const float* bias,
-                                     float slope, float scale, void* stream)
-{
-    if (major <= 0 || major > 65535 || in_h <= 0 || in_w <= 0 || !out || !input || !kernel || (noise && !noise_weight)) {
-        set_error("bad fir4x4_noise_bias_act_forward arguments");
-        return AG_ERR_INVALID_ARGUMENT;
-    }
-    UpfirdnParams p;
-    p.up_x = p.up_y = p.down_x = p.down_y = 1; p.pad_x0 = p.pad_y0 = pad0;
-    p.major = major; p.in_h = in_h; p.in_w = in_w; p.kernel_h = p.kernel_w = 4;
-    p.out_h = in_h + pad0 + pad1 - 3; p.out_w = in_w + pad0 + pad1 - 3;
-    if (p.out_h <= 0 || p.out_w <= 0) { set_error("fir4x4: empty output"); return AG_ERR_INVALID_ARGUMENT; }
-    FirAct act{ noise, noise_weight, bias, slope, scale };
-    dim3 grid((p.out_w + 255) / 256, (p.out_h + 7) / 8, major);
-    hipLaunchKernelGGL(fir4x4_kernel<true>, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), out, input, kernel, p, act);
-    return check_hip(hipGetLastError(), "fir4x4_kernel<act>");
-}
-
-/* Its backward for pads (1, 1): g_in [major, OH + 1, OW + 1] from g_out / the saved output y [major, OH, OW]; kernel_flipped = the taps
- * flipped in both axes; gbias [major] / gnoise_weight [1] are zeroed here and accumulated (either may be NULL). */
-int ag_fir4x4_noise_bias_act_backward(float* g_in, const float* g_out, const float* y, const float* kernel_flipped, int32_t major,
-                                      int32_t OH, int32_t OW, const float* noise, float* gbias, float* gnoise_weight, float slope,
-                                      float scale, void* stream)
-{
-    if (major <= 0 || major > 65535 || OH <= 0 || OW <= 0 || !g_in || !g_out || !y || !kernel_flipped || (gnoise_weight && !noise)) {
-        set_error("bad fir4x4_noise_bias_act_backward arguments");
-        return AG_ERR_INVALID_ARGUMENT;
-    }
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (gbias && gnoise_weight == gbias + major) {
-        if (check_hip(hipMemsetAsync(gbias, 0, (size_t)(major + 1) * sizeof(float), s), "memset gbias+gnw")) return AG_ERR_HIP;
-    } else {
-        if (gbias && check_hip(hipMemsetAsync(gbias, 0, (size_t)major * sizeof(float), s), "memset gbias")) return AG_ERR_HIP;
-        if (gnoise_weight && check_hip(hipMemsetAsync(gnoise_weight, 0, sizeof(float), s), "memset gnw")) return AG_ERR_HIP;
-    }
-    dim3 grid((OW + 1 + 255) / 256, (OH + 1 + kFirBwdRows - 1) / kFirBwdRows, major);
-    hipLaunchKernelGGL(fir4x4_nba_backward_kernel, grid, dim3(256), 0, s, g_in, g_out, y, kernel_flipped, gnoise_weight ? noise : nullptr,
-                       gbias, gnoise_weight, OH, OW, slope, scale);
-    return check_hip(hipGetLastError(), "fir4x4_nba_backward_kernel");
 }
 
 }  // extern "C"

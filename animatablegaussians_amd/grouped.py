@@ -1,0 +1,590 @@
+"""Grouped execution of the avatar's StyleUNets (round 4; include/ag_layers.h ``AgGroupedLayerArgs``).
+
+``network/avatar.py:34-36`` builds three ``DualStyleUNet`` with identical layer shapes -- only the ToRGB heads differ (12 / 12 / 32
+rows) -- and ``:93-124`` evaluates all three on the same pose map; each runs two decoders of identical shapes
+(``dual_styleunet.py:869-905``).  Run one network at a time that is ~1500 small launches per network pass, most of them layers at
+<= 64^2 with a handful of workgroups each.  Here the three encoders run as ONE launch chain with a group dimension G = 3 and the six
+decoders as one chain with G = 6: activations are stacked ``[G, C, H, W]``, every kernel gets G times the workgroups, the launch count
+drops by the same factor.  The parameters stay the reference's separate tensors (checkpoints, optimiser state and ``parameters()``
+order are untouched): a grouped layer takes a table of G device pointers per parameter kind, and writes the G gradients stacked so
+that each parameter's gradient is a dense view of its own shape.
+
+Numerics: the same kernels in the same order as the one-network path; the only difference is the split-K slice count of a convolution
+(a function of the workgroup count), i.e. fp32 summation order.  ``tests/test_grouped_gpu.py`` pins grouped against one-by-one.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+import os
+
+import torch
+
+from . import _lib
+from .styleunet_ops import _HAAR_SYNTHESIS, _flipped, _skip_taps_host, upfirdn2d_nchw
+
+_SQRT2 = 2 ** 0.5
+_SIZES = {}
+
+
+def _stream(dev):
+    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+_INDEX = {}
+
+
+def _index(values, dev):
+    """Cached int64 index tensor (built once per device: creating it is a host-to-device copy, which a hipGraph capture does not allow)."""
+    key = (tuple(values), dev)
+    t = _INDEX.get(key)
+    if t is None:
+        t = _INDEX[key] = torch.tensor(list(values), dtype=torch.int64, device=dev)
+    return t
+
+
+def _fill(table, tensors):
+    for i, t in enumerate(tensors):
+        table[i] = t.data_ptr() if t is not None else None
+
+
+def _layer_args(G, x, w0, resample, modulated, scale, shared):
+    a = _lib.AgGroupedLayerArgs()
+    a.G = G
+    a.Cout, a.Cin, a.k = int(w0.shape[-4]), int(w0.shape[-3]), int(w0.shape[-1])
+    a.H, a.W = int(x.shape[2]), int(x.shape[3])
+    if int(x.shape[1]) != a.Cin or x.shape[0] != (1 if shared else G):
+        raise RuntimeError(f"grouped layer: input {tuple(x.shape)} does not match G = {G}, Cin = {a.Cin} (shared = {shared})")
+    a.resample, a.modulated = int(bool(resample)), int(bool(modulated))
+    a.scale, a.slope, a.act_scale = float(scale), 0.2, _SQRT2
+    a.x_group_stride = 0 if shared else a.Cin * a.H * a.W
+    return a
+
+
+def _layer_sizes(a):
+    key = ("L", a.G, a.Cin, a.Cout, a.H, a.W, a.k, a.resample, a.modulated)
+    v = _SIZES.get(key)
+    if v is None:
+        L = _lib.lib()
+        oh, ow = ctypes.c_int32(0), ctypes.c_int32(0)
+        _lib.check(L.ag_grouped_layer_output_size(ctypes.byref(a), ctypes.byref(oh), ctypes.byref(ow)), "ag_grouped_layer_output_size")
+        v = _SIZES[key] = (oh.value, ow.value, int(L.ag_grouped_layer_scratch_floats(ctypes.byref(a), 0)),
+                           int(L.ag_grouped_layer_scratch_floats(ctypes.byref(a), 1)), int(L.ag_grouped_layer_workspace_bytes(ctypes.byref(a))))
+    return v
+
+
+def _scratch(nfloats, ws_bytes, dev):
+    buf = torch.empty(nfloats * 4 + ws_bytes + 512, dtype=torch.uint8, device=dev)
+    base = (buf.data_ptr() + 255) & ~255
+    return buf, base, base + ((nfloats * 4 + 255) & ~255)
+
+
+class _GroupedLayer(torch.autograd.Function):
+    """G instances of a ConvLayer (``modulated`` False) or StyledConv as ONE native call each way.
+    ``params`` = weights[G] (+ styles[G], noises[G], noise_weights[G] when modulated) + biases[G]."""
+
+    @staticmethod
+    def forward(ctx, G, shared, resample, modulated, scale, k_blur, x, *params):
+        x = x.contiguous()
+        ws = [p.contiguous() for p in params[:G]]
+        if modulated:
+            styles = [p.contiguous() for p in params[G:2 * G]]
+            noises, nws, biases = params[2 * G:3 * G], params[3 * G:4 * G], params[4 * G:5 * G]
+        else:
+            styles, noises, nws, biases = [None] * G, [None] * G, [None] * G, params[G:2 * G]
+        dev = x.device
+        a = _layer_args(G, x, ws[0], resample, modulated, scale, shared)
+        oh, ow, f_fwd, _, wsb = _layer_sizes(a)
+        out = torch.empty((G, a.Cout, oh, ow), dtype=torch.float32, device=dev)
+        keep = None
+        wnum = ws[0].numel()
+        if modulated:
+            keep = torch.empty(G * (wnum + a.Cout), dtype=torch.float32, device=dev)       # modulated weights, then the demodulation coefficients
+            a.w_mod, a.demod = keep.data_ptr(), keep.data_ptr() + 4 * G * wnum
+            for st in styles:
+                if st.numel() != a.Cin:
+                    raise RuntimeError("style must have one entry per input channel")
+            for nz in noises:
+                if nz is not None and nz.numel() != oh * ow:
+                    raise RuntimeError("noise must be [1, 1, OH, OW]")
+            _fill(a.style, styles)
+            _fill(a.noise, noises)
+            _fill(a.noise_weight, nws)
+        elif resample:
+            keep = torch.empty(((1 if shared else G), a.Cin, a.H + 1, a.W + 1), dtype=torch.float32, device=dev)     # the blurred input
+            a.x_blur = keep.data_ptr()
+        _fill(a.weight, ws)
+        _fill(a.act_bias, biases)
+        a.x, a.out = x.data_ptr(), out.data_ptr()
+        a.k_blur = k_blur.data_ptr() if resample else None
+        buf, a.scratch, a.workspace = _scratch(f_fwd, wsb, dev)
+        a.workspace_bytes = wsb
+        with _lib.on_device(dev):
+            _lib.check(_lib.lib().ag_grouped_layer_forward(ctypes.byref(a), _stream(dev)), "ag_grouped_layer_forward")
+        ctx.save_for_backward(x, out, keep, _flipped(k_blur) if resample else None, *ws, *styles, *noises, *nws, *biases)
+        ctx.cfg = (G, bool(shared), bool(resample), bool(modulated), float(scale))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        G, shared, resample, modulated, scale = ctx.cfg
+        x, out, keep, k_flip = ctx.saved_tensors[:4]
+        rest = ctx.saved_tensors[4:]
+        ws, styles, noises, nws, biases = (rest[i * G:(i + 1) * G] for i in range(5))
+        dev = x.device
+        g = g.contiguous()
+        a = _layer_args(G, x, ws[0], resample, modulated, scale, shared)
+        _, _, _, f_bwd, wsb = _layer_sizes(a)
+        nig = ctx.needs_input_grad
+        nx = nig[6]
+        pn = nig[7:]
+        need_w = any(pn[:G])
+        if modulated:
+            need_s, need_nw, need_b = any(pn[G:2 * G]), any(pn[3 * G:4 * G]), any(pn[4 * G:5 * G])
+        else:
+            need_s, need_nw, need_b = False, False, any(pn[G:2 * G])
+        wnum = ws[0].numel()
+        gx = torch.empty_like(x) if (nx and not shared) else None
+        if nx and shared:
+            raise RuntimeError("grouped layer: an input shared by the instances cannot receive a gradient")
+        want_w = need_w or (modulated and need_s)
+        gw = torch.empty((G,) + tuple(ws[0].shape), dtype=torch.float32, device=dev) if want_w else None
+        gs = gbn = None
+        _fill(a.weight, ws)
+        _fill(a.act_bias, biases)
+        if modulated:
+            a.w_mod, a.demod = keep.data_ptr(), keep.data_ptr() + 4 * G * wnum
+            _fill(a.style, styles)
+            _fill(a.noise, noises)
+            _fill(a.noise_weight, nws)
+            if want_w:
+                gs = torch.empty((G,) + tuple(styles[0].shape), dtype=torch.float32, device=dev)
+        elif resample:
+            a.x_blur = keep.data_ptr()
+        has_bias = all(b is not None for b in biases)
+        has_noise = modulated and all(n is not None and w is not None for n, w in zip(noises, nws))
+        a.want_bias = int(bool(need_b and has_bias))
+        a.want_noise_weight = int(bool(need_nw and has_noise))
+        if a.want_bias or a.want_noise_weight:
+            gbn = torch.empty((G, a.Cout + 1), dtype=torch.float32, device=dev)
+        a.x, a.out, a.g_out = x.data_ptr(), out.data_ptr(), g.data_ptr()
+        a.k_blur = k_flip.data_ptr() if resample else None
+        a.g_x = gx.data_ptr() if gx is not None else None
+        a.g_weight = gw.data_ptr() if gw is not None else None
+        a.g_style = gs.data_ptr() if gs is not None else None
+        a.g_bias_noise = gbn.data_ptr() if gbn is not None else None
+        buf, a.scratch, a.workspace = _scratch(f_bwd, wsb, dev)
+        a.workspace_bytes = wsb
+        with _lib.on_device(dev):
+            _lib.check(_lib.lib().ag_grouped_layer_backward(ctypes.byref(a), _stream(dev)), "ag_grouped_layer_backward")
+        none = [None] * G
+        g_ws = [gw[i] if (gw is not None and pn[i]) else None for i in range(G)]
+        g_bs = [gbn[i, :a.Cout] if a.want_bias else None for i in range(G)]
+        if not modulated:
+            return (None, None, None, None, None, None, gx, *g_ws, *g_bs)
+        g_ss = [gs[i] if (gs is not None and pn[G + i]) else None for i in range(G)]
+        g_nws = [gbn[i, a.Cout:].view(nws[i].shape) if a.want_noise_weight else None for i in range(G)]
+        return (None, None, None, None, None, None, gx, *g_ws, *g_ss, *none, *g_nws, *g_bs)
+
+
+def grouped_conv_layer(x, weights, biases, k_blur, scale, downsample, shared=False):
+    """G ConvLayers ([Blur +] EqualConv2d + FusedLeakyReLU, dual_styleunet.py:326-371): x [G, Cin, H, W] ([1, ...] when ``shared``)."""
+    G = len(weights)
+    return _GroupedLayer.apply(G, bool(shared), bool(downsample), False, float(scale), k_blur, x, *weights, *biases)
+
+
+def grouped_styled_conv(x, weights, styles, noises, noise_weights, biases, k_blur, scale, upsample):
+    """G StyledConvs (ModulatedConv2d + NoiseInjection + FusedLeakyReLU, dual_styleunet.py:225-313,570-604): x [G, Cin, H, W]."""
+    G = len(weights)
+    return _GroupedLayer.apply(G, False, bool(upsample), True, float(scale), k_blur, x, *weights, *styles, *noises, *noise_weights, *biases)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# ToRGB
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _rgb_args(G, x, w0, scale):
+    a = _lib.AgGroupedToRgbArgs()
+    a.G, a.Cout, a.Cin = G, int(w0.shape[-4]), int(w0.shape[-3])
+    a.H, a.W = int(x.shape[2]), int(x.shape[3])
+    if tuple(x.shape[:2]) != (G, a.Cin):
+        raise RuntimeError("grouped ToRGB: input does not match the weights")
+    a.scale = float(scale)
+    return a
+
+
+def _rgb_sizes(a):
+    key = ("R", a.G, a.Cin, a.Cout, a.H, a.W)
+    v = _SIZES.get(key)
+    if v is None:
+        L = _lib.lib()
+        v = _SIZES[key] = (int(L.ag_grouped_to_rgb_scratch_floats(ctypes.byref(a), 0)), int(L.ag_grouped_to_rgb_scratch_floats(ctypes.byref(a), 1)),
+                           int(L.ag_grouped_to_rgb_workspace_bytes(ctypes.byref(a))))
+    return v
+
+
+class _GroupedToRGB(torch.autograd.Function):
+    """G ToRGB heads of one shape (dual_styleunet.py:607-633): modulated 1 x 1 convolution + bias + the wavelet skip, one native call."""
+
+    @staticmethod
+    def forward(ctx, G, scale, k_up, x, skip, *params):
+        x = x.contiguous()
+        ws = [p.contiguous() for p in params[:G]]
+        styles = [p.contiguous() for p in params[G:2 * G]]
+        biases = [p.contiguous() for p in params[2 * G:3 * G]]
+        dev = x.device
+        a = _rgb_args(G, x, ws[0], scale)
+        f_fwd, _, wsb = _rgb_sizes(a)
+        out = torch.empty((G, a.Cout, a.H, a.W), dtype=torch.float32, device=dev)
+        wm = torch.empty(G * a.Cout * a.Cin, dtype=torch.float32, device=dev)
+        _fill(a.weight, ws)
+        _fill(a.style, styles)
+        _fill(a.bias, biases)
+        a.x, a.out, a.w_mod = x.data_ptr(), out.data_ptr(), wm.data_ptr()
+        if skip is not None:
+            skip = skip.contiguous()
+            if tuple(skip.shape) != (G, a.Cout, a.H // 2, a.W // 2):
+                raise RuntimeError("grouped ToRGB: skip must be [G, Cout, H / 2, W / 2]")
+            a.skip, a.skip_taps = skip.data_ptr(), _skip_taps_host(k_up)
+        buf, a.scratch, a.workspace = _scratch(f_fwd, wsb, dev)
+        a.workspace_bytes = wsb
+        with _lib.on_device(dev):
+            _lib.check(_lib.lib().ag_grouped_to_rgb_forward(ctypes.byref(a), _stream(dev)), "ag_grouped_to_rgb_forward")
+        ctx.save_for_backward(x, wm, *ws, *styles)
+        ctx.cfg = (G, float(scale), skip is not None, tuple(biases[0].shape))
+        ctx.k_up = k_up                       # a module buffer, not an output of this node
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        G, scale, has_skip, bshape = ctx.cfg
+        x, wm = ctx.saved_tensors[:2]
+        ws, styles = ctx.saved_tensors[2:2 + G], ctx.saved_tensors[2 + G:2 + 2 * G]
+        dev = x.device
+        g = g.contiguous()
+        nig = ctx.needs_input_grad
+        nx, nskip, pn = nig[3], nig[4], nig[5:]
+        a = _rgb_args(G, x, ws[0], scale)
+        _, f_bwd, wsb = _rgb_sizes(a)
+        want_w = any(pn[:2 * G])
+        gx = torch.empty_like(x) if nx else None
+        gw = torch.empty((G,) + tuple(ws[0].shape), dtype=torch.float32, device=dev) if want_w else None
+        gs = torch.empty((G,) + tuple(styles[0].shape), dtype=torch.float32, device=dev) if want_w else None
+        gskip = torch.empty((G, a.Cout, a.H // 2, a.W // 2), dtype=torch.float32, device=dev) if (has_skip and nskip) else None
+        gb = g.sum((2, 3)) if any(pn[2 * G:3 * G]) else None                  # [G, Cout], torch's deterministic reduction
+        _fill(a.weight, ws)
+        _fill(a.style, styles)
+        a.x, a.w_mod, a.g_out = x.data_ptr(), wm.data_ptr(), g.data_ptr()
+        a.g_x = gx.data_ptr() if gx is not None else None
+        a.g_weight = gw.data_ptr() if gw is not None else None
+        a.g_style = gs.data_ptr() if gs is not None else None
+        if gskip is not None:
+            a.g_skip, a.skip_taps = gskip.data_ptr(), _skip_taps_host(ctx.k_up)
+        buf, a.scratch, a.workspace = _scratch(f_bwd, wsb, dev)
+        a.workspace_bytes = wsb
+        with _lib.on_device(dev):
+            _lib.check(_lib.lib().ag_grouped_to_rgb_backward(ctypes.byref(a), _stream(dev)), "ag_grouped_to_rgb_backward")
+        g_ws = [gw[i] if pn[i] else None for i in range(G)]
+        g_ss = [gs[i] if pn[G + i] else None for i in range(G)]
+        g_bs = [gb[i].view(bshape) if pn[2 * G + i] else None for i in range(G)]
+        return (None, None, None, gx, gskip, *g_ws, *g_ss, *g_bs)
+
+
+def grouped_to_rgb(x, weights, styles, biases, skip, k_up, scale):
+    G = len(weights)
+    return _GroupedToRGB.apply(G, float(scale), k_up, x, skip, *weights, *styles, *biases)
+
+
+class _GroupedHaarMerge(torch.autograd.Function):
+    """InverseHaarTransform (dual_styleunet.py:406-425) of G stacked tensors: [G, 4C, h, w] -> [G, C, 2h, 2w], one kernel."""
+
+    @staticmethod
+    def _run(x, matrix, merge):
+        x = x.contiguous()
+        G = int(x.shape[0])
+        if merge:
+            C, h, w = int(x.shape[1]) // 4, int(x.shape[2]), int(x.shape[3])
+            out = torch.empty((G, C, 2 * h, 2 * w), dtype=torch.float32, device=x.device)
+        else:
+            C, h, w = int(x.shape[1]), int(x.shape[2]) // 2, int(x.shape[3]) // 2
+            out = torch.empty((G, 4 * C, h, w), dtype=torch.float32, device=x.device)
+        m = (ctypes.c_float * 16)(*matrix)
+        with _lib.on_device(x.device):
+            _lib.check(_lib.lib().ag_grouped_block2x2(ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(x.data_ptr()), ctypes.cast(m, ctypes.c_void_p),
+                                                      int(merge), G, C, h, w, _stream(x.device)), "ag_grouped_block2x2")
+        return out
+
+    @staticmethod
+    def forward(ctx, x):
+        return _GroupedHaarMerge._run(x, _HAAR_SYNTHESIS, True)
+
+    @staticmethod
+    def backward(ctx, g):
+        # adjoint of a merge with B = a split with B^T (the Haar basis is orthonormal: B^T = the analysis matrix)
+        bt = tuple(_HAAR_SYNTHESIS[4 * c + r] for r in range(4) for c in range(4))
+        return _GroupedHaarMerge._run(g, bt, False)
+
+
+class _CatLevels(torch.autograd.Function):
+    """Input of a decoder stage's comb convolution for the stacked members (dual_styleunet.py:877-879): ``cat([out, level], channel)`` with
+    member m reading ``out[src[m]]`` (+ its view-direction feature, :881-883) and the encoder level of its network ``lev[net[m]]``.
+    One buffer, filled by slice copies; the gradients are slice reads (sums where a source feeds several members)."""
+
+    @staticmethod
+    def forward(ctx, out, lev, vf, src, net, vf_rows):
+        M = len(src)
+        C1, C2 = int(out.shape[1]), int(lev.shape[1])
+        buf = torch.empty((M, C1 + C2) + tuple(out.shape[2:]), dtype=out.dtype, device=out.device)
+        ident = list(src) == list(range(out.shape[0]))
+        pairs = M == 2 * lev.shape[0] and list(net) == [i // 2 for i in range(M)]
+        if ident:
+            buf[:, :C1].copy_(out)
+        else:
+            buf[:, :C1].copy_(out.index_select(0, _index(src, out.device)))
+        one = list(net) == list(range(lev.shape[0]))
+        if pairs:
+            buf.view(M // 2, 2, C1 + C2, *out.shape[2:])[:, :, C1:].copy_(lev[:, None])
+        elif one:
+            buf[:, C1:].copy_(lev)
+        else:
+            buf[:, C1:].copy_(lev.index_select(0, _index(net, out.device)))
+        if vf is not None:
+            r0, r1 = vf_rows
+            buf[r0:r1, :C1].add_(vf)
+        ctx.cfg = (tuple(src), tuple(net), vf_rows, ident, pairs, C1, int(out.shape[0]), int(lev.shape[0]), vf is not None)
+        return buf
+
+    @staticmethod
+    def backward(ctx, g):
+        src, net, vf_rows, ident, pairs, C1, n_out, n_lev, has_vf = ctx.cfg
+        M = g.shape[0]
+        g_out = g_lev = g_vf = None
+        if ctx.needs_input_grad[0]:
+            if ident:
+                g_out = g[:, :C1].contiguous()
+            else:
+                g_out = torch.zeros((n_out, C1) + tuple(g.shape[2:]), dtype=g.dtype, device=g.device)
+                g_out.index_add_(0, _index(src, g.device), g[:, :C1])
+        if ctx.needs_input_grad[1]:
+            if pairs:
+                g_lev = g.view(M // 2, 2, *g.shape[1:])[:, :, C1:].sum(1)
+            elif list(net) == list(range(n_lev)):
+                g_lev = g[:, C1:].contiguous()
+            else:
+                g_lev = torch.zeros((n_lev, g.shape[1] - C1) + tuple(g.shape[2:]), dtype=g.dtype, device=g.device)
+                g_lev.index_add_(0, _index(net, g.device), g[:, C1:])
+        if has_vf and ctx.needs_input_grad[2]:
+            g_vf = g[vf_rows[0]:vf_rows[1], :C1].contiguous()
+        return g_out, g_lev, g_vf, None, None, None
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# The three networks as one chain
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _runs(values):
+    """[(start, end)] of the maximal runs of equal consecutive values."""
+    out, s = [], 0
+    for i in range(1, len(values) + 1):
+        if i == len(values) or values[i] != values[s]:
+            out.append((s, i))
+            s = i
+    return out
+
+
+class GroupedStyleUNets:
+    """Evaluates several ``DualStyleUNet`` modules of the same trunk shape (their ``out_ch`` may differ) on ONE conditioning image as grouped
+    launch chains.  The modules keep their parameters; this object holds no state of its own besides shape tables."""
+
+    def __init__(self, nets):
+        self.nets = list(nets)
+        n0 = self.nets[0]
+        for n in self.nets[1:]:
+            if (n.inp_size, n.inp_ch, n.out_size, n.style_dim, n.enc, n.dec, n.n_comb, n.num_layers) != \
+               (n0.inp_size, n0.inp_ch, n0.out_size, n0.style_dim, n0.enc, n0.dec, n0.n_comb, n0.num_layers):
+                raise ValueError("grouped execution needs networks of one trunk shape")
+        if len(self.nets) * 2 > _lib.AG_MAX_GROUPS:
+            raise ValueError("too many networks for one group")
+        if not (n0.VIEW_STAGE + 1 < n0.n_comb and n0.VIEW_STAGE + 1 < len(n0.dec)):
+            raise ValueError("grouped execution expects the view-dependent stage to start with a comb convolution")
+
+    @staticmethod
+    def supported(nets) -> bool:
+        try:
+            GroupedStyleUNets(nets)
+            return True
+        except ValueError:
+            return False
+
+    # ---- layers over a list of (network, parameter prefix) ----------------------------------------------------------------------
+    @staticmethod
+    def _conv_layer(x, nets, prefix, downsample=False, shared=False):
+        base = 1 if downsample else 0
+        ws = [n._p(f"{prefix}.{base}.weight") for n in nets]
+        bs = [n._p(f"{prefix}.{base + 1}.bias") for n in nets]
+        k = ws[0].shape[-1]
+        return grouped_conv_layer(x, ws, bs, nets[0]._k_blur, 1 / math.sqrt(ws[0].shape[1] * k * k), downsample, shared)
+
+    def _encode(self, x):
+        """Pose map [1, inp_ch, S, S] -> levels, finest first, each [n_nets, C, h, w]  (dual_styleunet.py:854-864 for every network)."""
+        nets, n0 = self.nets, self.nets[0]
+        out = self._conv_layer(x, nets, "conv_in", downsample=True, shared=True)
+        levels = [out]
+        img = x
+        for n, _, _ in n0.enc:
+            img = upfirdn2d_nchw(img, n0._k_blur, down=2, pad=(1, 1))            # Downsample: the same image pyramid for all networks
+            out = self._conv_layer(img, nets, f"from_rgbs.{n}.conv", shared=True) + out
+            out = self._conv_layer(out, nets, f"cond_convs.{n}.conv1")
+            out = self._conv_layer(out, nets, f"cond_convs.{n}.conv2", downsample=True)
+            levels.append(out)
+        return levels
+
+    def _stage(self, n, members, styles, noises, out, skips, levels, src=None, vf=None, vf_rows=None):
+        """One decoder stage for the stacked members.  members: [(network index, branch)]; styles[m]: {prefix: style} of member m;
+        out: [M', C, h, w] of the previous stage (None at stage 0), member m continues ``out[src[m]]``; skips: {(start, end): tensor}
+        per run of equal ToRGB width."""
+        nets, n0 = self.nets, self.nets[0]
+        M = len(members)
+        mnets = [nets[i] for i, _ in members]
+        net_idx = [i for i, _ in members]
+        if n == 0:
+            o3 = self._conv_layer(levels[-1], nets, f"comb_convs.{n0.n_comb - 1}")     # branch-independent: once per network (:873 runs it per branch)
+            out = o3.index_select(0, _index(net_idx, o3.device))
+        elif n < n0.n_comb:
+            src = list(range(M)) if src is None else src
+            cat = _CatLevels.apply(out, levels[-1 - n], vf, tuple(src), tuple(net_idx), vf_rows)
+            out = self._conv_layer(cat, mnets, f"comb_convs.{n0.n_comb - 1 - n}")
+        pre = [f"convs{b}.{2 * n}" for _, b in members]
+        w = [net._p(f"{p}.conv.weight") for net, p in zip(mnets, pre)]
+        k = w[0].shape[-1]
+        out = grouped_styled_conv(out, w, [styles[m][f"{p}.conv"] for m, p in enumerate(pre)], [noises[i][2 * n] for i in net_idx],
+                                  [net._p(f"{p}.noise.weight") for net, p in zip(mnets, pre)],
+                                  [net._p(f"{p}.activate.bias") for net, p in zip(mnets, pre)], n0._k_blur_up, 1 / math.sqrt(w[0].shape[2] * k * k), True)
+        pre = [f"convs{b}.{2 * n + 1}" for _, b in members]
+        w = [net._p(f"{p}.conv.weight") for net, p in zip(mnets, pre)]
+        out = grouped_styled_conv(out, w, [styles[m][f"{p}.conv"] for m, p in enumerate(pre)], [noises[i][2 * n + 1] for i in net_idx],
+                                  [net._p(f"{p}.noise.weight") for net, p in zip(mnets, pre)],
+                                  [net._p(f"{p}.activate.bias") for net, p in zip(mnets, pre)], None, 1 / math.sqrt(w[0].shape[2] * k * k), False)
+        # ToRGB: one call per run of members with the same head width
+        new_skips = {}
+        for (s, e) in _runs([net.out_ch for net in mnets]):
+            pr = [f"to_rgbs{b}.{n}" for _, b in members[s:e]]
+            ns = mnets[s:e]
+            wr = [net._p(f"{p}.conv.weight") for net, p in zip(ns, pr)]
+            new_skips[(s, e)] = grouped_to_rgb(out[s:e], wr, [styles[s + j][f"{p}.conv"] for j, p in enumerate(pr)],
+                                               [net._p(f"{p}.bias").reshape(-1) for net, p in zip(ns, pr)],
+                                               skips.get((s, e)) if skips else None, n0._k_blur_up,
+                                               1 / math.sqrt(wr[0].shape[2] * wr[0].shape[-1] * wr[0].shape[-1]))
+        return out, new_skips
+
+    def forward(self, styles, x, view_features=None):
+        """styles[i]: the style vector [1, style_dim] of network i; x: [1, inp_ch, S, S]; view_features: {network index: (f1, f2)} or
+        {network index: [(f1, f2), ...]} for several views of the pose (the view-dependent stages then run once per view).
+        Returns per network the image [1, 2 out_ch, S', S'] (= ``DualStyleUNet.forward(...)[0]``), or a list of them per view."""
+        nets = self.nets
+        view_features = dict(view_features or {})
+        lat, noises = zip(*(n._latent_and_noise([s], False, None, False) for n, s in zip(nets, styles)))
+        levels = self._encode(x)
+        multi = {i: isinstance(v, (list, tuple)) and len(v) > 0 and isinstance(v[0], (list, tuple)) for i, v in view_features.items()}
+        views = {i: (list(view_features[i]) if multi[i] else [view_features[i]]) for i in view_features}
+        # AG_GROUPED_STREAMS=2: the decoders as two chains (branch 1 / branch 2 of every network, G = 3 each) on two HIP streams
+        # instead of one chain with G = 6 -- twice the decoder launches, but the latency-bound layers at <= 32^2 overlap
+        nstreams = int(os.environ.get("AG_GROUPED_STREAMS", "1"))
+        if nstreams == 2 and not torch.cuda.is_current_stream_capturing() and os.environ.get("AG_SINGLE_STREAM") != "1":
+            cur = torch.cuda.current_stream()
+            if getattr(self, "_side", None) is None or self._side.device != cur.device:
+                self._side = torch.cuda.Stream(cur.device)
+                quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+                if quiet is not None:
+                    quiet(False)
+            side = self._side
+            side.wait_stream(cur)
+            shared = list(levels) + list(lat) + [f for vs in views.values() for fb in vs if fb is not None for f in fb if f is not None]
+            for t in shared:
+                t.record_stream(side)
+            with torch.cuda.stream(side):
+                r2 = self._decode([(i, 2) for i in range(len(nets))], lat, noises, levels, views)
+            results = self._decode([(i, 1) for i in range(len(nets))], lat, noises, levels, views)
+            cur.wait_stream(side)
+            for t in r2.values():
+                t.record_stream(cur)
+            results.update(r2)
+        else:
+            results = self._decode([(i, b) for i in range(len(nets)) for b in (1, 2)], lat, noises, levels, views)
+        outs = []
+        for i in range(len(nets)):
+            nv = len(views.get(i, [None]))
+            per_view = []
+            for v in range(nv):
+                a, bb = results[(i, v, 1)], results[(i, v, 2)]
+                # the two branches of a (network, view) are neighbours in one stacked tensor: their channel concatenation is a view
+                if a._base is not None and a._base is bb._base and a.data_ptr() + a.numel() * 4 == bb.data_ptr():
+                    base = a._base
+                    off = (a.data_ptr() - base.data_ptr()) // (4 * a.numel())
+                    per_view.append(base[off:off + 2].reshape(1, 2 * a.shape[1], *a.shape[2:]))
+                else:
+                    per_view.append(torch.cat([a, bb], 1))
+            outs.append(per_view if multi.get(i, False) else per_view[0])
+        return outs
+
+    def _decode(self, members, lat, noises, levels, views):
+        """The decoders of ``members`` [(network index, branch)] as one chain -> {(network, view, branch): image [1, out_ch, S', S']}."""
+        nets, n0 = self.nets, self.nets[0]
+        shared_stages = list(range(0, min(n0.VIEW_STAGE + 1, len(n0.dec))))
+        tail_stages = list(range(n0.VIEW_STAGE + 1, len(n0.dec)))
+        st = [nets[i]._stage_styles(b, shared_stages, lat[i]) for i, b in members]
+        out, skips = None, None
+        for n in shared_stages:
+            out, skips = self._stage(n, members, st, noises, out, skips, levels)
+        # view-dependent tail: every member once, the members of a network with V views V times
+        tail = []                                                      # (network, branch, source member, view number)
+        for m, (i, b) in enumerate(members):
+            if m and members[m - 1][0] == i:
+                continue                                               # the members of network i are handled together below
+            ms = [(mm, bb) for mm, (ii, bb) in enumerate(members) if ii == i]
+            for v in range(len(views.get(i, [None]))):
+                for mm, bb in ms:
+                    tail.append((i, bb, mm, v))
+        results = {}
+        step = _lib.AG_MAX_GROUPS
+        for c0 in range(0, len(tail), step):
+            chunk = tail[c0:c0 + step]
+            tm = [(i, b) for i, b, _, _ in chunk]
+            src = [m for _, _, m, _ in chunk]
+            tst = [nets[i]._stage_styles(b, tail_stages, lat[i]) for i, b in tm]
+            # view features: the members that have one must be one contiguous run (they are: members are ordered by network)
+            rows = [r for r, (i, b, _, v) in enumerate(chunk) if views.get(i) and views[i][v] is not None and views[i][v][b - 1] is not None]
+            vf = None
+            if rows:
+                if rows != list(range(rows[0], rows[-1] + 1)):
+                    raise RuntimeError("grouped networks: view features must belong to consecutive members")
+                feats = []
+                for r in rows:
+                    i, b, _, v = chunk[r]
+                    f = views[i][v][b - 1]
+                    if f.shape[-2:] != out.shape[-2:]:
+                        f = torch.nn.functional.interpolate(f, out.shape[-2:], mode="bilinear")
+                    feats.append(f)
+                vf = torch.cat(feats, 0) if len(feats) > 1 else feats[0]
+            o, sk = out, None
+            for j, n in enumerate(tail_stages):
+                if j == 0:
+                    # skips of the chunk's members, per run of equal head width
+                    if tm == list(members):
+                        sk = skips                                          # one view: the stacked skips as they are
+                    else:
+                        sk = {}
+                        for (s, e) in _runs([nets[i].out_ch for i, _ in tm]):
+                            parts = []
+                            for r in range(s, e):
+                                m = src[r]
+                                (ks, ke) = next(k for k in skips if k[0] <= m < k[1])
+                                parts.append(skips[(ks, ke)][m - ks:m - ks + 1])
+                            sk[(s, e)] = torch.cat(parts, 0) if len(parts) > 1 else parts[0]
+                    o, sk = self._stage(n, tm, tst, noises, o, sk, levels, src=src, vf=vf, vf_rows=(rows[0], rows[-1] + 1) if rows else None)
+                else:
+                    o, sk = self._stage(n, tm, tst, noises, o, sk, levels)
+            for (s, e), t in sk.items():
+                img = _GroupedHaarMerge.apply(t)                             # [e - s, out_ch, S', S']
+                for r in range(s, e):
+                    i, b, _, v = chunk[r]
+                    results[(i, v, b)] = img[r - s:r - s + 1]
+        return results

@@ -109,12 +109,12 @@ class BucketedGradSync:
         self._world = dist.get_world_size() if dist.is_initialized() else 1
         self._passthrough = self._world == 1 and not flat_when_single
         if self._passthrough:
-            self.flat, self.buckets, self._handles, self._works = None, [], [], []
+            self._flat, self.buckets, self._handles, self._works = None, [], [], []
             return
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device
         self._cuda = dev.type == "cuda"
-        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        self._flat = torch.zeros(n, dtype=torch.float32, device=dev)
         # reverse order: the last-registered parameters (decoder heads) get their gradients first
         order = list(reversed(self.params))
         self.buckets = []          # [start, end) element ranges of the flat buffer
@@ -127,7 +127,7 @@ class BucketedGradSync:
                 self.buckets.append((b_start, off))
                 self._pending_init.append(b_count)
                 b_start, b_count = off, 0
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            p.grad = self._flat[off:off + p.numel()].view_as(p)
             self._bucket_of[p] = len(self.buckets)
             off += p.numel()
             b_count += 1
@@ -137,12 +137,24 @@ class BucketedGradSync:
         self._arm()
         self._handles = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
 
+    @property
+    def flat(self) -> torch.Tensor:
+        """The flat gradient buffer every ``param.grad`` is a view of.  It exists when gradients are exchanged (world size > 1, or
+        ``flat_when_single=True``); the world-size-1 pass-through keeps no such buffer -- read the parameters' ``.grad`` there (they are
+        ordinary tensors, set to None by ``zero()``), or construct with ``flat_when_single=True``."""
+        if self._flat is None:
+            raise AttributeError("BucketedGradSync is a pass-through at world size 1 (no flat gradient buffer, .grad are plain tensors); "
+                                 "construct it with flat_when_single=True to keep the flat buffer on one rank")
+        return self._flat
+
     def _arm(self):
         self._pending = list(self._pending_init)
         self._works = []
         self._fired = set()
         self._events = [[] for _ in self.buckets]      # per bucket: one event per gradient, on the stream that accumulated it
         self._launched = [False] * len(self.buckets)
+        self._next = 0                                  # collectives are issued strictly in bucket order (see _on_grad)
+        self.launch_order = []                          # the order they were issued in this step (the same on every rank by construction)
 
     def zero(self):
         """Start of a step: clear the flat gradient buffer and re-arm the buckets."""
@@ -152,7 +164,7 @@ class BucketedGradSync:
             return
         if any(w is not None for w in self._works):
             raise RuntimeError("BucketedGradSync.zero() while collectives of the previous step are in flight: call finish() first")
-        self.flat.zero_()
+        self._flat.zero_()
         self._arm()
 
     def _launch(self, b):
@@ -162,24 +174,25 @@ class BucketedGradSync:
         producers of this bucket and nothing else waits."""
         s, e = self.buckets[b]
         self._launched[b] = True
+        self.launch_order.append(b)
         if self._cuda:
             for ev in self._events[b]:
                 self._comm.wait_event(ev)
             self._events[b] = []
             with torch.cuda.stream(self._comm):
-                self._works.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, async_op=True))
+                self._works.append(dist.all_reduce(self._flat[s:e], op=dist.ReduceOp.SUM, async_op=True))
             return
         self._events[b] = []
-        self._works.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, async_op=True))
+        self._works.append(dist.all_reduce(self._flat[s:e], op=dist.ReduceOp.SUM, async_op=True))
 
     def _on_grad(self, p):
         # autograd accumulated into the existing .grad view in place; guard against it having been replaced
-        if p.grad.data_ptr() < self.flat.data_ptr() or p.grad.data_ptr() >= self.flat.data_ptr() + self.flat.numel() * 4:
+        if p.grad.data_ptr() < self._flat.data_ptr() or p.grad.data_ptr() >= self._flat.data_ptr() + self._flat.numel() * 4:
             raise RuntimeError("a parameter's .grad was re-allocated; use BucketedGradSync.zero(), not zero_grad(set_to_none=True)")
         b = self._bucket_of[p]
         if self._cuda:
             ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(self.flat.device))     # the hook runs on the stream that accumulated this gradient
+            ev.record(torch.cuda.current_stream(self._flat.device))     # the hook runs on the stream that accumulated this gradient
             self._events[b].append(ev)
         if self.defer_to_finish:
             return
@@ -191,8 +204,15 @@ class BucketedGradSync:
                                "reduced in finish())")
         self._fired.add(id(p))
         self._pending[b] -= 1
-        if self._pending[b] == 0 and self._world > 1:
-            self._launch(b)
+        # Launch in BUCKET-INDEX order only: bucket b goes out when it and every bucket before it are complete.  The order in which the
+        # gradients of different buckets land is whatever the autograd engine's queues yield (the backward runs on several HIP streams),
+        # and it may differ between ranks; collectives of one communicator must be issued in the same order on every rank or they pair
+        # up wrongly / hang (the reason DDP launches its buckets in order).  A bucket that completes early simply waits for its
+        # predecessors; finish() flushes whatever is left, in order.
+        if self._world > 1:
+            while self._next < len(self.buckets) and self._pending[self._next] == 0:
+                self._launch(self._next)
+                self._next += 1
 
     def finish(self):
         """End of backward: launch the buckets that have not been launched (parameters without gradient this step, or
@@ -200,18 +220,19 @@ class BucketedGradSync:
         if self._passthrough:
             return
         if self._world > 1:
-            for b in range(len(self.buckets)):
+            for b in range(len(self.buckets)):           # ascending: the same order on every rank
                 if not self._launched[b]:
                     self._launch(b)
+            self._next = len(self.buckets)
             for w in self._works:
                 w.wait()                                   # the CURRENT stream waits for the collective (and the host for gloo)
             if self._cuda:
-                torch.cuda.current_stream(self.flat.device).wait_stream(self._comm)
+                torch.cuda.current_stream(self._flat.device).wait_stream(self._comm)
             self._works = []
             if self.average:
-                self.flat /= self._world
+                self._flat /= self._world
         elif self._cuda:
-            cur = torch.cuda.current_stream(self.flat.device)
+            cur = torch.cuda.current_stream(self._flat.device)
             for evs in self._events:
                 for ev in evs:
                     cur.wait_event(ev)

@@ -431,8 +431,10 @@ class FusedRasterStep:
 
         The host does not wait for the view's instance count here (``ag_raster_forward_backward_enqueue``): it is read when the slot is
         used next or at :meth:`join` (``ag_raster_collect``).  Should the view turn out to have more instances than the slot's binning
-        buffer holds (first frames of a configuration), it is redone at that point -- until then its images are not valid; the
-        gradient sums are never touched by a view that does not fit."""
+        buffer holds, it is redone at that point -- until then its images are not valid; the gradient sums are never touched by a view
+        that does not fit.  So: consume the returned images only after :meth:`join` (or after the next ``run`` on the same slot).
+        While the instance count of this configuration has not been learned yet (the first views of a (P, W, H) on this device) the view
+        is collected before returning, so a first frame is never handed out unfinished."""
         L = _lib.lib()
         P, dev = self.P, self.dev
         sl = self.slots[h.slot]
@@ -460,6 +462,8 @@ class FusedRasterStep:
                        "ag_raster_forward_backward_enqueue")
         if tk.value >= 0:
             sl["pending"] = (tk.value, h, cap)
+            if not _capacity.get(self.key):
+                self._collect(sl)                                 # capacity not learned yet: synchronous until it is
         sl["used"] = True
         if not inputs_outlive_join:
             for t in h.checked + h.image_grads:
@@ -509,6 +513,19 @@ class FusedRasterStep:
         for t in h.keep + [h.color, h.depth, h.alpha, h.radii]:
             t.record_stream(st)
         return out
+
+    def close(self):
+        """Collect every view still pending on a slot: releases their entries of the library's ticket table (64 per process -- an object
+        dropped with pending views, e.g. by an exception in the middle of a step, would otherwise leak them until every enqueue fails).
+        Called by ``__del__``; safe to call more than once."""
+        for sl in getattr(self, "slots", []):
+            try:
+                self._collect(sl)
+            except Exception:                                    # interpreter shutdown / a library that is already gone
+                sl["pending"] = None
+
+    def __del__(self):
+        self.close()
 
     def join(self):
         """Order the caller's stream after every internal stream and return the gradients summed over the slots that were used since

@@ -30,7 +30,10 @@ from .styleunet_ops import fused_leaky_relu, haar_merge, haar_split, modulate_we
 
 _SQRT2 = 2 ** 0.5
 # ConvLayer / StyledConv / ToRGB as one autograd node each (fused_layers.py: same kernels, same order, bit-identical results, a third of
-# the autograd nodes).  AG_UNFUSED_LAYERS=1 or set_fused_layers(False) runs the per-kernel chain (A/B and the equality test).
+# the autograd nodes) -- with one exception: ToRGB's skip path iwt -> Upsample -> dwt runs as ONE composed kernel by default
+# (AG_SKIP_CHAIN, fused_layers.set_skip_chain), which equals the three-kernel chain to 1e-6 of the largest value, not to the bit
+# (tests/test_styleunet_ops.py::test_skip_chain_*).  AG_UNFUSED_LAYERS=1 or set_fused_layers(False) runs the per-kernel chain (A/B and
+# the equality test).
 _FUSED_LAYERS = os.environ.get("AG_UNFUSED_LAYERS") != "1"
 
 

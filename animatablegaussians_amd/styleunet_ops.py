@@ -176,6 +176,19 @@ def upfirdn2d_nchw(input, kernel, up=1, down=1, pad=(0, 0)):
     return _UpFirDn2d.apply(input, kernel, up, down, pad)
 
 
+_PARTIALS = {}
+
+
+def _partial_floats(kind, a, b):
+    """Floats of scratch the deterministic parameter-gradient reductions need (a function of the shape: asked once)."""
+    key = (kind, a, b)
+    n = _PARTIALS.get(key)
+    if n is None:
+        L = _lib.lib()
+        n = _PARTIALS[key] = max(1, int(L.ag_noise_bias_act_partial_floats(a, b) if kind == "nba" else L.ag_modulate_weight_partial_floats(a, b)))
+    return n
+
+
 class _NoiseBiasAct(torch.autograd.Function):
     """StyledConv tail ``lrelu(x + w * noise + bias) * sqrt(2)`` in one kernel each way (include/ag_styleunet.h)."""
 
@@ -206,15 +219,14 @@ class _NoiseBiasAct(torch.autograd.Function):
         gx = torch.empty_like(y)
         # frozen parameters (the VGG trunk of LPIPS): no reduction, no buffer
         want_b, want_w = has_bias and ctx.needs_input_grad[3], has_nw and ctx.needs_input_grad[2]
-        if want_b and want_w:                       # one buffer, one fill: the noise-strength sum sits right behind the C bias sums
-            both = torch.empty(C + 1, dtype=torch.float32, device=y.device)
-            gb, gw = both[:C], both[C:]
-        else:
-            gb = torch.empty(C, dtype=torch.float32, device=y.device) if want_b else None
-            gw = torch.empty(1, dtype=torch.float32, device=y.device) if want_w else None
+        gb = torch.empty(C, dtype=torch.float32, device=y.device) if want_b else None
+        gw = torch.empty(1, dtype=torch.float32, device=y.device) if want_w else None
+        part = None
+        if want_b or want_w:                        # per-workgroup partial sums of the deterministic two-stage reductions
+            part = torch.empty(_partial_floats("nba", C, HW), dtype=torch.float32, device=y.device)
         with _lib.on_device(y.device):
             _lib.check(_lib.lib().ag_noise_bias_act_backward(_p(gx), _p(gy), _p(y), _p(noise) if gw is not None else None, _p(gb), _p(gw),
-                                                             C, HW, slope, scale, _stream(y.device)),
+                                                             _p(part), C, HW, slope, scale, _stream(y.device)),
                        "ag_noise_bias_act_backward")
         return gx, None, gw, gb, None, None
 
@@ -252,8 +264,9 @@ class _ModulateWeight(torch.autograd.Function):
         g = g.contiguous()
         dW = torch.empty_like(w)
         ds = torch.empty(Ci, dtype=torch.float32, device=w.device)
+        part = torch.empty(_partial_floats("mod", Co, Ci), dtype=torch.float32, device=w.device)
         with _lib.on_device(w.device):
-            _lib.check(_lib.lib().ag_modulate_weight_backward(_p(dW), _p(ds), _p(g), _p(w), _p(st), _p(dcoef), scale, int(demodulate),
+            _lib.check(_lib.lib().ag_modulate_weight_backward(_p(dW), _p(ds), _p(part), _p(g), _p(w), _p(st), _p(dcoef), scale, int(demodulate),
                                                               Co, Ci, K2, int(transposed), _stream(w.device)),
                        "ag_modulate_weight_backward")
         return dW.view(wshape), ds.view(sshape), None, None, None
@@ -400,10 +413,12 @@ def _skip_taps_host(k_up: torch.Tensor):
     """The 48 coefficients as a ctypes float array (host memory: the library passes them to its kernels by value), cached per kernel
     tensor -- one read-back of 16 floats the first time."""
     key = (k_up.device, k_up.data_ptr(), k_up._version)
-    t = _SKIP_TAPS.get(key)
-    if t is None:
-        t = _SKIP_TAPS[key] = (ctypes.c_float * 48)(*skip_chain_taps_1d(k_up.detach().cpu().numpy()))
-    return ctypes.cast(t, ctypes.c_void_p)
+    e = _SKIP_TAPS.get(key)
+    if e is None or e[0] is not k_up:       # the entry holds its source tensor: a freed block handed to ANOTHER kernel tensor is not a hit
+        if len(_SKIP_TAPS) > 64:
+            _SKIP_TAPS.clear()
+        e = _SKIP_TAPS[key] = (k_up, (ctypes.c_float * 48)(*skip_chain_taps_1d(k_up.detach().cpu().numpy())))
+    return ctypes.cast(e[1], ctypes.c_void_p)
 
 
 def skip_chain_forward_(out: torch.Tensor, skip: torch.Tensor, k_up: torch.Tensor, accumulate: bool = True) -> torch.Tensor:

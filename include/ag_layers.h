@@ -64,6 +64,89 @@ size_t ag_layer_scratch_floats(const AgLayerArgs* a, int32_t backward);
 int ag_layer_forward(const AgLayerArgs* a, void* stream);
 int ag_layer_backward(const AgLayerArgs* a, void* stream);
 
+/*
+ * Grouped layers (round 4): G instances of one layer shape in ONE call and one launch per kernel kind.
+ *
+ * The avatar runs three DualStyleUNets with identical layer shapes on the same pose map (network/avatar.py:34-36,93-124), each with two
+ * decoders of identical shapes (dual_styleunet.py:869-905): six instances of every decoder layer, three of every encoder layer, that
+ * differ only in their parameter tensors.  Activations are stacked [G][C][H][W]; the parameters stay the reference's separate tensors and
+ * are passed as tables of G device pointers (no copies, gradients are written stacked [G][...] so that each instance's slice is a dense
+ * tensor of its parameter's shape).  AgLayerArgs above is the G = 1 case and runs through the same code.
+ */
+#define AG_MAX_GROUPS 16
+
+typedef struct AgGroupedLayerArgs {
+    int32_t G;                     /* instances, 1 .. AG_MAX_GROUPS */
+    int32_t Cin, Cout, H, W, k, resample, modulated;   /* as AgLayerArgs */
+    float scale, slope, act_scale, reserved_f;
+    const float* x;                /* [G][Cin][H][W] */
+    int64_t x_group_stride;        /* floats between the instances' inputs: Cin*H*W, or 0 = ONE input [Cin][H][W] shared by all instances
+                                      (the pose map / its image pyramid; g_x must then be NULL).  Ignored when G = 1 */
+    const float* weight[AG_MAX_GROUPS];        /* per instance: [Cout, Cin, k, k] */
+    const float* style[AG_MAX_GROUPS];         /* StyledConv: [Cin] */
+    const float* noise[AG_MAX_GROUPS];         /* StyledConv: [OH * OW] or NULL */
+    const float* noise_weight[AG_MAX_GROUPS];  /* StyledConv: [1] or NULL */
+    const float* act_bias[AG_MAX_GROUPS];      /* [Cout] or NULL */
+    const float* k_blur;           /* [4, 4] FIR taps (resample only); backward: the FLIPPED taps */
+    float* w_mod;                  /* StyledConv: [G][Cout * Cin * k * k] modulated weights (per instance laid out as AgLayerArgs.w_mod) */
+    float* demod;                  /* StyledConv: [G][Cout] */
+    float* x_blur;                 /* down-sampling ConvLayer: [G][Cin][H + 1][W + 1] ([Cin][H + 1][W + 1] when the input is shared) */
+    float* out;                    /* [G][Cout][OH][OW] */
+    float* scratch;                /* ag_grouped_layer_scratch_floats(args, backward) floats */
+    void* workspace;               /* ag_grouped_layer_workspace_bytes(args) bytes */
+    size_t workspace_bytes;
+    /* backward only */
+    const float* g_out;            /* [G][Cout][OH][OW] */
+    float* g_x;                    /* [G][Cin][H][W] or NULL */
+    float* g_weight;               /* [G][Cout][Cin][k][k] or NULL */
+    float* g_style;                /* StyledConv: [G][Cin] (required with g_weight) */
+    float* g_bias_noise;           /* [G][Cout + 1]: the bias sums of an instance, then its noise-strength sum; NULL: no parameter gradient */
+    int32_t want_bias, want_noise_weight;
+} AgGroupedLayerArgs;
+
+size_t ag_grouped_layer_args_bytes(void);
+int ag_grouped_layer_output_size(const AgGroupedLayerArgs* a, int32_t* OH, int32_t* OW);
+size_t ag_grouped_layer_scratch_floats(const AgGroupedLayerArgs* a, int32_t backward);
+size_t ag_grouped_layer_workspace_bytes(const AgGroupedLayerArgs* a);
+int ag_grouped_layer_forward(const AgGroupedLayerArgs* a, void* stream);
+int ag_grouped_layer_backward(const AgGroupedLayerArgs* a, void* stream);
+
+/*
+ * ToRGB (dual_styleunet.py:607-633) for G instances: modulated 1 x 1 convolution without demodulation + bias, plus the wavelet-domain
+ * up-sampled skip (InverseHaarTransform -> Upsample -> HaarTransform, one kernel) accumulated into the output.
+ * The bias gradient (sum of g_out over the pixels) is left to the caller.
+ */
+typedef struct AgGroupedToRgbArgs {
+    int32_t G, Cin, Cout, H, W;
+    float scale;                   /* 1 / sqrt(Cin) */
+    const float* x;                /* [G][Cin][H][W] */
+    const float* weight[AG_MAX_GROUPS];   /* [Cout, Cin] */
+    const float* style[AG_MAX_GROUPS];    /* [Cin] */
+    const float* bias[AG_MAX_GROUPS];     /* [Cout] or NULL */
+    const float* skip;             /* [G][Cout][H / 2][W / 2] or NULL */
+    const float* skip_taps;        /* HOST pointer to the 48 coefficients of ag_skip_chain_forward (with skip / g_skip) */
+    float* w_mod;                  /* [G][Cout * Cin]: written forward, read backward */
+    float* out;                    /* [G][Cout][H][W] */
+    float* scratch;                /* ag_grouped_to_rgb_scratch_floats floats */
+    void* workspace;               /* ag_grouped_to_rgb_workspace_bytes bytes */
+    size_t workspace_bytes;
+    /* backward only */
+    const float* g_out;            /* [G][Cout][H][W] */
+    float* g_x;                    /* [G][Cin][H][W] or NULL */
+    float* g_weight;               /* [G][Cout][Cin] or NULL */
+    float* g_style;                /* [G][Cin] (required with g_weight) */
+    float* g_skip;                 /* [G][Cout][H / 2][W / 2] or NULL */
+} AgGroupedToRgbArgs;
+
+size_t ag_grouped_to_rgb_args_bytes(void);
+size_t ag_grouped_to_rgb_scratch_floats(const AgGroupedToRgbArgs* a, int32_t backward);
+size_t ag_grouped_to_rgb_workspace_bytes(const AgGroupedToRgbArgs* a);
+int ag_grouped_to_rgb_forward(const AgGroupedToRgbArgs* a, void* stream);
+int ag_grouped_to_rgb_backward(const AgGroupedToRgbArgs* a, void* stream);
+
+/* ag_block2x2_transform (ag_styleunet.h) on G stacked tensors: in [G][C][2h][2w] <-> out [G][4][C][h][w]. */
+int ag_grouped_block2x2(float* out, const float* in, const float* matrix16, int32_t merge, int32_t G, int32_t C, int32_t h, int32_t w, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

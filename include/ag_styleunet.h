@@ -52,11 +52,13 @@ int ag_noise_bias_act_forward(float* y, const float* x, const float* noise, cons
 /*
  * Backward of the above from the saved OUTPUT y (the sign of y selects the slope, fused_bias_act_kernel.cu:41):
  *   gx = gy * (y > 0 ? 1 : slope) * scale;  gbias[c] = sum_p gx[c][p];  gnoise_weight[0] = sum_{c,p} gx[c][p] * noise[p]
- * gbias / gnoise_weight may be NULL (not needed); they are overwritten (zeroed, then accumulated with float atomics, one per
- * workgroup).
+ * gbias / gnoise_weight may be NULL (not needed); they are overwritten.  DETERMINISTIC since round 4: every workgroup stores its partial
+ * sums in `partials` (ag_noise_bias_act_partial_floats(C, HW) floats of caller-owned scratch, required when either sum is wanted) and a
+ * one-workgroup finish adds them in a fixed order -- bit-identical from run to run given the same inputs (float atomics before).
  */
+size_t ag_noise_bias_act_partial_floats(int32_t C, int32_t HW);
 int ag_noise_bias_act_backward(float* gx, const float* gy, const float* y, const float* noise, float* gbias, float* gnoise_weight,
-                               int32_t C, int32_t HW, float slope, float scale, void* stream);
+                               float* partials, int32_t C, int32_t HW, float slope, float scale, void* stream);
 
 /*
  * Weight modulation + demodulation of ModulatedConv2d's fused branch (network/styleunet/dual_styleunet.py:254-259):
@@ -67,9 +69,13 @@ int ag_noise_bias_act_backward(float* gx, const float* gy, const float* y, const
 int ag_modulate_weight_forward(float* out, float* dcoef, const float* W, const float* style, float scale, int32_t demodulate,
                                int32_t Co, int32_t Ci, int32_t K2, int32_t transposed, void* stream);
 
-/* Backward: g = dL/dout (same layout as out).  dW [Co][Ci][K2] and dstyle [Ci] are overwritten. */
-int ag_modulate_weight_backward(float* dW, float* dstyle, const float* g, const float* W, const float* style, const float* dcoef,
-                                float scale, int32_t demodulate, int32_t Co, int32_t Ci, int32_t K2, int32_t transposed, void* stream);
+/* Backward: g = dL/dout (same layout as out).  dW [Co][Ci][K2] and dstyle [Ci] are overwritten.  Deterministic since round 4: the per-(co, ci)
+ * tap sums go to `partials` (ag_modulate_weight_partial_floats(Co, Ci) = Co * Ci floats of caller-owned scratch) and are added over co in
+ * a fixed order. */
+size_t ag_modulate_weight_partial_floats(int32_t Co, int32_t Ci);
+int ag_modulate_weight_backward(float* dW, float* dstyle, float* partials, const float* g, const float* W, const float* style,
+                                const float* dcoef, float scale, int32_t demodulate, int32_t Co, int32_t Ci, int32_t K2, int32_t transposed,
+                                void* stream);
 
 /*
  * 2x2 block transform = HaarTransform / InverseHaarTransform of the wavelet skip path (dual_styleunet.py:374-425: four
@@ -78,16 +84,6 @@ int ag_modulate_weight_backward(float* dW, float* dstyle, const float* g, const 
  *   merge != 0        : in [4][C][h][w] -> out [C][2h][2w],  out[c][2i + p/2][2j + p%2] = sum_b matrix16[4p + b] * in[b][c][i][j]
  * matrix16 is a HOST pointer to the 16 coefficients.  The adjoint of a split with M is a merge with M^T and vice versa.
  */
-/* Round 3: the Blur behind an up-sampling ModulatedConv2d (dual_styleunet.py:188-193) and the StyledConv tail (NoiseInjection :301-311 +
- * FusedLeakyReLU :596) as one pass each way.  Forward: out [major, in_h + pad0 + pad1 - 3, ...] = act(FIR_4x4(input) + noise_weight * noise
- * + bias[channel]); backward (pads (1, 1) only): g_in [major, OH + 1, OW + 1] = FIR^T(g_out * act'(y)), bias / noise-strength sums zeroed
- * here and accumulated (either may be NULL; pass gnoise_weight = gbias + major for one fill). */
-int ag_fir4x4_noise_bias_act_forward(float* out, const float* input, const float* kernel, int32_t major, int32_t in_h, int32_t in_w,
-                                     int32_t pad0, int32_t pad1, const float* noise, const float* noise_weight, const float* bias,
-                                     float slope, float scale, void* stream);
-int ag_fir4x4_noise_bias_act_backward(float* g_in, const float* g_out, const float* y, const float* kernel_flipped, int32_t major,
-                                      int32_t OH, int32_t OW, const float* noise, float* gbias, float* gnoise_weight, float slope,
-                                      float scale, void* stream);
 int ag_block2x2_transform(float* out, const float* in, const float* matrix16, int32_t merge, int32_t C, int32_t h, int32_t w,
                           void* stream);
 /* Round 3: ToRGB's wavelet-domain skip path (dual_styleunet.py:607-633: InverseHaarTransform :406-425 -> Upsample :32-50 -> HaarTransform

@@ -1,0 +1,101 @@
+"""Per-layer time of the grouped StyleUNet chain (round 4):  python profiles/grouped_layers.py [out.csv]
+Records every grouped ConvLayer / StyledConv / ToRGB call of one AvatarNet.get_maps (shape, group size), then times each distinct call
+forward and backward on its own (HIP events, median of 5) and prints time, conv FLOPs and TFLOP/s (algorithmic fp32 FLOPs: forward 1x,
+backward 2x = input gradient + weight gradient)."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from animatablegaussians_amd import grouped as gr  # noqa: E402
+from animatablegaussians_amd.avatar import AvatarNet  # noqa: E402
+
+dev = torch.device("cuda:0")
+torch.manual_seed(31359)
+net = AvatarNet.synthetic({'with_viewdirs': True}, device=dev)
+calls = []
+orig_layer, orig_rgb = gr._GroupedLayer.apply, gr._GroupedToRGB.apply
+
+
+def rec_layer(G, shared, resample, modulated, scale, k_blur, x, *params):
+    w = params[0]
+    calls.append(("styled" if modulated else "conv", G, int(w.shape[-3]), int(w.shape[-4]), int(x.shape[2]), int(w.shape[-1]), bool(resample), bool(shared)))
+    return orig_layer(G, shared, resample, modulated, scale, k_blur, x, *params)
+
+
+def rec_rgb(G, scale, k_up, x, skip, *params):
+    w = params[0]
+    calls.append(("torgb", G, int(w.shape[-3]), int(w.shape[-4]), int(x.shape[2]), 1, skip is not None, False))
+    return orig_rgb(G, scale, k_up, x, skip, *params)
+
+
+gr._GroupedLayer.apply, gr._GroupedToRGB.apply = rec_layer, rec_rgb
+pose = torch.randn(3, 512, 512, device=dev)
+vf = torch.randn(1, 128, 128, 128, device=dev)
+with torch.no_grad():
+    net.get_maps(pose, vf, vf)
+gr._GroupedLayer.apply, gr._GroupedToRGB.apply = orig_layer, orig_rgb
+kb = net.position_net._k_blur
+kbu = net.position_net._k_blur_up
+
+
+def timed(fn, reps=5):
+    ts = []
+    for _ in range(reps + 1):
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b))
+    return float(np.median(ts[1:]))
+
+
+rows = []
+seen = {}
+for c in calls:
+    seen[c] = seen.get(c, 0) + 1
+g = torch.Generator().manual_seed(0)
+for c, count in seen.items():
+    kind, G, Cin, Cout, H, k, res, shared = c
+    x = torch.randn(1 if shared else G, Cin, H, H, device=dev).requires_grad_(not shared)
+    if kind == "conv":
+        ws = [torch.randn(Cout, Cin, k, k, device=dev).requires_grad_(True) for _ in range(G)]
+        bs = [torch.zeros(Cout, device=dev).requires_grad_(True) for _ in range(G)]
+        fn = lambda: gr.grouped_conv_layer(x, ws, bs, kb, 1 / (Cin * k * k) ** 0.5, res, shared)      # noqa: E731
+        OH = H // 2 if res else H
+    elif kind == "styled":
+        OH = 2 * H if res else H
+        ws = [torch.randn(1, Cout, Cin, k, k, device=dev).requires_grad_(True) for _ in range(G)]
+        st = [torch.ones(1, Cin, device=dev).requires_grad_(True) for _ in range(G)]
+        nz = [torch.randn(1, 1, OH, OH, device=dev) for _ in range(G)]
+        nw = [torch.zeros(1, device=dev).requires_grad_(True) for _ in range(G)]
+        bs = [torch.zeros(Cout, device=dev).requires_grad_(True) for _ in range(G)]
+        fn = lambda: gr.grouped_styled_conv(x, ws, st, nz, nw, bs, kbu if res else None, 1 / (Cin * k * k) ** 0.5, res)      # noqa: E731
+    else:
+        OH = H
+        ws = [torch.randn(1, Cout, Cin, 1, 1, device=dev).requires_grad_(True) for _ in range(G)]
+        st = [torch.ones(1, Cin, device=dev).requires_grad_(True) for _ in range(G)]
+        bs = [torch.zeros(Cout, device=dev).requires_grad_(True) for _ in range(G)]
+        sk = torch.randn(G, Cout, H // 2, H // 2, device=dev).requires_grad_(True) if res else None
+        fn = lambda: gr.grouped_to_rgb(x, ws, st, bs, sk, kbu, 1 / Cin ** 0.5)      # noqa: E731
+    flop = 2.0 * G * Cout * Cin * k * k * (OH * OH if not (kind == "conv" and res) else OH * OH)
+    with torch.no_grad():
+        tf = timed(fn)
+    out = fn()
+    up = torch.randn_like(out)
+    tb = timed(lambda: torch.autograd.grad(out, [t for t in [x] + ws + bs if t.requires_grad], up, retain_graph=True, allow_unused=True))
+    nbwd = 1.0 if shared else 2.0
+    rows.append((kind, G, Cin, Cout, H, k, res, shared, count, tf, tb, flop / 1e9, flop / tf / 1e9, nbwd * flop / tb / 1e9))
+rows.sort(key=lambda r: -(r[9] + r[10]) * r[8])
+hdr = "kind,G,Cin,Cout,H,k,resample,shared,calls,fwd_ms,bwd_ms,fwd_GFLOP,fwd_TFLOPs,bwd_TFLOPs"
+lines = [hdr] + [",".join(str(round(v, 3)) if isinstance(v, float) else str(v) for v in r) for r in rows]
+tot_f = sum(r[9] * r[8] for r in rows)
+tot_b = sum(r[10] * r[8] for r in rows)
+lines.append(f"# total of the layer calls: forward {tot_f:.2f} ms, backward {tot_b:.2f} ms; conv FLOPs forward {sum(r[11] * r[8] for r in rows) / 1e3:.2f} TFLOP")
+print("\n".join(lines))
+if len(sys.argv) > 1:
+    open(sys.argv[1], "w").write("\n".join(lines) + "\n")

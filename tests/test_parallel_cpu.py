@@ -148,3 +148,76 @@ def test_bucketed_grad_sync_gloo_world2():
         p.join(180)
         assert p.exitcode == 0
     assert dict(out) == {0: True, 1: True}
+
+
+def _order_worker(rank, world, port, out):
+    """The two ranks receive their gradients in DIFFERENT orders (rank 0: last parameter first, as a plain backward; rank 1: first
+    parameter first, then a shuffle) -- what a backward spread over several HIP streams can produce.  Collectives must still be issued in
+    the same (bucket-index) order on both ranks, and the sums must be right."""
+    from animatablegaussians_amd.parallel import BucketedGradSync
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    params = [torch.nn.Parameter(torch.zeros(300)) for _ in range(12)]
+    sync = BucketedGradSync(params, bucket_bytes=2 * 300 * 4, average=False)       # 2 parameters per bucket -> 6 buckets
+    assert len(sync.buckets) == 6
+    ok = True
+    orders = {0: [list(range(11, -1, -1)), [5, 4, 11, 10, 1, 0, 7, 6, 3, 2, 9, 8]],
+              1: [list(range(12)), [0, 7, 3, 10, 1, 6, 11, 4, 9, 2, 5, 8]]}
+    launch_orders = []
+    for step in range(2):
+        sync.zero()
+        for i in orders[rank][step]:                       # drive the accumulate hooks one parameter at a time, in this rank's order
+            (params[i] * float((rank + 1) * (i + 1))).sum().backward()
+        mid = list(sync.launch_order)                      # what went out during the "backward"
+        sync.finish()
+        launch_orders.append(list(sync.launch_order))
+        ok = ok and sync.launch_order == sorted(sync.launch_order) == list(range(6)) and mid == sorted(mid)
+        for i, p in enumerate(params):
+            ok = ok and bool(torch.allclose(p.grad, torch.full((300,), float(sum((r + 1) * (i + 1) for r in range(world))))))
+    out[rank] = (bool(ok), launch_orders)
+    sync.close()
+    dist.destroy_process_group()
+
+
+def test_bucket_collectives_are_issued_in_the_same_order_on_every_rank():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    out = ctx.Manager().dict()
+    procs = [ctx.Process(target=_order_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    res = dict(out)
+    assert res[0][0] and res[1][0], res
+    assert res[0][1] == res[1][1] == [list(range(6))] * 2
+
+
+def test_world_size_one_pass_through_surface():
+    """at world size 1 the exchange object is a pass-through by default.  `.flat` then raises a clear error instead of being
+    None, `zero()` / `finish()` / an optimizer step work through the default constructor, and `flat_when_single=True` keeps the buffer."""
+    import pytest
+    from animatablegaussians_amd.parallel import BucketedGradSync
+    net = torch.nn.Linear(4, 3)
+    sync = BucketedGradSync(list(net.parameters()))
+    with pytest.raises(AttributeError, match="flat_when_single"):
+        sync.flat
+    opt = torch.optim.SGD(net.parameters(), lr=0.1)
+    before = net.weight.detach().clone()
+    for _ in range(2):
+        sync.zero()
+        assert all(p.grad is None for p in net.parameters())
+        net(torch.ones(2, 4)).sum().backward()
+        sync.finish()
+        opt.step()
+    assert not torch.equal(before, net.weight)
+    sync.close()
+    kept = BucketedGradSync(list(net.parameters()), flat_when_single=True)
+    kept.zero()
+    net(torch.ones(2, 4)).sum().backward()
+    kept.finish()
+    assert kept.flat.numel() == 15 and all(p.grad.data_ptr() >= kept.flat.data_ptr() for p in net.parameters())
+    assert float(kept.flat.abs().sum()) > 0
+    kept.close()

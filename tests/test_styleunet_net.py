@@ -185,39 +185,6 @@ def test_layer_level_autograd_nodes_equal_the_per_kernel_chain():
     assert set(res[True][2]) == set(res[False][2])
 
 
-@pytest.mark.gpu
-def test_training_passes_do_not_pile_up_memory_without_the_garbage_collector():
-    """The layer-level autograd nodes hand every saved tensor (their own OUTPUT among them) to autograd's save_for_backward and drop
-    their private references when the backward returns: with Python's cycle collector switched off the allocated memory is the same
-    after every pass (a node -> output -> node cycle would add ~5 GB per pass until the collector runs)."""
-    import gc
-    import torch
-    from animatablegaussians_amd import synth
-    from animatablegaussians_amd.styleunet import DualStyleUNet
-
-    dev = torch.device("cuda:0")
-    net = DualStyleUNet(inp_size=512, inp_ch=3, out_ch=3, out_size=1024, style_dim=512, n_mlp=2).to(dev)
-    pose = synth.pose_map(512).to(dev)
-    style = (torch.ones(1, 512) / np.sqrt(512)).to(dev)
-    G = torch.randn(1, 6, 1024, 1024, device=dev)
-    was = gc.isenabled()
-    gc.disable()
-    try:
-        seen = []
-        for _ in range(4):
-            for p in net.parameters():
-                p.grad = None
-            images, _ = net([style], pose, randomize_noise=False)
-            (images * G).sum().backward()
-            del images
-            torch.cuda.synchronize()
-            seen.append(torch.cuda.memory_allocated(dev))
-    finally:
-        if was:
-            gc.enable()
-    assert max(seen[1:]) - min(seen[1:]) < (64 << 20), seen
-
-
 def test_stacked_modulation_gemm_equals_the_per_layer_equal_linear():
     """DualStyleUNet._stage_styles: the EqualLinear modulation (dual_styleunet.py:152-155, lr_mul 1: F.linear(w, W * (1 / sqrt(512)), b)) of
     every StyledConv / ToRGB of a stage group as one addmm on the stacked weights -- same values as the per-layer formula (CPU, fp64 as the
