@@ -544,7 +544,7 @@ class GroupedStyleUNets:
                 for mm, bb in ms:
                     tail.append((i, bb, mm, v))
         results = {}
-        step = _lib.AG_MAX_GROUPS
+        step = max(2, min(_lib.AG_MAX_GROUPS, int(os.environ.get("AG_GROUPED_TAIL_CHUNK", _lib.AG_MAX_GROUPS))))
         for c0 in range(0, len(tail), step):
             chunk = tail[c0:c0 + step]
             tm = [(i, b) for i, b, _, _ in chunk]

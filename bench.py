@@ -209,6 +209,20 @@ def main() -> None:
     elapsed = time.perf_counter() - t0
     prof = _lib.prof_collect()
     _lib.prof_enable([])
+    # stability evidence for short timed regions (the driver's --steps 20 is a 3-ms region that includes the fill and drain of the
+    # stream pipeline): the same number of steps again, five more times, each block timed like the region above
+    value_blocks = []
+    for b in range(5):
+        sync_all()
+        tb = time.perf_counter()
+        for i in range(args.steps):
+            step(args.warmup + args.steps * (b + 1) + i)
+        sync_all()
+        value_blocks.append(time.perf_counter() - tb)
+    if world > 1:
+        tbk = torch.tensor(value_blocks, device=dev, dtype=torch.float64)
+        dist.all_reduce(tbk, op=dist.ReduceOp.MAX)
+        value_blocks = [float(x) for x in tbk.tolist()]
     if world > 1:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -337,6 +351,9 @@ def main() -> None:
         "value": round(value, 2), "unit": "views/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
+        "value_blocks": {"views_per_s": [round(args.gpus * args.steps / t, 1) for t in value_blocks],
+                         "note": f"five more blocks of {args.steps} steps right after the timed region, each timed the same way (max over ranks): "
+                                 "how far `value` moves from block to block at this region length"},
         "config": {
             "workload": "BASELINE configs[1]: avatar front|back map, 1 view @1024x1024 per step, rasterizer fwd+bwd "
                         + ("through GaussianRasterizer + torch.autograd" if args.operator_path else
@@ -403,6 +420,7 @@ def main() -> None:
             leaf.grad = None
         torch.cuda.empty_cache()
         out["roofline_mfma"] = bench_avatar.conv_roofline(dev)
+        out["roofline_avatar_kernels"] = bench_avatar.avatar_kernel_rooflines(dev)
         out["full_step"] = bench_avatar.full_step_probe(dev)
 
     if world == 1 and not args.no_stress:

@@ -57,7 +57,7 @@ class TrainingStep:
     """The training iteration of config 3 as a callable: ``step(i, V)`` renders V cameras of one pose, takes the loss, back-propagates,
     exchanges gradients (N > 1) and applies fused Adam.  Shared by this script and by bench.py's ``full_step`` leg."""
 
-    def __init__(self, dev, viewdirs=True, lpips=False, world=1, rank=0):
+    def __init__(self, dev, viewdirs=True, lpips=False, world=1, rank=0, lr=None):
         import numpy as np
         import torch
         from animatablegaussians_amd import synth
@@ -76,7 +76,14 @@ class TrainingStep:
         self.target = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(11)).to(dev)
         net.train()
         self.sync = BucketedGradSync(list(net.parameters()))
-        self.opt = torch.optim.Adam(net.parameters(), lr=5e-4, fused=True)      # one pass over the 224 M parameters
+        # One fused pass over the 224 M parameters.  The benchmark's learning rate is 1e-7, not the trainer's 5e-4: the loss target is random
+        # noise, and at 5e-4 a few dozen Adam steps towards it inflate the Gaussians until every view has several times the instances
+        # (steps of the SAME process went from 66 to 214 ms within 40 steps, profiles/r04_fullstep_degrade.txt) -- the timed workload must
+        # not drift while it is being timed.  Adam's kernel does the same work at any learning rate.  AG_BENCH_LR overrides.
+        if lr is None:
+            lr = float(os.environ.get("AG_BENCH_LR", "1e-7"))
+        self.lr = lr
+        self.opt = torch.optim.Adam(net.parameters(), lr=lr, fused=True)
         self.lp = None
         if lpips:
             from animatablegaussians_amd import losses
@@ -155,24 +162,25 @@ def conv_roofline(dev, steps=3):
     product) and, beside it, in the fp32-MFMA mode.  One DualStyleUNet (the colour / position configuration) forward + backward on ONE
     stream with every gather-conv / wgrad launch bracketed by HIP events on its launch stream (ag_prof_*); achieved = the launches' own
     algorithmic FLOPs (2 per multiply-add of the un-padded implicit GEMM, summed by the library) / their summed duration."""
-    import numpy as np
     import torch
     from animatablegaussians_amd import _lib, conv as agc, synth
-    from animatablegaussians_amd.styleunet import DualStyleUNet
+    from animatablegaussians_amd.avatar import AvatarNet
     torch.manual_seed(31359)
-    net = DualStyleUNet(inp_size=512, inp_ch=3, out_ch=3, out_size=1024, style_dim=512, n_mlp=2).to(dev)
-    pose = synth.pose_map(512).to(dev)
-    style = (torch.ones(1, 512) / np.sqrt(512)).to(dev)
-    G = torch.randn(1, 6, 1024, 1024, generator=torch.Generator().manual_seed(4242)).to(dev)
+    av = AvatarNet.synthetic({'with_viewdirs': True}, device=dev)       # the product's three networks, run as the product runs them:
+    net = av                                                            # one grouped chain (grouped.py), G = 3 encoders / G = 6 decoders
+    pose = synth.pose_map(512).to(dev)[0]
+    gen = torch.Generator().manual_seed(4242)
+    vf = [torch.randn(1, 128, 128, 128, generator=gen).to(dev) for _ in range(2)]
+    ups = [torch.randn(1, c, 1024, 1024, generator=gen).to(dev) for c in (6, 16, 6)]
 
     def fwd(_i):
         with torch.no_grad():
-            net([style], pose, randomize_noise=False)
+            av.get_maps(pose, vf[0], vf[1])
 
     def one(_i):
         net.zero_grad(set_to_none=True)
-        images, _ = net([style], pose, randomize_noise=False)
-        (images * G).sum().backward()
+        maps = av.get_maps(pose, vf[0], vf[1])
+        torch.autograd.backward(list(maps), ups)
 
     def measure():
         one(0)
@@ -195,13 +203,14 @@ def conv_roofline(dev, steps=3):
                 os.environ.pop("AG_SINGLE_STREAM", None)
             else:
                 os.environ["AG_SINGLE_STREAM"] = prev
-        r = {"network_forward_ms": round(fwd_ms, 2), "network_forward_backward_ms": round(both_ms, 2),
-             "network_forward_TFLOPs": round(NET_FWD_GFLOP / fwd_ms, 1), "network_forward_backward_TFLOPs": round(3 * NET_FWD_GFLOP / both_ms, 1)}
+        r = {"three_networks_forward_ms": round(fwd_ms, 2), "three_networks_forward_backward_ms": round(both_ms, 2),
+             "three_networks_forward_TFLOPs": round(3 * NET_FWD_GFLOP / fwd_ms, 1),
+             "three_networks_forward_backward_TFLOPs": round(9 * NET_FWD_GFLOP / both_ms, 1)}
         tot_w = tot_ms = 0.0
         for k in ("gather_conv_kernel", "wgrad_kernel"):
             if n[k]:
                 r[k] = {"launches_timed": n[k], "avg_launch_us": round(1e3 * ms[k] / n[k], 2), "TFLOPs": round(work[k] / (ms[k] * 1e-3) / 1e12, 2),
-                        "GFLOP_per_network_pass": round(work[k] / steps / 1e9, 1)}
+                        "GFLOP_per_pass_of_the_three_networks": round(work[k] / steps / 1e9, 1)}
                 tot_w += work[k]
                 tot_ms += ms[k]
         r["achieved"] = round(tot_w / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0, 2)
@@ -212,7 +221,7 @@ def conv_roofline(dev, steps=3):
         agc.set_math("fp32")
         f32, f32_both = measure()
         f32.update({"peak": MFMA_F32_PEAK_TF, "frac": round(f32["achieved"] / MFMA_F32_PEAK_TF, 4),
-                    "whole_network_frac": round(3 * NET_FWD_GFLOP / f32_both / MFMA_F32_PEAK_TF, 4)})
+                    "whole_network_frac": round(9 * NET_FWD_GFLOP / f32_both / MFMA_F32_PEAK_TF, 4)})
         agc.set_math(mode0)
         out, both_ms = measure()
     finally:
@@ -220,11 +229,12 @@ def conv_roofline(dev, steps=3):
     terms = {"split_bf16": 6, "split_bf16x3": 3}.get(mode0, 0)
     ach = out["achieved"]
     out.update({"bound": "mfma", "unit": "TFLOP/s", "traffic": None, "math": mode0,
-                "kernel": "gather_conv kernels + wgrad kernels (every convolution of one DualStyleUNet forward + backward, one stream)"})
+                "kernel": "gather_conv kernels + wgrad kernels (every convolution of the three DualStyleUNets' forward + backward as the product "
+                          "runs them: one grouped launch chain, network/avatar.py:93-124)"})
     if terms:
         out.update({"executed": round(terms * ach, 1), "peak": MFMA_BF16_PEAK_TF, "frac": round(terms * ach / MFMA_BF16_PEAK_TF, 4),
                     "frac_of_fp32_mfma_peak": round(ach / MFMA_F32_PEAK_TF, 4),
-                    "whole_network_frac_of_fp32_mfma_peak": round(3 * NET_FWD_GFLOP / both_ms / MFMA_F32_PEAK_TF, 4),
+                    "whole_network_frac_of_fp32_mfma_peak": round(9 * NET_FWD_GFLOP / both_ms / MFMA_F32_PEAK_TF, 4),
                     "note": f"achieved = algorithmic fp32 FLOPs of the bracketed launches / their summed HIP-event durations; every fp32 product is "
                             f"{terms} bf16 MFMA products, so executed = {terms} x achieved is what is priced against the dense bf16 MFMA peak.  "
                             "With real (random-mantissa) operands the bf16 pipe is power-limited to ~0.66 of that peak on this part "
@@ -232,6 +242,104 @@ def conv_roofline(dev, steps=3):
     else:
         out.update({"peak": MFMA_F32_PEAK_TF, "frac": round(ach / MFMA_F32_PEAK_TF, 4)})
     out["fp32_mfma_mode"] = f32
+    return out
+
+
+def avatar_kernel_rooflines(dev, reps=20):
+    """HBM rooflines of the per-Gaussian assembly and skinning kernels (network/avatar.py:84-124: get_positions / get_others / get_colors,
+    transform_cano2live) -- the third hand-written stage north_star names.  Each kernel's launches are captured ``reps`` times in a
+    hipGraph and replayed between two HIP events (the host needs ~30 us per call, the kernels 10-25: an eager loop would time the host).
+    Algorithmic bytes per Gaussian (fp32; the LBS rows in their sparse form, K (joint u8, weight f32) pairs as the kernels read them):
+      gather forward   104 read (pixel index 4, 14 map channels 56, xyz 12, raw opacity / scale / rotation 32) + 56 written
+      gather backward  124 read (index 4, 14 upstream gradients 56, 8 other-map channels 32, raws 32) + 56 written, plus the zero fill of
+                       the three gradient maps (28 channels x S^2 x 4 B: pixels outside the mask have zero gradient)
+      LBS forward      28 + 5K read, 28 written;   LBS backward  56 + 5K read, 28 written.
+    PMC traffic of the same kernels: profiles/traffic_head.json (separate rocprofv3 --pmc passes)."""
+    import json as _json
+    import torch
+    from animatablegaussians_amd import avatar_ops as ops
+    from animatablegaussians_amd.avatar import AvatarRenderCore
+
+    class _Sub:                                            # stands in for autograd's ctx: the Functions' static methods are called directly
+        def __init__(self, needs=()):
+            self.saved_tensors, self.needs_input_grad = (), needs
+
+        def save_for_backward(self, *ts):
+            self.saved_tensors = ts
+
+    core = AvatarRenderCore.synthetic(device=dev)
+    N, S = int(core.xyz.shape[0]), int(core.map_side)
+    K = int(core.lbs_sparse.idx.shape[0]) if core.lbs_sparse is not None else None
+    gen = torch.Generator().manual_seed(7)
+    maps = [torch.randn(1, c, S, S, generator=gen).to(dev) for c in (6, 16, 6)]
+    A = joint_transforms(core.lbs.shape[1], dev)
+    g5 = [torch.randn(N, c, generator=gen).to(dev) for c in (3, 1, 3, 4, 3)]
+    gpr = [torch.randn(N, c, generator=gen).to(dev) for c in (3, 4)]
+    with torch.no_grad():
+        pos, opa, sca, rot, col = ops.gather_activate(*maps, core.pix, core.xyz, core.opacity_raw, core.scaling_raw, core.rotation_raw)
+
+    def gather_fwd():
+        ops._GatherActivate.forward(_Sub(), *maps, core.pix, core.xyz, core.opacity_raw, core.scaling_raw, core.rotation_raw)
+
+    ctx_g = _Sub()
+    ops._GatherActivate.forward(ctx_g, *maps, core.pix, core.xyz, core.opacity_raw, core.scaling_raw, core.rotation_raw)
+
+    def gather_bwd():
+        ops._GatherActivate.backward(ctx_g, *g5)
+
+    def lbs_fwd():
+        ops._LbsTransform.forward(_Sub(), pos, rot, core.lbs, A, core.lbs_sparse)
+
+    ctx_l = _Sub((True, True, False, False, False))
+    ops._LbsTransform.forward(ctx_l, pos, rot, core.lbs, A, core.lbs_sparse)
+
+    def lbs_bwd():
+        ops._LbsTransform.backward(ctx_l, *gpr)
+
+    def graph_us(fn):
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side), torch.no_grad():
+            fn()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(g):
+            for _ in range(reps):
+                fn()
+        us = []
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize(dev)
+            e0.record()
+            g.replay()
+            e1.record()
+            e1.synchronize()
+            us.append(1e3 * e0.elapsed_time(e1) / reps)
+        return float(sorted(us)[len(us) // 2])
+
+    kk = K if K is not None else 44                        # dense rows: 220 B = 44 five-byte pairs' worth
+    alg = {"gather_forward": 160 * N, "gather_backward": 180 * N + 28 * S * S * 4, "lbs_forward": (56 + 5 * kk) * N, "lbs_backward": (84 + 5 * kk) * N}
+    fns = {"gather_forward": gather_fwd, "gather_backward": gather_bwd, "lbs_forward": lbs_fwd, "lbs_backward": lbs_bwd}
+    traffic = {}
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic_head.json")) as f:
+            tj = _json.load(f).get("kernels", {})
+        for name, frag in (("gather_forward", "gather_forward_kernel"), ("gather_backward", "gather_backward_kernel"),
+                           ("lbs_forward", "lbs_forward_kernel"), ("lbs_backward", "lbs_backward_kernel")):
+            hit = [v for k, v in tj.items() if frag in k]
+            if hit:
+                traffic[name] = int(hit[0]["hbm_bytes"])
+    except (OSError, ValueError, KeyError):
+        pass
+    out = {"gaussians": N, "sparse_lbs_pairs_per_gaussian": K, "launches_per_figure": reps,
+           "note": "hipGraph replays of `launches_per_figure` back-to-back launches between two HIP events; gather backward = its three "
+                   "zero fills + the scatter kernel; traffic = PMC bytes per launch of the kernel alone from profiles/traffic_head.json "
+                   "(separate rocprofv3 --pmc passes, not this run)"}
+    for name, fn in fns.items():
+        us = graph_us(fn)
+        gbs = alg[name] / (us * 1e-6) / 1e9
+        out[name] = {"bound": "hbm", "algorithmic_bytes_per_launch": int(alg[name]), "avg_launch_us": round(us, 2), "achieved": round(gbs, 1),
+                     "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4), "traffic": traffic.get(name)}
     return out
 
 
@@ -285,7 +393,33 @@ def full_step_probe(dev, block=4, blocks=5):
     out = {"workload": "BASELINE configs[2]: StyleUNet x3 + LBS + raster fwd+bwd + L1/offset loss + fused Adam, 268 k Gaussians @1024^2",
            "conv_math": mode0}
     out.update(rec(mode0))
-    out.update({"steps_timed": [block * blocks, block * blocks], "parameters": step.n_params,
+    # BASELINE configs[3] at N = 1 (the anchor of the 8-GPU curve: 16 views of one pose per step, which 8 ranks render 2 each) and the
+    # reference's WHOLE loss in the step (main_avatar.py:197-246: boundary compositing, L1, mask loss, 512^2 crop, 0.1 x LPIPS-VGG16),
+    # both in the product's arithmetic, blocks of 2 steps
+    try:
+        import torch
+        torch.cuda.empty_cache()
+        timed(lambda i: step(i, 16), 1, 1, dev)
+        t16 = [timed(lambda i: step(i, 16), 2, 0, dev) for _ in range(3)]
+        ms16 = float(np.median(t16))
+        out["views16_one_pose_configs3_n1"] = {"views_per_s": round(16e3 / ms16, 2), "ms_per_step": round(ms16, 2),
+                                               "ms_per_step_min_max": [round(float(np.min(t16)), 2), round(float(np.max(t16)), 2)], "steps_timed": 6}
+        del step
+        torch.cuda.empty_cache()
+        step_lp = TrainingStep(dev, lpips=True)
+        timed(lambda i: step_lp(i, 1), 1, 2, dev)
+        tl = [timed(lambda i: step_lp(i, 1), block, 0, dev) for _ in range(blocks)]
+        msl = float(np.median(tl))
+        out["with_the_references_full_loss"] = {"views_per_s_1view_per_step": round(1e3 / msl, 2), "ms_per_step_1view": round(msl, 2),
+                                                "ms_per_step_min_max": [round(float(np.min(tl)), 2), round(float(np.max(tl)), 2)],
+                                                "loss": "boundary-mask compositing + L1 + 0.1 mask + 512^2 crop + 0.1 LPIPS-VGG16 + 0.005 offset "
+                                                        "(main_avatar.py:197-246), random-initialised VGG trunk", "steps_timed": block * blocks}
+        n_params = step_lp.n_params
+        del step_lp
+    except Exception as e:                       # a leg that fails must not take the line with it
+        out["extra_legs_error"] = repr(e)[:300]
+        n_params = None
+    out.update({"steps_timed": [block * blocks, block * blocks], "parameters": n_params if n_params is not None else 0,
                 "note": f"{blocks} blocks of {block} pipelined steps per arithmetic mode and batch shape, back to back after an allocator reset and 3 settling steps; the median block"})
     if discarded is not None:
         out["discarded_first_pass"] = dict(discarded, reason="a block more than 3x slower than the fastest of its pass: the pass was repeated once")

@@ -22,3 +22,19 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
 bench.main()
+
+# the per-Gaussian assembly and skinning kernels (gather_* / lbs_* of ag_avatar.hip), a few eager launches each
+import bench_avatar  # noqa: E402
+from animatablegaussians_amd import avatar_ops as ops  # noqa: E402
+from animatablegaussians_amd.avatar import AvatarRenderCore  # noqa: E402
+
+dev = torch.device("cuda:0")
+core = AvatarRenderCore.synthetic(device=dev)
+S = int(core.map_side)
+maps = [torch.randn(1, c, S, S, device=dev).requires_grad_(True) for c in (6, 16, 6)]
+A = bench_avatar.joint_transforms(core.lbs.shape[1], dev)
+for _ in range(6):
+    pos, opa, sca, rot, col = ops.gather_activate(*maps, core.pix, core.xyz, core.opacity_raw, core.scaling_raw, core.rotation_raw)
+    p2, r2 = ops.lbs_transform(pos, rot, core.lbs, A, core.lbs_sparse)
+    (p2.sum() + r2.sum() + opa.sum() + sca.sum() + col.sum()).backward()
+torch.cuda.synchronize()
