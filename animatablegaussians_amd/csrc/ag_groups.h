@@ -70,10 +70,10 @@ struct AgConvDesc;
 namespace ag {
 size_t conv_workspace_bytes_g(const AgConvDesc* d, int G);
 int conv_forward_g(const AgConvDesc* d, int G, const float* x, long long x_gs, const PtrTable& w, const float* out_scale, const PtrTable& bias,
-                   float* y, long long y_gs, void* workspace, size_t workspace_bytes, hipStream_t s);
+                   float* y, long long y_gs, void* workspace, size_t workspace_bytes, hipStream_t s, bool wt_oihw = false);
 int conv_backward_input_g(const AgConvDesc* d, int G, const float* dy, long long dy_gs, const PtrTable& w, float* dx, long long dx_gs,
-                          void* workspace, size_t workspace_bytes, hipStream_t s);
+                          void* workspace, size_t workspace_bytes, hipStream_t s, bool wt_oihw = false);
 int conv_backward_weight_g(const AgConvDesc* d, int G, const float* x, long long x_gs, const float* dy, long long dy_gs, float* dw, long long dw_gs,
-                           void* workspace, size_t workspace_bytes, hipStream_t s);
+                           void* workspace, size_t workspace_bytes, hipStream_t s, bool wt_oihw = false);
 
 }  // namespace ag

@@ -147,7 +147,9 @@ int ag_grouped_layer_forward(const AgGroupedLayerArgs* a, void* stream)
     }
     const PtrTable style_t = table_of(a->style, G);
     if (!table_complete(style_t, G) || !a->w_mod || !a->demod) { set_error("ag_layer_forward: StyledConv needs style, w_mod and demod"); return AG_ERR_INVALID_ARGUMENT; }
-    if ((rc = modulate_weight_forward_g(a->w_mod, a->demod, G, w_t, style_t, a->scale, 1, a->Cout, a->Cin, a->k * a->k, a->resample ? 1 : 0, s))) return rc;
+    // the modulated weight is kept [Cout][Cin][k][k] for the transposed convolution too (wt_oihw below): the modulation kernels read and
+    // write it coalesced both ways (conv_transpose2d's own [Cin][Cout] order made them 9x slower than their bytes, round 4)
+    if ((rc = modulate_weight_forward_g(a->w_mod, a->demod, G, w_t, style_t, a->scale, 1, a->Cout, a->Cin, a->k * a->k, 0, s))) return rc;
     // the modulated weights of the instances, stacked
     PtrTable wm_t{};
     const size_t wn = (size_t)a->Cout * a->Cin * a->k * a->k;
@@ -157,7 +159,7 @@ int ag_grouped_layer_forward(const AgGroupedLayerArgs* a, void* stream)
         if (a->noise[i] && a->noise_weight[i]) { noise_t.p[i] = a->noise[i]; nw_t.p[i] = a->noise_weight[i]; }
     if (a->resample) {
         if (!a->k_blur) { set_error("ag_layer_forward: resampling layer without FIR taps"); return AG_ERR_INVALID_ARGUMENT; }
-        if ((rc = conv_forward_g(&g.d, G, a->x, x_gs, wm_t, nullptr, PtrTable{}, aux, (long long)a->Cout * g.CH * g.CW, a->workspace, a->workspace_bytes, s))) return rc;
+        if ((rc = conv_forward_g(&g.d, G, a->x, x_gs, wm_t, nullptr, PtrTable{}, aux, (long long)a->Cout * g.CH * g.CW, a->workspace, a->workspace_bytes, s, true))) return rc;
         if ((rc = ag_upfirdn2d(pre, aux, a->k_blur, G * a->Cout, g.CH, g.CW, 4, 4, 1, 1, 1, 1, 1, 1, 1, 1, stream))) return rc;
     } else {
         if ((rc = conv_forward_g(&g.d, G, a->x, x_gs, wm_t, nullptr, PtrTable{}, pre, pre_gs, a->workspace, a->workspace_bytes, s))) return rc;
@@ -222,13 +224,13 @@ int ag_grouped_layer_backward(const AgGroupedLayerArgs* a, void* stream)
         g_conv = aux;
         gconv_gs = (long long)a->Cout * g.CH * g.CW;
     }
-    if (a->g_x && (rc = conv_backward_input_g(&g.d, G, g_conv, gconv_gs, wm_t, a->g_x, (long long)a->Cin * a->H * a->W, a->workspace, a->workspace_bytes, s))) return rc;
+    if (a->g_x && (rc = conv_backward_input_g(&g.d, G, g_conv, gconv_gs, wm_t, a->g_x, (long long)a->Cin * a->H * a->W, a->workspace, a->workspace_bytes, s, true))) return rc;
     if (a->g_weight) {
         if (!a->g_style) { set_error("ag_layer_backward: g_weight without g_style"); return AG_ERR_INVALID_ARGUMENT; }
         float* g_wm = a->scratch + L.g_wm;
-        if ((rc = conv_backward_weight_g(&g.d, G, a->x, x_gs, g_conv, gconv_gs, g_wm, (long long)wn, a->workspace, a->workspace_bytes, s))) return rc;
+        if ((rc = conv_backward_weight_g(&g.d, G, a->x, x_gs, g_conv, gconv_gs, g_wm, (long long)wn, a->workspace, a->workspace_bytes, s, true))) return rc;
         if ((rc = modulate_weight_backward_g(a->g_weight, a->g_style, a->scratch + L.mod_part, g_wm, G, w_t, style_t, a->demod, a->scale, 1, a->Cout, a->Cin,
-                                             a->k * a->k, a->resample ? 1 : 0, s))) return rc;
+                                             a->k * a->k, 0, s))) return rc;
     }
     return AG_OK;
 }

@@ -223,75 +223,102 @@ def _rgb_sizes(a):
 
 
 class _GroupedToRGB(torch.autograd.Function):
-    """G ToRGB heads of one shape (dual_styleunet.py:607-633): modulated 1 x 1 convolution + bias + the wavelet skip, one native call."""
+    """The ToRGB heads (dual_styleunet.py:607-633: modulated 1 x 1 convolution + bias + the wavelet skip) of ALL stacked members as one
+    autograd node.  ``runs`` = [(start, end)] of members with the same head width (12 / 12 / 32 rows: network/avatar.py:34-36): one native
+    call per run on its slice of the input, one output per run.  One node (and not one per run on a slice of ``x``) because the input
+    gradient is then written by the runs straight into ONE tensor: slicing ``x`` outside would make autograd pad every run's gradient
+    to the full size (a zero fill + a copy each) and add the padded tensors up (measured: ~1 ms of fills / copies / additions per step).
+    ``rest`` = skips[len(runs)] (None where a run has none) + weights[M] + styles[M] + biases[M]."""
 
     @staticmethod
-    def forward(ctx, G, scale, k_up, x, skip, *params):
+    def forward(ctx, runs, scale, k_up, x, *rest):
         x = x.contiguous()
-        ws = [p.contiguous() for p in params[:G]]
-        styles = [p.contiguous() for p in params[G:2 * G]]
-        biases = [p.contiguous() for p in params[2 * G:3 * G]]
+        R, M = len(runs), int(x.shape[0])
+        skips = [t.contiguous() if t is not None else None for t in rest[:R]]
+        ws = [p.contiguous() for p in rest[R:R + M]]
+        styles = [p.contiguous() for p in rest[R + M:R + 2 * M]]
+        biases = [p.contiguous() for p in rest[R + 2 * M:R + 3 * M]]
         dev = x.device
-        a = _rgb_args(G, x, ws[0], scale)
-        f_fwd, _, wsb = _rgb_sizes(a)
-        out = torch.empty((G, a.Cout, a.H, a.W), dtype=torch.float32, device=dev)
-        wm = torch.empty(G * a.Cout * a.Cin, dtype=torch.float32, device=dev)
-        _fill(a.weight, ws)
-        _fill(a.style, styles)
-        _fill(a.bias, biases)
-        a.x, a.out, a.w_mod = x.data_ptr(), out.data_ptr(), wm.data_ptr()
-        if skip is not None:
-            skip = skip.contiguous()
-            if tuple(skip.shape) != (G, a.Cout, a.H // 2, a.W // 2):
-                raise RuntimeError("grouped ToRGB: skip must be [G, Cout, H / 2, W / 2]")
-            a.skip, a.skip_taps = skip.data_ptr(), _skip_taps_host(k_up)
-        buf, a.scratch, a.workspace = _scratch(f_fwd, wsb, dev)
-        a.workspace_bytes = wsb
-        with _lib.on_device(dev):
-            _lib.check(_lib.lib().ag_grouped_to_rgb_forward(ctypes.byref(a), _stream(dev)), "ag_grouped_to_rgb_forward")
-        ctx.save_for_backward(x, wm, *ws, *styles)
-        ctx.cfg = (G, float(scale), skip is not None, tuple(biases[0].shape))
+        Cin, H, W = int(x.shape[1]), int(x.shape[2]), int(x.shape[3])
+        outs, wms = [], []
+        for (s, e), skip in zip(runs, skips):
+            G = e - s
+            a = _rgb_args(G, x[s:e], ws[s], scale)
+            f_fwd, _, wsb = _rgb_sizes(a)
+            out = torch.empty((G, a.Cout, H, W), dtype=torch.float32, device=dev)
+            wm = torch.empty(G * a.Cout * Cin, dtype=torch.float32, device=dev)
+            _fill(a.weight, ws[s:e])
+            _fill(a.style, styles[s:e])
+            _fill(a.bias, biases[s:e])
+            a.x, a.out, a.w_mod = x.data_ptr() + 4 * s * Cin * H * W, out.data_ptr(), wm.data_ptr()
+            if skip is not None:
+                if tuple(skip.shape) != (G, a.Cout, H // 2, W // 2):
+                    raise RuntimeError("grouped ToRGB: skip must be [G, Cout, H / 2, W / 2]")
+                a.skip, a.skip_taps = skip.data_ptr(), _skip_taps_host(k_up)
+            buf, a.scratch, a.workspace = _scratch(f_fwd, wsb, dev)
+            a.workspace_bytes = wsb
+            with _lib.on_device(dev):
+                _lib.check(_lib.lib().ag_grouped_to_rgb_forward(ctypes.byref(a), _stream(dev)), "ag_grouped_to_rgb_forward")
+            outs.append(out)
+            wms.append(wm)
+        ctx.save_for_backward(x, *wms, *ws, *styles)
+        ctx.cfg = (tuple(runs), float(scale), tuple(t is not None for t in skips), tuple(tuple(b.shape) for b in biases))
         ctx.k_up = k_up                       # a module buffer, not an output of this node
-        return out
+        return tuple(outs)
 
     @staticmethod
-    def backward(ctx, g):
-        G, scale, has_skip, bshape = ctx.cfg
-        x, wm = ctx.saved_tensors[:2]
-        ws, styles = ctx.saved_tensors[2:2 + G], ctx.saved_tensors[2 + G:2 + 2 * G]
+    def backward(ctx, *gs):
+        runs, scale, has_skip, bshapes = ctx.cfg
+        R = len(runs)
+        x = ctx.saved_tensors[0]
+        M = int(x.shape[0])
+        wms = ctx.saved_tensors[1:1 + R]
+        ws, styles = ctx.saved_tensors[1 + R:1 + R + M], ctx.saved_tensors[1 + R + M:1 + R + 2 * M]
         dev = x.device
-        g = g.contiguous()
+        Cin, H, W = int(x.shape[1]), int(x.shape[2]), int(x.shape[3])
         nig = ctx.needs_input_grad
-        nx, nskip, pn = nig[3], nig[4], nig[5:]
-        a = _rgb_args(G, x, ws[0], scale)
-        _, f_bwd, wsb = _rgb_sizes(a)
-        want_w = any(pn[:2 * G])
-        gx = torch.empty_like(x) if nx else None
-        gw = torch.empty((G,) + tuple(ws[0].shape), dtype=torch.float32, device=dev) if want_w else None
-        gs = torch.empty((G,) + tuple(styles[0].shape), dtype=torch.float32, device=dev) if want_w else None
-        gskip = torch.empty((G, a.Cout, a.H // 2, a.W // 2), dtype=torch.float32, device=dev) if (has_skip and nskip) else None
-        gb = g.sum((2, 3)) if any(pn[2 * G:3 * G]) else None                  # [G, Cout], torch's deterministic reduction
-        _fill(a.weight, ws)
-        _fill(a.style, styles)
-        a.x, a.w_mod, a.g_out = x.data_ptr(), wm.data_ptr(), g.data_ptr()
-        a.g_x = gx.data_ptr() if gx is not None else None
-        a.g_weight = gw.data_ptr() if gw is not None else None
-        a.g_style = gs.data_ptr() if gs is not None else None
-        if gskip is not None:
-            a.g_skip, a.skip_taps = gskip.data_ptr(), _skip_taps_host(ctx.k_up)
-        buf, a.scratch, a.workspace = _scratch(f_bwd, wsb, dev)
-        a.workspace_bytes = wsb
-        with _lib.on_device(dev):
-            _lib.check(_lib.lib().ag_grouped_to_rgb_backward(ctypes.byref(a), _stream(dev)), "ag_grouped_to_rgb_backward")
-        g_ws = [gw[i] if pn[i] else None for i in range(G)]
-        g_ss = [gs[i] if pn[G + i] else None for i in range(G)]
-        g_bs = [gb[i].view(bshape) if pn[2 * G + i] else None for i in range(G)]
-        return (None, None, None, gx, gskip, *g_ws, *g_ss, *g_bs)
+        nx, nskips, pn = nig[3], nig[4:4 + R], nig[4 + R:]
+        gx = torch.empty_like(x) if nx else None                     # every run writes its slice
+        g_skips, g_ws, g_ss, g_bs = [None] * R, [None] * M, [None] * M, [None] * M
+        for r, ((s, e), g) in enumerate(zip(runs, gs)):
+            G = e - s
+            g = g.contiguous()
+            a = _rgb_args(G, x[s:e], ws[s], scale)
+            _, f_bwd, wsb = _rgb_sizes(a)
+            want_w = any(pn[s:e]) or any(pn[M + s:M + e])
+            gw = torch.empty((G,) + tuple(ws[s].shape), dtype=torch.float32, device=dev) if want_w else None
+            gst = torch.empty((G,) + tuple(styles[s].shape), dtype=torch.float32, device=dev) if want_w else None
+            gskip = torch.empty((G, a.Cout, H // 2, W // 2), dtype=torch.float32, device=dev) if (has_skip[r] and nskips[r]) else None
+            gb = g.sum((2, 3)) if any(pn[2 * M + s:2 * M + e]) else None          # [G, Cout], torch's deterministic reduction
+            _fill(a.weight, ws[s:e])
+            _fill(a.style, styles[s:e])
+            a.x, a.w_mod, a.g_out = x.data_ptr() + 4 * s * Cin * H * W, wms[r].data_ptr(), g.data_ptr()
+            a.g_x = gx.data_ptr() + 4 * s * Cin * H * W if gx is not None else None
+            a.g_weight = gw.data_ptr() if gw is not None else None
+            a.g_style = gst.data_ptr() if gst is not None else None
+            if gskip is not None:
+                a.g_skip, a.skip_taps = gskip.data_ptr(), _skip_taps_host(ctx.k_up)
+            buf, a.scratch, a.workspace = _scratch(f_bwd, wsb, dev)
+            a.workspace_bytes = wsb
+            with _lib.on_device(dev):
+                _lib.check(_lib.lib().ag_grouped_to_rgb_backward(ctypes.byref(a), _stream(dev)), "ag_grouped_to_rgb_backward")
+            g_skips[r] = gskip
+            for i in range(G):
+                g_ws[s + i] = gw[i] if (gw is not None and pn[s + i]) else None
+                g_ss[s + i] = gst[i] if (gst is not None and pn[M + s + i]) else None
+                g_bs[s + i] = gb[i].view(bshapes[s + i]) if (gb is not None and pn[2 * M + s + i]) else None
+        return (None, None, None, gx, *g_skips, *g_ws, *g_ss, *g_bs)
 
 
 def grouped_to_rgb(x, weights, styles, biases, skip, k_up, scale):
+    """One run: the G = len(weights) heads of one width.  -> [G, Cout, H, W]."""
     G = len(weights)
-    return _GroupedToRGB.apply(G, float(scale), k_up, x, skip, *weights, *styles, *biases)
+    return _GroupedToRGB.apply(((0, G),), float(scale), k_up, x, skip, *weights, *styles, *biases)[0]
+
+
+def grouped_to_rgb_runs(x, runs, weights, styles, biases, skips, k_up, scale):
+    """All members' heads, ``runs`` = [(start, end)] of equal head width; skips[r] = the run's skip tensor or None.  -> one output per run."""
+    return _GroupedToRGB.apply(tuple(runs), float(scale), k_up, x, *skips, *weights, *styles, *biases)
 
 
 class _GroupedHaarMerge(torch.autograd.Function):
@@ -463,16 +490,14 @@ class GroupedStyleUNets:
         out = grouped_styled_conv(out, w, [styles[m][f"{p}.conv"] for m, p in enumerate(pre)], [noises[i][2 * n + 1] for i in net_idx],
                                   [net._p(f"{p}.noise.weight") for net, p in zip(mnets, pre)],
                                   [net._p(f"{p}.activate.bias") for net, p in zip(mnets, pre)], None, 1 / math.sqrt(w[0].shape[2] * k * k), False)
-        # ToRGB: one call per run of members with the same head width
-        new_skips = {}
-        for (s, e) in _runs([net.out_ch for net in mnets]):
-            pr = [f"to_rgbs{b}.{n}" for _, b in members[s:e]]
-            ns = mnets[s:e]
-            wr = [net._p(f"{p}.conv.weight") for net, p in zip(ns, pr)]
-            new_skips[(s, e)] = grouped_to_rgb(out[s:e], wr, [styles[s + j][f"{p}.conv"] for j, p in enumerate(pr)],
-                                               [net._p(f"{p}.bias").reshape(-1) for net, p in zip(ns, pr)],
-                                               skips.get((s, e)) if skips else None, n0._k_blur_up,
-                                               1 / math.sqrt(wr[0].shape[2] * wr[0].shape[-1] * wr[0].shape[-1]))
+        # ToRGB: one native call per run of members with the same head width, all runs in ONE autograd node
+        runs = _runs([net.out_ch for net in mnets])
+        pr = [f"to_rgbs{b}.{n}" for _, b in members]
+        wr = [net._p(f"{p}.conv.weight") for net, p in zip(mnets, pr)]
+        outs = grouped_to_rgb_runs(out, runs, wr, [styles[m][f"{p}.conv"] for m, p in enumerate(pr)],
+                                   [net._p(f"{p}.bias").reshape(-1) for net, p in zip(mnets, pr)],
+                                   [skips.get(r) if skips else None for r in runs], n0._k_blur_up, 1 / math.sqrt(wr[0].shape[2]))
+        new_skips = dict(zip(runs, outs))
         return out, new_skips
 
     def forward(self, styles, x, view_features=None):

@@ -38,7 +38,8 @@ typedef struct AgLayerArgs {
     const float* noise_weight;     /* StyledConv: [1] or NULL */
     const float* act_bias;         /* [Cout] or NULL */
     const float* k_blur;           /* [4, 4] FIR taps of the layer's Blur (resample only); backward: the FLIPPED taps */
-    float* w_mod;                  /* StyledConv: modulated weight [Cout, Cin, k, k] ([Cin, Cout, k, k] when resample), written forward, read backward */
+    float* w_mod;                  /* StyledConv: modulated weight [Cout, Cin, k, k] (also when resample: the transposed convolution reads this
+                                      layout directly), written forward, read backward */
     float* demod;                  /* StyledConv: demodulation coefficients [Cout], written forward, read backward */
     float* x_blur;                 /* down-sampling ConvLayer: the blurred input [Cin, H + 1, W + 1], written forward, read by the weight gradient */
     float* out;                    /* forward: [Cout, OH, OW]; backward: the saved forward output (the activation's backward reads its sign) */
