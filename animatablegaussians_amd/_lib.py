@@ -114,6 +114,14 @@ class AgGroupedToRgbArgs(ctypes.Structure):   # include/ag_layers.h
                 + [(n, c_vp) for n in ("g_out", "g_x", "g_weight", "g_style", "g_skip")])
 
 
+class AgGroupedCombArgs(ctypes.Structure):    # include/ag_layers.h
+    _fields_ = ([(n, c_i32) for n in ("M", "N", "C1", "C2", "Cout", "H", "W")] + [("member_begin", c_i32 * (AG_MAX_GROUPS + 1))]
+                + [(n, c_f) for n in ("scale", "slope", "act_scale", "reserved_f")]
+                + [("x", c_vp), ("lev", c_vp), ("weight", _PTRS), ("act_bias", _PTRS)]
+                + [(n, c_vp) for n in ("out", "scratch", "workspace")] + [("workspace_bytes", c_sz)]
+                + [(n, c_vp) for n in ("g_out", "g_x", "g_lev", "g_weight_x", "g_weight_lev", "g_bias")])
+
+
 class AgSmplxModel(ctypes.Structure):
     _fields_ = [("V", c_i32), ("J", c_i32), ("NB", c_i32), ("reserved", c_i32)] + [(n, c_vp) for n in (
         "v_template", "shapedirs", "posedirs", "J_regressor", "parents", "lbs_weights", "joint_template", "joint_dirs")]
@@ -199,6 +207,11 @@ SYMBOLS = [
     ("ag_grouped_to_rgb_forward", ctypes.c_int, [ctypes.POINTER(AgGroupedToRgbArgs), c_vp]),
     ("ag_grouped_to_rgb_backward", ctypes.c_int, [ctypes.POINTER(AgGroupedToRgbArgs), c_vp]),
     ("ag_grouped_block2x2", ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    ("ag_grouped_comb_args_bytes", c_sz, []),
+    ("ag_grouped_comb_scratch_floats", c_sz, [ctypes.POINTER(AgGroupedCombArgs), c_i32]),
+    ("ag_grouped_comb_workspace_bytes", c_sz, [ctypes.POINTER(AgGroupedCombArgs)]),
+    ("ag_grouped_comb_forward", ctypes.c_int, [ctypes.POINTER(AgGroupedCombArgs), c_vp]),
+    ("ag_grouped_comb_backward", ctypes.c_int, [ctypes.POINTER(AgGroupedCombArgs), c_vp]),
     # include/ag_conv.h
     ("ag_conv_output_size", ctypes.c_int, [ctypes.POINTER(AgConvDesc), ctypes.POINTER(c_i32), ctypes.POINTER(c_i32)]),
     ("ag_conv_workspace_bytes", c_sz, [ctypes.POINTER(AgConvDesc)]),

@@ -1436,7 +1436,7 @@ extern "C" {
 //   or the 4 output-parity classes of a stride-2 "scatter" (transposed conv forward, input gradient of a stride-2 conv)
 static int run_gather_family(const AgConvDesc* d, bool backward_input, int G, const float* xin, long long x_gs, const PtrTable& w,
                              const float* out_scale, const PtrTable& bias, float* yout, long long y_gs, void* workspace, size_t workspace_bytes,
-                             hipStream_t s, bool wt_oihw = false)
+                             hipStream_t s, const ConvOpts& opt = ConvOpts())
 {
     int OH, OW;
     out_size(d, OH, OW);
@@ -1458,8 +1458,10 @@ static int run_gather_family(const AgConvDesc* d, bool backward_input, int G, co
     // weight layout: conv [Cout][Cin][k][k], transposed conv [Cin][Cout][k][k]
     // wt_oihw: a transposed convolution whose weight is kept [Cout][Cin][k][k] like a convolution's (the layer calls: the modulated weight
     // and its gradient then have ONE layout and the modulation kernels read and write them coalesced)
-    const bool oihw = conv || wt_oihw;
-    const long long s_co = oihw ? (long long)d->Cin * k2 : k2, s_ci = oihw ? k2 : (long long)d->Cout * k2;
+    const bool oihw = conv || opt.wt_oihw;
+    if (opt.w_cin_total && (!conv || opt.w_cin_total < d->Cin)) { set_error("conv: a weight slice needs AG_CONV and w_cin_total >= Cin"); return AG_ERR_INVALID_ARGUMENT; }
+    const long long cin_rows = opt.w_cin_total ? opt.w_cin_total : d->Cin;       // channels of the weight tensor the rows belong to
+    const long long s_co = oihw ? cin_rows * k2 : k2, s_ci = oihw ? k2 : (long long)d->Cout * k2;
     stride_c = backward_input ? s_co : s_ci;
     stride_m = backward_input ? s_ci : s_co;
     gp.Cg = Cg; gp.Hg = Hg; gp.Wg = Wg; gp.M = M; const int bm = pick_bm(M); gp.Mpad = round_up(M, bm); gp.OHf = OHf; gp.OWf = OWf;
@@ -1532,28 +1534,28 @@ static int run_gather_family(const AgConvDesc* d, bool backward_input, int G, co
 namespace ag {
 
 int conv_forward_g(const AgConvDesc* d, int G, const float* x, long long x_gs, const PtrTable& w, const float* out_scale, const PtrTable& bias,
-                   float* y, long long y_gs, void* workspace, size_t workspace_bytes, hipStream_t s, bool wt_oihw)
+                   float* y, long long y_gs, void* workspace, size_t workspace_bytes, hipStream_t s, const ConvOpts& o)
 {
     int rc = validate(d);
     if (rc) return rc;
     if (G < 1 || G > kMaxGroups || !x || !table_complete(w, G) || !y) { set_error("null conv tensor / bad group count"); return AG_ERR_INVALID_ARGUMENT; }
-    if ((rc = pointwise_forward(d, G, x, x_gs, w, out_scale, bias, y, y_gs, s)) != 0) return rc < 0 ? rc : AG_OK;
-    return run_gather_family(d, false, G, x, x_gs, w, out_scale, bias, y, y_gs, workspace, workspace_bytes, s, wt_oihw);
+    if (!o.w_cin_total && (rc = pointwise_forward(d, G, x, x_gs, w, out_scale, bias, y, y_gs, s)) != 0) return rc < 0 ? rc : AG_OK;
+    return run_gather_family(d, false, G, x, x_gs, w, out_scale, bias, y, y_gs, workspace, workspace_bytes, s, o);
 }
 
 int conv_backward_input_g(const AgConvDesc* d, int G, const float* dy, long long dy_gs, const PtrTable& w, float* dx, long long dx_gs,
-                          void* workspace, size_t workspace_bytes, hipStream_t s, bool wt_oihw)
+                          void* workspace, size_t workspace_bytes, hipStream_t s, const ConvOpts& o)
 {
     int rc = validate(d);
     if (rc) return rc;
     if (G < 1 || G > kMaxGroups || !dy || !table_complete(w, G) || !dx) { set_error("null conv tensor / bad group count"); return AG_ERR_INVALID_ARGUMENT; }
-    if ((rc = pointwise_backward_input(d, G, dy, dy_gs, w, dx, dx_gs, s)) != 0) return rc < 0 ? rc : AG_OK;
-    return run_gather_family(d, true, G, dy, dy_gs, w, nullptr, PtrTable{}, dx, dx_gs, workspace, workspace_bytes, s, wt_oihw);
+    if (!o.w_cin_total && (rc = pointwise_backward_input(d, G, dy, dy_gs, w, dx, dx_gs, s)) != 0) return rc < 0 ? rc : AG_OK;
+    return run_gather_family(d, true, G, dy, dy_gs, w, nullptr, PtrTable{}, dx, dx_gs, workspace, workspace_bytes, s, o);
 }
 
 // dw: G gradients stacked at dw_gs floats (each the shape of one weight); overwritten
 int conv_backward_weight_g(const AgConvDesc* d, int G, const float* x, long long x_gs, const float* dy, long long dy_gs, float* dw, long long dw_gs,
-                           void* workspace, size_t workspace_bytes, hipStream_t s, bool wt_oihw)
+                           void* workspace, size_t workspace_bytes, hipStream_t s, const ConvOpts& o)
 {
     int rc = validate(d);
     if (rc) return rc;
@@ -1574,7 +1576,7 @@ int conv_backward_weight_g(const AgConvDesc* d, int G, const float* x, long long
     }
     wp.c = dw; wp.c_gs = dw_gs; wp.G = G; wp.ntaps = k2; wp.wscale = wscale_of(d);
     wp.c_row_stride = wp.Cg * k2; wp.c_chan_stride = k2;                         // [Mw][Cg][taps]
-    if (wt_oihw && d->kind == AG_CONV_TRANSPOSE) { wp.c_row_stride = k2; wp.c_chan_stride = wp.Mw * k2; }   // rows = Cin: [Cout][Cin][taps]
+    if (o.wt_oihw && d->kind == AG_CONV_TRANSPOSE) { wp.c_row_stride = k2; wp.c_chan_stride = wp.Mw * k2; }   // rows = Cin: [Cout][Cin][taps]
     const int Kp = wp.gh * wp.gw, Nw = wp.Cg * k2;
     const int bm = pick_bm(wp.Mw), BN = bn_of(bm);
     const int tiles = ((Nw + BN - 1) / BN) * ((wp.Mw + bm - 1) / bm) * G;
@@ -1634,19 +1636,19 @@ extern "C" {
 int ag_conv_forward(const AgConvDesc* d, const float* x, const float* w, const float* out_scale, const float* bias, float* y,
                     void* workspace, size_t workspace_bytes, void* stream)
 {
-    return conv_forward_g(d, 1, x, 0, table_of(w), out_scale, table_of(bias), y, 0, workspace, workspace_bytes, reinterpret_cast<hipStream_t>(stream), false);
+    return conv_forward_g(d, 1, x, 0, table_of(w), out_scale, table_of(bias), y, 0, workspace, workspace_bytes, reinterpret_cast<hipStream_t>(stream));
 }
 
 int ag_conv_backward_input(const AgConvDesc* d, const float* dy, const float* w, float* dx, void* workspace,
                            size_t workspace_bytes, void* stream)
 {
-    return conv_backward_input_g(d, 1, dy, 0, table_of(w), dx, 0, workspace, workspace_bytes, reinterpret_cast<hipStream_t>(stream), false);
+    return conv_backward_input_g(d, 1, dy, 0, table_of(w), dx, 0, workspace, workspace_bytes, reinterpret_cast<hipStream_t>(stream));
 }
 
 int ag_conv_backward_weight(const AgConvDesc* d, const float* x, const float* dy, float* dw, void* workspace,
                             size_t workspace_bytes, void* stream)
 {
-    return conv_backward_weight_g(d, 1, x, 0, dy, 0, dw, 0, workspace, workspace_bytes, reinterpret_cast<hipStream_t>(stream), false);
+    return conv_backward_weight_g(d, 1, x, 0, dy, 0, dw, 0, workspace, workspace_bytes, reinterpret_cast<hipStream_t>(stream));
 }
 
 int ag_conv_set_math(int mode)

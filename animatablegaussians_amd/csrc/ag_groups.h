@@ -45,6 +45,11 @@ inline bool table_complete(const PtrTable& t, int G)
 // y [G][C][HW] = lrelu(x + nw_g[0] * noise_g[pix] + bias_g[c]) * scale; a null table entry = no noise / no bias for that instance
 int noise_bias_act_forward_g(float* y, const float* x, int G, const PtrTable& noise, const PtrTable& nw, const PtrTable& bias, int C, int HW,
                              float slope, float scale, hipStream_t s);
+// the same with a per-instance addend [C][HW] inside the activation: y = lrelu(x + addend_g + bias_g[c]) * scale (null entry: none)
+int bias_act_forward_addend_g(float* y, const float* x, int G, const PtrTable& addend, const PtrTable& bias, int C, int HW, float slope, float scale,
+                              hipStream_t s);
+// out[r] = sum of in[m] over the members m in [begin[r], begin[r + 1]) -- instances of n floats each, R <= kMaxGroups ranges
+int sum_member_ranges(float* out, const float* in, const int* begin, int R, long long n, hipStream_t s);
 // floats of `partials` the backward needs
 size_t noise_bias_act_partial_floats(int G, int C, int HW);
 // gbias: instance g writes C sums at gbias + g * gb_stride (null: not wanted); gnw: one sum at gnw + g * gnw_stride (null: not wanted).
@@ -68,12 +73,21 @@ int block2x2_transform_g(float* out, const float* in, const float* matrix16_host
 }  // namespace ag
 struct AgConvDesc;
 namespace ag {
+// Options of a grouped convolution call.
+struct ConvOpts {
+    bool wt_oihw = false;     // the weights (and weight gradients) of a TRANSPOSED convolution are laid out [Cout][Cin][k][k] like a convolution's
+                              // instead of conv_transpose2d's [Cin][Cout][k][k] (ignored for AG_CONV)
+    int w_cin_total = 0;      // forward / input gradient of an AG_CONV on a channel SLICE of a wider weight tensor [Cout][w_cin_total][k][k]: the
+                              // weight pointers point at the slice's first channel, rows are w_cin_total * k * k floats apart.  0: exactly d->Cin
+                              // channels.  (The weight gradient does not read the weights: it is always written [Cout][d->Cin][k][k].)
+};
 size_t conv_workspace_bytes_g(const AgConvDesc* d, int G);
 int conv_forward_g(const AgConvDesc* d, int G, const float* x, long long x_gs, const PtrTable& w, const float* out_scale, const PtrTable& bias,
-                   float* y, long long y_gs, void* workspace, size_t workspace_bytes, hipStream_t s, bool wt_oihw = false);
+                   float* y, long long y_gs, void* workspace, size_t workspace_bytes, hipStream_t s, const ConvOpts& o = ConvOpts());
 int conv_backward_input_g(const AgConvDesc* d, int G, const float* dy, long long dy_gs, const PtrTable& w, float* dx, long long dx_gs,
-                          void* workspace, size_t workspace_bytes, hipStream_t s, bool wt_oihw = false);
+                          void* workspace, size_t workspace_bytes, hipStream_t s, const ConvOpts& o = ConvOpts());
+// dw: the G gradients at dw_gs floats (stacked when dw_gs = the size of one weight); overwritten
 int conv_backward_weight_g(const AgConvDesc* d, int G, const float* x, long long x_gs, const float* dy, long long dy_gs, float* dw, long long dw_gs,
-                           void* workspace, size_t workspace_bytes, hipStream_t s, bool wt_oihw = false);
+                           void* workspace, size_t workspace_bytes, hipStream_t s, const ConvOpts& o = ConvOpts());
 
 }  // namespace ag

@@ -49,6 +49,8 @@ bool geometry(const AgGroupedLayerArgs* a, Geo& g)
 
 size_t pad64(size_t n) { return (n + 63) / 64 * 64; }
 
+const ConvOpts kOihw = [] { ConvOpts o; o.wt_oihw = true; return o; }();
+
 // float offsets of the regions inside `scratch`
 struct Scratch {
     size_t pre, aux, g_blur, g_wm, nba_part, mod_part, total;
@@ -159,7 +161,7 @@ int ag_grouped_layer_forward(const AgGroupedLayerArgs* a, void* stream)
         if (a->noise[i] && a->noise_weight[i]) { noise_t.p[i] = a->noise[i]; nw_t.p[i] = a->noise_weight[i]; }
     if (a->resample) {
         if (!a->k_blur) { set_error("ag_layer_forward: resampling layer without FIR taps"); return AG_ERR_INVALID_ARGUMENT; }
-        if ((rc = conv_forward_g(&g.d, G, a->x, x_gs, wm_t, nullptr, PtrTable{}, aux, (long long)a->Cout * g.CH * g.CW, a->workspace, a->workspace_bytes, s, true))) return rc;
+        if ((rc = conv_forward_g(&g.d, G, a->x, x_gs, wm_t, nullptr, PtrTable{}, aux, (long long)a->Cout * g.CH * g.CW, a->workspace, a->workspace_bytes, s, kOihw))) return rc;
         if ((rc = ag_upfirdn2d(pre, aux, a->k_blur, G * a->Cout, g.CH, g.CW, 4, 4, 1, 1, 1, 1, 1, 1, 1, 1, stream))) return rc;
     } else {
         if ((rc = conv_forward_g(&g.d, G, a->x, x_gs, wm_t, nullptr, PtrTable{}, pre, pre_gs, a->workspace, a->workspace_bytes, s))) return rc;
@@ -224,11 +226,11 @@ int ag_grouped_layer_backward(const AgGroupedLayerArgs* a, void* stream)
         g_conv = aux;
         gconv_gs = (long long)a->Cout * g.CH * g.CW;
     }
-    if (a->g_x && (rc = conv_backward_input_g(&g.d, G, g_conv, gconv_gs, wm_t, a->g_x, (long long)a->Cin * a->H * a->W, a->workspace, a->workspace_bytes, s, true))) return rc;
+    if (a->g_x && (rc = conv_backward_input_g(&g.d, G, g_conv, gconv_gs, wm_t, a->g_x, (long long)a->Cin * a->H * a->W, a->workspace, a->workspace_bytes, s, kOihw))) return rc;
     if (a->g_weight) {
         if (!a->g_style) { set_error("ag_layer_backward: g_weight without g_style"); return AG_ERR_INVALID_ARGUMENT; }
         float* g_wm = a->scratch + L.g_wm;
-        if ((rc = conv_backward_weight_g(&g.d, G, a->x, x_gs, g_conv, gconv_gs, g_wm, (long long)wn, a->workspace, a->workspace_bytes, s, true))) return rc;
+        if ((rc = conv_backward_weight_g(&g.d, G, a->x, x_gs, g_conv, gconv_gs, g_wm, (long long)wn, a->workspace, a->workspace_bytes, s, kOihw))) return rc;
         if ((rc = modulate_weight_backward_g(a->g_weight, a->g_style, a->scratch + L.mod_part, g_wm, G, w_t, style_t, a->demod, a->scale, 1, a->Cout, a->Cin,
                                              a->k * a->k, 0, s))) return rc;
     }
@@ -338,6 +340,97 @@ int ag_grouped_to_rgb_backward(const AgGroupedToRgbArgs* a, void* stream)
         float* part = a->scratch + pad64((size_t)G * a->Cout * a->Cin);
         if ((rc = conv_backward_weight_g(&d, G, a->x, a->Cin * hw, a->g_out, a->Cout * hw, g_wm, (long long)a->Cout * a->Cin, a->workspace, a->workspace_bytes, s))) return rc;
         if ((rc = modulate_weight_backward_g(a->g_weight, a->g_style, part, g_wm, G, w_t, style_t, nullptr, a->scale, 0, a->Cout, a->Cin, 1, 0, s))) return rc;
+    }
+    return AG_OK;
+}
+
+// ---- comb convolution of a decoder stage without the concatenation (include/ag_layers.h AgGroupedCombArgs) ------------------------------
+static bool comb_ok(const AgGroupedCombArgs* a)
+{
+    if (!a || a->M < 1 || a->M > AG_MAX_GROUPS || a->N < 1 || a->N > a->M || a->C1 <= 0 || a->C2 <= 0 || a->Cout <= 0 || a->H <= 0 || a->W <= 0) return false;
+    if (a->member_begin[0] != 0 || a->member_begin[a->N] != a->M) return false;
+    for (int r = 0; r < a->N; r++)
+        if (a->member_begin[r + 1] <= a->member_begin[r]) return false;
+    return ((long long)a->H * a->W * a->Cout) % 4 == 0;
+}
+
+static AgConvDesc comb_desc(const AgGroupedCombArgs* a, int cin)
+{
+    AgConvDesc d{};
+    d.kind = AG_CONV; d.Cin = cin; d.Cout = a->Cout; d.H = a->H; d.W = a->W; d.k = 3; d.stride = 1; d.padding = 1; d.weight_scale = a->scale;
+    return d;
+}
+
+size_t ag_grouped_comb_args_bytes(void) { return sizeof(AgGroupedCombArgs); }
+
+size_t ag_grouped_comb_workspace_bytes(const AgGroupedCombArgs* a)
+{
+    if (!comb_ok(a)) return 0;
+    const AgConvDesc d = comb_desc(a, a->C1 > a->C2 ? a->C1 : a->C2);
+    return conv_workspace_bytes_g(&d, a->M);
+}
+
+size_t ag_grouped_comb_scratch_floats(const AgGroupedCombArgs* a, int32_t backward)
+{
+    if (!comb_ok(a)) return 0;
+    const size_t hw = (size_t)a->H * a->W;
+    size_t n = pad64((size_t)a->M * a->Cout * hw) + pad64((size_t)a->N * a->Cout * hw);        // pre-activation (its gradient), the level half (its gradient)
+    if (backward) n += pad64(noise_bias_act_partial_floats(a->M, a->Cout, (int)hw));
+    return n + 64;
+}
+
+int ag_grouped_comb_forward(const AgGroupedCombArgs* a, void* stream)
+{
+    if (!comb_ok(a) || !a->x || !a->lev || !a->out || !a->scratch) { set_error("ag_grouped_comb_forward: bad arguments"); return AG_ERR_INVALID_ARGUMENT; }
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const long long hw = (long long)a->H * a->W;
+    float* pre = a->scratch;
+    float* t = a->scratch + pad64((size_t)a->M * a->Cout * hw);
+    ConvOpts o;
+    o.w_cin_total = a->C1 + a->C2;
+    PtrTable w1{}, w2{}, addend{}, bias = table_of(a->act_bias, a->M);
+    for (int r = 0; r < a->N; r++) {
+        if (!a->weight[r]) { set_error("ag_grouped_comb_forward: null weight"); return AG_ERR_INVALID_ARGUMENT; }
+        w2.p[r] = a->weight[r] + (size_t)a->C1 * 9;
+        for (int m = a->member_begin[r]; m < a->member_begin[r + 1]; m++) { w1.p[m] = a->weight[r]; addend.p[m] = t + (size_t)r * a->Cout * hw; }
+    }
+    const AgConvDesc d1 = comb_desc(a, a->C1), d2 = comb_desc(a, a->C2);
+    int rc;
+    if ((rc = conv_forward_g(&d2, a->N, a->lev, a->C2 * hw, w2, nullptr, PtrTable{}, t, a->Cout * hw, a->workspace, a->workspace_bytes, s, o))) return rc;
+    if ((rc = conv_forward_g(&d1, a->M, a->x, a->C1 * hw, w1, nullptr, PtrTable{}, pre, a->Cout * hw, a->workspace, a->workspace_bytes, s, o))) return rc;
+    return bias_act_forward_addend_g(a->out, pre, a->M, addend, bias, a->Cout, (int)hw, a->slope, a->act_scale, s);
+}
+
+int ag_grouped_comb_backward(const AgGroupedCombArgs* a, void* stream)
+{
+    if (!comb_ok(a) || !a->x || !a->lev || !a->out || !a->scratch || !a->g_out) { set_error("ag_grouped_comb_backward: bad arguments"); return AG_ERR_INVALID_ARGUMENT; }
+    if ((a->g_weight_x == nullptr) != (a->g_weight_lev == nullptr)) { set_error("ag_grouped_comb_backward: both weight gradients or none"); return AG_ERR_INVALID_ARGUMENT; }
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const long long hw = (long long)a->H * a->W;
+    float* g_pre = a->scratch;
+    float* g_t = a->scratch + pad64((size_t)a->M * a->Cout * hw);
+    float* part = g_t + pad64((size_t)a->N * a->Cout * hw);
+    ConvOpts o;
+    o.w_cin_total = a->C1 + a->C2;
+    PtrTable w1{}, w2{};
+    for (int r = 0; r < a->N; r++) {
+        if (!a->weight[r]) { set_error("ag_grouped_comb_backward: null weight"); return AG_ERR_INVALID_ARGUMENT; }
+        w2.p[r] = a->weight[r] + (size_t)a->C1 * 9;
+        for (int m = a->member_begin[r]; m < a->member_begin[r + 1]; m++) w1.p[m] = a->weight[r];
+    }
+    const AgConvDesc d1 = comb_desc(a, a->C1), d2 = comb_desc(a, a->C2);
+    int rc;
+    if ((rc = noise_bias_act_backward_g(g_pre, a->g_out, a->out, a->M, PtrTable{}, a->g_bias, a->Cout, nullptr, 0, part, a->Cout, (int)hw, a->slope,
+                                        a->act_scale, s))) return rc;
+    if (a->g_x && (rc = conv_backward_input_g(&d1, a->M, g_pre, a->Cout * hw, w1, a->g_x, a->C1 * hw, a->workspace, a->workspace_bytes, s, o))) return rc;
+    const bool need_t = a->g_lev || a->g_weight_lev;
+    if (need_t && (rc = sum_member_ranges(g_t, g_pre, a->member_begin, a->N, a->Cout * hw, s))) return rc;       // the level half sees the SUM of its members' gradients
+    if (a->g_lev && (rc = conv_backward_input_g(&d2, a->N, g_t, a->Cout * hw, w2, a->g_lev, a->C2 * hw, a->workspace, a->workspace_bytes, s, o))) return rc;
+    if (a->g_weight_x) {
+        if ((rc = conv_backward_weight_g(&d1, a->M, a->x, a->C1 * hw, g_pre, a->Cout * hw, a->g_weight_x, (long long)a->Cout * a->C1 * 9, a->workspace,
+                                         a->workspace_bytes, s))) return rc;
+        if ((rc = conv_backward_weight_g(&d2, a->N, a->lev, a->C2 * hw, g_t, a->Cout * hw, a->g_weight_lev, (long long)a->Cout * a->C2 * 9, a->workspace,
+                                         a->workspace_bytes, s))) return rc;
     }
     return AG_OK;
 }

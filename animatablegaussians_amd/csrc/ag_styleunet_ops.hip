@@ -65,15 +65,18 @@ __global__ void __launch_bounds__(256) fused_bias_act_kernel(float* __restrict__
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int kNbaChunk = 4096;   // pixels per workgroup (16 per thread)
 
+// ADDEND: a second pre-activation term [C][HW] per instance (the encoder-level half of a decoder's comb convolution, computed once per
+// network and shared by its members: ag_layers.hip ag_grouped_comb_*), in the place of the noise term
+template <bool ADDEND>
 __global__ void __launch_bounds__(256) noise_bias_act_forward_kernel(float* __restrict__ y, const float* __restrict__ x,
                                                                     const PtrTable noise_t, const PtrTable nw_t, const PtrTable bias_t,
                                                                     int C, int HW, int chunks, float slope, float scale)
 {
     const int cg = blockIdx.x / chunks, p0 = (blockIdx.x - cg * chunks) * kNbaChunk;      // cg: channel index over all instances
     const int grp = cg / C, c = cg - grp * C;
-    const float* __restrict__ noise = noise_t.p[grp];
+    const float* __restrict__ noise = ADDEND ? (noise_t.p[grp] ? noise_t.p[grp] + (size_t)c * HW : nullptr) : noise_t.p[grp];
     const float* __restrict__ bias = bias_t.p[grp];
-    const float b = bias ? bias[c] : 0.f, w = noise ? nw_t.p[grp][0] : 0.f;
+    const float b = bias ? bias[c] : 0.f, w = ADDEND ? 1.0f : (noise ? nw_t.p[grp][0] : 0.f);
     const float* xr = x + (size_t)cg * HW;
     float* yr = y + (size_t)cg * HW;
     const int pend = min(HW, p0 + kNbaChunk);
@@ -595,8 +598,48 @@ int noise_bias_act_forward_g(float* y, const float* x, int G, const PtrTable& no
         if (noise.p[g] && !nw.p[g]) { set_error("noise_bias_act: noise without a noise weight"); return AG_ERR_INVALID_ARGUMENT; }
     if (C == 0 || HW == 0) return AG_OK;
     const int chunks = (HW + kNbaChunk - 1) / kNbaChunk;
-    hipLaunchKernelGGL(noise_bias_act_forward_kernel, dim3(G * C * chunks), dim3(256), 0, s, y, x, noise, nw, bias, C, HW, chunks, slope, scale);
+    hipLaunchKernelGGL(noise_bias_act_forward_kernel<false>, dim3(G * C * chunks), dim3(256), 0, s, y, x, noise, nw, bias, C, HW, chunks, slope, scale);
     return check_hip(hipGetLastError(), "noise_bias_act_forward_kernel");
+}
+
+int bias_act_forward_addend_g(float* y, const float* x, int G, const PtrTable& addend, const PtrTable& bias, int C, int HW, float slope, float scale,
+                              hipStream_t s)
+{
+    if (bad_groups(G) || C <= 0 || HW <= 0 || !y || !x) { set_error("bad bias_act_forward_addend arguments"); return AG_ERR_INVALID_ARGUMENT; }
+    const int chunks = (HW + kNbaChunk - 1) / kNbaChunk;
+    // x + 1.0f * addend + bias: the multiplication by 1 is exact, so this is the sum of the two convolution halves in the order (x + addend) + bias
+    hipLaunchKernelGGL(noise_bias_act_forward_kernel<true>, dim3(G * C * chunks), dim3(256), 0, s, y, x, addend, PtrTable{}, bias, C, HW, chunks, slope, scale);
+    return check_hip(hipGetLastError(), "noise_bias_act_forward_kernel<addend>");
+}
+
+struct MemberRanges { int begin[kMaxGroups + 1]; };
+
+__global__ void __launch_bounds__(256) sum_member_ranges_kernel(float* __restrict__ out, const float* __restrict__ in, MemberRanges r, long long n)
+{
+    const int rr = blockIdx.y;
+    const int m0 = r.begin[rr], m1 = r.begin[rr + 1];
+    const long long n4 = n >> 2;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        float4 acc = reinterpret_cast<const float4*>(in + (size_t)m0 * n)[i];
+        for (int m = m0 + 1; m < m1; m++) {
+            const float4 v = reinterpret_cast<const float4*>(in + (size_t)m * n)[i];
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        reinterpret_cast<float4*>(out + (size_t)rr * n)[i] = acc;
+    }
+}
+
+int sum_member_ranges(float* out, const float* in, const int* begin, int R, long long n, hipStream_t s)
+{
+    if (R < 1 || R > kMaxGroups || n <= 0 || (n & 3) || !out || !in || !begin) { set_error("bad sum_member_ranges arguments"); return AG_ERR_INVALID_ARGUMENT; }
+    MemberRanges r{};
+    for (int i = 0; i <= R; i++) r.begin[i] = begin[i];
+    for (int i = 0; i < R; i++)
+        if (r.begin[i + 1] <= r.begin[i]) { set_error("sum_member_ranges: empty range"); return AG_ERR_INVALID_ARGUMENT; }
+    long long blocks = (n / 4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(sum_member_ranges_kernel, dim3((int)blocks, R), dim3(256), 0, s, out, in, r, n);
+    return check_hip(hipGetLastError(), "sum_member_ranges_kernel");
 }
 
 size_t noise_bias_act_partial_floats(int G, int C, int HW)

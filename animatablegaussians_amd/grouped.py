@@ -25,6 +25,15 @@ from .styleunet_ops import _HAAR_SYNTHESIS, _flipped, _skip_taps_host, upfirdn2d
 
 _SQRT2 = 2 ** 0.5
 _SIZES = {}
+# the decoders' comb convolutions without the concatenation, the encoder-level half once per network (AG_COMB_SPLIT=0: cat + one convolution
+# per member, for the A/B and the equality test)
+_COMB_SPLIT = os.environ.get("AG_COMB_SPLIT") != "0"
+
+
+def set_comb_split(on: bool) -> bool:
+    global _COMB_SPLIT
+    prev, _COMB_SPLIT = _COMB_SPLIT, bool(on)
+    return prev
 
 
 def _stream(dev):
@@ -321,6 +330,126 @@ def grouped_to_rgb_runs(x, runs, weights, styles, biases, skips, k_up, scale):
     return _GroupedToRGB.apply(tuple(runs), float(scale), k_up, x, *skips, *weights, *styles, *biases)
 
 
+def _comb_args(begin, x, lev, w0, scale):
+    a = _lib.AgGroupedCombArgs()
+    a.M, a.N = int(x.shape[0]), int(lev.shape[0])
+    a.C1, a.C2, a.Cout = int(x.shape[1]), int(lev.shape[1]), int(w0.shape[0])
+    a.H, a.W = int(x.shape[2]), int(x.shape[3])
+    if len(begin) != a.N + 1 or begin[0] != 0 or begin[-1] != a.M or tuple(lev.shape[2:]) != tuple(x.shape[2:]) or tuple(w0.shape[1:]) != (a.C1 + a.C2, 3, 3):
+        raise RuntimeError("grouped comb convolution: shapes / member ranges do not match")
+    for i, b in enumerate(begin):
+        a.member_begin[i] = int(b)
+    a.scale, a.slope, a.act_scale = float(scale), 0.2, _SQRT2
+    return a
+
+
+def _comb_sizes(a):
+    key = ("C", a.M, a.N, a.C1, a.C2, a.Cout, a.H, a.W)
+    v = _SIZES.get(key)
+    if v is None:
+        L = _lib.lib()
+        v = _SIZES[key] = (int(L.ag_grouped_comb_scratch_floats(ctypes.byref(a), 0)), int(L.ag_grouped_comb_scratch_floats(ctypes.byref(a), 1)),
+                           int(L.ag_grouped_comb_workspace_bytes(ctypes.byref(a))))
+        if not v[0] or not v[2]:
+            raise RuntimeError("grouped comb convolution: the library refused the shape")
+    return v
+
+
+class _GroupedComb(torch.autograd.Function):
+    """The comb convolution of a decoder stage for the stacked members WITHOUT the concatenation (include/ag_layers.h AgGroupedCombArgs):
+    conv(cat(x_m, lev_r), W_r) = conv(x_m, W_r[:, :C1]) + conv(lev_r, W_r[:, C1:]), the second half once per network.
+    ``begin``: member ranges of the networks; ``rest`` = weights[N] (per network) + biases[M] (per member)."""
+
+    @staticmethod
+    def forward(ctx, begin, scale, x, lev, *rest):
+        x, lev = x.contiguous(), lev.contiguous()
+        N, M = int(lev.shape[0]), int(x.shape[0])
+        ws = [p.contiguous() for p in rest[:N]]
+        bs = [p.contiguous() for p in rest[N:N + M]]
+        dev = x.device
+        a = _comb_args(begin, x, lev, ws[0], scale)
+        f_fwd, _, wsb = _comb_sizes(a)
+        out = torch.empty((M, a.Cout, a.H, a.W), dtype=torch.float32, device=dev)
+        _fill(a.weight, ws)
+        _fill(a.act_bias, bs)
+        a.x, a.lev, a.out = x.data_ptr(), lev.data_ptr(), out.data_ptr()
+        buf, a.scratch, a.workspace = _scratch(f_fwd, wsb, dev)
+        a.workspace_bytes = wsb
+        with _lib.on_device(dev):
+            _lib.check(_lib.lib().ag_grouped_comb_forward(ctypes.byref(a), _stream(dev)), "ag_grouped_comb_forward")
+        ctx.save_for_backward(x, lev, out, *ws, *bs)
+        ctx.cfg = (tuple(begin), float(scale))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        begin, scale = ctx.cfg
+        x, lev, out = ctx.saved_tensors[:3]
+        N, M = int(lev.shape[0]), int(x.shape[0])
+        ws, bs = ctx.saved_tensors[3:3 + N], ctx.saved_tensors[3 + N:3 + N + M]
+        dev = x.device
+        g = g.contiguous()
+        a = _comb_args(begin, x, lev, ws[0], scale)
+        _, f_bwd, wsb = _comb_sizes(a)
+        nig = ctx.needs_input_grad
+        nx, nlev, pn = nig[2], nig[3], nig[4:]
+        need_w, need_b = any(pn[:N]), any(pn[N:N + M])
+        gx = torch.empty_like(x) if nx else None
+        glev = torch.empty_like(lev) if nlev else None
+        gw1 = torch.empty((M, a.Cout, a.C1, 3, 3), dtype=torch.float32, device=dev) if need_w else None
+        gw2 = torch.empty((N, a.Cout, a.C2, 3, 3), dtype=torch.float32, device=dev) if need_w else None
+        gb = torch.empty((M, a.Cout), dtype=torch.float32, device=dev) if need_b else None
+        _fill(a.weight, ws)
+        _fill(a.act_bias, bs)
+        a.x, a.lev, a.out, a.g_out = x.data_ptr(), lev.data_ptr(), out.data_ptr(), g.data_ptr()
+        a.g_x = gx.data_ptr() if gx is not None else None
+        a.g_lev = glev.data_ptr() if glev is not None else None
+        a.g_weight_x = gw1.data_ptr() if gw1 is not None else None
+        a.g_weight_lev = gw2.data_ptr() if gw2 is not None else None
+        a.g_bias = gb.data_ptr() if gb is not None else None
+        buf, a.scratch, a.workspace = _scratch(f_bwd, wsb, dev)
+        a.workspace_bytes = wsb
+        with _lib.on_device(dev):
+            _lib.check(_lib.lib().ag_grouped_comb_backward(ctypes.byref(a), _stream(dev)), "ag_grouped_comb_backward")
+        g_ws = [None] * N
+        if need_w:
+            for r in range(N):
+                if pn[r]:
+                    m0, m1 = begin[r], begin[r + 1]
+                    half = gw1[m0] if m1 - m0 == 1 else gw1[m0:m1].sum(0)
+                    g_ws[r] = torch.cat([half, gw2[r]], 1)
+        g_bs = [gb[m] if (gb is not None and pn[N + m]) else None for m in range(M)]
+        return (None, None, gx, glev, *g_ws, *g_bs)
+
+
+class _SelectAddRows(torch.autograd.Function):
+    """x[m] = out[src[m]] (+ vf on the rows [r0, r1)): the input of a view-dependent stage, where member m continues the shared state
+    ``out[src[m]]`` and the colour members add their view-direction feature (dual_styleunet.py:881-883)."""
+
+    @staticmethod
+    def forward(ctx, out, vf, src, rows):
+        ident = list(src) == list(range(out.shape[0]))
+        x = out.clone() if ident else out.index_select(0, _index(src, out.device))
+        if vf is not None:
+            x[rows[0]:rows[1]].add_(vf)
+        ctx.cfg = (tuple(src), rows, ident, int(out.shape[0]), vf is not None)
+        return x
+
+    @staticmethod
+    def backward(ctx, g):
+        src, rows, ident, n_out, has_vf = ctx.cfg
+        g_out = g_vf = None
+        if ctx.needs_input_grad[0]:
+            if ident:
+                g_out = g
+            else:
+                g_out = torch.zeros((n_out,) + tuple(g.shape[1:]), dtype=g.dtype, device=g.device)
+                g_out.index_add_(0, _index(src, g.device), g)
+        if has_vf and ctx.needs_input_grad[1]:
+            g_vf = g[rows[0]:rows[1]]
+        return g_out, g_vf, None, None
+
+
 class _GroupedHaarMerge(torch.autograd.Function):
     """InverseHaarTransform (dual_styleunet.py:406-425) of G stacked tensors: [G, 4C, h, w] -> [G, C, 2h, 2w], one kernel."""
 
@@ -476,9 +605,22 @@ class GroupedStyleUNets:
             o3 = self._conv_layer(levels[-1], nets, f"comb_convs.{n0.n_comb - 1}")     # branch-independent: once per network (:873 runs it per branch)
             out = o3.index_select(0, _index(net_idx, o3.device))
         elif n < n0.n_comb:
-            src = list(range(M)) if src is None else src
-            cat = _CatLevels.apply(out, levels[-1 - n], vf, tuple(src), tuple(net_idx), vf_rows)
-            out = self._conv_layer(cat, mnets, f"comb_convs.{n0.n_comb - 1 - n}")
+            src = list(range(M)) if src is None else list(src)
+            if _COMB_SPLIT and net_idx == sorted(net_idx):
+                # the comb convolution without the concatenation: the encoder-level half once per network (ag_grouped_comb_*)
+                if vf is not None or src != list(range(out.shape[0])):
+                    out = _SelectAddRows.apply(out, vf, tuple(src), vf_rows)
+                used = sorted(set(net_idx))
+                begin = [net_idx.index(r) for r in used] + [M]
+                lev = levels[-1 - n]
+                if used != list(range(lev.shape[0])):
+                    lev = lev.index_select(0, _index(used, lev.device))
+                prefix = f"comb_convs.{n0.n_comb - 1 - n}"
+                wts = [nets[r]._p(f"{prefix}.0.weight") for r in used]
+                out = _GroupedComb.apply(tuple(begin), 1 / math.sqrt(wts[0].shape[1] * 9), out, lev, *wts, *[net._p(f"{prefix}.1.bias") for net in mnets])
+            else:
+                cat = _CatLevels.apply(out, levels[-1 - n], vf, tuple(src), tuple(net_idx), vf_rows)
+                out = self._conv_layer(cat, mnets, f"comb_convs.{n0.n_comb - 1 - n}")
         pre = [f"convs{b}.{2 * n}" for _, b in members]
         w = [net._p(f"{p}.conv.weight") for net, p in zip(mnets, pre)]
         k = w[0].shape[-1]

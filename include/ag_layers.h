@@ -145,6 +145,44 @@ size_t ag_grouped_to_rgb_workspace_bytes(const AgGroupedToRgbArgs* a);
 int ag_grouped_to_rgb_forward(const AgGroupedToRgbArgs* a, void* stream);
 int ag_grouped_to_rgb_backward(const AgGroupedToRgbArgs* a, void* stream);
 
+/*
+ * The comb convolution of a decoder stage (dual_styleunet.py:877-879: ``comb_convs[..](cat([out, cond_list[..]], 1))``, a 3 x 3 ConvLayer
+ * with bias + leaky ReLU) for M stacked decoder instances of N networks, WITHOUT building the concatenation:
+ *     conv(cat(out_m, lev_r), W_r) = conv(out_m, W_r[:, :C1]) + conv(lev_r, W_r[:, C1:])
+ * and the second term depends on the network r only -- both branches of a network (and every camera view of the colour network) read the same
+ * encoder level through the same weights -- so it is computed once per network (t) and added inside the activation kernel of every
+ * member: a quarter of the comb convolutions' FLOPs at two members per network, forward and backward (the gradients of the members of a
+ * network are summed BEFORE the level half's input / weight gradient).  Same values up to the association of the sum over the input
+ * channels (the two halves are accumulated separately and added in fp32).
+ */
+typedef struct AgGroupedCombArgs {
+    int32_t M, N;                  /* decoder instances, networks */
+    int32_t C1, C2, Cout, H, W;    /* channels of the members' input / of the encoder level / of the output; 3 x 3, stride 1, padding 1 */
+    int32_t member_begin[AG_MAX_GROUPS + 1];   /* the members of network r are [member_begin[r], member_begin[r + 1]) (consecutive, non-empty) */
+    float scale, slope, act_scale, reserved_f;   /* EqualConv2d scale 1 / sqrt((C1 + C2) * 9); leaky ReLU slope and gain */
+    const float* x;                /* [M][C1][H][W] */
+    const float* lev;              /* [N][C2][H][W] */
+    const float* weight[AG_MAX_GROUPS];     /* per NETWORK: the comb weight [Cout][C1 + C2][3][3] */
+    const float* act_bias[AG_MAX_GROUPS];   /* per MEMBER: [Cout] (the members of a network pass the same pointer) */
+    float* out;                    /* [M][Cout][H][W] */
+    float* scratch;                /* ag_grouped_comb_scratch_floats floats */
+    void* workspace;               /* ag_grouped_comb_workspace_bytes bytes */
+    size_t workspace_bytes;
+    /* backward only */
+    const float* g_out;            /* [M][Cout][H][W] */
+    float* g_x;                    /* [M][C1][H][W] or NULL */
+    float* g_lev;                  /* [N][C2][H][W] or NULL */
+    float* g_weight_x;             /* [M][Cout][C1][3][3]: per member, w.r.t. W_r[:, :C1] (NULL: no weight gradients) */
+    float* g_weight_lev;           /* [N][Cout][C2][3][3]: per network, w.r.t. W_r[:, C1:] (required with g_weight_x) */
+    float* g_bias;                 /* [M][Cout] or NULL */
+} AgGroupedCombArgs;
+
+size_t ag_grouped_comb_args_bytes(void);
+size_t ag_grouped_comb_scratch_floats(const AgGroupedCombArgs* a, int32_t backward);
+size_t ag_grouped_comb_workspace_bytes(const AgGroupedCombArgs* a);
+int ag_grouped_comb_forward(const AgGroupedCombArgs* a, void* stream);
+int ag_grouped_comb_backward(const AgGroupedCombArgs* a, void* stream);
+
 /* ag_block2x2_transform (ag_styleunet.h) on G stacked tensors: in [G][C][2h][2w] <-> out [G][4][C][h][w]. */
 int ag_grouped_block2x2(float* out, const float* in, const float* matrix16, int32_t merge, int32_t G, int32_t C, int32_t h, int32_t w, void* stream);
 

@@ -109,6 +109,38 @@ def test_grouped_to_rgb_equals_the_heads_one_by_one(G, Cin, Cout, H, with_skip):
         _close(a, b, i, tol=5e-5)
 
 
+@pytest.mark.parametrize("begin,C1,C2,Cout,H", [((0, 2, 4, 6), 32, 32, 16, 12), ((0, 2, 6, 8), 16, 48, 32, 10), ((0, 4), 64, 64, 64, 8), ((0, 1, 2, 3), 16, 16, 128, 16)])
+def test_comb_convolution_without_the_concatenation_equals_the_concatenated_one(begin, C1, C2, Cout, H):
+    """ag_grouped_comb_* (dual_styleunet.py:877-879): conv(cat(out_m, lev_r), W_r) as conv(out_m, W_r[:, :C1]) + conv(lev_r, W_r[:, C1:]) with
+    the second half once per network, against the concatenation + one grouped ConvLayer per member; uneven member counts per network
+    (several camera views of the colour network) included.  Differences: the association of the channel sum (two partial sums added in
+    fp32)."""
+    import torch
+    from animatablegaussians_amd import grouped as gr
+    N, M = len(begin) - 1, begin[-1]
+    net_of = [r for r in range(N) for _ in range(begin[r + 1] - begin[r])]
+    g = torch.Generator().manual_seed(M * 100 + C1)
+    x = torch.randn(M, C1, H, H, generator=g).cuda()
+    lev = torch.randn(N, C2, H, H, generator=g).cuda()
+    ws = [torch.randn(Cout, C1 + C2, 3, 3, generator=g).cuda().requires_grad_(True) for _ in range(N)]
+    bs = [(torch.randn(Cout, generator=g) * 0.1).cuda().requires_grad_(True) for _ in range(N)]
+    scale = 1 / ((C1 + C2) * 9) ** 0.5
+    up = torch.randn(M, Cout, H, H, generator=g).cuda()
+    xa, la = x.clone().requires_grad_(True), lev.clone().requires_grad_(True)
+    out = gr._GroupedComb.apply(tuple(begin), scale, xa, la, *ws, *[bs[r] for r in net_of])
+    out.backward(up)
+    got = [out.detach(), xa.grad, la.grad] + [w.grad.clone() for w in ws] + [b.grad.clone() for b in bs]
+    for t in ws + bs:
+        t.grad = None
+    xb, lb = x.clone().requires_grad_(True), lev.clone().requires_grad_(True)
+    cat = torch.cat([xb, lb[net_of]], 1)
+    ref = gr.grouped_conv_layer(cat, [ws[r] for r in net_of], [bs[r] for r in net_of], None, scale, False)
+    ref.backward(up)
+    want = [ref.detach(), xb.grad, lb.grad] + [w.grad for w in ws] + [b.grad for b in bs]
+    for i, (a, b) in enumerate(zip(got, want)):
+        _close(a, b, i, tol=5e-5)
+
+
 @pytest.fixture(scope="module")
 def net():
     import torch
