@@ -149,7 +149,6 @@ SYMBOLS = [
     ("ag_prof_kernel_name", ctypes.c_char_p, [c_i32]),
     ("ag_prof_enable", ctypes.c_int, [ctypes.c_uint32]),
     ("ag_prof_collect", ctypes.c_int, [ctypes.POINTER(c_i32), ctypes.POINTER(c_f), ctypes.POINTER(ctypes.c_double)]),
-    ("ag_debug_wave_reduce16", ctypes.c_int, [c_vp, c_vp, c_vp]),
     ("ag_debug_atomic_rate", ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
     ("ag_noise_bias_act_forward", ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_float,
                                                ctypes.c_float, c_vp]),

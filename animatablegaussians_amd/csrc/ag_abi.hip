@@ -385,10 +385,6 @@ int ag_prof_collect(int32_t* launches, float* total_ms, double* work)
     return rc;
 }
 
-int ag_debug_wave_reduce16(const float* in, float* out, void* stream)
-{
-    return launch_debug_wave_reduce16(in, out, reinterpret_cast<hipStream_t>(stream));
-}
 
 int ag_debug_atomic_rate(float* accum, int32_t lines, int32_t blocks, int32_t iters, int32_t comps, void* stream)
 {

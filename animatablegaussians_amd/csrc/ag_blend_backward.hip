@@ -84,37 +84,6 @@ __device__ __forceinline__ void swap16(float& a, float& b)
     b = __uint_as_float(r[1]);
 }
 
-// Sum each of v[0..15] over the 64 lanes; on return lane l holds the total of v[(l >> 2) & 15].  (Used by the
-// wave-per-quad variant of this kernel and kept as a tested building block: tests/test_raster_gpu.py.)
-__device__ __forceinline__ float wave_reduce16_transposed(float (&v)[16], int lane)
-{
-    float s[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        swap32(v[i], v[i + 8]);
-        s[i] = v[i] + v[i + 8];
-    }
-    float u[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        swap16(s[i], s[i + 4]);
-        u[i] = s[i] + s[i + 4];
-    }
-    float w[2];
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-        const float lo = u[i] + dpp<AG_DPP_ROW_ROR(8)>(u[i]);
-        const float hi = u[i + 2] + dpp<AG_DPP_ROW_ROR(8)>(u[i + 2]);
-        w[i] = (lane & 8) ? hi : lo;
-    }
-    const float lo = w[0] + dpp<AG_DPP_ROW_SHL(4)>(w[0]);
-    const float hi = w[1] + dpp<AG_DPP_ROW_SHR(4)>(w[1]);
-    float x = (lane & 4) ? hi : lo;
-    x += dpp<AG_DPP_QUAD_PERM(1, 0, 3, 2)>(x);
-    x += dpp<AG_DPP_QUAD_PERM(2, 3, 0, 1)>(x);
-    return x;
-}
-
 // What the per-item timeline of the round-2 region kernel showed (profiles/r03_bwd_timeline.txt, bench view): its body runs at the rate six
 // waves sharing a SIMD's VALU allow (1.8 us per 32-entry sub-chunk = the ~180 VALU instructions of each of the six), so the kernel is
 // bound by instruction count, and 84 % of its (pixel, entry) lane slots are dead: a wave walks ALL survivors of the 8x4 region cull
@@ -200,15 +169,6 @@ extern "C" int ag_debug_bwd_stats(unsigned long long* out)
 #define ST(k, v) do { } while (0)
 #endif
 
-#ifndef AG_BWD_MFMA_REDUCE
-#define AG_BWD_MFMA_REDUCE 0    /* 1: the sum over the block's rows on the matrix pipe (below).  Parity-green, measured same-box 80.8 -> 119.5 us (118.5
-                                   with two independent accumulators): ten v_mfma_f32_16x16x4_f32 per step cost more than the 16 VALU instructions
-                                   they replace.  Kept as the record of the experiment; off. */
-#endif
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-#ifndef AG_BWD_KNOCKOUT
-#define AG_BWD_KNOCKOUT 0       /* diagnostic builds only (profiles/ub/build_variant.sh): bit 0 = the flush issues no atomics, bit 1 = no blend steps (walk + cull only), bit 2 = steps without the sum over the pixels / window, bit 3 = no permlane swaps, bit 4 = no window stores / flush */
-#endif
 #ifndef AG_BWD_WAVE_OCC
 #define AG_BWD_WAVE_OCC 6       // waves per SIMD the register budget is cut for
 #endif
@@ -225,14 +185,7 @@ __global__ void __launch_bounds__(64, AG_BWD_WAVE_OCC) blend_backward_wave_kerne
     const float bg0 = p.bg[0], bg1 = p.bg[1], bg2 = p.bg[2];
     // flush lane (entry, component): component -> window slot [row][4]: rows hold the values (0, 1, 2) (3, 4, -) (5, 6, 7) (8, 9, -)
     const int out_comp = lane & 15;
-#if AG_BWD_MFMA_REDUCE
-    const int out_slot = out_comp;
-    float sel[10];               // A operands of the row-sum MFMAs: lane (i = lane % 16, k = lane / 16) holds A_t[i][k] = (i == t)
-#pragma unroll
-    for (int t = 0; t < 10; t++) sel[t] = ((lane & 15) == t) ? 1.0f : 0.0f;
-#else
     const int out_slot = out_comp < 3 ? out_comp : out_comp < 5 ? out_comp + 1 : out_comp < 8 ? out_comp + 3 : out_comp < 10 ? out_comp + 4 : 15;
-#endif
     const float bank0 = (e == 0) ? 1.0f : 0.0f;
 
     WaveItemIter it(blockIdx.x, gridDim.x, n_active);
@@ -293,11 +246,7 @@ __global__ void __launch_bounds__(64, AG_BWD_WAVE_OCC) blend_backward_wave_kerne
 #pragma unroll
             for (int pass = 0; pass < kWin / 4; pass++) {
                 const int ent = pass * 4 + (lane >> 4), comp = lane & 15;
-#if AG_BWD_KNOCKOUT & 1     /* diagnostic: no atomics (the values are kept alive) */
-                if (ent < win && comp < 10 && val[pass] == 123.456f) atomicAdd(p.accum + (size_t)gid[pass] * kAccumFloats + comp, val[pass]);
-#else
                 if (ent < win && comp < 10 && val[pass] != 0.f) atomicAdd(p.accum + (size_t)gid[pass] * kAccumFloats + comp, val[pass]);
-#endif
             }
             win = 0;
         };
@@ -339,9 +288,6 @@ __global__ void __launch_bounds__(64, AG_BWD_WAVE_OCC) blend_backward_wave_kerne
                 const bool ev = idx < cnt;
                 const int slot = (kRing & (kRing - 1)) ? (ev ? idx : cnt - 1) % kRing : (int)((uint32_t)(ev ? idx : cnt - 1) & (uint32_t)(kRing - 1));
                 head += 4;
-#if AG_BWD_KNOCKOUT & 2     /* diagnostic: the walk and the cull only */
-                continue;
-#endif
                 const float4 a = s_ring[slot * 3 + 0];   // x, y, conic a, conic b
                 const float4 b = s_ring[slot * 3 + 1];   // conic c, opacity, r, g
                 const float4 c = s_ring[slot * 3 + 2];   // b, depth, position, id
@@ -416,52 +362,18 @@ __global__ void __launch_bounds__(64, AG_BWD_WAVE_OCC) blend_backward_wave_kerne
                 asm volatile("s_nop 1\n\t"
                              "v_mul_f32_dpp %0, %1, %2 row_ror:4 row_mask:0xf bank_mask:0xf" : "=&v"(S) : "v"(B), "v"(bank0));
 
-#if AG_BWD_KNOCKOUT & 4     /* diagnostic: no sum over the pixels, no window */
-                { float acc = 0.f; for (int i = 0; i < 10; i++) acc += v[i]; asm volatile("" :: "v"(acc)); win = 0; continue; }
-#endif
-#if AG_BWD_MFMA_REDUCE
-                // (Experiment, off: see AG_BWD_MFMA_REDUCE.)  Sum over the block's 16 pixels per entry, over y (the wave's four 16-lane rows) on
-                // the MATRIX pipe, which this kernel leaves idle: v_mfma_f32_16x16x4_f32 computes D[i][j] = sum_k A[i][k] B[k][j] with B[k][j] read from lane 16 k + j, i.e. a
-                // sum over the four rows for every (entry, x) column j; A = e_t (x) ones puts value t's sums into row t of ONE accumulator
-                // (fp32 products with 1.0 / 0.0 and fp32 accumulation: the plain sum).  Ten MFMAs replace 8 permlane swaps + 8 additions, and
-                // D arrives laid out for the window: lane (16 g + 4 e + x) holds the sums of values 4 g .. 4 g + 3 of entry e in 4
-                // consecutive registers.  Then x inside the quads with two DPP butterflies per register.
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int t = 0; t < 10; t++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(sel[t], v[t], acc, 0, 0, 0);
-                float d0 = acc[0], d1 = acc[1], d2 = acc[2], d3 = acc[3];
-                asm volatile("s_nop 1\n\t"
-                             "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-                             "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-                             "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-                             "v_add_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-                             "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-                             "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-                             "v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-                             "v_add_f32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
-                             : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3));
-                // window: [entry][16 slots], slot = value index; lanes of entries past the end of the ring hold exact zeros (act is false)
-                if (qx == 0) {
-                    *reinterpret_cast<float4*>(s_out + (win + e) * 16 + ry * 4) = make_float4(d0, d1, d2, d3);
-                    if (ry == 0) s_wgid[win + e] = __float_as_uint(c.w);
-                }
-#else
                 // sum over the block's 16 pixels per entry: rows (y) by register exchange 10 -> 5 -> 3, then x inside the quads
                 float s[6];
 #pragma unroll
                 for (int i = 0; i < 5; i++) {
-#if !(AG_BWD_KNOCKOUT & 8)  /* diagnostic: without the permlane swaps (wrong sums, same arithmetic) */
                     swap32(v[i], v[i + 5]);
-#endif
                     s[i] = v[i] + v[i + 5];
                 }
                 s[5] = 0.f;
                 float u[3];
 #pragma unroll
                 for (int i = 0; i < 3; i++) {
-#if !(AG_BWD_KNOCKOUT & 8)
                     swap16(s[i], s[i + 3]);
-#endif
                     u[i] = s[i] + s[i + 3];      // row 0: value i, row 1: value i+3, row 2: value i+5, row 3: value i+8 (odd rows: u[2] = 0)
                 }
                 // x inside the quads: two butterflies as DPP operands of the additions (spelled out: the compiler sinks the second
@@ -475,15 +387,11 @@ __global__ void __launch_bounds__(64, AG_BWD_WAVE_OCC) blend_backward_wave_kerne
                              "v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
                              : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]));
                 // window: [entry][row][4]; lanes of entries past the end of the ring hold exact zeros (act is false there)
-#if AG_BWD_KNOCKOUT & 16    /* diagnostic: sums computed, no window / flush */
-                asm volatile("" :: "v"(u[0]), "v"(u[1]), "v"(u[2])); continue;
-#endif
                 if (qx == 0) {
                     float* dst = s_out + (win + e) * 16 + ry * 4;
                     dst[0] = u[0]; dst[1] = u[1]; dst[2] = u[2];
                     if (ry == 0) s_wgid[win + e] = __float_as_uint(c.w);
                 }
-#endif
                 win += 4;
                 if (win == kWin) flush();
             }
@@ -510,21 +418,6 @@ int launch_debug_atomic_rate(float* accum, int lines, int blocks, int iters, int
 {
     hipLaunchKernelGGL(debug_atomic_rate_kernel, dim3(blocks), dim3(512), 0, s, accum, (uint32_t)lines, iters, comps);
     return check_hip(hipGetLastError(), "debug_atomic_rate_kernel");
-}
-
-__global__ void __launch_bounds__(64) debug_wave_reduce16_kernel(const float* __restrict__ in, float* __restrict__ out)
-{
-    const int lane = threadIdx.x;
-    float v[16];
-#pragma unroll
-    for (int i = 0; i < 16; i++) v[i] = in[lane * 16 + i];
-    out[lane] = wave_reduce16_transposed(v, lane);
-}
-
-int launch_debug_wave_reduce16(const float* in, float* out, hipStream_t s)
-{
-    hipLaunchKernelGGL(debug_wave_reduce16_kernel, dim3(1), dim3(64), 0, s, in, out);
-    return check_hip(hipGetLastError(), "debug_wave_reduce16_kernel");
 }
 
 int launch_blend_backward(const AgRasterBackwardArgs& a, hipStream_t s)

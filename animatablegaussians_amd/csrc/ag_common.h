@@ -177,7 +177,6 @@ int launch_bin_sort(const AgRasterForwardArgs& a, int R, hipStream_t s);
 int launch_blend_forward(const AgRasterForwardArgs& a, int R, hipStream_t s);
 int launch_blend_backward(const AgRasterBackwardArgs& a, hipStream_t s);
 int launch_preprocess_backward(const AgRasterBackwardArgs& a, hipStream_t s);
-int launch_debug_wave_reduce16(const float* in, float* out, hipStream_t s);
 int launch_debug_atomic_rate(float* accum, int lines, int blocks, int iters, int comps, hipStream_t s);
 int launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t s);
 

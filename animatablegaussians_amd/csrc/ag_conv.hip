@@ -459,14 +459,9 @@ __device__ __forceinline__ void mma_split(const SplitOperands<WMB, WNB>& o, f32x
 // after the barrier, the split + LDS writes of tile k + 1 run under their latency, then the twelve MFMAs.
 // CEXACT: the channel count is a multiple of 16 (every layer but the 3- and 12-channel inputs): no channel clamp, the KG plane
 // pointers of a thread group are kernel constants in scalar registers and the channel-block advance is one scalar byte offset.
-// AG_CONV_KNOCKOUT (diagnostic builds only, profiles/ub/pk_hazard.hip; 0 in the product = every `if constexpr` below keeps the full
-// kernel): phases of the kernel removed one at a time to find which of them disturbs another wave.  Results are garbage when set.
-//   1 no global gathers (A chunks and B activations come from the thread id)     2 no split arithmetic (v_cvt_pk_bf16_f32 and the
-//   exact subtractions; the raw fp32 bits are stored)     4 no LDS writes     8 no LDS operand reads     16 no MFMAs
-#ifndef AG_CONV_KNOCKOUT
-#define AG_CONV_KNOCKOUT 0
-#endif
-constexpr int kKO = AG_CONV_KNOCKOUT;
+// (Round 3 carried compile-time knock-outs of the kernel's phases here -- AG_CONV_KNOCKOUT, used to bisect which phase of this kernel disturbs
+// packed-fp32 instructions of a co-resident wave: profiles/r03_packed_fp32_hazard.md, stand-alone reproducer profiles/ub/pk_hazard.hip.
+// Removed in round 4; commit fa8b937 has them.)
 
 template <int WMB, int WNB, int WVM, int WVN, bool CEXACT, int NTERMS>
 __global__ void __launch_bounds__(64 * WVM * WVN, AG_CONV_WAVES_PER_SIMD) gather_conv_split_kernel(GatherProblem p)
@@ -551,21 +546,15 @@ __global__ void __launch_bounds__(64 * WVM * WVN, AG_CONV_WAVES_PER_SIMD) gather
     Stage S[2];
     SplitOperands<WMB, WNB> O;
     auto gload = [&](Stage& st) {
-        if constexpr (kKO & 1) {
-            st.ra0 = (u32x4){ (uint32_t)tid, 0x3f803f80u, (uint32_t)t_cur, 0x3f003f00u };
-            if constexpr (A2) st.ra1 = st.ra0;
-        } else {
-            st.ra0 = *reinterpret_cast<const u32x4*>(a_ptr + a_voff0);
-            if constexpr (A2) st.ra1 = *reinterpret_cast<const u32x4*>(a_ptr + a_voff1);
-        }
+        st.ra0 = *reinterpret_cast<const u32x4*>(a_ptr + a_voff0);
+        if constexpr (A2) st.ra1 = *reinterpret_cast<const u32x4*>(a_ptr + a_voff1);
         a_ptr += T::a_bytes;
         st.tap_ok = (vmask >> t_cur) & 1u;
         const int toff = __builtin_amdgcn_readlane(toff_vec, t_cur);
         const uint32_t voff = st.tap_ok ? (uint32_t)(pix + toff) * 4u + (CEXACT ? cb_off : 0u) : 0u;
 #pragma unroll
         for (int j = 0; j < KG; j++) {
-            if constexpr (kKO & 1) st.rb[j] = __uint_as_float(0x3f800000u + ((voff + 977u * j) & 0x7fffffu));
-            else st.rb[j] = *reinterpret_cast<const float*>(cbase[j] + voff);     // global_load_dword v, v_off, s[base]
+            st.rb[j] = *reinterpret_cast<const float*>(cbase[j] + voff);     // global_load_dword v, v_off, s[base]
         }
         t_cur++;
         if constexpr (CEXACT) {
@@ -579,14 +568,9 @@ __global__ void __launch_bounds__(64 * WVM * WVN, AG_CONV_WAVES_PER_SIMD) gather
     auto lstore = [&](int buf, const Stage& st) {
         char* As = As0 + buf * T::a_bytes;
         char* Bs = Bs0 + buf * T::b_bytes;
-        if constexpr (!(kKO & 4)) {
-            if (a_thread0) *reinterpret_cast<u32x4*>(As + tid * 16) = st.ra0;
-            if constexpr (A2) {
-                if (a_thread1) *reinterpret_cast<u32x4*>(As + (NT + tid) * 16) = st.ra1;
-            }
-        } else {
-            asm volatile("" :: "v"(st.ra0));
-            if constexpr (A2) asm volatile("" :: "v"(st.ra1));
+        if (a_thread0) *reinterpret_cast<u32x4*>(As + tid * 16) = st.ra0;
+        if constexpr (A2) {
+            if (a_thread1) *reinterpret_cast<u32x4*>(As + (NT + tid) * 16) = st.ra1;
         }
 #pragma unroll
         for (int q = 0; q < KG / 4; q++) {
@@ -595,50 +579,19 @@ __global__ void __launch_bounds__(64 * WVM * WVN, AG_CONV_WAVES_PER_SIMD) gather
             for (int e = 0; e < 2; e++) {
                 const float x0 = st.tap_ok ? st.rb[4 * q + 2 * e] : 0.f, x1 = st.tap_ok ? st.rb[4 * q + 2 * e + 1] : 0.f;
                 uint32_t a, b, c;
-                if constexpr (kKO & 2) { a = __float_as_uint(x0); b = __float_as_uint(x1); c = a ^ b; }
-                else split_pair(x0, x1, a, b, c);
+                split_pair(x0, x1, a, b, c);
                 w0[e] = a; w1[e] = b; w2[e] = c;
             }
-            if constexpr (!(kKO & 4)) {
-                *reinterpret_cast<u32x2*>(Bs + 0 * BN * kRowB + b_woff + 8 * q) = w0;
-                *reinterpret_cast<u32x2*>(Bs + 1 * BN * kRowB + b_woff + 8 * q) = w1;
-                *reinterpret_cast<u32x2*>(Bs + 2 * BN * kRowB + b_woff + 8 * q) = w2;
-            } else {
-                asm volatile("" :: "v"(w0), "v"(w1), "v"(w2));
-            }
+            *reinterpret_cast<u32x2*>(Bs + 0 * BN * kRowB + b_woff + 8 * q) = w0;
+            *reinterpret_cast<u32x2*>(Bs + 1 * BN * kRowB + b_woff + 8 * q) = w1;
+            *reinterpret_cast<u32x2*>(Bs + 2 * BN * kRowB + b_woff + 8 * q) = w2;
         }
     };
     auto lread = [&](int buf) {
-        if constexpr (kKO & 8) {
-#pragma unroll
-            for (int i = 0; i < WMB; i++)
-#pragma unroll
-                for (int pl = 0; pl < kPlanes; pl++) {
-                    u32x4 t = { 0x3f803f80u + (uint32_t)lane, 0x3f003f80u, 0x3f803f00u + (uint32_t)(buf + pl), 0x3e803f80u };
-                    asm volatile("" : "+v"(t));
-                    O.a[i][pl] = __builtin_bit_cast(bf16x8, t);
-                }
-#pragma unroll
-            for (int j = 0; j < WNB; j++)
-#pragma unroll
-                for (int pl = 0; pl < kPlanes; pl++) {
-                    u32x4 t = { 0x3f803f80u + (uint32_t)lane, 0x3f003f80u, 0x3f803f00u + (uint32_t)(buf + pl), 0x3e803f80u };
-                    asm volatile("" : "+v"(t));
-                    O.b[j][pl] = __builtin_bit_cast(bf16x8, t);
-                }
-        } else {
-            read_split_operands<WMB, WNB, BM, BN, NTERMS>(As0 + buf * T::a_bytes, Bs0 + buf * T::b_bytes, wm, wn, lane, O);
-        }
+        read_split_operands<WMB, WNB, BM, BN, NTERMS>(As0 + buf * T::a_bytes, Bs0 + buf * T::b_bytes, wm, wn, lane, O);
     };
     auto mma = [&]() {
-        if constexpr (kKO & 16) {
-#pragma unroll
-            for (int i = 0; i < WMB; i++)
-#pragma unroll
-                for (int j = 0; j < WNB; j++) asm volatile("" : "+v"(acc[i][j]) : "v"(O.a[i][0]), "v"(O.a[i][1]), "v"(O.a[i][2]), "v"(O.b[j][0]), "v"(O.b[j][1]), "v"(O.b[j][2]));
-        } else {
-            mma_split<WMB, WNB, NTERMS>(O, acc);
-        }
+        mma_split<WMB, WNB, NTERMS>(O, acc);
     };
 
     if (nkt > 0) {

@@ -223,12 +223,6 @@ int ag_prof_enable(uint32_t kernel_mask);
 int ag_prof_collect(int32_t* launches /*[AG_K_COUNT]*/, float* total_ms /*[AG_K_COUNT]*/, double* work /*[AG_K_COUNT] or NULL*/);
 
 /*
- * Test hook (tests/ only): runs the wave64 transposed butterfly reduction used by the blend backward on one
- * wavefront.  in: [64 lanes][16 values] floats, out: [64] floats; out[l] = sum over lanes of in[.][(l >> 2) & 15].
- */
-int ag_debug_wave_reduce16(const float* in, float* out, void* stream);
-
-/*
  * Calibration hook (profiles/atomic_rate.py): `blocks` workgroups of 8 waves; every wave issues `iters` instructions, each adding
  * 1.0f to the first `comps` (<= 16) floats of 4 pseudo-random 64-byte lines of accum [lines][16] -- the access shape of the blend
  * backward's flush.  Measures the line-atomic rate of the memory side.

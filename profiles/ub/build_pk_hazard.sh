@@ -2,6 +2,9 @@
 # Builds the stand-alone packed-fp32 hazard reproducer (profiles/ub/pk_hazard) and the knock-out builds of the convolution library it
 # dlopens (profiles/ub/ko/libag_ko<mask>.so = libag_hip.so with ag_conv.hip compiled under -DAG_CONV_KNOCKOUT=<mask>).  Needs the
 # product objects (animatablegaussians_amd/csrc/build.sh) to exist.  Cross-compiles without a GPU.
+# NOTE (round 4): the knock-out switches (-DAG_CONV_KNOCKOUT) were removed from ag_conv.hip once their results were recorded
+# (profiles/r03_packed_fp32_hazard.md); the knock-out library variants build from the round-3 tree: `git checkout fa8b937 -- animatablegaussians_amd/csrc/ag_conv.hip`
+# in a scratch worktree.  The stand-alone reproducer (pk_hazard.hip, its own synthetic aggressor kernel) builds from this tree as before.
 set -eo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 ROOT="$HERE/../.."

@@ -27,22 +27,6 @@ def _bitexact(gpu, ref):
     assert np.array_equal(gpu["point_list"], ref["point_list"]), "sorted point_list differs"
 
 
-def test_wave_reduce16_transposed():
-    import torch
-    from animatablegaussians_amd import _lib
-    rs = np.random.RandomState(0)
-    x = rs.normal(0, 1, (64, 16)).astype(np.float32)
-    # asymmetric, integer-valued part so a wrong lane/value mapping cannot cancel out
-    x += (np.arange(64)[:, None] * 16 + np.arange(16)[None, :]).astype(np.float32)
-    xi = torch.from_numpy(x).cuda()
-    out = torch.zeros(64, device="cuda")
-    _lib.check(_lib.lib().ag_debug_wave_reduce16(ctypes.c_void_p(xi.data_ptr()), ctypes.c_void_p(out.data_ptr()),
-                                                 ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "reduce")
-    torch.cuda.synchronize()
-    want = x.astype(np.float64).sum(0)[(np.arange(64) >> 2) & 15]
-    np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-5)
-
-
 @pytest.mark.parametrize("P,img", [(10000, 512), (3000, 500)])
 def test_forward_config1_bitexact_and_images(P, img):
     scene = synth.random_gaussians(P=P, img=img)
