@@ -153,9 +153,9 @@ class _GroupedLayer(torch.autograd.Function):
         else:
             need_s, need_nw, need_b = False, False, any(pn[G:2 * G])
         wnum = ws[0].numel()
-        gx = torch.empty_like(x) if (nx and not shared) else None
-        if nx and shared:
-            raise RuntimeError("grouped layer: an input shared by the instances cannot receive a gradient")
+        if nx and shared and G > 1:
+            raise RuntimeError("grouped layer: an input shared by several instances cannot receive a gradient")
+        gx = torch.empty_like(x) if nx else None
         want_w = need_w or (modulated and need_s)
         gw = torch.empty((G,) + tuple(ws[0].shape), dtype=torch.float32, device=dev) if want_w else None
         gs = gbn = None

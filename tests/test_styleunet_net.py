@@ -11,10 +11,12 @@ tensor's max |grad| (noise-strength scalars: sums of ~1e7 signed terms), 4e-3 on
 The fixture therefore stores the float64 values plus, per tensor, err32 = that reference-fp32 deviation, and this
 test requires of our fp32 path (dev = |ours - ref64| / max|ref64| per tensor):
   * forward images: dev <= 1e-4 (the north-star tolerance; measured 3e-6, the reference's fp32 1e-6);
-  * gradients, as a distribution over the 219 tensors: our 50/75/90/95/99th percentiles of dev are within 4x the same
-    percentiles of err32 (measured ~2.7x at every percentile: sequential-K MFMA accumulation is a little noisier
-    than oneDNN's blocked sums, and more forward noise selects a few more leaky-ReLU slopes differently);
-  * every single tensor: dev <= 3e-2 (0.25 for the twelve scalar noise strengths) -- a mis-wired layer is O(1)."""
+  * gradients, as a distribution over the 219 tensors: our 50/75/90/95/99th percentiles of dev are within 3x the same
+    percentiles of err32 (measured 1.5-2.7x: sequential-K MFMA accumulation is a little noisier than oneDNN's blocked
+    sums, and more forward noise selects a few more leaky-ReLU slopes differently);
+  * every single tensor: dev <= 1e-2 (5e-2 for the twelve scalar noise strengths, 3e-2 for the pose-map gradient) -- a mis-wired
+    layer is O(1).
+The same bars hold for the single-network path in both arithmetic modes AND for the product's grouped launch chain (grouped.py)."""
 import os
 
 import numpy as np
@@ -94,7 +96,14 @@ def test_dual_styleunet_forward_backward_vs_reference_golden(math):
         agc.set_math(prev)
 
 
-def _golden_body(math):
+@pytest.mark.gpu
+def test_grouped_chain_forward_backward_vs_reference_golden():
+    """The PRODUCT path -- the grouped launch chain of grouped.py (here over one network: one encoder instance, its two decoders as a
+    group of two, the comb convolutions without the concatenation) -- against the same fixture of the reference module, same bars."""
+    _golden_body("split_bf16", grouped=True)
+
+
+def _golden_body(math, grouped=False):
     import torch
     from animatablegaussians_amd import synth
     from animatablegaussians_amd.styleunet import DualStyleUNet
@@ -106,7 +115,11 @@ def _golden_body(math):
     net = net.to(dev)
     pose = synth.pose_map(512).to(dev).requires_grad_(True)
     style = (torch.ones(1, 512) / np.sqrt(512)).to(dev)
-    images, _ = net([style], pose, randomize_noise=False)
+    if grouped:
+        from animatablegaussians_amd.grouped import GroupedStyleUNets
+        images = GroupedStyleUNets([net]).forward([style], pose)[0]
+    else:
+        images, _ = net([style], pose, randomize_noise=False)
     assert images.shape == (1, 6, 1024, 1024)
 
     scale = float(gold["images_max"])
@@ -132,19 +145,24 @@ def _golden_body(math):
     ours, ref = np.array([o for o, _, _ in rows]), np.array([r for _, r, _ in rows])
     out_dir = os.environ.get("AG_TEST_REPORT_DIR")
     if out_dir:
-        with open(os.path.join(out_dir, f"styleunet_grad_report_{math}.txt"), "w") as f:
+        with open(os.path.join(out_dir, f"styleunet_grad_report_{math}{'_grouped' if grouped else ''}.txt"), "w") as f:
             for o, r, n in fwd_rows:
                 f.write(f"forward {n}: ours {o:.3e} ref32 {r:.3e}\n")
             for q in (50, 75, 90, 95, 99, 100):
                 f.write(f"p{q}: ours {np.percentile(ours, q):.3e} ref32 {np.percentile(ref, q):.3e}\n")
             for o, r, n in sorted(rows, reverse=True):
                 f.write(f"ours {o:.3e} ref32 {r:.3e} {n}\n")
+    # Round 4 (bias / noise-strength / style reductions deterministic, two-stage): measured ours / reference-fp32 = 2.7, 1.7-2.2, 1.6-2.1,
+    # 1.7-2.3, 1.5-1.6 at the 50/75/90/95/99th percentiles (profiles/r04_styleunet_grad_report_*.txt, all three paths): bar 3x (was 4x)
     for q in (50, 75, 90, 95, 99):
-        assert np.percentile(ours, q) <= 4 * np.percentile(ref, q), (q, np.percentile(ours, q), np.percentile(ref, q))
-    # per-tensor caps: 3e-2 of the tensor's largest gradient; the noise-strength scalars (one number each, a sum over a whole feature map
-    # of products with mixed signs) are where the reference's own fp32 deviates most from its fp64 (6e-2): twice that
+        assert np.percentile(ours, q) <= 3 * np.percentile(ref, q), (q, np.percentile(ours, q), np.percentile(ref, q))
+    # per-tensor caps (fraction of the tensor's largest gradient; were 3e-2 / 0.12 with the atomically summed scalars): 1e-2 for
+    # parameter tensors (measured worst 5.4e-3); 5e-2 for the twelve noise-strength scalars -- one number each, a sum over a whole
+    # feature map of products with mixed signs, where the reference's OWN fp32 run is off by 6.1e-2 (convs2.5; ours 3.0e-2 there, every
+    # other one <= 5.4e-3); 3e-2 for the pose-map gradient (an activation gradient, max over 98 k samples: isolated leaky-ReLU slope
+    # flips; reference fp32 4.3e-3, ours 1.7e-2 on the grouped chain)
     for o, _, n in rows:
-        assert o <= (0.12 if n.endswith("noise.weight") else 3e-2), (n, o)
+        assert o <= (5e-2 if n.endswith("noise.weight") else 3e-2 if n == "pose" else 1e-2), (n, o)
 
 
 @pytest.mark.gpu
