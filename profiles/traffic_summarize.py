@@ -28,6 +28,10 @@ def find(acc, frag):
 # calibration: the clone kernel (a vectorised elementwise copy) with exactly 256 MiB read and written per launch
 cal_f = [v for k, vs in fetch.items() if "direct_copy" in k or "copy" in k.lower() for v in vs if v * KB > 0.2 * cal_bytes]
 cal_w = [v for k, vs in write.items() if "direct_copy" in k or "copy" in k.lower() for v in vs if v * KB > 0.2 * cal_bytes]
+# the calibration clones are the LARGEST copies of the run (other copies -- gradient accumulation of the probe's 64-MB maps -- pass the
+# size filter too since round 4's probe also runs the gather / LBS kernels): keep the launches within 5 % of the largest
+cal_f = [v for v in cal_f if v >= 0.95 * max(cal_f)] if cal_f else cal_f
+cal_w = [v for v in cal_w if v >= 0.95 * max(cal_w)] if cal_w else cal_w
 fcorr = cal_bytes / (sum(cal_f) / len(cal_f) * KB) if cal_f else None
 wcorr = cal_bytes / (sum(cal_w) / len(cal_w) * KB) if cal_w else None
 out = {"calibration": {"bytes_each_way": cal_bytes, "fetch_correction": fcorr, "write_correction": wcorr,

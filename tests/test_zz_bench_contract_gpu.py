@@ -63,10 +63,10 @@ def test_bench_json_line():
     for k in ("gather_conv_kernel", "wgrad_kernel"):
         assert q[k]["launches_timed"] > 0 and 1.0 < q[k]["TFLOPs"] < 157.3
     # every convolution FLOP of the three networks' forward + backward is accounted for: 3 x 586 GFLOP x 3 (forward, input gradient,
-    # weight gradient); the pose map needs no gradient and the grouped chain runs the branch-independent first comb convolution once
-    # per network instead of once per branch, so a little less than 9 x 586
+    # weight gradient); the pose map needs no gradient and the grouped chain runs the branch-independent parts of the comb convolutions
+    # (the whole first one, the encoder-level half of the others) once per network instead of once per branch: 11 % less than 9 x 586
     total = m["gather_conv_kernel"]["GFLOP_per_pass_of_the_three_networks"] + m["wgrad_kernel"]["GFLOP_per_pass_of_the_three_networks"]
-    assert 0.93 * 9 * 585.8 < total < 1.01 * 9 * 585.8, total
+    assert 0.85 * 9 * 585.8 < total < 1.01 * 9 * 585.8, total          # 4700 of 5272 GFLOP: the comb convolutions' level halves run once per network
     # the per-Gaussian assembly / skinning kernels against HBM (north_star's third hand-written stage)
     a = d["roofline_avatar_kernels"]
     for k in ("gather_forward", "gather_backward", "lbs_forward", "lbs_backward"):
