@@ -404,6 +404,19 @@ def full_step_probe(dev, block=4, blocks=5):
         ms16 = float(np.median(t16))
         out["views16_one_pose_configs3_n1"] = {"views_per_s": round(16e3 / ms16, 2), "ms_per_step": round(ms16, 2),
                                                "ms_per_step_min_max": [round(float(np.min(t16)), 2), round(float(np.max(t16)), 2)], "steps_timed": 6}
+        # SURVEY 3.4 (`--mode=test`: animation / free-view synthesis): the eval-mode render of one view (three networks forward, assembly, LBS,
+        # rasterizer forward), eager and with the networks replayed from ONE captured hipGraph (AvatarNet.enable_graphs)
+        step.net.eval()
+        try:
+            e_ms = float(np.median([timed(lambda i: step.infer(i, 1), block, 0 if r else 2, dev) for r in range(3)]))
+            step.net.enable_graphs(True)
+            g_ms = float(np.median([timed(lambda i: step.infer(i, 1), block, 0 if r else 3, dev) for r in range(3)]))
+            out["inference_1view"] = {"views_per_s": round(1e3 / e_ms, 2), "ms_per_view": round(e_ms, 2),
+                                      "views_per_s_hip_graphs": round(1e3 / g_ms, 2), "ms_per_view_hip_graphs": round(g_ms, 2),
+                                      "what": "AvatarNet.render in eval mode under no_grad, pose map included (main_avatar.py:525-776)"}
+        finally:
+            step.net.enable_graphs(False)
+            step.net.train()
         del step
         torch.cuda.empty_cache()
         step_lp = TrainingStep(dev, lpips=True)

@@ -235,3 +235,32 @@ def test_grouped_multi_view_equals_per_view_renders(net):
             # the image goes through the rasterizer's discrete decisions: compare away from them
             d = (m['rgb_map'] - single['rgb_map']).abs()
             assert float((d > 1e-3).float().mean()) < 1e-3, float((d > 1e-3).float().mean())
+
+
+def test_grouped_chain_without_view_directions_and_under_no_grad():
+    """`with_viewdirs=False` (network/avatar.py:21,42): no view feature reaches the colour network -- the grouped chain then never copies the
+    shared decoder state; eval / no-grad calls; one and three views."""
+    import torch
+    from animatablegaussians_amd import synth
+    from animatablegaussians_amd.avatar import AvatarNet
+    torch.manual_seed(31359)
+    net = AvatarNet.synthetic({'with_viewdirs': False})
+    items = _items(net)
+    net.get_pose_map(items)
+    net.eval()
+    pose = items['smpl_pos_map'][:3]
+    with torch.no_grad():
+        got = net.get_maps(pose)
+        prev = net.set_grouped(False)
+        try:
+            want = net.get_maps(pose)
+        finally:
+            net.set_grouped(prev)
+        for a, b, name in zip(got, want, ("position", "other", "colour")):
+            _close(a, b, name, tol=2e-5)
+        cams = synth.free_view_cameras(3, img=1024)
+        views = [{'extr': torch.from_numpy(np.ascontiguousarray(c["extr"])).float().cuda(),
+                  'intr': torch.from_numpy(np.ascontiguousarray(c["intr"])).float().cuda(), 'img_w': 1024, 'img_h': 1024} for c in cams]
+        multi = net.render_views(items, views)
+        single = net.render({**items, **views[1]})
+        _close(multi[1]['cano_tex_map'], single['cano_tex_map'], "colour map of view 1", tol=2e-5)

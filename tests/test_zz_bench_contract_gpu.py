@@ -79,6 +79,8 @@ def test_bench_json_line():
     assert "extra_legs_error" not in f, f.get("extra_legs_error")
     v16 = f["views16_one_pose_configs3_n1"]
     assert abs(v16["views_per_s"] * v16["ms_per_step"] - 16000.0) < 100.0 and v16["views_per_s"] > f["views_per_s_4views_per_step"] * 0.8
+    inf = f["inference_1view"]
+    assert inf["views_per_s"] > 2 * f["views_per_s_1view_per_step"] and inf["views_per_s_hip_graphs"] > 0.8 * inf["views_per_s"]
     lp = f["with_the_references_full_loss"]
     assert 1.0 < lp["views_per_s_1view_per_step"] <= f["views_per_s_1view_per_step"] * 1.1
 
