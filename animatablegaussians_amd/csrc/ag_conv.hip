@@ -146,6 +146,12 @@ struct GatherProblem {
     long long at_gs;       // packed-weight elements (the unit of GatherClass::at_off) between the instances' packed weights
     long long part_gs;     // floats between the instances' split-K partial images (= splits * Mpad * Ncols)
     PtrTable bias_t;       // per-instance bias (replaces `bias`, which is kept for the epilogue's signature and set per workgroup)
+    // activation inside the epilogue / the split-K finish (round 4; plain gathers only): y = lrelu((acc + nw * noise[pix] | + addend[m][pix])
+    // + bias[m], slope) * act_scale -- the expression of noise_bias_act_forward_kernel, so the pre-activation tensor never goes to memory
+    int act;               // 0: none, 1: noise form, 2: addend form
+    float slope, act_scale;
+    PtrTable noise_t;      // act 1: per-instance noise [OHf * OWf] (null: no noise); act 2: per-instance addend [M][OHf * OWf]
+    PtrTable nw_t;         // act 1: per-instance noise weight [1]
     GatherClass cls[kMaxClasses];
 };
 
@@ -156,6 +162,8 @@ struct GroupView {
     float* yout;
     float* partial;
     const float* bias;
+    const float* noise;          // activation operands of the instance (GatherProblem::act)
+    float nw;
 };
 __device__ __forceinline__ GroupView group_view(const GatherProblem& p)
 {
@@ -166,6 +174,8 @@ __device__ __forceinline__ GroupView group_view(const GatherProblem& p)
     v.yout = p.yout + (size_t)v.grp * p.y_gs;
     v.partial = p.partial ? p.partial + (size_t)v.grp * p.part_gs : nullptr;
     v.bias = p.bias_t.p[v.grp];
+    v.noise = p.act ? p.noise_t.p[v.grp] : nullptr;
+    v.nw = (p.act == 1 && v.noise) ? p.nw_t.p[v.grp][0] : 1.0f;
     return v;
 }
 
@@ -210,6 +220,17 @@ __device__ __forceinline__ void gather_epilogue(const GatherProblem& p, const Gr
             if (m >= p.M) continue;
             const float sc = has_scale ? p.out_scale[m] : 1.f, bi = has_bias ? gv.bias[m] : 0.f;
             float* row = gv.yout + (size_t)m * p.OHf * p.OWf;
+            if (p.act) {
+                // noise: one value per pixel; addend: one per (row, pixel)
+                const float* nz = gv.noise ? (p.act == 2 ? gv.noise + (size_t)m * p.OHf * p.OWf : gv.noise) : nullptr;
+#pragma unroll
+                for (int j = 0; j < WNB; j++)
+                    if (nn[j] < N) {
+                        const float t = fmaf(gv.nw, nz ? nz[opix[j]] : 0.f, acc[i][j][r]) + bi;
+                        row[opix[j]] = (t > 0.f ? t : t * p.slope) * p.act_scale;
+                    }
+                continue;
+            }
 #pragma unroll
             for (int j = 0; j < WNB; j++)
                 if (nn[j] < N) row[opix[j]] = acc[i][j][r] * sc + bi;
@@ -643,10 +664,18 @@ __global__ void __launch_bounds__(256) reduce_splits_kernel(GatherProblem p, int
     const float* __restrict__ partial = p.partial + (size_t)grp * p.part_gs;
     const float* __restrict__ bias = p.bias_t.p[grp];
     float* __restrict__ yout = p.yout + (size_t)grp * p.y_gs;
+    const float* __restrict__ noise = p.act ? p.noise_t.p[grp] : nullptr;
+    const float nw = (p.act == 1 && noise) ? p.nw_t.p[grp][0] : 1.0f;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int m = (int)(i / Nc), colg = (int)(i - (long long)m * Nc);
         float v = 0.f;
         for (int z = 0; z < splits; z++) v += partial[z * zstride + i];
+        if (p.act) {        // plain gather (one class, os = 1): column = output pixel
+            const float nv = noise ? (p.act == 2 ? noise[(size_t)m * Nc + colg] : noise[colg]) : 0.f;
+            const float t = fmaf(nw, nv, v) + (bias ? bias[m] : 0.f);
+            yout[(size_t)m * Nc + colg] = (t > 0.f ? t : t * p.slope) * p.act_scale;
+            continue;
+        }
         if (p.out_scale) v *= p.out_scale[m];
         if (bias) v += bias[m];
         int ci = 0;
@@ -1402,6 +1431,10 @@ static int run_gather_family(const AgConvDesc* d, bool backward_input, int G, co
     GatherProblem gp;
     gp.out_scale = out_scale; gp.bias_t = bias; gp.yout = yout; gp.xin = xin;
     gp.G = G; gp.x_gs = x_gs; gp.y_gs = y_gs;
+    gp.act = opt.act ? opt.act->kind : 0;
+    gp.slope = opt.act ? opt.act->slope : 0.f; gp.act_scale = opt.act ? opt.act->scale : 1.f;
+    gp.noise_t = opt.act ? opt.act->noise : PtrTable{}; gp.nw_t = opt.act ? opt.act->nw : PtrTable{};
+    if (gp.act && (out_scale || backward_input)) { set_error("conv: the fused activation is a forward option without out_scale"); return AG_ERR_INVALID_ARGUMENT; }
     const bool conv = d->kind == AG_CONV;
     // input of the GEMM / output of the GEMM in tensor terms
     int Cg, Hg, Wg, M, OHf, OWf;
@@ -1424,6 +1457,7 @@ static int run_gather_family(const AgConvDesc* d, bool backward_input, int G, co
     // "gather" cases: forward conv, input gradient of a transposed conv (a stride-2 conv over dy), input gradient of a
     // stride-1 conv (taps mirrored).  "scatter" cases (stride 2): transposed conv forward, input gradient of a stride-2 conv.
     const bool scatter = (conv && backward_input && d->stride == 2) || (!conv && !backward_input);
+    if (gp.act && scatter) { set_error("conv: the fused activation needs a plain gather (no transposed convolution)"); return AG_ERR_UNSUPPORTED; }
     if (!scatter) {
         TapSet& ts = taps[0]; ts.n = k2;
         for (int ky = 0; ky < k; ky++) for (int kx = 0; kx < k; kx++) { ts.ky[ky * k + kx] = ky; ts.kx[ky * k + kx] = kx; }
@@ -1492,7 +1526,7 @@ int conv_forward_g(const AgConvDesc* d, int G, const float* x, long long x_gs, c
     int rc = validate(d);
     if (rc) return rc;
     if (G < 1 || G > kMaxGroups || !x || !table_complete(w, G) || !y) { set_error("null conv tensor / bad group count"); return AG_ERR_INVALID_ARGUMENT; }
-    if (!o.w_cin_total && (rc = pointwise_forward(d, G, x, x_gs, w, out_scale, bias, y, y_gs, s)) != 0) return rc < 0 ? rc : AG_OK;
+    if (!o.w_cin_total && !o.act && (rc = pointwise_forward(d, G, x, x_gs, w, out_scale, bias, y, y_gs, s)) != 0) return rc < 0 ? rc : AG_OK;
     return run_gather_family(d, false, G, x, x_gs, w, out_scale, bias, y, y_gs, workspace, workspace_bytes, s, o);
 }
 

@@ -73,8 +73,20 @@ int block2x2_transform_g(float* out, const float* in, const float* matrix16_host
 }  // namespace ag
 struct AgConvDesc;
 namespace ag {
+// Activation applied inside a forward convolution's epilogue (or its split-K finish): y = lrelu((acc + nw_g[0] * noise_g[pix]) + bias_g[m], slope)
+// * scale (kind 1, the StyledConv / ConvLayer tail: dual_styleunet.py:598-604,367-369; a null noise entry = no noise) or
+// y = lrelu((acc + addend_g[m][pix]) + bias_g[m], slope) * scale (kind 2: a comb convolution's level half).  The bias is the call's bias table.
+// Same expression, same bits as noise_bias_act_forward_kernel on the stored pre-activation tensor.
+struct ConvAct {
+    int kind;
+    float slope, scale;
+    PtrTable noise;          // kind 1: noise maps; kind 2: addends
+    PtrTable nw;             // kind 1: noise weights
+};
+
 // Options of a grouped convolution call.
 struct ConvOpts {
+    const ConvAct* act = nullptr;   // forward, plain gathers (not the transposed convolution) only
     bool wt_oihw = false;     // the weights (and weight gradients) of a TRANSPOSED convolution are laid out [Cout][Cin][k][k] like a convolution's
                               // instead of conv_transpose2d's [Cin][Cout][k][k] (ignored for AG_CONV)
     int w_cin_total = 0;      // forward / input gradient of an AG_CONV on a channel SLICE of a wider weight tensor [Cout][w_cin_total][k][k]: the

@@ -51,6 +51,14 @@ size_t pad64(size_t n) { return (n + 63) / 64 * 64; }
 
 const ConvOpts kOihw = [] { ConvOpts o; o.wt_oihw = true; return o; }();
 
+// The activation pass (noise + bias + leaky ReLU) inside the convolution's epilogue wherever no Blur sits between the two (round 4: the
+// pre-activation tensor is neither written nor re-read).  AG_FUSED_ACT=0: the separate pass (same bits; same-box A/B, profiles/).
+bool fused_act()
+{
+    static const bool on = [] { const char* e = getenv("AG_FUSED_ACT"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 // float offsets of the regions inside `scratch`
 struct Scratch {
     size_t pre, aux, g_blur, g_wm, nba_part, mod_part, total;
@@ -144,6 +152,12 @@ int ag_grouped_layer_forward(const AgGroupedLayerArgs* a, void* stream)
             cx = a->x_blur;
             cx_gs = n_in == 1 ? 0 : (long long)a->Cin * g.BH * g.BW;
         }
+        if (fused_act() && !(a->k == 1 && a->Cin <= 4)) {       // (the 3-channel FromRGB convolutions run on the streaming 1 x 1 kernel, which has no such epilogue)
+            ConvAct act{ 1, a->slope, a->act_scale, PtrTable{}, PtrTable{} };
+            ConvOpts o;
+            o.act = &act;
+            return conv_forward_g(&g.d, G, cx, cx_gs, w_t, nullptr, bias_t, a->out, pre_gs, a->workspace, a->workspace_bytes, s, o);
+        }
         if ((rc = conv_forward_g(&g.d, G, cx, cx_gs, w_t, nullptr, PtrTable{}, pre, pre_gs, a->workspace, a->workspace_bytes, s))) return rc;
         return noise_bias_act_forward_g(a->out, pre, G, PtrTable{}, PtrTable{}, bias_t, a->Cout, g.OH * g.OW, a->slope, a->act_scale, s);
     }
@@ -164,6 +178,12 @@ int ag_grouped_layer_forward(const AgGroupedLayerArgs* a, void* stream)
         if ((rc = conv_forward_g(&g.d, G, a->x, x_gs, wm_t, nullptr, PtrTable{}, aux, (long long)a->Cout * g.CH * g.CW, a->workspace, a->workspace_bytes, s, kOihw))) return rc;
         if ((rc = ag_upfirdn2d(pre, aux, a->k_blur, G * a->Cout, g.CH, g.CW, 4, 4, 1, 1, 1, 1, 1, 1, 1, 1, stream))) return rc;
     } else {
+        if (fused_act()) {
+            ConvAct act{ 1, a->slope, a->act_scale, noise_t, nw_t };
+            ConvOpts o;
+            o.act = &act;
+            return conv_forward_g(&g.d, G, a->x, x_gs, wm_t, nullptr, bias_t, a->out, pre_gs, a->workspace, a->workspace_bytes, s, o);
+        }
         if ((rc = conv_forward_g(&g.d, G, a->x, x_gs, wm_t, nullptr, PtrTable{}, pre, pre_gs, a->workspace, a->workspace_bytes, s))) return rc;
     }
     return noise_bias_act_forward_g(a->out, pre, G, noise_t, nw_t, bias_t, a->Cout, g.OH * g.OW, a->slope, a->act_scale, s);
@@ -397,6 +417,12 @@ int ag_grouped_comb_forward(const AgGroupedCombArgs* a, void* stream)
     const AgConvDesc d1 = comb_desc(a, a->C1), d2 = comb_desc(a, a->C2);
     int rc;
     if ((rc = conv_forward_g(&d2, a->N, a->lev, a->C2 * hw, w2, nullptr, PtrTable{}, t, a->Cout * hw, a->workspace, a->workspace_bytes, s, o))) return rc;
+    if (fused_act()) {
+        ConvAct act{ 2, a->slope, a->act_scale, addend, PtrTable{} };
+        ConvOpts oa = o;
+        oa.act = &act;
+        return conv_forward_g(&d1, a->M, a->x, a->C1 * hw, w1, nullptr, bias, a->out, a->Cout * hw, a->workspace, a->workspace_bytes, s, oa);
+    }
     if ((rc = conv_forward_g(&d1, a->M, a->x, a->C1 * hw, w1, nullptr, PtrTable{}, pre, a->Cout * hw, a->workspace, a->workspace_bytes, s, o))) return rc;
     return bias_act_forward_addend_g(a->out, pre, a->M, addend, bias, a->Cout, (int)hw, a->slope, a->act_scale, s);
 }

@@ -87,15 +87,16 @@ __global__ void __launch_bounds__(256) noise_bias_act_forward_kernel(float* __re
             if (noise) n = *reinterpret_cast<const float4*>(noise + p);
             float4 o;
             float t;
-            t = v.x + w * n.x + b; o.x = (t > 0.f ? t : t * slope) * scale;
-            t = v.y + w * n.y + b; o.y = (t > 0.f ? t : t * slope) * scale;
-            t = v.z + w * n.z + b; o.z = (t > 0.f ? t : t * slope) * scale;
-            t = v.w + w * n.w + b; o.w = (t > 0.f ? t : t * slope) * scale;
+            // fmaf spelled out: the convolution epilogue evaluates the same expression when the activation is fused into it (ag_conv.hip)
+            t = fmaf(w, n.x, v.x) + b; o.x = (t > 0.f ? t : t * slope) * scale;
+            t = fmaf(w, n.y, v.y) + b; o.y = (t > 0.f ? t : t * slope) * scale;
+            t = fmaf(w, n.z, v.z) + b; o.z = (t > 0.f ? t : t * slope) * scale;
+            t = fmaf(w, n.w, v.w) + b; o.w = (t > 0.f ? t : t * slope) * scale;
             *reinterpret_cast<float4*>(yr + p) = o;
         }
     } else {
         for (int p = p0 + threadIdx.x; p < pend; p += 256) {
-            const float t = xr[p] + (noise ? w * noise[p] : 0.f) + b;
+            const float t = fmaf(w, noise ? noise[p] : 0.f, xr[p]) + b;
             yr[p] = (t > 0.f ? t : t * slope) * scale;
         }
     }
