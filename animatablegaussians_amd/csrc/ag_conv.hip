@@ -978,14 +978,23 @@ __global__ void __launch_bounds__(64 * WVM * WVN, AG_CONV_WAVES_PER_SIMD) wgrad_
 // pixels of a row (one 8-byte LDS write per plane); B: one pixel of BC columns -- neighbouring lanes hold neighbouring pixels, so
 // lane pairs swap one value per column pair (DPP quad_perm) and every lane ends up with TWO adjacent pixels of one column of the pair:
 // a 4-byte LDS write per plane and column pair instead of four 2-byte ones.
-template <int WMB, int WNB, int WVM, int WVN, bool AVEC, int NTERMS>
+// BVEC (round 4): the gathered operand loaded along the K axis as well.  For a stride-1 "same" convolution whose row length is a multiple of
+// 16, the 16 pixels of a K tile are one run of one image row, so a column (channel, tap) of the tile is 16 CONSECUTIVE input values (shifted by
+// the tap): a thread takes 4 of them with one 16-byte load (unaligned 16-byte loads are free on this part: profiles/ub/load_rate.hip) instead
+// of one value of 4 / 8 columns with as many 4-byte gathers, holds both values of every bf16 pair itself (no DPP exchange with the neighbour
+// lane) and writes 8 bytes per plane.  Zero padding: a row outside the image masks the whole quad; a tap displacement of -1 / +1 reaches
+// outside at the first / last quad of a row -- that quad is loaded UN-shifted and moved by one register with a zero at the open end, so
+// every load stays inside the tensor and unconditional.  PMC of the scalar form (r04_pmc_wgrad_256_256_128.txt): 140 VALU instructions per wave
+// and K tile for 12 MFMAs -- the weight gradient was bound by its loader's instruction count, not by the matrix pipe.
+template <int WMB, int WNB, int WVM, int WVN, bool AVEC, int NTERMS, bool BVEC = false>
 __global__ void __launch_bounds__(64 * WVM * WVN, AG_CONV_WAVES_PER_SIMD) wgrad_split_kernel(WgradProblem p)
 {
     using T = SplitTile<WMB, WNB, WVM, WVN>;
     constexpr int BM = T::BM, BN = T::BN, NT = T::NT;
     constexpr int BSTEP = NT / 16;
     constexpr int BC = BN / BSTEP;
-    static_assert(BM * 4 <= NT && BC % 2 == 0, "loader shapes");
+    constexpr int BCV = BN / (NT / 4);                 // BVEC: columns per thread (a thread = 4 consecutive k of a column)
+    static_assert(BM * 4 <= NT && BC % 2 == 0 && BCV >= 1, "loader shapes");
     __shared__ __attribute__((aligned(16))) char smem[T::lds_bytes];
     char* const As0 = smem;
     char* const Bs0 = smem + 2 * T::a_bytes;
@@ -1027,6 +1036,21 @@ __global__ void __launch_bounds__(64 * WVM * WVN, AG_CONV_WAVES_PER_SIMD) wgrad_
     int kpix = kbeg + bk;
     int gy = kpix / p.gw, gx = kpix - gy * p.gw;
     const int qstep = BK / p.gw, rstep = BK - qstep * p.gw;
+    // BVEC state: this thread's k quad, its columns' channel base / tap displacement, LDS word, and the tile's first pixel (row gy0, column gx0)
+    const int vq = tid & 3, vn = tid >> 2;
+    int vcol_base[BCV], vcol_dy[BCV], vcol_dx[BCV], vb_woff[BCV];
+    if constexpr (BVEC) {
+#pragma unroll
+        for (int j = 0; j < BCV; j++) {
+            const int nn = n0 + vn + (NT / 4) * j;
+            const int c = min(nn / p.ntaps, p.Cg - 1), t = nn % p.ntaps;
+            vcol_dy[j] = (nn < Nw) ? p.dy[t] : (1 << 28);
+            vcol_dx[j] = p.dx[t];
+            vcol_base[j] = c * plane;
+            vb_woff[j] = chunk_off(vn + (NT / 4) * j, (4 * vq) >> 3) + ((4 * vq) & 7) * 2;
+        }
+    }
+    int gy0 = kbeg / p.gw, gx0 = kbeg - gy0 * p.gw;
 
     f32x16 acc[WMB][WNB];
 #pragma unroll
@@ -1038,8 +1062,9 @@ __global__ void __launch_bounds__(64 * WVM * WVN, AG_CONV_WAVES_PER_SIMD) wgrad_
 
     struct Stage {
         f32x4 ra;
-        float rb[BC];
-        uint32_t ok;
+        float rb[BVEC ? 1 : BC];
+        f32x4 rv[BVEC ? BCV : 1];
+        uint32_t ok;           // bit 31: the A quad is real; scalar form: bit j = column j's value is real; BVEC: 2 bits per column (row ok, edge code)
     };
     Stage S[2];
     SplitOperands<WMB, WNB> O;
@@ -1057,6 +1082,25 @@ __global__ void __launch_bounds__(64 * WVM * WVN, AG_CONV_WAVES_PER_SIMD) wgrad_
             }
         }
         uint32_t ok = a_ok ? 0x80000000u : 0u;
+        if constexpr (BVEC) {
+            // whole tiles only (host: pixel count and slice length are multiples of 16): row gy0, columns gx0 .. gx0 + 15
+            const int x0 = gx0 + 4 * vq;
+#pragma unroll
+            for (int j = 0; j < BCV; j++) {
+                const int iy = gy0 + vcol_dy[j], ix = x0 + vcol_dx[j];
+                const bool row_ok = (unsigned)iy < (unsigned)p.Hg;
+                const int edge = ix < 0 ? 1 : (ix + 4 > p.Wg ? 2 : 0);           // the quad sticks out by one element on the left / right
+                const int lx = ix + (edge == 1 ? 1 : 0) - (edge == 2 ? 1 : 0);
+                st.rv[j] = *reinterpret_cast<const f32x4*>(xin_g + vcol_base[j] + (row_ok ? iy : gy0) * p.Wg + lx);
+                ok |= ((row_ok ? 1u : 0u) | ((uint32_t)edge << 1)) << (3 * j);
+            }
+            st.ok = ok;
+            gx0 += BK;
+            const bool wrap0 = gx0 >= p.gw;
+            gx0 -= wrap0 ? p.gw : 0;
+            gy0 += wrap0 ? 1 : 0;
+            return;
+        }
         const bool k_ok = kpix < kend;
         const int iy0 = gy * p.sy, ix0 = gx * p.sx;
         const int pixoff = iy0 * p.Wg + ix0;
@@ -1090,6 +1134,28 @@ __global__ void __launch_bounds__(64 * WVM * WVN, AG_CONV_WAVES_PER_SIMD) wgrad_
             *reinterpret_cast<u32x2*>(As + 0 * BM * kRowB + a_woff) = w0;
             *reinterpret_cast<u32x2*>(As + 1 * BM * kRowB + a_woff) = w1;
             *reinterpret_cast<u32x2*>(As + 2 * BM * kRowB + a_woff) = w2;
+        }
+        if constexpr (BVEC) {
+#pragma unroll
+            for (int j = 0; j < BCV; j++) {
+                const uint32_t f = (st.ok >> (3 * j)) & 7u;
+                const f32x4 L = st.rv[j];
+                f32x4 v = L;
+                if (f & 2u) v = f32x4{ 0.f, L[0], L[1], L[2] };           // left edge: loaded un-shifted, element -1 is padding
+                if (f & 4u) v = f32x4{ L[1], L[2], L[3], 0.f };           // right edge
+                if (!(f & 1u)) v = f32x4{ 0.f, 0.f, 0.f, 0.f };           // row outside the image (or a column past the last one)
+                u32x2 w0, w1, w2;
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    uint32_t a, b, c;
+                    split_pair(v[2 * e], v[2 * e + 1], a, b, c);
+                    w0[e] = a; w1[e] = b; w2[e] = c;
+                }
+                *reinterpret_cast<u32x2*>(Bs + 0 * BN * kRowB + vb_woff[j]) = w0;
+                *reinterpret_cast<u32x2*>(Bs + 1 * BN * kRowB + vb_woff[j]) = w1;
+                *reinterpret_cast<u32x2*>(Bs + 2 * BN * kRowB + vb_woff[j]) = w2;
+            }
+            return;
         }
 #pragma unroll
         for (int h = 0; h < BC / 2; h++) {
@@ -1598,6 +1664,16 @@ int conv_backward_weight_g(const AgConvDesc* d, int G, const float* x, long long
     if (split_math()) {
         const bool six = split_terms() == 6;
 #define AG_LAUNCH_WSPLIT(WMB, WNB, AV, NTM) hipLaunchKernelGGL((wgrad_split_kernel<WMB, WNB, 2, 4, AV, NTM>), grid, dim3(512), 0, s, wp)
+#define AG_LAUNCH_WSPLIT_V(WMB, WNB, NTM) hipLaunchKernelGGL((wgrad_split_kernel<WMB, WNB, 2, 4, true, NTM, true>), grid, dim3(512), 0, s, wp)
+        // the K-vectorised loader of the gathered operand: stride-1 "same" convolutions with rows of a multiple of 16 pixels (every 3 x 3 stride-1
+        // layer of the product), whole K tiles per slice; AG_WGRAD_BVEC=0 keeps the scalar gathers (A/B)
+        static const bool bvec_on = [] { const char* e = getenv("AG_WGRAD_BVEC"); return !(e && e[0] == '0'); }();
+        const bool bvec = bvec_on && avec && d->kind == AG_CONV && d->stride == 1 && wp.gw == wp.Wg && wp.gh == wp.Hg && (wp.gw & 15) == 0 && wp.gw >= 16 &&
+                          (Kp & 15) == 0 && (wp.ksplit_len & 15) == 0 && 2 * d->padding + 1 == k && k <= 3;
+        if (bvec) {
+            if (bm == 64) { if (six) AG_LAUNCH_WSPLIT_V(1, 2, 6); else AG_LAUNCH_WSPLIT_V(1, 2, 3); }
+            else          { if (six) AG_LAUNCH_WSPLIT_V(2, 1, 6); else AG_LAUNCH_WSPLIT_V(2, 1, 3); }
+        } else
         if (bm == 64) {
             if (avec) { if (six) AG_LAUNCH_WSPLIT(1, 2, true, 6); else AG_LAUNCH_WSPLIT(1, 2, true, 3); }
             else      { if (six) AG_LAUNCH_WSPLIT(1, 2, false, 6); else AG_LAUNCH_WSPLIT(1, 2, false, 3); }
@@ -1606,6 +1682,7 @@ int conv_backward_weight_g(const AgConvDesc* d, int G, const float* x, long long
             else      { if (six) AG_LAUNCH_WSPLIT(2, 1, false, 6); else AG_LAUNCH_WSPLIT(2, 1, false, 3); }
         }
 #undef AG_LAUNCH_WSPLIT
+#undef AG_LAUNCH_WSPLIT_V
     } else if (bm == 64) {
         if (avec) hipLaunchKernelGGL((wgrad_kernel<1, 2, 2, 4, true>), grid, dim3(512), 0, s, wp);
         else      hipLaunchKernelGGL((wgrad_kernel<1, 2, 2, 4, false>), grid, dim3(512), 0, s, wp);

@@ -40,6 +40,11 @@ CASES = [
     ("tiles_c3x3_s2_dgrad", "conv", 16, 32, 129, 129, 3, 2, 0),
     ("tiles_c1x1", "conv", 64, 160, 64, 64, 1, 1, 0),
     ("tiles_c3x3_k_split", "conv", 256, 64, 32, 32, 3, 1, 1),
+    # the K-vectorised weight-gradient loader (round 4: stride-1 "same" convolutions with rows of a multiple of 16 pixels): a row length that
+    # is not a power of two, the narrowest row (every quad of a row is an edge quad or next to one), more than one column per thread
+    ("bvec_c3x3_w48", "conv", 24, 40, 20, 48, 3, 1, 1),
+    ("bvec_c3x3_w16", "conv", 40, 72, 23, 16, 3, 1, 1),
+    ("bvec_c3x3_m64", "conv", 48, 64, 32, 64, 3, 1, 1),
 ]
 
 
