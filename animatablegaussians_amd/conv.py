@@ -15,7 +15,7 @@ import torch
 from . import _lib
 
 AG_CONV, AG_CONV_TRANSPOSE = 0, 1
-MATH_MODES = {"fp32": 0, "split_bf16": 1, "split_bf16x3": 2}      # include/ag_conv.h AgConvMath
+MATH_MODES = {"fp32": 0, "split_bf16": 1, "split_bf16x3": 2, "split_f16": 3}      # include/ag_conv.h AgConvMath
 
 
 def set_math(mode: str) -> str:

@@ -152,6 +152,11 @@ struct GatherProblem {
     float slope, act_scale;
     PtrTable noise_t;      // act 1: per-instance noise [OHf * OWf] (null: no noise); act 2: per-instance addend [M][OHf * OWf]
     PtrTable nw_t;         // act 1: per-instance noise weight [1]
+    // fp16 split form: partial maxima (absmax_kernel) of the packed weights' source tensors [G][kAmaxParts] and of the gathered tensor
+    // ([G][kAmaxParts], or one row when the instances share their input); amax_a_mult = |weight_scale| (the packed values are w * scale)
+    const float* amax_a;
+    const float* amax_b;
+    float amax_a_mult;
     GatherClass cls[kMaxClasses];
 };
 
@@ -424,14 +429,102 @@ __device__ __forceinline__ void split_pair(float x0, float x1, uint32_t& p0, uin
     const float s0 = r0 - __uint_as_float(p1 << 16), s1 = r1 - __uint_as_float(p1 & 0xffff0000u);
     p2 = pack_bf16(s0, s1);
 }
+// ------------------------------------------------------------------------------------------------------------------
+// fp32 products on the fp16 matrix pipe: two-way split under a per-tensor power-of-two scale, three MFMAs per K tile (round 4)
+// ------------------------------------------------------------------------------------------------------------------
+// fp16 carries 11 significant bits against bf16's 8, so TWO parts hold 22 bits where the bf16 split needs three: with y = s x
+// (s a power of two that puts the tensor's largest magnitude into [2^14, 2^15): exact),  h = rn_f16(y),  l = rn_f16(2^11 (y - h))
+// (y - h is exact in fp32 and <= 2^-11 |y|, so l has the magnitude of y and is a NORMAL fp16 number wherever h is: down to 2^-28 of the
+// tensor's maximum), |y - h - 2^-11 l| <= 2^-23 |y|.  A product is a_h b_h + 2^-11 (a_h b_l + a_l b_h): the first term goes to one fp32
+// accumulator, the two cross terms to a second one that is scaled and added once at the end; the dropped a_l b_l is <= 2^-24 |a| |b|, the
+// part conversions add 2^-23 each -- the same grade as the six-product bf16 form (2^-23 worst case) at HALF the matrix instructions and two
+// thirds of the LDS traffic.  The price is the scale: fp16 has 5 exponent bits, so every operand tensor needs its largest magnitude known
+// before its consumer starts (absmax_kernel below: per-workgroup partial maxima, finished by the consumer; no atomics, no host round
+// trip).  Elements below 2^-28 of the maximum lose relative precision gracefully (absolute error <= 2^-53 of the maximum).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+constexpr int kF16 = 2;                 // value of the kernels' NTERMS parameter that selects this form (6 / 3: the bf16 forms)
+constexpr int kAmaxParts = 256;         // partial maxima per tensor instance
+constexpr int kF16Waves = 2;            // waves per SIMD of the fp16 kernels (__launch_bounds__): the second accumulator set does not fit 128 registers
+constexpr float kLoUp = 2048.0f, kLoDown = 1.0f / 2048.0f;
+
+__device__ __forceinline__ uint32_t pack_f16(float lo, float hi)        // round to nearest even
+{
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){ lo, hi }, f16x2));
+}
+// two fp32 values, already multiplied by the tensor's scale -> two words holding (lo, hi) fp16 pairs of the two planes
+__device__ __forceinline__ void split_pair_h(float y0, float y1, uint32_t& p0, uint32_t& p1)
+{
+    p0 = pack_f16(y0, y1);
+    const f16x2 h = __builtin_bit_cast(f16x2, p0);
+    p1 = pack_f16((y0 - (float)h[0]) * kLoUp, (y1 - (float)h[1]) * kLoUp);
+}
+// scale of a tensor instance from the partial maxima of absmax_kernel (wave-uniform): s = 2^(14 - e) for a maximum in [2^e, 2^(e+1)),
+// 1 / s exactly; an all-zero (or non-finite) tensor gets s = 1
+struct TensorScale { float s, inv; };
+__device__ __forceinline__ TensorScale tensor_scale(const float* __restrict__ parts, float mult, int lane)
+{
+    float m = 0.f;
+#pragma unroll
+    for (int i = 0; i < kAmaxParts / 64; i++) m = fmaxf(m, parts[i * 64 + lane]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    m *= mult;
+    int e = (int)((__float_as_uint(m) >> 23) & 0xffu);          // biased exponent
+    TensorScale t;
+    if (e == 0 || e == 255) { t.s = 1.f; t.inv = 1.f; return t; }
+    e = max(e, 16);
+    e = __builtin_amdgcn_readfirstlane(e);
+    t.s = __uint_as_float((uint32_t)(268 - e) << 23);           // 2^(14 - (e - 127))
+    t.inv = __uint_as_float((uint32_t)(e - 14) << 23);
+    return t;
+}
+
+// Partial maxima of |x| of up to 2 * kMaxGroups tensors in one launch: grid (kAmaxParts, jobs).  A job is `rows` runs of `len` floats
+// `stride` floats apart (an activation stack: one run; a channel slice of a wider weight tensor: one run per output channel).
+struct AmaxJobs {
+    const float* ptr[2 * kMaxGroups];
+    long long len[2 * kMaxGroups], stride[2 * kMaxGroups];
+    int rows[2 * kMaxGroups], slot[2 * kMaxGroups];
+    float* out;                         // job j writes out[slot[j]][kAmaxParts]
+};
+__global__ void __launch_bounds__(256) absmax_kernel(AmaxJobs J)
+{
+    const int job = blockIdx.y;
+    const float* __restrict__ x = J.ptr[job];
+    const long long len = J.len[job];
+    float m = 0.f;
+    if (J.rows[job] == 1 && (len & 3) == 0 && (((size_t)x) & 15) == 0) {
+        const long long n4 = len >> 2;
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)kAmaxParts * 256) {
+            const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+        }
+    } else {
+        const long long n = len * J.rows[job];
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)kAmaxParts * 256) {
+            const long long r = i / len;
+            m = fmaxf(m, fabsf(x[r * J.stride[job] + (i - r * len)]));
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    __shared__ float wm[4];
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) J.out[(size_t)J.slot[job] * kAmaxParts + blockIdx.x] = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+}
+
 // Byte offset of the 16-byte chunk (row, kh) inside a plane of 32-byte rows.  The XOR puts rows r and r + 8 (same banks at a 32-byte
 // pitch) on different halves, so the ds_read_b128 of 16 consecutive rows covers all 64 banks once.
 __device__ __forceinline__ int chunk_off(int row, int kh) { return row * kRowB + ((kh ^ ((row >> 3) & 1)) << 4); }
 
-template <int WMB, int WNB, int WVM, int WVN>
+constexpr int planes_of(int nterms) { return nterms == 6 ? 3 : 2; }      // parts per operand that the form stores and reads
+
+template <int WMB, int WNB, int WVM, int WVN, int NPL>
 struct SplitTile {
     static constexpr int BM = 32 * WMB * WVM, BN = 32 * WNB * WVN, NT = 64 * WVM * WVN;
-    static constexpr int a_bytes = kPlanes * BM * kRowB, b_bytes = kPlanes * BN * kRowB;
+    static constexpr int a_bytes = NPL * BM * kRowB, b_bytes = NPL * BN * kRowB;
     static constexpr int lds_bytes = 2 * (a_bytes + b_bytes);
 };
 
@@ -445,7 +538,7 @@ template <int WMB, int WNB, int BM, int BN, int NTERMS>
 __device__ __forceinline__ void read_split_operands(const char* __restrict__ As, const char* __restrict__ Bs, int wm, int wn, int lane,
                                                     SplitOperands<WMB, WNB>& o)
 {
-    constexpr int NPL = NTERMS == 6 ? 3 : 2;
+    constexpr int NPL = planes_of(NTERMS);
     const int r = lane & 31, kh = lane >> 5;
 #pragma unroll
     for (int i = 0; i < WMB; i++)
@@ -473,6 +566,32 @@ __device__ __forceinline__ void mma_split(const SplitOperands<WMB, WNB>& o, f32x
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o.a[i][ta[t]], o.b[j][tb[t]], acc[i][j], 0, 0, 0);
 }
 
+// the fp16 form: a_h b_h into acc, the cross terms into acc1 (scaled by 2^-11 and added by fold_f16 at the end)
+template <int WMB, int WNB>
+__device__ __forceinline__ void mma_split_h(const SplitOperands<WMB, WNB>& o, f32x16 (&acc)[WMB][WNB], f32x16 (&acc1)[WMB][WNB])
+{
+#pragma unroll
+    for (int t = 0; t < 3; t++)
+#pragma unroll
+        for (int i = 0; i < WMB; i++)
+#pragma unroll
+            for (int j = 0; j < WNB; j++) {
+                const f16x8 a = __builtin_bit_cast(f16x8, o.a[i][t == 1 ? 1 : 0]), b = __builtin_bit_cast(f16x8, o.b[j][t == 0 ? 1 : 0]);
+                if (t == 2) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[i][j], 0, 0, 0);
+                else        acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc1[i][j], 0, 0, 0);
+            }
+}
+template <int WMB, int WNB>
+__device__ __forceinline__ void fold_f16(f32x16 (&acc)[WMB][WNB], const f32x16 (&acc1)[WMB][WNB], float inv_a, float inv_b)
+{
+#pragma unroll
+    for (int i = 0; i < WMB; i++)
+#pragma unroll
+        for (int j = 0; j < WNB; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = fmaf(acc1[i][j][r], kLoDown, acc[i][j][r]) * inv_a * inv_b;
+}
+
 // gather_conv_kernel on the split engine.  Same K order, same classes, same epilogue; differences: the packed weights arrive already
 // split (pack_weights_split_kernel: per K tile three planes [BM][16] bf16, chunks pre-swizzled, so the loader copies 16-byte chunks
 // straight through), the gathered activations are split by the loader thread between the global load and the LDS write, and one set
@@ -485,12 +604,14 @@ __device__ __forceinline__ void mma_split(const SplitOperands<WMB, WNB>& o, f32x
 // Removed in round 4; commit fa8b937 has them.)
 
 template <int WMB, int WNB, int WVM, int WVN, bool CEXACT, int NTERMS>
-__global__ void __launch_bounds__(64 * WVM * WVN, AG_CONV_WAVES_PER_SIMD) gather_conv_split_kernel(GatherProblem p)
+__global__ void __launch_bounds__(64 * WVM * WVN, NTERMS == kF16 ? kF16Waves : AG_CONV_WAVES_PER_SIMD) gather_conv_split_kernel(GatherProblem p)
 {
-    using T = SplitTile<WMB, WNB, WVM, WVN>;
+    constexpr int NPL = planes_of(NTERMS);
+    constexpr bool F16 = NTERMS == kF16;
+    using T = SplitTile<WMB, WNB, WVM, WVN, NPL>;
     constexpr int BM = T::BM, BN = T::BN, NT = T::NT;
     constexpr int G = NT / BN, KG = BK / G;           // B loader: G thread groups, each KG consecutive k's of a pixel
-    constexpr int AC = kPlanes * BM * 2;              // A loader: 16-byte chunks in a tile
+    constexpr int AC = NPL * BM * 2;                  // A loader: 16-byte chunks in a tile
     constexpr bool A2 = AC > NT;                      // the first AC - NT threads move a second chunk
     static_assert(AC <= 2 * NT && (KG == 4 || KG == 8) && BN >= 64, "loader shapes");
     __shared__ __attribute__((aligned(16))) char smem[T::lds_bytes];
@@ -540,8 +661,22 @@ __global__ void __launch_bounds__(64 * WVM * WVN, AG_CONV_WAVES_PER_SIMD) gather
     const size_t plane_b = (size_t)p.Hg * p.Wg * sizeof(float);
     const char* const xin_b = reinterpret_cast<const char*>(gv.xin);
     const int c_last = p.Cg - 1;
-    // packed weights: cl.at_off counts fp32-tile floats (BM * 16 per tile); a split tile has a_bytes = 6 bytes per element
-    const char* a_ptr = reinterpret_cast<const char*>(p.At) + ((size_t)gv.grp * p.at_gs + (size_t)cl.at_off) * 6 + ((size_t)gv.my * nkt_all + kt_beg) * T::a_bytes;
+    // packed weights: cl.at_off counts fp32-tile floats (BM * 16 per tile); a split tile has a_bytes = 2 bytes per element and plane
+    const char* a_ptr = reinterpret_cast<const char*>(p.At) + ((size_t)gv.grp * p.at_gs + (size_t)cl.at_off) * (2 * NPL) + ((size_t)gv.my * nkt_all + kt_beg) * T::a_bytes;
+    TensorScale sa{ 1.f, 1.f }, sb{ 1.f, 1.f };
+    if constexpr (F16) {
+        sa = tensor_scale(p.amax_a + (size_t)gv.grp * kAmaxParts, p.amax_a_mult, lane);
+        sb = tensor_scale(p.amax_b + (p.x_gs ? (size_t)gv.grp * kAmaxParts : 0), 1.f, lane);
+    }
+    f32x16 acc1[WMB][WNB];
+    if constexpr (F16) {
+#pragma unroll
+        for (int i = 0; i < WMB; i++)
+#pragma unroll
+            for (int j = 0; j < WNB; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc1[i][j][r] = 0.f;
+    }
     const uint32_t a_voff0 = (uint32_t)min(tid, AC - 1) * 16u;
     const uint32_t a_voff1 = (uint32_t)min(NT + tid, AC - 1) * 16u;
     const bool a_thread0 = tid < AC;                  // wave-uniform (AC is a multiple of 64)
@@ -599,20 +734,22 @@ __global__ void __launch_bounds__(64 * WVM * WVN, AG_CONV_WAVES_PER_SIMD) gather
 #pragma unroll
             for (int e = 0; e < 2; e++) {
                 const float x0 = st.tap_ok ? st.rb[4 * q + 2 * e] : 0.f, x1 = st.tap_ok ? st.rb[4 * q + 2 * e + 1] : 0.f;
-                uint32_t a, b, c;
-                split_pair(x0, x1, a, b, c);
+                uint32_t a, b, c = 0;
+                if constexpr (F16) split_pair_h(x0 * sb.s, x1 * sb.s, a, b);
+                else               split_pair(x0, x1, a, b, c);
                 w0[e] = a; w1[e] = b; w2[e] = c;
             }
             *reinterpret_cast<u32x2*>(Bs + 0 * BN * kRowB + b_woff + 8 * q) = w0;
             *reinterpret_cast<u32x2*>(Bs + 1 * BN * kRowB + b_woff + 8 * q) = w1;
-            *reinterpret_cast<u32x2*>(Bs + 2 * BN * kRowB + b_woff + 8 * q) = w2;
+            if constexpr (NPL == 3) *reinterpret_cast<u32x2*>(Bs + 2 * BN * kRowB + b_woff + 8 * q) = w2;
         }
     };
     auto lread = [&](int buf) {
         read_split_operands<WMB, WNB, BM, BN, NTERMS>(As0 + buf * T::a_bytes, Bs0 + buf * T::b_bytes, wm, wn, lane, O);
     };
     auto mma = [&]() {
-        mma_split<WMB, WNB, NTERMS>(O, acc);
+        if constexpr (F16) mma_split_h<WMB, WNB>(O, acc, acc1);
+        else               mma_split<WMB, WNB, NTERMS>(O, acc);
     };
 
     if (nkt > 0) {
@@ -651,6 +788,7 @@ __global__ void __launch_bounds__(64 * WVM * WVN, AG_CONV_WAVES_PER_SIMD) gather
             step_tail(kt, S[1], false);
         }
     }
+    if constexpr (F16) fold_f16<WMB, WNB>(acc, acc1, sa.inv, sb.inv);
     gather_epilogue<WMB, WNB>(p, gv, cl, acc, m0, n0, N, wm, wn, lane);
 }
 
@@ -703,6 +841,8 @@ struct PackProblem {
     long long stride_c, stride_m;
     float wscale;
     int has_wscale;
+    int planes;              // split engine: parts stored per element (planes_of)
+    const float* amax;       // fp16 split form: partial maxima of the instances' weight tensors [G][kAmaxParts]; null: the bf16 forms
     int ntaps[kMaxClasses], zero[kMaxClasses];
     long long begin[kMaxClasses + 1];        // element offsets of the classes inside At
     int tapoff[kMaxClasses][kMaxTaps];
@@ -771,20 +911,26 @@ __global__ void __launch_bounds__(256) pack_weights_split_kernel(PackProblem p)
     const int i0 = (m_inner ? ml : 2 * kp) * k2, i1 = (m_inner ? ml : 2 * kp + 1) * k2;
     const int ctiles = p.Cpad / BK;
     const size_t plane = (size_t)p.BM * kRowB;
+    const int npl = p.planes;
+    const bool f16 = p.amax != nullptr;
+    float sc = 1.f;
+    if (f16) sc = tensor_scale(p.amax + (size_t)blockIdx.z * kAmaxParts, p.has_wscale ? fabsf(p.wscale) : 1.f, tid & 63).s;
     for (int ci = 0; ci < p.nclasses; ci++) {
         const int ntaps = p.ntaps[ci];
         const long long nkt = (long long)ntaps * ctiles;
-        char* base = reinterpret_cast<char*>(p.At) + ((size_t)blockIdx.z * p.at_gs + (size_t)p.begin[ci]) * 6 + (size_t)(mt * nkt + (long long)cb * ntaps) * (kPlanes * plane)
+        char* base = reinterpret_cast<char*>(p.At) + ((size_t)blockIdx.z * p.at_gs + (size_t)p.begin[ci]) * (2 * npl) + (size_t)(mt * nkt + (long long)cb * ntaps) * (npl * plane)
                      + chunk_off(mrow, kp >> 2) + (kp & 3) * 4;
         const bool zero = p.zero[ci] != 0;
         for (int t = th; t < ntaps; t += 2) {
             const int to = p.tapoff[ci][t];
-            uint32_t a, b, c;
-            split_pair(zero ? 0.f : blk[o0][i0 + to], zero ? 0.f : blk[o1][i1 + to], a, b, c);
-            char* d = base + (size_t)t * (kPlanes * plane);
+            const float v0 = zero ? 0.f : blk[o0][i0 + to], v1 = zero ? 0.f : blk[o1][i1 + to];
+            uint32_t a, b, c = 0;
+            if (f16) split_pair_h(v0 * sc, v1 * sc, a, b);
+            else     split_pair(v0, v1, a, b, c);
+            char* d = base + (size_t)t * (npl * plane);
             *reinterpret_cast<uint32_t*>(d) = a;
             *reinterpret_cast<uint32_t*>(d + plane) = b;
-            *reinterpret_cast<uint32_t*>(d + 2 * plane) = c;
+            if (npl == 3) *reinterpret_cast<uint32_t*>(d + 2 * plane) = c;
         }
     }
 }
@@ -801,6 +947,8 @@ struct WgradProblem {
     float wscale;          // the forward convolved with w * wscale: dL/dw = wscale * dL/d(w * wscale)
     int G, mtiles;         // grouped launch: gridDim.y = G * mtiles
     long long a_gs, xin_gs, c_gs;     // floats between the instances' operands / outputs
+    const float* amax_a;   // fp16 split form: partial maxima of `a` and of `xin` ([G][kAmaxParts], one row where the instances share the tensor)
+    const float* amax_b;
     int c_row_stride, c_chan_stride;  // element (m, nn = (channel, tap)) of the output sits at m * c_row_stride + channel * c_chan_stride + tap:
                                       // (Nw, ntaps) = the natural [Mw][Cg][taps]; (ntaps, Mw * ntaps) = [Cg][Mw][taps] (a transposed convolution's
                                       // weight gradient written in the [Cout][Cin][k][k] layout its modulated weight is kept in)
@@ -987,9 +1135,11 @@ __global__ void __launch_bounds__(64 * WVM * WVN, AG_CONV_WAVES_PER_SIMD) wgrad_
 // every load stays inside the tensor and unconditional.  PMC of the scalar form (r04_pmc_wgrad_256_256_128.txt): 140 VALU instructions per wave
 // and K tile for 12 MFMAs -- the weight gradient was bound by its loader's instruction count, not by the matrix pipe.
 template <int WMB, int WNB, int WVM, int WVN, bool AVEC, int NTERMS, bool BVEC = false>
-__global__ void __launch_bounds__(64 * WVM * WVN, AG_CONV_WAVES_PER_SIMD) wgrad_split_kernel(WgradProblem p)
+__global__ void __launch_bounds__(64 * WVM * WVN, NTERMS == kF16 ? kF16Waves : AG_CONV_WAVES_PER_SIMD) wgrad_split_kernel(WgradProblem p)
 {
-    using T = SplitTile<WMB, WNB, WVM, WVN>;
+    constexpr int NPL = planes_of(NTERMS);
+    constexpr bool F16 = NTERMS == kF16;
+    using T = SplitTile<WMB, WNB, WVM, WVN, NPL>;
     constexpr int BM = T::BM, BN = T::BN, NT = T::NT;
     constexpr int BSTEP = NT / 16;
     constexpr int BC = BN / BSTEP;
@@ -1052,13 +1202,24 @@ __global__ void __launch_bounds__(64 * WVM * WVN, AG_CONV_WAVES_PER_SIMD) wgrad_
     }
     int gy0 = kbeg / p.gw, gx0 = kbeg - gy0 * p.gw;
 
-    f32x16 acc[WMB][WNB];
+    f32x16 acc[WMB][WNB], acc1[WMB][WNB];
 #pragma unroll
     for (int i = 0; i < WMB; i++)
 #pragma unroll
         for (int j = 0; j < WNB; j++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+            for (int r = 0; r < 16; r++) { acc[i][j][r] = 0.f; if constexpr (F16) acc1[i][j][r] = 0.f; }
+    TensorScale sa{ 1.f, 1.f }, sb{ 1.f, 1.f };
+    if constexpr (F16) {
+        sa = tensor_scale(p.amax_a + (p.a_gs ? (size_t)grp * kAmaxParts : 0), 1.f, lane);
+        sb = tensor_scale(p.amax_b + (p.xin_gs ? (size_t)grp * kAmaxParts : 0), 1.f, lane);
+    }
+    // one pair of fp32 values -> its words in the planes (w2 unused by the two-plane forms)
+    auto split2 = [&](float x0, float x1, float sc, uint32_t& a, uint32_t& b, uint32_t& c) {
+        c = 0;
+        if constexpr (F16) split_pair_h(x0 * sc, x1 * sc, a, b);
+        else               split_pair(x0, x1, a, b, c);
+    };
 
     struct Stage {
         f32x4 ra;
@@ -1128,12 +1289,12 @@ __global__ void __launch_bounds__(64 * WVM * WVN, AG_CONV_WAVES_PER_SIMD) wgrad_
 #pragma unroll
             for (int e = 0; e < 2; e++) {
                 uint32_t a, b, c;
-                split_pair(v[2 * e], v[2 * e + 1], a, b, c);
+                split2(v[2 * e], v[2 * e + 1], sa.s, a, b, c);
                 w0[e] = a; w1[e] = b; w2[e] = c;
             }
             *reinterpret_cast<u32x2*>(As + 0 * BM * kRowB + a_woff) = w0;
             *reinterpret_cast<u32x2*>(As + 1 * BM * kRowB + a_woff) = w1;
-            *reinterpret_cast<u32x2*>(As + 2 * BM * kRowB + a_woff) = w2;
+            if constexpr (NPL == 3) *reinterpret_cast<u32x2*>(As + 2 * BM * kRowB + a_woff) = w2;
         }
         if constexpr (BVEC) {
 #pragma unroll
@@ -1148,12 +1309,12 @@ __global__ void __launch_bounds__(64 * WVM * WVN, AG_CONV_WAVES_PER_SIMD) wgrad_
 #pragma unroll
                 for (int e = 0; e < 2; e++) {
                     uint32_t a, b, c;
-                    split_pair(v[2 * e], v[2 * e + 1], a, b, c);
+                    split2(v[2 * e], v[2 * e + 1], sb.s, a, b, c);
                     w0[e] = a; w1[e] = b; w2[e] = c;
                 }
                 *reinterpret_cast<u32x2*>(Bs + 0 * BN * kRowB + vb_woff[j]) = w0;
                 *reinterpret_cast<u32x2*>(Bs + 1 * BN * kRowB + vb_woff[j]) = w1;
-                *reinterpret_cast<u32x2*>(Bs + 2 * BN * kRowB + vb_woff[j]) = w2;
+                if constexpr (NPL == 3) *reinterpret_cast<u32x2*>(Bs + 2 * BN * kRowB + vb_woff[j]) = w2;
             }
             return;
         }
@@ -1164,14 +1325,19 @@ __global__ void __launch_bounds__(64 * WVM * WVN, AG_CONV_WAVES_PER_SIMD) wgrad_
             const float give = odd ? v0 : v1, keep = odd ? v1 : v0;
             const float got = __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(give), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
             uint32_t a, b, c;
-            split_pair(odd ? got : keep, odd ? keep : got, a, b, c);        // (pixel k & ~1, pixel (k & ~1) + 1)
+            split2(odd ? got : keep, odd ? keep : got, sb.s, a, b, c);        // (pixel k & ~1, pixel (k & ~1) + 1)
             *reinterpret_cast<uint32_t*>(Bs + 0 * BN * kRowB + b_woff[h]) = a;
             *reinterpret_cast<uint32_t*>(Bs + 1 * BN * kRowB + b_woff[h]) = b;
-            *reinterpret_cast<uint32_t*>(Bs + 2 * BN * kRowB + b_woff[h]) = c;
+            if constexpr (NPL == 3) *reinterpret_cast<uint32_t*>(Bs + 2 * BN * kRowB + b_woff[h]) = c;
         }
     };
     auto lread = [&](int buf) {
         read_split_operands<WMB, WNB, BM, BN, NTERMS>(As0 + buf * T::a_bytes, Bs0 + buf * T::b_bytes, wm, wn, lane, O);
+    };
+
+    auto mma = [&]() {
+        if constexpr (F16) mma_split_h<WMB, WNB>(O, acc, acc1);
+        else               mma_split<WMB, WNB, NTERMS>(O, acc);
     };
 
     const int nkt = (kend - kbeg + BK - 1) / BK;
@@ -1183,13 +1349,13 @@ __global__ void __launch_bounds__(64 * WVM * WVN, AG_CONV_WAVES_PER_SIMD) wgrad_
         lread(kt & 1);
         gload(kbeg + (kt + 2) * BK, s_same);
         lstore((kt + 1) & 1, s_next);
-        mma_split<WMB, WNB, NTERMS>(O, acc);
+        mma();
         lds_barrier();
     };
     auto step_tail = [&](int kt, Stage& s_next, bool has_next) {
         lread(kt & 1);
         if (has_next) lstore((kt + 1) & 1, s_next);
-        mma_split<WMB, WNB, NTERMS>(O, acc);
+        mma();
         if (has_next) lds_barrier();
     };
     int kt = 0;
@@ -1221,7 +1387,9 @@ __global__ void __launch_bounds__(64 * WVM * WVN, AG_CONV_WAVES_PER_SIMD) wgrad_
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int m = m0 + (wm * WMB + i) * 32 + (r & 3) + 8 * (r >> 2) + rbase;
-                if (m < p.Mw) atomicAdd(cn + (size_t)m * p.c_row_stride, acc[i][j][r] * p.wscale);
+                float v = acc[i][j][r];
+                if constexpr (F16) v = fmaf(acc1[i][j][r], kLoDown, v) * sa.inv * sb.inv;
+                if (m < p.Mw) atomicAdd(cn + (size_t)m * p.c_row_stride, v * p.wscale);
             }
         }
 }
@@ -1279,12 +1447,31 @@ static int round_up(int v, int a) { return (v + a - 1) / a * a; }
 
 // arithmetic of the MFMA convolutions (ag_conv_set_math): process-wide, read at every call
 static std::atomic<int> g_conv_math{ AG_CONV_MATH_SPLIT_BF16 };
-static int split_terms()        // 0: fp32 MFMA engine, else the number of bf16 products per fp32 product
+static int split_terms()        // 0: fp32 MFMA engine; 6 / 3: bf16 products per fp32 product; kF16 (2): the two-part fp16 form
 {
     const int m = g_conv_math.load(std::memory_order_relaxed);
-    return m == AG_CONV_MATH_SPLIT_BF16 ? 6 : m == AG_CONV_MATH_SPLIT_BF16X3 ? 3 : 0;
+    return m == AG_CONV_MATH_SPLIT_BF16 ? 6 : m == AG_CONV_MATH_SPLIT_BF16X3 ? 3 : m == AG_CONV_MATH_SPLIT_F16 ? kF16 : 0;
 }
 static bool split_math() { return split_terms() != 0; }
+
+// fp16 form: the partial maxima of a call's two operands live behind the split-K partial sums in the call's workspace
+constexpr size_t kAmaxBytes = 2 * (size_t)kMaxGroups * kAmaxParts * sizeof(float);
+struct AmaxTensor { const float* ptr; long long gs; long long len, stride; int rows; };     // G instances `gs` floats apart (0: one shared instance)
+// one launch for both operands: a's rows go to out[0 .. G), b's to out[kMaxGroups ..)
+static int launch_absmax(const AmaxTensor& a, const PtrTable* a_table, const AmaxTensor& b, int G, float* out, hipStream_t s)
+{
+    AmaxJobs J;
+    int n = 0;
+    auto add = [&](const float* ptr, const AmaxTensor& t, int slot) {
+        J.ptr[n] = ptr; J.len[n] = t.len; J.stride[n] = t.stride; J.rows[n] = t.rows; J.slot[n] = slot; n++;
+    };
+    const int na = a_table ? G : (a.gs ? G : 1), nb = b.gs ? G : 1;
+    for (int g = 0; g < na; g++) add(a_table ? a_table->p[g] : a.ptr + (size_t)g * a.gs, a, g);
+    for (int g = 0; g < nb; g++) add(b.ptr + (size_t)g * b.gs, b, kMaxGroups + g);
+    J.out = out;
+    hipLaunchKernelGGL(absmax_kernel, dim3(kAmaxParts, n), dim3(256), 0, s, J);
+    return check_hip(hipGetLastError(), "absmax_kernel");
+}
 
 static int validate(const AgConvDesc* d)
 {
@@ -1360,9 +1547,11 @@ static int choose_splits(long long tiles, int Mpad, int Ncols, int nkt, int G = 
 // Fills tile_begin / col_begin / at_off / nkt of the classes (dy, dx, gh, gw, y0, x0, ntaps set by the caller), packs the
 // weights of all classes with one launch and runs them with one launch (+ one split-K finish).
 static int pack_and_launch(GatherProblem& gp, const TapSet* taps, int bm, const PtrTable& w, long long stride_c, long long stride_m,
-                           float wscale, int k, float* At, float* partial, hipStream_t s)
+                           float wscale, int k, float* At, float* partial, float* amax, const AmaxTensor& w_shape, hipStream_t s)
 {
     const bool split = split_math();
+    const int terms = split_terms();
+    const bool f16 = terms == kF16;
     const int BN = bn_of(bm);
     const int G = gp.G;
     PackProblem pp;
@@ -1390,6 +1579,19 @@ static int pack_and_launch(GatherProblem& gp, const TapSet* taps, int bm, const 
     if (tiles == 0) return AG_OK;
     pp.k2 = k * k;
     if ((stride_c != pp.k2 && stride_m != pp.k2) || pp.k2 > kMaxTaps) { set_error("pack: unexpected weight strides"); return AG_ERR_INVALID_ARGUMENT; }
+    pp.planes = planes_of(terms);
+    pp.amax = nullptr;
+    gp.amax_a = gp.amax_b = nullptr;
+    gp.amax_a_mult = 1.f;
+    if (f16) {
+        const AmaxTensor xb{ gp.xin, gp.x_gs, (long long)gp.Cg * gp.Hg * gp.Wg, 0, 1 };
+        int rc0 = launch_absmax(w_shape, &w, xb, G, amax, s);
+        if (rc0) return rc0;
+        pp.amax = amax;
+        gp.amax_a = amax;
+        gp.amax_b = amax + (size_t)kMaxGroups * kAmaxParts;
+        gp.amax_a_mult = wscale != 1.f ? fabsf(wscale) : 1.f;
+    }
     if (split) hipLaunchKernelGGL(pack_weights_split_kernel, dim3(gp.Cpad / BK, gp.Mpad / 16, G), dim3(256), 0, s, pp);
     else       hipLaunchKernelGGL(pack_weights_kernel, dim3(gp.Cpad / BK, gp.Mpad / 16, G), dim3(256), 0, s, pp);
     int rc = check_hip(hipGetLastError(), "pack_weights_kernel");
@@ -1413,16 +1615,16 @@ static int pack_and_launch(GatherProblem& gp, const TapSet* taps, int bm, const 
     ProfScope ps(AG_K_GATHER_CONV, s, flops);      // covers the split-K finish too
     if (split) {
         const bool cexact = gp.Cg % BK == 0 && (size_t)gp.Cg * gp.Hg * gp.Wg * sizeof(float) < (size_t(1) << 32);
-        const bool six = split_terms() == 6;
-#define AG_LAUNCH_SPLIT(WMB, WNB, CE, NTM) hipLaunchKernelGGL((gather_conv_split_kernel<WMB, WNB, 2, 4, CE, NTM>), grid, dim3(512), 0, s, gp)
+#define AG_LAUNCH_SPLIT_T(WMB, WNB, CE, NTM) hipLaunchKernelGGL((gather_conv_split_kernel<WMB, WNB, 2, 4, CE, NTM>), grid, dim3(512), 0, s, gp)
+#define AG_LAUNCH_SPLIT(WMB, WNB, CE) do { if (terms == 6) AG_LAUNCH_SPLIT_T(WMB, WNB, CE, 6); else if (terms == 3) AG_LAUNCH_SPLIT_T(WMB, WNB, CE, 3); \
+                                           else AG_LAUNCH_SPLIT_T(WMB, WNB, CE, kF16); } while (0)
         if (bm == 64) {
-            if (cexact) { if (six) AG_LAUNCH_SPLIT(1, 2, true, 6); else AG_LAUNCH_SPLIT(1, 2, true, 3); }
-            else        { if (six) AG_LAUNCH_SPLIT(1, 2, false, 6); else AG_LAUNCH_SPLIT(1, 2, false, 3); }
+            if (cexact) AG_LAUNCH_SPLIT(1, 2, true); else AG_LAUNCH_SPLIT(1, 2, false);
         } else {
-            if (cexact) { if (six) AG_LAUNCH_SPLIT(2, 1, true, 6); else AG_LAUNCH_SPLIT(2, 1, true, 3); }
-            else        { if (six) AG_LAUNCH_SPLIT(2, 1, false, 6); else AG_LAUNCH_SPLIT(2, 1, false, 3); }
+            if (cexact) AG_LAUNCH_SPLIT(2, 1, true); else AG_LAUNCH_SPLIT(2, 1, false);
         }
 #undef AG_LAUNCH_SPLIT
+#undef AG_LAUNCH_SPLIT_T
     } else {
         if (bm == 64) hipLaunchKernelGGL((gather_conv_kernel<1, 2, 2, 4>), grid, dim3(512), 0, s, gp);
         else          hipLaunchKernelGGL((gather_conv_kernel<2, 1, 2, 4>), grid, dim3(512), 0, s, gp);
@@ -1464,7 +1666,7 @@ size_t ag_conv_workspace_bytes(const AgConvDesc* d)
 {
     if (validate(d)) return 0;
     // packed weights of all tap subsets together + split-K partial sums (choose_splits keeps them under the cap)
-    return packed_bytes(d) + kMaxPartialBytes + 512;
+    return packed_bytes(d) + kMaxPartialBytes + kAmaxBytes + 512;
 }
 
 }  // extern "C"
@@ -1473,7 +1675,7 @@ namespace ag {
 size_t conv_workspace_bytes_g(const AgConvDesc* d, int G)
 {
     if (validate(d) || G < 1 || G > kMaxGroups) return 0;
-    return (size_t)G * packed_bytes(d) + kMaxPartialBytes + 512;
+    return (size_t)G * packed_bytes(d) + kMaxPartialBytes + kAmaxBytes + 512;
 }
 }  // namespace ag
 
@@ -1493,6 +1695,7 @@ static int run_gather_family(const AgConvDesc* d, bool backward_input, int G, co
     if (G > 1 && out_scale) { set_error("grouped convolution: out_scale is a single-instance option"); return AG_ERR_UNSUPPORTED; }
     float* At = reinterpret_cast<float*>(aligned_base(workspace));
     float* partial = reinterpret_cast<float*>(aligned_base(workspace) + (size_t)G * packed_bytes(d));
+    float* amax = reinterpret_cast<float*>(aligned_base(workspace) + (size_t)G * packed_bytes(d) + kMaxPartialBytes);
 
     GatherProblem gp;
     gp.out_scale = out_scale; gp.bias_t = bias; gp.yout = yout; gp.xin = xin;
@@ -1516,6 +1719,9 @@ static int run_gather_family(const AgConvDesc* d, bool backward_input, int G, co
     const long long s_co = oihw ? cin_rows * k2 : k2, s_ci = oihw ? k2 : (long long)d->Cout * k2;
     stride_c = backward_input ? s_co : s_ci;
     stride_m = backward_input ? s_ci : s_co;
+    // the weight tensor of an instance as runs of floats (absmax of the fp16 form): whole and contiguous, or Cout rows of a channel slice
+    AmaxTensor w_shape{ nullptr, 0, (long long)d->Cout * d->Cin * k2, 0, 1 };
+    if (opt.w_cin_total && opt.w_cin_total != d->Cin) { w_shape.len = (long long)d->Cin * k2; w_shape.stride = cin_rows * k2; w_shape.rows = d->Cout; }
     gp.Cg = Cg; gp.Hg = Hg; gp.Wg = Wg; gp.M = M; const int bm = pick_bm(M); gp.Mpad = round_up(M, bm); gp.OHf = OHf; gp.OWf = OWf;
     gp.Cpad = round_up(Cg, BK);
     TapSet taps[kMaxClasses];
@@ -1541,7 +1747,7 @@ static int run_gather_family(const AgConvDesc* d, bool backward_input, int G, co
             for (int t = 0; t < k2; t++) { cl.dy[t] = ts.ky[t]; cl.dx[t] = ts.kx[t]; }
         }
         for (int t = k2; t < kMaxTaps; t++) cl.dy[t] = cl.dx[t] = 0;
-        return pack_and_launch(gp, taps, bm, w, stride_c, stride_m, wscale_of(d), k, At, partial, s);
+        return pack_and_launch(gp, taps, bm, w, stride_c, stride_m, wscale_of(d), k, At, partial, amax, w_shape, s);
     }
     // scatter with stride 2: output coordinate o = 2*i + ky - poff  (poff = padding for the conv gradient, 0 for convT).
     // Class (qy, qx) = parity of the output coordinate; it receives only taps with ky = (o + poff) mod 2, from
@@ -1579,7 +1785,7 @@ static int run_gather_family(const AgConvDesc* d, bool backward_input, int G, co
             gp.cls[pos] = cl; taps[pos] = ts;
             gp.nclasses++;
         }
-    return pack_and_launch(gp, taps, bm, w, stride_c, stride_m, wscale_of(d), k, At, partial, s);
+    return pack_and_launch(gp, taps, bm, w, stride_c, stride_m, wscale_of(d), k, At, partial, amax, w_shape, s);
 }
 
 }  // extern "C"
@@ -1661,28 +1867,40 @@ int conv_backward_weight_g(const AgConvDesc* d, int G, const float* x, long long
     dim3 grid((Nw + BN - 1) / BN, wp.mtiles * G, splits);
     ProfScope ps(AG_K_WGRAD, s, 2.0 * G * wp.Mw * (double)Kp * Nw);
     const bool avec = (Kp & 3) == 0;      // rows of A 16-byte aligned
+    wp.amax_a = wp.amax_b = nullptr;
     if (split_math()) {
-        const bool six = split_terms() == 6;
-#define AG_LAUNCH_WSPLIT(WMB, WNB, AV, NTM) hipLaunchKernelGGL((wgrad_split_kernel<WMB, WNB, 2, 4, AV, NTM>), grid, dim3(512), 0, s, wp)
-#define AG_LAUNCH_WSPLIT_V(WMB, WNB, NTM) hipLaunchKernelGGL((wgrad_split_kernel<WMB, WNB, 2, 4, true, NTM, true>), grid, dim3(512), 0, s, wp)
+        const int terms = split_terms();
+        if (terms == kF16) {
+            if (!workspace || workspace_bytes < conv_workspace_bytes_g(d, G)) { set_error("conv workspace too small"); return AG_ERR_SCRATCH_TOO_SMALL; }
+            float* amax = reinterpret_cast<float*>(aligned_base(workspace) + (size_t)G * packed_bytes(d) + kMaxPartialBytes);
+            const AmaxTensor ta{ wp.a, wp.a_gs, (long long)wp.Mw * Kp, 0, 1 }, tb{ wp.xin, wp.xin_gs, (long long)wp.Cg * wp.Hg * wp.Wg, 0, 1 };
+            if ((rc = launch_absmax(ta, nullptr, tb, G, amax, s))) return rc;
+            wp.amax_a = amax;
+            wp.amax_b = amax + (size_t)kMaxGroups * kAmaxParts;
+        }
+#define AG_LAUNCH_WSPLIT_T(WMB, WNB, AV, NTM) hipLaunchKernelGGL((wgrad_split_kernel<WMB, WNB, 2, 4, AV, NTM>), grid, dim3(512), 0, s, wp)
+#define AG_LAUNCH_WSPLIT_VT(WMB, WNB, NTM) hipLaunchKernelGGL((wgrad_split_kernel<WMB, WNB, 2, 4, true, NTM, true>), grid, dim3(512), 0, s, wp)
+#define AG_LAUNCH_WSPLIT(WMB, WNB, AV) do { if (terms == 6) AG_LAUNCH_WSPLIT_T(WMB, WNB, AV, 6); else if (terms == 3) AG_LAUNCH_WSPLIT_T(WMB, WNB, AV, 3); \
+                                            else AG_LAUNCH_WSPLIT_T(WMB, WNB, AV, kF16); } while (0)
+#define AG_LAUNCH_WSPLIT_V(WMB, WNB) do { if (terms == 6) AG_LAUNCH_WSPLIT_VT(WMB, WNB, 6); else if (terms == 3) AG_LAUNCH_WSPLIT_VT(WMB, WNB, 3); \
+                                          else AG_LAUNCH_WSPLIT_VT(WMB, WNB, kF16); } while (0)
         // the K-vectorised loader of the gathered operand: stride-1 "same" convolutions with rows of a multiple of 16 pixels (every 3 x 3 stride-1
         // layer of the product), whole K tiles per slice; AG_WGRAD_BVEC=0 keeps the scalar gathers (A/B)
         static const bool bvec_on = [] { const char* e = getenv("AG_WGRAD_BVEC"); return !(e && e[0] == '0'); }();
         const bool bvec = bvec_on && avec && d->kind == AG_CONV && d->stride == 1 && wp.gw == wp.Wg && wp.gh == wp.Hg && (wp.gw & 15) == 0 && wp.gw >= 16 &&
                           (Kp & 15) == 0 && (wp.ksplit_len & 15) == 0 && 2 * d->padding + 1 == k && k <= 3;
         if (bvec) {
-            if (bm == 64) { if (six) AG_LAUNCH_WSPLIT_V(1, 2, 6); else AG_LAUNCH_WSPLIT_V(1, 2, 3); }
-            else          { if (six) AG_LAUNCH_WSPLIT_V(2, 1, 6); else AG_LAUNCH_WSPLIT_V(2, 1, 3); }
+            if (bm == 64) AG_LAUNCH_WSPLIT_V(1, 2); else AG_LAUNCH_WSPLIT_V(2, 1);
         } else
         if (bm == 64) {
-            if (avec) { if (six) AG_LAUNCH_WSPLIT(1, 2, true, 6); else AG_LAUNCH_WSPLIT(1, 2, true, 3); }
-            else      { if (six) AG_LAUNCH_WSPLIT(1, 2, false, 6); else AG_LAUNCH_WSPLIT(1, 2, false, 3); }
+            if (avec) AG_LAUNCH_WSPLIT(1, 2, true); else AG_LAUNCH_WSPLIT(1, 2, false);
         } else {
-            if (avec) { if (six) AG_LAUNCH_WSPLIT(2, 1, true, 6); else AG_LAUNCH_WSPLIT(2, 1, true, 3); }
-            else      { if (six) AG_LAUNCH_WSPLIT(2, 1, false, 6); else AG_LAUNCH_WSPLIT(2, 1, false, 3); }
+            if (avec) AG_LAUNCH_WSPLIT(2, 1, true); else AG_LAUNCH_WSPLIT(2, 1, false);
         }
 #undef AG_LAUNCH_WSPLIT
 #undef AG_LAUNCH_WSPLIT_V
+#undef AG_LAUNCH_WSPLIT_T
+#undef AG_LAUNCH_WSPLIT_VT
     } else if (bm == 64) {
         if (avec) hipLaunchKernelGGL((wgrad_kernel<1, 2, 2, 4, true>), grid, dim3(512), 0, s, wp);
         else      hipLaunchKernelGGL((wgrad_kernel<1, 2, 2, 4, false>), grid, dim3(512), 0, s, wp);
@@ -1717,7 +1935,7 @@ int ag_conv_backward_weight(const AgConvDesc* d, const float* x, const float* dy
 
 int ag_conv_set_math(int mode)
 {
-    if (mode != AG_CONV_MATH_FP32_MFMA && mode != AG_CONV_MATH_SPLIT_BF16 && mode != AG_CONV_MATH_SPLIT_BF16X3) { set_error("unknown conv math mode"); return AG_ERR_INVALID_ARGUMENT; }
+    if (mode != AG_CONV_MATH_FP32_MFMA && mode != AG_CONV_MATH_SPLIT_BF16 && mode != AG_CONV_MATH_SPLIT_BF16X3 && mode != AG_CONV_MATH_SPLIT_F16) { set_error("unknown conv math mode"); return AG_ERR_INVALID_ARGUMENT; }
     g_conv_math.store(mode, std::memory_order_relaxed);
     return AG_OK;
 }

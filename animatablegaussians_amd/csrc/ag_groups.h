@@ -54,6 +54,8 @@ int sum_member_ranges(float* out, const float* in, const int* begin, int R, long
 size_t noise_bias_act_partial_floats(int G, int C, int HW);
 // gbias: instance g writes C sums at gbias + g * gb_stride (null: not wanted); gnw: one sum at gnw + g * gnw_stride (null: not wanted).
 // Deterministic: per-workgroup partial sums + a fixed-order finish (no float atomics).
+int blur_act_forward_g(float* y, const float* x, const float* taps, int G, const PtrTable& noise, const PtrTable& nw, const PtrTable& bias,
+                       int C, int H, int W, float slope, float scale, hipStream_t s);
 int noise_bias_act_backward_g(float* gx, const float* gy, const float* y, int G, const PtrTable& noise, float* gbias, long long gb_stride,
                               float* gnw, long long gnw_stride, float* partials, int C, int HW, float slope, float scale, hipStream_t s);
 // out [G][Co][Ci][K2] (or [G][Ci][Co][K2] transposed), dcoef [G][Co] (may be null)

@@ -176,6 +176,8 @@ int ag_grouped_layer_forward(const AgGroupedLayerArgs* a, void* stream)
     if (a->resample) {
         if (!a->k_blur) { set_error("ag_layer_forward: resampling layer without FIR taps"); return AG_ERR_INVALID_ARGUMENT; }
         if ((rc = conv_forward_g(&g.d, G, a->x, x_gs, wm_t, nullptr, PtrTable{}, aux, (long long)a->Cout * g.CH * g.CW, a->workspace, a->workspace_bytes, s, kOihw))) return rc;
+        // Blur + noise + bias + leaky ReLU in one pass (the backward needs the output only, so the blurred pre-activation is never stored)
+        if (fused_act()) return blur_act_forward_g(a->out, aux, a->k_blur, G, noise_t, nw_t, bias_t, a->Cout, g.CH, g.CW, a->slope, a->act_scale, s);
         if ((rc = ag_upfirdn2d(pre, aux, a->k_blur, G * a->Cout, g.CH, g.CW, 4, 4, 1, 1, 1, 1, 1, 1, 1, 1, stream))) return rc;
     } else {
         if (fused_act()) {

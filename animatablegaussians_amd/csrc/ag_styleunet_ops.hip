@@ -527,46 +527,71 @@ __global__ void __launch_bounds__(256) upfirdn2d_kernel(float* __restrict__ out,
 // The network's heavy FIR calls are plain 4 x 4 filters (up = down = 1: the blur behind every transposed convolution, the blur in front
 // of every stride-2 convolution, and their adjoints).  The general kernel above spends ~40 integer instructions (two 64-bit divisions)
 // and 16 dependent scalar loads per output: 203 us for the 64-channel 512^2 blur where the bytes take 27.  Here a thread produces a
-// 4 x 2 block of outputs from a 7 x 5 window read as ten 16-byte loads (alignment is free on this part: profiles/ub/load_rate.hip), grid
-// (x quads, row pairs, image) so there is no division at all; same accumulation order per output as the general kernel (rows, then
-// columns, ascending; out-of-image taps contribute exact zeros), hence the same bits.
-// (A variant that also applied NoiseInjection + FusedLeakyReLU to the filtered value, and its fused backward, existed in round 3: bit-identical,
-// no gain -- 12 of ~1500 launches of a network pass, slower backward -- and removed in round 4: profiles/r03_fused_tail_ab.txt.)
+// 4-wide, kFirRows-tall strip of outputs while sliding a 4-row window of 8 columns down the image (two 16-byte loads per input row;
+// alignment is free on this part: profiles/ub/load_rate.hip), threads numbered (column quad, strip) linearly over a plane so narrow
+// images still fill their wavefronts; same accumulation order per output as the general kernel (rows, then columns, ascending;
+// out-of-image taps contribute exact zeros), hence the same bits.
+// Edges without divergence (round 4): the 16-byte loads are issued wherever they stay inside the TENSOR (a window hanging over a row's
+// end reads the neighbouring row or plane) and the out-of-image columns are zeroed by selects; only the few threads whose loads would
+// leave the tensor take the element-wise path.  The round-3 form branched per row on "window inside the row", and with 64 lanes on half
+// a 512-pixel row EVERY wavefront had an edge lane and ran both paths (2.65 TB/s, profiles/r04_kernel_stats_fullstep.txt).
+// ACT: NoiseInjection + FusedLeakyReLU applied to the filtered value before it is stored (the activation pass of an up-sampling
+// StyledConv, ag_layers.hip), the same expression as noise_bias_act_forward_kernel, hence the same bits as the two passes.
+constexpr int kFirRows = 8;
+struct FirAct { PtrTable noise, nw, bias; int C; float slope, scale; };
+
+template <bool ACT>
 __global__ void __launch_bounds__(256) fir4x4_kernel(float* __restrict__ out, const float* __restrict__ input,
-                                                     const float* __restrict__ kernel, UpfirdnParams p)
+                                                     const float* __restrict__ kernel, UpfirdnParams p, int quads, int strips,
+                                                     long long total, const FirAct act)
 {
-    __shared__ float taps[16];
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    if (threadIdx.x < 16) taps[threadIdx.x] = kernel[threadIdx.x];
-    __syncthreads();
-    const int ox0 = (blockIdx.x * 64 + tx) * 4, oy0 = (blockIdx.y * 4 + ty) * 2;
-    if (ox0 >= p.out_w || oy0 >= p.out_h) return;
-    const float* img = input + (size_t)blockIdx.z * p.in_h * p.in_w;
-    const int cx = ox0 - p.pad_x0, cy = oy0 - p.pad_y0;                 // window origin: columns cx .. cx + 6, rows cy .. cy + 4
-    float win[5][8];
-    const bool x_inside = cx >= 0 && cx + 8 <= p.in_w;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int strip = t / quads, quad = t - strip * quads;
+    if (strip >= strips) return;
+    float taps[16];
 #pragma unroll
-    for (int r = 0; r < 5; r++) {
+    for (int i = 0; i < 16; i++) taps[i] = kernel[i];                    // uniform address: scalar loads
+    const int plane = blockIdx.y;
+    const int ox0 = quad * 4, oy0 = strip * kFirRows;
+    const long long plane0 = (long long)plane * p.in_h * p.in_w;
+    const int cx = ox0 - p.pad_x0, cy = oy0 - p.pad_y0;                 // window origin: columns cx .. cx + 6, rows cy .. cy + kFirRows + 2
+    bool col_ok[8];
+#pragma unroll
+    for (int c = 0; c < 8; c++) col_ok[c] = c < 7 && cx + c >= 0 && cx + c < p.in_w;
+    float win[4][8];
+    auto load_row = [&](int r, float (&dst)[8]) {
         const int iy = cy + r;
-        const bool row_ok = iy >= 0 && iy < p.in_h;
-        const float* row = img + (size_t)(row_ok ? iy : 0) * p.in_w;
-        if (row_ok && x_inside) {
-            const float4 a = *reinterpret_cast<const float4*>(row + cx), b = *reinterpret_cast<const float4*>(row + cx + 4);
-            win[r][0] = a.x; win[r][1] = a.y; win[r][2] = a.z; win[r][3] = a.w;
-            win[r][4] = b.x; win[r][5] = b.y; win[r][6] = b.z; win[r][7] = b.w;
+        if (iy < 0 || iy >= p.in_h) {
+#pragma unroll
+            for (int c = 0; c < 8; c++) dst[c] = 0.0f;
+            return;
+        }
+        const long long off = plane0 + (long long)iy * p.in_w + cx;
+        if (off >= 0 && off + 8 <= total) {
+            const float4 a = *reinterpret_cast<const float4*>(input + off), b = *reinterpret_cast<const float4*>(input + off + 4);
+            dst[0] = col_ok[0] ? a.x : 0.f; dst[1] = col_ok[1] ? a.y : 0.f; dst[2] = col_ok[2] ? a.z : 0.f; dst[3] = col_ok[3] ? a.w : 0.f;
+            dst[4] = col_ok[4] ? b.x : 0.f; dst[5] = col_ok[5] ? b.y : 0.f; dst[6] = col_ok[6] ? b.z : 0.f; dst[7] = 0.f;
         } else {
 #pragma unroll
-            for (int c = 0; c < 7; c++) {
-                const int ix = cx + c;
-                win[r][c] = (row_ok && ix >= 0 && ix < p.in_w) ? row[ix] : 0.0f;
-            }
-            win[r][7] = 0.0f;
+            for (int c = 0; c < 8; c++) dst[c] = col_ok[c] ? input[off + c] : 0.0f;
         }
+    };
+    load_row(0, win[0]);
+    load_row(1, win[1]);
+    load_row(2, win[2]);
+    float* dst = out + ((size_t)plane * p.out_h + oy0) * p.out_w + ox0;
+    float nw = 0.f, bs = 0.f;
+    const float* noise = nullptr;
+    if (ACT) {
+        const int grp = plane / act.C, c = plane - grp * act.C;
+        noise = act.noise.p[grp];
+        nw = noise ? act.nw.p[grp][0] : 0.f;
+        bs = act.bias.p[grp] ? act.bias.p[grp][c] : 0.f;
     }
-    float* dst = out + ((size_t)blockIdx.z * p.out_h + oy0) * p.out_w + ox0;
 #pragma unroll
-    for (int dy = 0; dy < 2; dy++) {
+    for (int dy = 0; dy < kFirRows; dy++) {
         if (oy0 + dy >= p.out_h) break;
+        load_row(dy + 3, win[(dy + 3) & 3]);
         float v[4] = { 0.f, 0.f, 0.f, 0.f };
 #pragma unroll
         for (int y = 0; y < 4; y++)
@@ -574,22 +599,57 @@ __global__ void __launch_bounds__(256) fir4x4_kernel(float* __restrict__ out, co
             for (int x = 0; x < 4; x++) {
                 const float k = taps[(3 - y) * 4 + (3 - x)];
 #pragma unroll
-                for (int q = 0; q < 4; q++) v[q] = fmaf(win[dy + y][q + x], k, v[q]);
+                for (int q = 0; q < 4; q++) v[q] = fmaf(win[(dy + y) & 3][q + x], k, v[q]);
             }
-        if (ox0 + 4 <= p.out_w && (((size_t)(dst + (size_t)dy * p.out_w)) & 15) == 0) {
-            *reinterpret_cast<float4*>(dst + (size_t)dy * p.out_w) = make_float4(v[0], v[1], v[2], v[3]);
+        float* o = dst + (size_t)dy * p.out_w;
+        if (ACT) {
+            const size_t pix = (size_t)(oy0 + dy) * p.out_w + ox0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const float n = (noise && ox0 + q < p.out_w) ? noise[pix + q] : 0.f;
+                const float tv = fmaf(nw, n, v[q]) + bs;
+                v[q] = (tv > 0.f ? tv : tv * act.slope) * act.scale;
+            }
+        }
+        if (ox0 + 4 <= p.out_w && (((size_t)o) & 15) == 0) {
+            *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
         } else {
 #pragma unroll
             for (int q = 0; q < 4; q++)
-                if (ox0 + q < p.out_w) dst[(size_t)dy * p.out_w + q] = v[q];
+                if (ox0 + q < p.out_w) o[q] = v[q];
         }
     }
+}
+
+static int launch_fir4x4(float* out, const float* input, const float* kernel, const UpfirdnParams& p, int major, const FirAct* act, hipStream_t s)
+{
+    const int quads = (p.out_w + 3) / 4, strips = (p.out_h + kFirRows - 1) / kFirRows;
+    const long long threads = (long long)quads * strips, total = (long long)major * p.in_h * p.in_w;
+    dim3 grid((unsigned)((threads + 255) / 256), major);
+    if (act) hipLaunchKernelGGL(fir4x4_kernel<true>, grid, dim3(256), 0, s, out, input, kernel, p, quads, strips, total, *act);
+    else     hipLaunchKernelGGL(fir4x4_kernel<false>, grid, dim3(256), 0, s, out, input, kernel, p, quads, strips, total, FirAct{});
+    return check_hip(hipGetLastError(), "fir4x4_kernel");
 }
 
 // ------------------------------------------------------------------------------------------------------------------
 // grouped launchers (ag_groups.h); G = 1 is the per-kernel C ABI below
 // ------------------------------------------------------------------------------------------------------------------
 static bool bad_groups(int G) { return G < 1 || G > kMaxGroups; }
+
+// Blur pad (1, 1) of a [G][C][H][W] stack followed by the activation pass, one kernel (the tail of an up-sampling StyledConv)
+int blur_act_forward_g(float* y, const float* x, const float* taps, int G, const PtrTable& noise, const PtrTable& nw, const PtrTable& bias,
+                       int C, int H, int W, float slope, float scale, hipStream_t s)
+{
+    if (bad_groups(G) || C < 1 || H < 3 || W < 3 || !y || !x || !taps || (long long)G * C > 65535) { set_error("bad blur_act arguments"); return AG_ERR_INVALID_ARGUMENT; }
+    for (int g = 0; g < G; g++)
+        if (noise.p[g] && !nw.p[g]) { set_error("blur_act: noise without a noise weight"); return AG_ERR_INVALID_ARGUMENT; }
+    UpfirdnParams p;
+    p.up_x = p.up_y = p.down_x = p.down_y = 1; p.pad_x0 = p.pad_y0 = 1;
+    p.major = G * C; p.in_h = H; p.in_w = W; p.kernel_h = p.kernel_w = 4;
+    p.out_h = H - 1; p.out_w = W - 1;
+    FirAct act{ noise, nw, bias, C, slope, scale };
+    return launch_fir4x4(y, x, taps, p, G * C, &act, s);
+}
 
 int noise_bias_act_forward_g(float* y, const float* x, int G, const PtrTable& noise, const PtrTable& nw, const PtrTable& bias, int C, int HW,
                              float slope, float scale, hipStream_t s)
@@ -845,9 +905,7 @@ int ag_upfirdn2d(float* out, const float* input, const float* kernel, int32_t ma
     if (major == 0) return AG_OK;
     if (!out || !input || !kernel) { set_error("null pointer"); return AG_ERR_INVALID_ARGUMENT; }
     if (up_x == 1 && up_y == 1 && down_x == 1 && down_y == 1 && kernel_h == 4 && kernel_w == 4 && major <= 65535) {
-        dim3 grid((p.out_w + 255) / 256, (p.out_h + 7) / 8, major);
-        hipLaunchKernelGGL(fir4x4_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), out, input, kernel, p);
-        return check_hip(hipGetLastError(), "fir4x4_kernel");
+        return launch_fir4x4(out, input, kernel, p, major, nullptr, reinterpret_cast<hipStream_t>(stream));
     }
     const long long total = (long long)major * p.out_h * p.out_w;
     long long blocks = (total + 255) / 256;

@@ -72,7 +72,7 @@ int ag_conv_backward_weight(const AgConvDesc* d, const float* x, const float* dy
  *                              Not fp32-grade; for scale, the reference's cuDNN path runs TF32 (2^-11 per operand) by default --
  *                              conv2d_gradfix.py never disables it.
  * Returns AG_OK / AG_ERR_INVALID_ARGUMENT. */
-typedef enum AgConvMath { AG_CONV_MATH_FP32_MFMA = 0, AG_CONV_MATH_SPLIT_BF16 = 1, AG_CONV_MATH_SPLIT_BF16X3 = 2 } AgConvMath;
+typedef enum AgConvMath { AG_CONV_MATH_FP32_MFMA = 0, AG_CONV_MATH_SPLIT_BF16 = 1, AG_CONV_MATH_SPLIT_BF16X3 = 2, AG_CONV_MATH_SPLIT_F16 = 3 } AgConvMath;
 int ag_conv_set_math(int mode);
 int ag_conv_get_math(void);
 

@@ -69,7 +69,7 @@ for c in calls:
 g = torch.Generator().manual_seed(0)
 for c, count in seen.items():
     kind, G, Cin, Cout, H, k, res, shared = c
-    x = torch.randn(1 if shared else G, Cin, H, H, device=dev).requires_grad_(not (shared is True))
+    x = torch.randn(G if (kind == "comb" or not shared) else 1, Cin, H, H, device=dev).requires_grad_(not (shared is True))
     if kind == "comb":
         N, C2, begin = k, res, shared
         OH = H

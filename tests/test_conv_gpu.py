@@ -48,7 +48,7 @@ CASES = [
 ]
 
 
-@pytest.fixture(params=["split_bf16", "fp32"])
+@pytest.fixture(params=["split_bf16", "fp32", "split_f16"])
 def math_mode(request):
     from animatablegaussians_amd import conv as agc
     prev = agc.set_math(request.param)
@@ -162,7 +162,7 @@ def test_split_products_are_fp32_grade(kind, Cin, Cout, hw, k, stride, padding):
     refs = (ref.detach(), xd.grad, wd.grad)
     names = ("forward", "dL/dx", "dL/dw")
     rms, worst = {}, {}
-    for mode in ("fp32", "split_bf16", "split_bf16x3"):
+    for mode in ("fp32", "split_bf16", "split_f16", "split_bf16x3"):
         prev = agc.set_math(mode)
         try:
             xg, wg = (t.clone().cuda().requires_grad_(True) for t in (x, w))
@@ -180,6 +180,7 @@ def test_split_products_are_fp32_grade(kind, Cin, Cout, hw, k, stride, padding):
     for name in names:
         assert worst[("fp32", name)] <= 2.0 ** -19 and worst[("split_bf16", name)] <= 2.0 ** -19, (name, worst)
         assert rms[("split_bf16", name)] <= 1.5 * rms[("fp32", name)] + 1e-12, (name, rms)
+        assert worst[("split_f16", name)] <= 2.0 ** -19 and rms[("split_f16", name)] <= 1.5 * rms[("fp32", name)] + 1e-12, (name, worst, rms)
         assert worst[("split_bf16x3", name)] <= 3 * 2.0 ** -16 + 2.0 ** -19, (name, worst)
         assert rms[("split_bf16x3", name)] > 4.0 * rms[("split_bf16", name)], (name, rms)
 

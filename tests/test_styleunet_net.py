@@ -80,7 +80,7 @@ def test_state_dict_is_the_reference_modules_layout():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("math", ["split_bf16", "fp32"])
+@pytest.mark.parametrize("math", ["split_bf16", "fp32", "split_f16"])
 def test_dual_styleunet_forward_backward_vs_reference_golden(math):
     """Both arithmetic paths of the convolutions (include/ag_conv.h: the default six-product bf16 split and the fp32 MFMA) end to end
     against the fixture the reference module produced."""
