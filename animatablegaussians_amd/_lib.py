@@ -103,7 +103,7 @@ class AgGroupedLayerArgs(ctypes.Structure):   # include/ag_layers.h
                 + [(n, c_vp) for n in ("k_blur", "w_mod", "demod", "x_blur", "out", "scratch", "workspace")]
                 + [("workspace_bytes", c_sz)]
                 + [(n, c_vp) for n in ("g_out", "g_x", "g_weight", "g_style", "g_bias_noise")]
-                + [("want_bias", c_i32), ("want_noise_weight", c_i32)])
+                + [("want_bias", c_i32), ("want_noise_weight", c_i32), ("operand_maxima", c_vp)])
 
 
 class AgGroupedToRgbArgs(ctypes.Structure):   # include/ag_layers.h
@@ -198,6 +198,7 @@ SYMBOLS = [
     ("ag_grouped_layer_output_size", ctypes.c_int, [ctypes.POINTER(AgGroupedLayerArgs), ctypes.POINTER(c_i32), ctypes.POINTER(c_i32)]),
     ("ag_grouped_layer_scratch_floats", c_sz, [ctypes.POINTER(AgGroupedLayerArgs), c_i32]),
     ("ag_grouped_layer_workspace_bytes", c_sz, [ctypes.POINTER(AgGroupedLayerArgs)]),
+    ("ag_grouped_layer_maxima_floats", c_sz, []),
     ("ag_grouped_layer_forward", ctypes.c_int, [ctypes.POINTER(AgGroupedLayerArgs), c_vp]),
     ("ag_grouped_layer_backward", ctypes.c_int, [ctypes.POINTER(AgGroupedLayerArgs), c_vp]),
     ("ag_grouped_to_rgb_args_bytes", c_sz, []),

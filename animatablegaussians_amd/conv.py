@@ -19,9 +19,10 @@ MATH_MODES = {"fp32": 0, "split_bf16": 1, "split_bf16x3": 2, "split_f16": 3}    
 
 
 def set_math(mode: str) -> str:
-    """Arithmetic of the MFMA convolutions, process-wide: ``"split_bf16"`` (default: fp32 operands as three bf16 parts, six products
-    on the bf16 matrix pipe, fp32 accumulation -- products within 2^-23 of the exact ones), ``"fp32"`` (v_mfma_f32_32x32x2_f32) or
-    the opt-in ``"split_bf16x3"`` (three products, 3 * 2^-16 per product: not fp32-grade).  Returns the previous mode."""
+    """Arithmetic of the MFMA convolutions, process-wide: ``"split_f16"`` (default: fp32 operands as two fp16 parts under a per-tensor
+    power-of-two scale, three products on the fp16 matrix pipe, fp32 accumulation), ``"split_bf16"`` (three bf16 parts, six products) --
+    both with products within 2^-23 of the exact ones --, ``"fp32"`` (v_mfma_f32_32x32x2_f32) or the opt-in ``"split_bf16x3"`` (three
+    products, 3 * 2^-16 per product: not fp32-grade).  include/ag_conv.h has the contracts.  Returns the previous mode."""
     if mode not in MATH_MODES:
         raise ValueError(f"conv math mode must be one of {sorted(MATH_MODES)}")
     prev = get_math()

@@ -2,9 +2,10 @@
 //
 // Replaces the cuDNN calls behind network/styleunet/conv2d_gradfix.py (conv2d / conv_transpose2d) and their
 // backward.  Every variant is one of two implicit GEMMs, in one of two engines (ag_conv_set_math):
-//   * the split engine (default): fp32 operands as three bf16 parts, six products per fp32 product on
-//     v_mfma_f32_32x32x16_bf16, fp32 accumulation -- products within 2^-23 of exact (section "fp32 products on the bf16
-//     matrix pipe" below); an opt-in three-product form;
+//   * the split engine: fp32 operands as sums of 16-bit parts, fp32 accumulation.  Default (round 4): two fp16 parts under a per-tensor
+//     power-of-two scale, three products per fp32 product on v_mfma_f32_32x32x16_f16 (section "fp32 products on the fp16 matrix pipe");
+//     before: three bf16 parts, six products on v_mfma_f32_32x32x16_bf16 -- products within 2^-23 of exact either way; an opt-in
+//     three-product bf16 form (2^-16);
 //   * the fp32 engine: v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulate; 157 TF peak = the fp32 vector rate, but it
 //     leaves the VALU free for the gather arithmetic).
 // Both share the problem decomposition, the tiles, the K order, split-K and the epilogues:
@@ -433,20 +434,23 @@ __device__ __forceinline__ void split_pair(float x0, float x1, uint32_t& p0, uin
 // fp32 products on the fp16 matrix pipe: two-way split under a per-tensor power-of-two scale, three MFMAs per K tile (round 4)
 // ------------------------------------------------------------------------------------------------------------------
 // fp16 carries 11 significant bits against bf16's 8, so TWO parts hold 22 bits where the bf16 split needs three: with y = s x
-// (s a power of two that puts the tensor's largest magnitude into [2^14, 2^15): exact),  h = rn_f16(y),  l = rn_f16(2^11 (y - h))
-// (y - h is exact in fp32 and <= 2^-11 |y|, so l has the magnitude of y and is a NORMAL fp16 number wherever h is: down to 2^-28 of the
-// tensor's maximum), |y - h - 2^-11 l| <= 2^-23 |y|.  A product is a_h b_h + 2^-11 (a_h b_l + a_l b_h): the first term goes to one fp32
-// accumulator, the two cross terms to a second one that is scaled and added once at the end; the dropped a_l b_l is <= 2^-24 |a| |b|, the
-// part conversions add 2^-23 each -- the same grade as the six-product bf16 form (2^-23 worst case) at HALF the matrix instructions and two
-// thirds of the LDS traffic.  The price is the scale: fp16 has 5 exponent bits, so every operand tensor needs its largest magnitude known
-// before its consumer starts (absmax_kernel below: per-workgroup partial maxima, finished by the consumer; no atomics, no host round
-// trip).  Elements below 2^-28 of the maximum lose relative precision gracefully (absolute error <= 2^-53 of the maximum).
+// (s a power of two that puts the tensor's largest magnitude M into [2^14, 2^15): exact),  h = rn_f16(y),  l = rn_f16(y - h)  (y - h is
+// exact in fp32 and <= 2^-12 |y|),  |y - h - l| <= max(2^-24 |y|, 2^-25): the first bound wherever l is a normal fp16 number (|y| >= 2^-2,
+// i.e. |x| >= 2^-17 M), the second -- 2^-39 M in x's units -- below that, where l is subnormal.  A product is a_h b_h + a_h b_l + a_l b_h
+// (three exact fp32 products inside the matrix core, one fp32 accumulator); the dropped a_l b_l is <= 2^-24 |a| |b|.  Per output:
+//     |error| <= 3 * 2^-24 sum |a| |b|  +  2^-39 (M_b sum |a| + M_a sum |b|)
+// -- the six-product bf16 form's grade (2^-23) for every output whose operands are on average within 2^16 of their tensors' maxima, and for
+// the others an ABSOLUTE error 2^-15 of the rounding fp32 itself commits on the tensor's large outputs.  Half the matrix instructions and
+// two thirds of the LDS traffic of the bf16 form.  The price is the scale: fp16 has 5 exponent bits, so every operand tensor needs its
+// largest magnitude known before its consumer starts (absmax_kernel below: per-workgroup partial maxima, finished by the consumer; no
+// atomics, no host round trip).
+// (A variant that kept the low parts normal down to 2^-28 M -- l = rn_f16(2^11 (y - h)), the cross terms in a second accumulator scaled
+// by 2^-11 at the end -- measured the same deviations (profiles/r04_split_f16_products.txt) but needs 190 registers: one workgroup per CU,
+// 175 us per launch where this form runs 145; the three-product bf16 kernel confined to one workgroup per CU lands on the same 171 us:
+// profiles/r04_split_f16_ab.txt.  Commit c06b403 has it.)
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 constexpr int kF16 = 2;                 // value of the kernels' NTERMS parameter that selects this form (6 / 3: the bf16 forms)
-constexpr int kAmaxParts = 256;         // partial maxima per tensor instance
-constexpr int kF16Waves = 2;            // waves per SIMD of the fp16 kernels (__launch_bounds__): the second accumulator set does not fit 128 registers
-constexpr float kLoUp = 2048.0f, kLoDown = 1.0f / 2048.0f;
 
 __device__ __forceinline__ uint32_t pack_f16(float lo, float hi)        // round to nearest even
 {
@@ -457,7 +461,7 @@ __device__ __forceinline__ void split_pair_h(float y0, float y1, uint32_t& p0, u
 {
     p0 = pack_f16(y0, y1);
     const f16x2 h = __builtin_bit_cast(f16x2, p0);
-    p1 = pack_f16((y0 - (float)h[0]) * kLoUp, (y1 - (float)h[1]) * kLoUp);
+    p1 = pack_f16(y0 - (float)h[0], y1 - (float)h[1]);
 }
 // scale of a tensor instance from the partial maxima of absmax_kernel (wave-uniform): s = 2^(14 - e) for a maximum in [2^e, 2^(e+1)),
 // 1 / s exactly; an all-zero (or non-finite) tensor gets s = 1
@@ -488,31 +492,43 @@ struct AmaxJobs {
     int rows[2 * kMaxGroups], slot[2 * kMaxGroups];
     float* out;                         // job j writes out[slot[j]][kAmaxParts]
 };
-__global__ void __launch_bounds__(256) absmax_kernel(AmaxJobs J)
+constexpr int kAmaxThreads = 1024;      // 16 waves per workgroup: 256 workgroups per tensor have to keep HBM busy on their own
+__global__ void __launch_bounds__(kAmaxThreads) absmax_kernel(AmaxJobs J)
 {
     const int job = blockIdx.y;
     const float* __restrict__ x = J.ptr[job];
     const long long len = J.len[job];
     float m = 0.f;
     if (J.rows[job] == 1 && (len & 3) == 0 && (((size_t)x) & 15) == 0) {
-        const long long n4 = len >> 2;
-        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)kAmaxParts * 256) {
-            const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+        const long long n4 = len >> 2, step = (long long)kAmaxParts * kAmaxThreads;
+        const f32x4* __restrict__ x4 = reinterpret_cast<const f32x4*>(x);
+        long long i = (long long)blockIdx.x * kAmaxThreads + threadIdx.x;
+        for (; i + 3 * step < n4; i += 4 * step) {              // four loads in flight per thread: the sweep is latency-bound otherwise
+            const f32x4 v0 = x4[i], v1 = x4[i + step], v2 = x4[i + 2 * step], v3 = x4[i + 3 * step];
+#pragma unroll
+            for (int e = 0; e < 4; e++) m = fmaxf(fmaxf(m, fmaxf(fabsf(v0[e]), fabsf(v1[e]))), fmaxf(fabsf(v2[e]), fabsf(v3[e])));
+        }
+        for (; i < n4; i += step) {
+            const f32x4 v = x4[i];
             m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
         }
     } else {
         const long long n = len * J.rows[job];
-        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)kAmaxParts * 256) {
+        for (long long i = (long long)blockIdx.x * kAmaxThreads + threadIdx.x; i < n; i += (long long)kAmaxParts * kAmaxThreads) {
             const long long r = i / len;
             m = fmaxf(m, fabsf(x[r * J.stride[job] + (i - r * len)]));
         }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    __shared__ float wm[4];
+    __shared__ float wm[kAmaxThreads / 64];
     if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0) J.out[(size_t)J.slot[job] * kAmaxParts + blockIdx.x] = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 1; i < kAmaxThreads / 64; i++) m = fmaxf(m, wm[i]);
+        J.out[(size_t)J.slot[job] * kAmaxParts + blockIdx.x] = m;
+    }
 }
 
 // Byte offset of the 16-byte chunk (row, kh) inside a plane of 32-byte rows.  The XOR puts rows r and r + 8 (same banks at a 32-byte
@@ -566,9 +582,9 @@ __device__ __forceinline__ void mma_split(const SplitOperands<WMB, WNB>& o, f32x
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o.a[i][ta[t]], o.b[j][tb[t]], acc[i][j], 0, 0, 0);
 }
 
-// the fp16 form: a_h b_h into acc, the cross terms into acc1 (scaled by 2^-11 and added by fold_f16 at the end)
+// the fp16 form: smallest terms first, like mma_split
 template <int WMB, int WNB>
-__device__ __forceinline__ void mma_split_h(const SplitOperands<WMB, WNB>& o, f32x16 (&acc)[WMB][WNB], f32x16 (&acc1)[WMB][WNB])
+__device__ __forceinline__ void mma_split_h(const SplitOperands<WMB, WNB>& o, f32x16 (&acc)[WMB][WNB])
 {
 #pragma unroll
     for (int t = 0; t < 3; t++)
@@ -577,19 +593,18 @@ __device__ __forceinline__ void mma_split_h(const SplitOperands<WMB, WNB>& o, f3
 #pragma unroll
             for (int j = 0; j < WNB; j++) {
                 const f16x8 a = __builtin_bit_cast(f16x8, o.a[i][t == 1 ? 1 : 0]), b = __builtin_bit_cast(f16x8, o.b[j][t == 0 ? 1 : 0]);
-                if (t == 2) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[i][j], 0, 0, 0);
-                else        acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc1[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[i][j], 0, 0, 0);
             }
 }
 template <int WMB, int WNB>
-__device__ __forceinline__ void fold_f16(f32x16 (&acc)[WMB][WNB], const f32x16 (&acc1)[WMB][WNB], float inv_a, float inv_b)
+__device__ __forceinline__ void unscale_f16(f32x16 (&acc)[WMB][WNB], float inv_a, float inv_b)
 {
 #pragma unroll
     for (int i = 0; i < WMB; i++)
 #pragma unroll
         for (int j = 0; j < WNB; j++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) acc[i][j][r] = fmaf(acc1[i][j][r], kLoDown, acc[i][j][r]) * inv_a * inv_b;
+            for (int r = 0; r < 16; r++) acc[i][j][r] = acc[i][j][r] * inv_a * inv_b;
 }
 
 // gather_conv_kernel on the split engine.  Same K order, same classes, same epilogue; differences: the packed weights arrive already
@@ -604,7 +619,7 @@ __device__ __forceinline__ void fold_f16(f32x16 (&acc)[WMB][WNB], const f32x16 (
 // Removed in round 4; commit fa8b937 has them.)
 
 template <int WMB, int WNB, int WVM, int WVN, bool CEXACT, int NTERMS>
-__global__ void __launch_bounds__(64 * WVM * WVN, NTERMS == kF16 ? kF16Waves : AG_CONV_WAVES_PER_SIMD) gather_conv_split_kernel(GatherProblem p)
+__global__ void __launch_bounds__(64 * WVM * WVN, AG_CONV_WAVES_PER_SIMD) gather_conv_split_kernel(GatherProblem p)
 {
     constexpr int NPL = planes_of(NTERMS);
     constexpr bool F16 = NTERMS == kF16;
@@ -668,15 +683,7 @@ __global__ void __launch_bounds__(64 * WVM * WVN, NTERMS == kF16 ? kF16Waves : A
         sa = tensor_scale(p.amax_a + (size_t)gv.grp * kAmaxParts, p.amax_a_mult, lane);
         sb = tensor_scale(p.amax_b + (p.x_gs ? (size_t)gv.grp * kAmaxParts : 0), 1.f, lane);
     }
-    f32x16 acc1[WMB][WNB];
-    if constexpr (F16) {
-#pragma unroll
-        for (int i = 0; i < WMB; i++)
-#pragma unroll
-            for (int j = 0; j < WNB; j++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) acc1[i][j][r] = 0.f;
-    }
+
     const uint32_t a_voff0 = (uint32_t)min(tid, AC - 1) * 16u;
     const uint32_t a_voff1 = (uint32_t)min(NT + tid, AC - 1) * 16u;
     const bool a_thread0 = tid < AC;                  // wave-uniform (AC is a multiple of 64)
@@ -748,7 +755,7 @@ __global__ void __launch_bounds__(64 * WVM * WVN, NTERMS == kF16 ? kF16Waves : A
         read_split_operands<WMB, WNB, BM, BN, NTERMS>(As0 + buf * T::a_bytes, Bs0 + buf * T::b_bytes, wm, wn, lane, O);
     };
     auto mma = [&]() {
-        if constexpr (F16) mma_split_h<WMB, WNB>(O, acc, acc1);
+        if constexpr (F16) mma_split_h<WMB, WNB>(O, acc);
         else               mma_split<WMB, WNB, NTERMS>(O, acc);
     };
 
@@ -788,7 +795,7 @@ __global__ void __launch_bounds__(64 * WVM * WVN, NTERMS == kF16 ? kF16Waves : A
             step_tail(kt, S[1], false);
         }
     }
-    if constexpr (F16) fold_f16<WMB, WNB>(acc, acc1, sa.inv, sb.inv);
+    if constexpr (F16) unscale_f16<WMB, WNB>(acc, sa.inv, sb.inv);
     gather_epilogue<WMB, WNB>(p, gv, cl, acc, m0, n0, N, wm, wn, lane);
 }
 
@@ -1135,7 +1142,7 @@ __global__ void __launch_bounds__(64 * WVM * WVN, AG_CONV_WAVES_PER_SIMD) wgrad_
 // every load stays inside the tensor and unconditional.  PMC of the scalar form (r04_pmc_wgrad_256_256_128.txt): 140 VALU instructions per wave
 // and K tile for 12 MFMAs -- the weight gradient was bound by its loader's instruction count, not by the matrix pipe.
 template <int WMB, int WNB, int WVM, int WVN, bool AVEC, int NTERMS, bool BVEC = false>
-__global__ void __launch_bounds__(64 * WVM * WVN, NTERMS == kF16 ? kF16Waves : AG_CONV_WAVES_PER_SIMD) wgrad_split_kernel(WgradProblem p)
+__global__ void __launch_bounds__(64 * WVM * WVN, AG_CONV_WAVES_PER_SIMD) wgrad_split_kernel(WgradProblem p)
 {
     constexpr int NPL = planes_of(NTERMS);
     constexpr bool F16 = NTERMS == kF16;
@@ -1202,13 +1209,13 @@ __global__ void __launch_bounds__(64 * WVM * WVN, NTERMS == kF16 ? kF16Waves : A
     }
     int gy0 = kbeg / p.gw, gx0 = kbeg - gy0 * p.gw;
 
-    f32x16 acc[WMB][WNB], acc1[WMB][WNB];
+    f32x16 acc[WMB][WNB];
 #pragma unroll
     for (int i = 0; i < WMB; i++)
 #pragma unroll
         for (int j = 0; j < WNB; j++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) { acc[i][j][r] = 0.f; if constexpr (F16) acc1[i][j][r] = 0.f; }
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
     TensorScale sa{ 1.f, 1.f }, sb{ 1.f, 1.f };
     if constexpr (F16) {
         sa = tensor_scale(p.amax_a + (p.a_gs ? (size_t)grp * kAmaxParts : 0), 1.f, lane);
@@ -1336,7 +1343,7 @@ __global__ void __launch_bounds__(64 * WVM * WVN, NTERMS == kF16 ? kF16Waves : A
     };
 
     auto mma = [&]() {
-        if constexpr (F16) mma_split_h<WMB, WNB>(O, acc, acc1);
+        if constexpr (F16) mma_split_h<WMB, WNB>(O, acc);
         else               mma_split<WMB, WNB, NTERMS>(O, acc);
     };
 
@@ -1388,7 +1395,7 @@ __global__ void __launch_bounds__(64 * WVM * WVN, NTERMS == kF16 ? kF16Waves : A
             for (int r = 0; r < 16; r++) {
                 const int m = m0 + (wm * WMB + i) * 32 + (r & 3) + 8 * (r >> 2) + rbase;
                 float v = acc[i][j][r];
-                if constexpr (F16) v = fmaf(acc1[i][j][r], kLoDown, v) * sa.inv * sb.inv;
+                if constexpr (F16) v = v * sa.inv * sb.inv;
                 if (m < p.Mw) atomicAdd(cn + (size_t)m * p.c_row_stride, v * p.wscale);
             }
         }
@@ -1446,7 +1453,7 @@ __global__ void __launch_bounds__(256) mfma_rate_bf16_kernel(int iters, float* o
 static int round_up(int v, int a) { return (v + a - 1) / a * a; }
 
 // arithmetic of the MFMA convolutions (ag_conv_set_math): process-wide, read at every call
-static std::atomic<int> g_conv_math{ AG_CONV_MATH_SPLIT_BF16 };
+static std::atomic<int> g_conv_math{ AG_CONV_MATH_SPLIT_F16 };
 static int split_terms()        // 0: fp32 MFMA engine; 6 / 3: bf16 products per fp32 product; kF16 (2): the two-part fp16 form
 {
     const int m = g_conv_math.load(std::memory_order_relaxed);
@@ -1456,22 +1463,34 @@ static bool split_math() { return split_terms() != 0; }
 
 // fp16 form: the partial maxima of a call's two operands live behind the split-K partial sums in the call's workspace
 constexpr size_t kAmaxBytes = 2 * (size_t)kMaxGroups * kAmaxParts * sizeof(float);
-struct AmaxTensor { const float* ptr; long long gs; long long len, stride; int rows; };     // G instances `gs` floats apart (0: one shared instance)
-// one launch for both operands: a's rows go to out[0 .. G), b's to out[kMaxGroups ..)
-static int launch_absmax(const AmaxTensor& a, const PtrTable* a_table, const AmaxTensor& b, int G, float* out, hipStream_t s)
+// one launch for the partial maxima of up to three operand tensors (instances: `table` entries, or `ptr + g * gs`, or ONE shared instance
+// when gs == 0 and there is no table); tensor i's instance g goes to out[(i * kMaxGroups + g) * kAmaxParts ...]
+int conv_absmax(const AmaxTensor* t, int n, int G, float* out, hipStream_t s)
 {
     AmaxJobs J;
-    int n = 0;
-    auto add = [&](const float* ptr, const AmaxTensor& t, int slot) {
-        J.ptr[n] = ptr; J.len[n] = t.len; J.stride[n] = t.stride; J.rows[n] = t.rows; J.slot[n] = slot; n++;
-    };
-    const int na = a_table ? G : (a.gs ? G : 1), nb = b.gs ? G : 1;
-    for (int g = 0; g < na; g++) add(a_table ? a_table->p[g] : a.ptr + (size_t)g * a.gs, a, g);
-    for (int g = 0; g < nb; g++) add(b.ptr + (size_t)g * b.gs, b, kMaxGroups + g);
+    int jobs = 0;
+    for (int i = 0; i < n; i++) {
+        if (!t[i].ptr && !t[i].table) continue;
+        const int n_i = t[i].inst ? t[i].inst : G;
+        const int inst = t[i].table ? n_i : (t[i].gs ? n_i : 1);
+        for (int g = 0; g < inst; g++) {
+            if (jobs == 2 * kMaxGroups) {         // three full stacks of more than 10 instances: a second launch
+                J.out = out;
+                hipLaunchKernelGGL(absmax_kernel, dim3(kAmaxParts, jobs), dim3(kAmaxThreads), 0, s, J);
+                jobs = 0;
+            }
+            J.ptr[jobs] = t[i].table ? t[i].table->p[g] : t[i].ptr + (size_t)g * t[i].gs;
+            J.len[jobs] = t[i].len; J.stride[jobs] = t[i].stride; J.rows[jobs] = t[i].rows; J.slot[jobs] = i * kMaxGroups + g;
+            jobs++;
+        }
+    }
+    if (jobs == 0) return AG_OK;
     J.out = out;
-    hipLaunchKernelGGL(absmax_kernel, dim3(kAmaxParts, n), dim3(256), 0, s, J);
+    hipLaunchKernelGGL(absmax_kernel, dim3(kAmaxParts, jobs), dim3(kAmaxThreads), 0, s, J);
     return check_hip(hipGetLastError(), "absmax_kernel");
 }
+size_t conv_absmax_floats(int tensors) { return (size_t)tensors * kMaxGroups * kAmaxParts; }
+bool conv_math_needs_absmax() { return split_terms() == kF16; }
 
 static int validate(const AgConvDesc* d)
 {
@@ -1547,7 +1566,8 @@ static int choose_splits(long long tiles, int Mpad, int Ncols, int nkt, int G = 
 // Fills tile_begin / col_begin / at_off / nkt of the classes (dy, dx, gh, gw, y0, x0, ntaps set by the caller), packs the
 // weights of all classes with one launch and runs them with one launch (+ one split-K finish).
 static int pack_and_launch(GatherProblem& gp, const TapSet* taps, int bm, const PtrTable& w, long long stride_c, long long stride_m,
-                           float wscale, int k, float* At, float* partial, float* amax, const AmaxTensor& w_shape, hipStream_t s)
+                           float wscale, int k, float* At, float* partial, float* amax, const AmaxTensor& w_shape, const float* pre_w,
+                           const float* pre_in, hipStream_t s)
 {
     const bool split = split_math();
     const int terms = split_terms();
@@ -1584,12 +1604,15 @@ static int pack_and_launch(GatherProblem& gp, const TapSet* taps, int bm, const 
     gp.amax_a = gp.amax_b = nullptr;
     gp.amax_a_mult = 1.f;
     if (f16) {
-        const AmaxTensor xb{ gp.xin, gp.x_gs, (long long)gp.Cg * gp.Hg * gp.Wg, 0, 1 };
-        int rc0 = launch_absmax(w_shape, &w, xb, G, amax, s);
+        AmaxTensor t[2] = { w_shape, AmaxTensor{ gp.xin, nullptr, gp.x_gs, (long long)gp.Cg * gp.Hg * gp.Wg, 0, 1 } };
+        t[0].table = &w;
+        if (pre_w) t[0] = AmaxTensor{};           // the caller already has this operand's partial maxima (ConvOpts)
+        if (pre_in) t[1] = AmaxTensor{};
+        int rc0 = conv_absmax(t, 2, G, amax, s);
         if (rc0) return rc0;
-        pp.amax = amax;
-        gp.amax_a = amax;
-        gp.amax_b = amax + (size_t)kMaxGroups * kAmaxParts;
+        pp.amax = pre_w ? pre_w : amax;
+        gp.amax_a = pp.amax;
+        gp.amax_b = pre_in ? pre_in : amax + (size_t)kMaxGroups * kAmaxParts;
         gp.amax_a_mult = wscale != 1.f ? fabsf(wscale) : 1.f;
     }
     if (split) hipLaunchKernelGGL(pack_weights_split_kernel, dim3(gp.Cpad / BK, gp.Mpad / 16, G), dim3(256), 0, s, pp);
@@ -1720,7 +1743,8 @@ static int run_gather_family(const AgConvDesc* d, bool backward_input, int G, co
     stride_c = backward_input ? s_co : s_ci;
     stride_m = backward_input ? s_ci : s_co;
     // the weight tensor of an instance as runs of floats (absmax of the fp16 form): whole and contiguous, or Cout rows of a channel slice
-    AmaxTensor w_shape{ nullptr, 0, (long long)d->Cout * d->Cin * k2, 0, 1 };
+    AmaxTensor w_shape{ nullptr, nullptr, 0, (long long)d->Cout * d->Cin * k2, 0, 1 };
+    const float* const pre_in = backward_input ? opt.amax_dy : opt.amax_x;
     if (opt.w_cin_total && opt.w_cin_total != d->Cin) { w_shape.len = (long long)d->Cin * k2; w_shape.stride = cin_rows * k2; w_shape.rows = d->Cout; }
     gp.Cg = Cg; gp.Hg = Hg; gp.Wg = Wg; gp.M = M; const int bm = pick_bm(M); gp.Mpad = round_up(M, bm); gp.OHf = OHf; gp.OWf = OWf;
     gp.Cpad = round_up(Cg, BK);
@@ -1747,7 +1771,7 @@ static int run_gather_family(const AgConvDesc* d, bool backward_input, int G, co
             for (int t = 0; t < k2; t++) { cl.dy[t] = ts.ky[t]; cl.dx[t] = ts.kx[t]; }
         }
         for (int t = k2; t < kMaxTaps; t++) cl.dy[t] = cl.dx[t] = 0;
-        return pack_and_launch(gp, taps, bm, w, stride_c, stride_m, wscale_of(d), k, At, partial, amax, w_shape, s);
+        return pack_and_launch(gp, taps, bm, w, stride_c, stride_m, wscale_of(d), k, At, partial, amax, w_shape, opt.amax_w, pre_in, s);
     }
     // scatter with stride 2: output coordinate o = 2*i + ky - poff  (poff = padding for the conv gradient, 0 for convT).
     // Class (qy, qx) = parity of the output coordinate; it receives only taps with ky = (o + poff) mod 2, from
@@ -1785,7 +1809,7 @@ static int run_gather_family(const AgConvDesc* d, bool backward_input, int G, co
             gp.cls[pos] = cl; taps[pos] = ts;
             gp.nclasses++;
         }
-    return pack_and_launch(gp, taps, bm, w, stride_c, stride_m, wscale_of(d), k, At, partial, amax, w_shape, s);
+    return pack_and_launch(gp, taps, bm, w, stride_c, stride_m, wscale_of(d), k, At, partial, amax, w_shape, opt.amax_w, pre_in, s);
 }
 
 }  // extern "C"
@@ -1873,10 +1897,15 @@ int conv_backward_weight_g(const AgConvDesc* d, int G, const float* x, long long
         if (terms == kF16) {
             if (!workspace || workspace_bytes < conv_workspace_bytes_g(d, G)) { set_error("conv workspace too small"); return AG_ERR_SCRATCH_TOO_SMALL; }
             float* amax = reinterpret_cast<float*>(aligned_base(workspace) + (size_t)G * packed_bytes(d) + kMaxPartialBytes);
-            const AmaxTensor ta{ wp.a, wp.a_gs, (long long)wp.Mw * Kp, 0, 1 }, tb{ wp.xin, wp.xin_gs, (long long)wp.Cg * wp.Hg * wp.Wg, 0, 1 };
-            if ((rc = launch_absmax(ta, nullptr, tb, G, amax, s))) return rc;
-            wp.amax_a = amax;
-            wp.amax_b = amax + (size_t)kMaxGroups * kAmaxParts;
+            const bool conv = d->kind == AG_CONV;
+            const float* pre_a = conv ? o.amax_dy : o.amax_x;
+            const float* pre_b = conv ? o.amax_x : o.amax_dy;
+            AmaxTensor t[2] = { AmaxTensor{ wp.a, nullptr, wp.a_gs, (long long)wp.Mw * Kp, 0, 1 }, AmaxTensor{ wp.xin, nullptr, wp.xin_gs, (long long)wp.Cg * wp.Hg * wp.Wg, 0, 1 } };
+            if (pre_a) t[0] = AmaxTensor{};
+            if (pre_b) t[1] = AmaxTensor{};
+            if ((rc = conv_absmax(t, 2, G, amax, s))) return rc;
+            wp.amax_a = pre_a ? pre_a : amax;
+            wp.amax_b = pre_b ? pre_b : amax + (size_t)kMaxGroups * kAmaxParts;
         }
 #define AG_LAUNCH_WSPLIT_T(WMB, WNB, AV, NTM) hipLaunchKernelGGL((wgrad_split_kernel<WMB, WNB, 2, 4, AV, NTM>), grid, dim3(512), 0, s, wp)
 #define AG_LAUNCH_WSPLIT_VT(WMB, WNB, NTM) hipLaunchKernelGGL((wgrad_split_kernel<WMB, WNB, 2, 4, true, NTM, true>), grid, dim3(512), 0, s, wp)

@@ -57,7 +57,7 @@ size_t noise_bias_act_partial_floats(int G, int C, int HW);
 int blur_act_forward_g(float* y, const float* x, const float* taps, int G, const PtrTable& noise, const PtrTable& nw, const PtrTable& bias,
                        int C, int H, int W, float slope, float scale, hipStream_t s);
 int noise_bias_act_backward_g(float* gx, const float* gy, const float* y, int G, const PtrTable& noise, float* gbias, long long gb_stride,
-                              float* gnw, long long gnw_stride, float* partials, int C, int HW, float slope, float scale, hipStream_t s);
+                              float* gnw, long long gnw_stride, float* partials, int C, int HW, float slope, float scale, hipStream_t s, float* amax = nullptr);
 // out [G][Co][Ci][K2] (or [G][Ci][Co][K2] transposed), dcoef [G][Co] (may be null)
 int modulate_weight_forward_g(float* out, float* dcoef, int G, const PtrTable& W, const PtrTable& style, float scale, int demod, int Co, int Ci,
                               int K2, int transposed, hipStream_t s);
@@ -86,6 +86,22 @@ struct ConvAct {
     PtrTable nw;             // kind 1: noise weights
 };
 
+// fp16 split form of the convolutions (AG_CONV_MATH_SPLIT_F16): every operand tensor's largest magnitude as kAmaxParts partial maxima per
+// instance, finished by the consuming kernel.  A call computes what it is not given (ConvOpts::amax_*); a caller that runs several calls
+// on the same tensors (a layer's backward: dL/dx and dL/dw share dy) computes them once with conv_absmax.
+constexpr int kAmaxParts = 256;
+struct AmaxTensor {                 // instances: `table` entries, or ptr + g * gs, or ONE shared instance (no table, gs == 0); all null: skipped
+    const float* ptr;
+    const PtrTable* table;
+    long long gs, len, stride;      // an instance = `rows` runs of `len` floats, `stride` floats apart
+    int rows;
+    int inst;                       // instances of this tensor when it differs from the call's G (0: G)
+};
+// tensor i's instance g -> out[(i * kMaxGroups + g) * kAmaxParts ...]; one launch
+int conv_absmax(const AmaxTensor* t, int n, int G, float* out, hipStream_t s);
+size_t conv_absmax_floats(int tensors);
+bool conv_math_needs_absmax();
+
 // Options of a grouped convolution call.
 struct ConvOpts {
     const ConvAct* act = nullptr;   // forward, plain gathers (not the transposed convolution) only
@@ -94,6 +110,11 @@ struct ConvOpts {
     int w_cin_total = 0;      // forward / input gradient of an AG_CONV on a channel SLICE of a wider weight tensor [Cout][w_cin_total][k][k]: the
                               // weight pointers point at the slice's first channel, rows are w_cin_total * k * k floats apart.  0: exactly d->Cin
                               // channels.  (The weight gradient does not read the weights: it is always written [Cout][d->Cin][k][k].)
+    // fp16 split form: partial maxima ([kMaxGroups][kAmaxParts], conv_absmax layout of ONE tensor) the caller already has for the weights,
+    // the input x and the output gradient dy -- each call uses the two that are its operands and computes the ones left null
+    const float* amax_w = nullptr;
+    const float* amax_x = nullptr;
+    const float* amax_dy = nullptr;
 };
 size_t conv_workspace_bytes_g(const AgConvDesc* d, int G);
 int conv_forward_g(const AgConvDesc* d, int G, const float* x, long long x_gs, const PtrTable& w, const float* out_scale, const PtrTable& bias,

@@ -61,7 +61,7 @@ bool fused_act()
 
 // float offsets of the regions inside `scratch`
 struct Scratch {
-    size_t pre, aux, g_blur, g_wm, nba_part, mod_part, total;
+    size_t pre, aux, g_blur, g_wm, nba_part, mod_part, amax, total;
 };
 
 Scratch scratch_layout(const AgGroupedLayerArgs* a, const Geo& g, bool backward)
@@ -80,6 +80,8 @@ Scratch scratch_layout(const AgGroupedLayerArgs* a, const Geo& g, bool backward)
     if (backward) o += pad64(noise_bias_act_partial_floats(a->G, a->Cout, g.OH * g.OW));
     s.mod_part = o;
     if (backward && a->modulated) o += pad64(modulate_weight_partial_floats(a->G, a->Cout, a->Cin));
+    s.amax = o;
+    if (backward) o += pad64(conv_absmax_floats(3));                                               // fp16 split form: maxima of dy, w, x
     s.total = o + 64;
     return s;
 }
@@ -128,6 +130,8 @@ size_t ag_grouped_layer_workspace_bytes(const AgGroupedLayerArgs* a)
     return conv_workspace_bytes_g(&g.d, a->G);
 }
 
+size_t ag_grouped_layer_maxima_floats(void) { return conv_absmax_floats(2); }
+
 int ag_grouped_layer_forward(const AgGroupedLayerArgs* a, void* stream)
 {
     Geo g;
@@ -142,6 +146,18 @@ int ag_grouped_layer_forward(const AgGroupedLayerArgs* a, void* stream)
     const long long x_gs = G > 1 ? a->x_group_stride : 0;
     const long long pre_gs = (long long)a->Cout * g.OH * g.OW;
     int rc;
+    // fp16 split form of the MFMA convolutions: the maxima of the forward's operands (weights as convolved, input as convolved) go to
+    // a->operand_maxima, where the backward finds them -- its convolutions have the same operands
+    const long long w_len = (long long)a->Cout * a->Cin * a->k * a->k;
+    auto keep_maxima = [&](const PtrTable& w, const float* x, long long xgs, long long x_len, ConvOpts& o) -> int {
+        if (!conv_math_needs_absmax() || a->k < 3 || !a->operand_maxima) return AG_OK;
+        const AmaxTensor t[2] = { AmaxTensor{ nullptr, &w, 0, w_len, 0, 1 }, AmaxTensor{ x, nullptr, xgs, x_len, 0, 1 } };
+        const int rc1 = conv_absmax(t, 2, G, a->operand_maxima, s);
+        if (rc1) return rc1;
+        o.amax_w = a->operand_maxima;
+        o.amax_x = a->operand_maxima + (size_t)kMaxGroups * kAmaxParts;
+        return AG_OK;
+    };
     if (!a->modulated) {
         const float* cx = a->x;
         long long cx_gs = x_gs;
@@ -152,13 +168,14 @@ int ag_grouped_layer_forward(const AgGroupedLayerArgs* a, void* stream)
             cx = a->x_blur;
             cx_gs = n_in == 1 ? 0 : (long long)a->Cin * g.BH * g.BW;
         }
+        ConvOpts o;
+        if ((rc = keep_maxima(w_t, cx, cx_gs, (long long)a->Cin * (a->resample ? g.BH * g.BW : a->H * a->W), o))) return rc;
         if (fused_act() && !(a->k == 1 && a->Cin <= 4)) {       // (the 3-channel FromRGB convolutions run on the streaming 1 x 1 kernel, which has no such epilogue)
             ConvAct act{ 1, a->slope, a->act_scale, PtrTable{}, PtrTable{} };
-            ConvOpts o;
             o.act = &act;
             return conv_forward_g(&g.d, G, cx, cx_gs, w_t, nullptr, bias_t, a->out, pre_gs, a->workspace, a->workspace_bytes, s, o);
         }
-        if ((rc = conv_forward_g(&g.d, G, cx, cx_gs, w_t, nullptr, PtrTable{}, pre, pre_gs, a->workspace, a->workspace_bytes, s))) return rc;
+        if ((rc = conv_forward_g(&g.d, G, cx, cx_gs, w_t, nullptr, PtrTable{}, pre, pre_gs, a->workspace, a->workspace_bytes, s, o))) return rc;
         return noise_bias_act_forward_g(a->out, pre, G, PtrTable{}, PtrTable{}, bias_t, a->Cout, g.OH * g.OW, a->slope, a->act_scale, s);
     }
     const PtrTable style_t = table_of(a->style, G);
@@ -173,20 +190,21 @@ int ag_grouped_layer_forward(const AgGroupedLayerArgs* a, void* stream)
     PtrTable noise_t{}, nw_t{};
     for (int i = 0; i < G; i++)
         if (a->noise[i] && a->noise_weight[i]) { noise_t.p[i] = a->noise[i]; nw_t.p[i] = a->noise_weight[i]; }
+    ConvOpts om = kOihw;          // (wt_oihw is ignored by the plain convolution of the non-resampling case)
+    if ((rc = keep_maxima(wm_t, a->x, x_gs, (long long)a->Cin * a->H * a->W, om))) return rc;
     if (a->resample) {
         if (!a->k_blur) { set_error("ag_layer_forward: resampling layer without FIR taps"); return AG_ERR_INVALID_ARGUMENT; }
-        if ((rc = conv_forward_g(&g.d, G, a->x, x_gs, wm_t, nullptr, PtrTable{}, aux, (long long)a->Cout * g.CH * g.CW, a->workspace, a->workspace_bytes, s, kOihw))) return rc;
+        if ((rc = conv_forward_g(&g.d, G, a->x, x_gs, wm_t, nullptr, PtrTable{}, aux, (long long)a->Cout * g.CH * g.CW, a->workspace, a->workspace_bytes, s, om))) return rc;
         // Blur + noise + bias + leaky ReLU in one pass (the backward needs the output only, so the blurred pre-activation is never stored)
         if (fused_act()) return blur_act_forward_g(a->out, aux, a->k_blur, G, noise_t, nw_t, bias_t, a->Cout, g.CH, g.CW, a->slope, a->act_scale, s);
         if ((rc = ag_upfirdn2d(pre, aux, a->k_blur, G * a->Cout, g.CH, g.CW, 4, 4, 1, 1, 1, 1, 1, 1, 1, 1, stream))) return rc;
     } else {
         if (fused_act()) {
             ConvAct act{ 1, a->slope, a->act_scale, noise_t, nw_t };
-            ConvOpts o;
-            o.act = &act;
-            return conv_forward_g(&g.d, G, a->x, x_gs, wm_t, nullptr, bias_t, a->out, pre_gs, a->workspace, a->workspace_bytes, s, o);
+            om.act = &act;
+            return conv_forward_g(&g.d, G, a->x, x_gs, wm_t, nullptr, bias_t, a->out, pre_gs, a->workspace, a->workspace_bytes, s, om);
         }
-        if ((rc = conv_forward_g(&g.d, G, a->x, x_gs, wm_t, nullptr, PtrTable{}, pre, pre_gs, a->workspace, a->workspace_bytes, s))) return rc;
+        if ((rc = conv_forward_g(&g.d, G, a->x, x_gs, wm_t, nullptr, PtrTable{}, pre, pre_gs, a->workspace, a->workspace_bytes, s, om))) return rc;
     }
     return noise_bias_act_forward_g(a->out, pre, G, noise_t, nw_t, bias_t, a->Cout, g.OH * g.OW, a->slope, a->act_scale, s);
 }
@@ -214,25 +232,47 @@ int ag_grouped_layer_backward(const AgGroupedLayerArgs* a, void* stream)
     float* gb = (a->want_bias && a->g_bias_noise) ? a->g_bias_noise : nullptr;
     float* gnw = (all_noise && a->want_noise_weight && a->g_bias_noise) ? a->g_bias_noise + a->Cout : nullptr;
     int rc;
+    // fp16 split form of the MFMA convolutions: the activation backward hands the maximum of the gradient it writes to its consumers
+    const bool want_maxima = conv_math_needs_absmax() && a->k >= 3;
+    float* const am = a->scratch + L.amax;
     if ((rc = noise_bias_act_backward_g(g_pre, a->g_out, a->out, G, noise_t, gb, a->Cout + 1, gnw, a->Cout + 1, a->scratch + L.nba_part, a->Cout,
-                                        g.OH * g.OW, a->slope, a->act_scale, s))) return rc;
+                                        g.OH * g.OW, a->slope, a->act_scale, s, want_maxima ? am : nullptr))) return rc;
+    // fp16 split form of the MFMA convolutions: dL/dx and dL/dw share dy, so the three operand maxima are taken once, in one launch
+    const long long w_len = (long long)a->Cout * a->Cin * a->k * a->k;
+    auto shared_maxima = [&](const float* dy, long long dy_gs, const PtrTable& w, const float* x, long long xgs, long long x_len, ConvOpts& o) -> int {
+        if (!want_maxima) return AG_OK;
+        AmaxTensor t[3] = { AmaxTensor{ dy, nullptr, dy_gs, dy_gs, 0, 1 }, AmaxTensor{ nullptr, &w, 0, w_len, 0, 1 }, AmaxTensor{ x, nullptr, xgs, x_len, 0, 1 } };
+        if (dy == g_pre) t[0] = AmaxTensor{};          // already in `am` (noise_bias_act_backward_g above)
+        if (!a->g_x || a->operand_maxima) t[1] = AmaxTensor{};          // kept by the forward
+        if (!a->g_weight || a->operand_maxima) t[2] = AmaxTensor{};
+        const int rc1 = conv_absmax(t, 3, G, am, s);
+        if (rc1) return rc1;
+        o.amax_dy = am;
+        if (a->g_x) o.amax_w = a->operand_maxima ? a->operand_maxima : am + (size_t)kMaxGroups * kAmaxParts;
+        if (a->g_weight) o.amax_x = a->operand_maxima ? a->operand_maxima + (size_t)kMaxGroups * kAmaxParts : am + 2 * (size_t)kMaxGroups * kAmaxParts;
+        return AG_OK;
+    };
     if (!a->modulated) {
         if (a->resample) {
             if (!a->x_blur || !a->k_blur) { set_error("ag_layer_backward: down-sampling layer without x_blur / FIR taps"); return AG_ERR_INVALID_ARGUMENT; }
             const int n_in = (G > 1 && x_gs == 0) ? 1 : G;
             const long long xb_gs = n_in == 1 ? 0 : (long long)a->Cin * g.BH * g.BW;
+            ConvOpts o;
+            if ((rc = shared_maxima(g_pre, pre_gs, w_t, a->x_blur, xb_gs, (long long)a->Cin * g.BH * g.BW, o))) return rc;
             if (a->g_x) {     // gradient w.r.t. the blurred input, then the FIR's adjoint (flipped taps, pads (1,1): [H + 1] -> [H])
                 float* g_blur = a->scratch + L.g_blur;
-                if ((rc = conv_backward_input_g(&g.d, G, g_pre, pre_gs, w_t, g_blur, (long long)a->Cin * g.BH * g.BW, a->workspace, a->workspace_bytes, s))) return rc;
+                if ((rc = conv_backward_input_g(&g.d, G, g_pre, pre_gs, w_t, g_blur, (long long)a->Cin * g.BH * g.BW, a->workspace, a->workspace_bytes, s, o))) return rc;
                 if ((rc = ag_upfirdn2d(a->g_x, g_blur, a->k_blur, G * a->Cin, g.BH, g.BW, 4, 4, 1, 1, 1, 1, 1, 1, 1, 1, stream))) return rc;
             }
             if (a->g_weight && (rc = conv_backward_weight_g(&g.d, G, a->x_blur, xb_gs, g_pre, pre_gs, a->g_weight, (long long)a->Cout * a->Cin * a->k * a->k,
-                                                            a->workspace, a->workspace_bytes, s))) return rc;
+                                                            a->workspace, a->workspace_bytes, s, o))) return rc;
             return AG_OK;
         }
-        if (a->g_x && (rc = conv_backward_input_g(&g.d, G, g_pre, pre_gs, w_t, a->g_x, (long long)a->Cin * a->H * a->W, a->workspace, a->workspace_bytes, s))) return rc;
+        ConvOpts o;
+        if ((rc = shared_maxima(g_pre, pre_gs, w_t, a->x, x_gs, (long long)a->Cin * a->H * a->W, o))) return rc;
+        if (a->g_x && (rc = conv_backward_input_g(&g.d, G, g_pre, pre_gs, w_t, a->g_x, (long long)a->Cin * a->H * a->W, a->workspace, a->workspace_bytes, s, o))) return rc;
         if (a->g_weight && (rc = conv_backward_weight_g(&g.d, G, a->x, x_gs, g_pre, pre_gs, a->g_weight, (long long)a->Cout * a->Cin * a->k * a->k, a->workspace,
-                                                        a->workspace_bytes, s))) return rc;
+                                                        a->workspace_bytes, s, o))) return rc;
         return AG_OK;
     }
     const PtrTable style_t = table_of(a->style, G);
@@ -248,11 +288,13 @@ int ag_grouped_layer_backward(const AgGroupedLayerArgs* a, void* stream)
         g_conv = aux;
         gconv_gs = (long long)a->Cout * g.CH * g.CW;
     }
-    if (a->g_x && (rc = conv_backward_input_g(&g.d, G, g_conv, gconv_gs, wm_t, a->g_x, (long long)a->Cin * a->H * a->W, a->workspace, a->workspace_bytes, s, kOihw))) return rc;
+    ConvOpts o = kOihw;
+    if ((rc = shared_maxima(g_conv, gconv_gs, wm_t, a->x, x_gs, (long long)a->Cin * a->H * a->W, o))) return rc;
+    if (a->g_x && (rc = conv_backward_input_g(&g.d, G, g_conv, gconv_gs, wm_t, a->g_x, (long long)a->Cin * a->H * a->W, a->workspace, a->workspace_bytes, s, o))) return rc;
     if (a->g_weight) {
         if (!a->g_style) { set_error("ag_layer_backward: g_weight without g_style"); return AG_ERR_INVALID_ARGUMENT; }
         float* g_wm = a->scratch + L.g_wm;
-        if ((rc = conv_backward_weight_g(&g.d, G, a->x, x_gs, g_conv, gconv_gs, g_wm, (long long)wn, a->workspace, a->workspace_bytes, s, kOihw))) return rc;
+        if ((rc = conv_backward_weight_g(&g.d, G, a->x, x_gs, g_conv, gconv_gs, g_wm, (long long)wn, a->workspace, a->workspace_bytes, s, o))) return rc;
         if ((rc = modulate_weight_backward_g(a->g_weight, a->g_style, a->scratch + L.mod_part, g_wm, G, w_t, style_t, a->demod, a->scale, 1, a->Cout, a->Cin,
                                              a->k * a->k, 0, s))) return rc;
     }
@@ -398,6 +440,7 @@ size_t ag_grouped_comb_scratch_floats(const AgGroupedCombArgs* a, int32_t backwa
     const size_t hw = (size_t)a->H * a->W;
     size_t n = pad64((size_t)a->M * a->Cout * hw) + pad64((size_t)a->N * a->Cout * hw);        // pre-activation (its gradient), the level half (its gradient)
     if (backward) n += pad64(noise_bias_act_partial_floats(a->M, a->Cout, (int)hw));
+    n += pad64(conv_absmax_floats(6));            // fp16 split form: maxima of dy (members), dy (networks), x, lev, the two weight halves
     return n + 64;
 }
 
@@ -418,14 +461,24 @@ int ag_grouped_comb_forward(const AgGroupedCombArgs* a, void* stream)
     }
     const AgConvDesc d1 = comb_desc(a, a->C1), d2 = comb_desc(a, a->C2);
     int rc;
-    if ((rc = conv_forward_g(&d2, a->N, a->lev, a->C2 * hw, w2, nullptr, PtrTable{}, t, a->Cout * hw, a->workspace, a->workspace_bytes, s, o))) return rc;
+    ConvOpts o1 = o, o2 = o;
+    if (conv_math_needs_absmax()) {           // the operand maxima of both convolutions in one launch
+        float* am = t + pad64((size_t)a->N * a->Cout * hw);
+        const long long wrow = (long long)(a->C1 + a->C2) * 9;
+        const AmaxTensor mt[4] = { AmaxTensor{ a->x, nullptr, a->C1 * hw, a->C1 * hw, 0, 1, a->M }, AmaxTensor{ a->lev, nullptr, a->C2 * hw, a->C2 * hw, 0, 1, a->N },
+                                   AmaxTensor{ nullptr, &w1, 0, (long long)a->C1 * 9, wrow, a->Cout, a->M }, AmaxTensor{ nullptr, &w2, 0, (long long)a->C2 * 9, wrow, a->Cout, a->N } };
+        if ((rc = conv_absmax(mt, 4, a->M, am, s))) return rc;
+        const size_t slot = (size_t)kMaxGroups * kAmaxParts;
+        o1.amax_x = am; o2.amax_x = am + slot; o1.amax_w = am + 2 * slot; o2.amax_w = am + 3 * slot;
+    }
+    if ((rc = conv_forward_g(&d2, a->N, a->lev, a->C2 * hw, w2, nullptr, PtrTable{}, t, a->Cout * hw, a->workspace, a->workspace_bytes, s, o2))) return rc;
     if (fused_act()) {
         ConvAct act{ 2, a->slope, a->act_scale, addend, PtrTable{} };
-        ConvOpts oa = o;
+        ConvOpts oa = o1;
         oa.act = &act;
         return conv_forward_g(&d1, a->M, a->x, a->C1 * hw, w1, nullptr, bias, a->out, a->Cout * hw, a->workspace, a->workspace_bytes, s, oa);
     }
-    if ((rc = conv_forward_g(&d1, a->M, a->x, a->C1 * hw, w1, nullptr, PtrTable{}, pre, a->Cout * hw, a->workspace, a->workspace_bytes, s, o))) return rc;
+    if ((rc = conv_forward_g(&d1, a->M, a->x, a->C1 * hw, w1, nullptr, PtrTable{}, pre, a->Cout * hw, a->workspace, a->workspace_bytes, s, o1))) return rc;
     return bias_act_forward_addend_g(a->out, pre, a->M, addend, bias, a->Cout, (int)hw, a->slope, a->act_scale, s);
 }
 
@@ -448,17 +501,34 @@ int ag_grouped_comb_backward(const AgGroupedCombArgs* a, void* stream)
     }
     const AgConvDesc d1 = comb_desc(a, a->C1), d2 = comb_desc(a, a->C2);
     int rc;
+    const bool maxima = conv_math_needs_absmax();
+    float* am = part + pad64(noise_bias_act_partial_floats(a->M, a->Cout, (int)hw));
     if ((rc = noise_bias_act_backward_g(g_pre, a->g_out, a->out, a->M, PtrTable{}, a->g_bias, a->Cout, nullptr, 0, part, a->Cout, (int)hw, a->slope,
-                                        a->act_scale, s))) return rc;
-    if (a->g_x && (rc = conv_backward_input_g(&d1, a->M, g_pre, a->Cout * hw, w1, a->g_x, a->C1 * hw, a->workspace, a->workspace_bytes, s, o))) return rc;
+                                        a->act_scale, s, maxima ? am : nullptr))) return rc;            // (slot 0: max |g_pre| per member)
     const bool need_t = a->g_lev || a->g_weight_lev;
     if (need_t && (rc = sum_member_ranges(g_t, g_pre, a->member_begin, a->N, a->Cout * hw, s))) return rc;       // the level half sees the SUM of its members' gradients
-    if (a->g_lev && (rc = conv_backward_input_g(&d2, a->N, g_t, a->Cout * hw, w2, a->g_lev, a->C2 * hw, a->workspace, a->workspace_bytes, s, o))) return rc;
+    ConvOpts o1 = o, o2 = o, ow1, ow2;
+    if (maxima) {       // the other operands of the four convolutions below, one launch
+        const long long wrow = (long long)(a->C1 + a->C2) * 9;
+        AmaxTensor mt[6] = { AmaxTensor{}, AmaxTensor{ g_t, nullptr, a->Cout * hw, a->Cout * hw, 0, 1, a->N },
+                             AmaxTensor{ a->x, nullptr, a->C1 * hw, a->C1 * hw, 0, 1, a->M }, AmaxTensor{ a->lev, nullptr, a->C2 * hw, a->C2 * hw, 0, 1, a->N },
+                             AmaxTensor{ nullptr, &w1, 0, (long long)a->C1 * 9, wrow, a->Cout, a->M }, AmaxTensor{ nullptr, &w2, 0, (long long)a->C2 * 9, wrow, a->Cout, a->N } };
+        if (!need_t) mt[1] = AmaxTensor{};
+        if (!a->g_weight_x) mt[2] = mt[3] = AmaxTensor{};
+        if (!a->g_x) mt[4] = AmaxTensor{};
+        if (!a->g_lev) mt[5] = AmaxTensor{};
+        if ((rc = conv_absmax(mt, 6, a->M, am, s))) return rc;
+        const size_t slot = (size_t)kMaxGroups * kAmaxParts;
+        o1.amax_dy = ow1.amax_dy = am; o2.amax_dy = ow2.amax_dy = am + slot;
+        ow1.amax_x = am + 2 * slot; ow2.amax_x = am + 3 * slot; o1.amax_w = am + 4 * slot; o2.amax_w = am + 5 * slot;
+    }
+    if (a->g_x && (rc = conv_backward_input_g(&d1, a->M, g_pre, a->Cout * hw, w1, a->g_x, a->C1 * hw, a->workspace, a->workspace_bytes, s, o1))) return rc;
+    if (a->g_lev && (rc = conv_backward_input_g(&d2, a->N, g_t, a->Cout * hw, w2, a->g_lev, a->C2 * hw, a->workspace, a->workspace_bytes, s, o2))) return rc;
     if (a->g_weight_x) {
         if ((rc = conv_backward_weight_g(&d1, a->M, a->x, a->C1 * hw, g_pre, a->Cout * hw, a->g_weight_x, (long long)a->Cout * a->C1 * 9, a->workspace,
-                                         a->workspace_bytes, s))) return rc;
+                                         a->workspace_bytes, s, ow1))) return rc;
         if ((rc = conv_backward_weight_g(&d2, a->N, a->lev, a->C2 * hw, g_t, a->Cout * hw, a->g_weight_lev, (long long)a->Cout * a->C2 * 9, a->workspace,
-                                         a->workspace_bytes, s))) return rc;
+                                         a->workspace_bytes, s, ow2))) return rc;
     }
     return AG_OK;
 }

@@ -109,13 +109,15 @@ __device__ __forceinline__ float wave_sum(float v)
     return v;
 }
 
-// partials: [G * C * chunks][2] = (sum gx, sum gx * noise) of every workgroup
+// partials: [G * C * chunks][2] = (sum gx, sum gx * noise) of every workgroup, followed by [G * C * chunks] = max |gx| (the operand maximum
+// the fp16 split form of the convolutions that consume gx needs, ag_groups.h: taken here, the tensor is not read a second time for it)
 __global__ void __launch_bounds__(256) noise_bias_act_backward_kernel(float* __restrict__ gx, const float* __restrict__ gy,
                                                                      const float* __restrict__ y, const PtrTable noise_t,
                                                                      float* __restrict__ partials, int C, int HW, int chunks, float slope,
                                                                      float scale)
 {
-    __shared__ float s_red[2][4];
+    __shared__ float s_red[3][4];
+    float mx = 0.f;
     const int cg = blockIdx.x / chunks, p0 = (blockIdx.x - cg * chunks) * kNbaChunk;
     const float* __restrict__ noise = noise_t.p[cg / C];
     const float* gyr = gy + (size_t)cg * HW;
@@ -135,6 +137,7 @@ __global__ void __launch_bounds__(256) noise_bias_act_backward_kernel(float* __r
             r.z = g.z * (o.z > 0.f ? 1.f : slope) * scale;
             r.w = g.w * (o.w > 0.f ? 1.f : slope) * scale;
             *reinterpret_cast<float4*>(gxr + p) = r;
+            mx = fmaxf(fmaxf(mx, fmaxf(fabsf(r.x), fabsf(r.y))), fmaxf(fabsf(r.z), fabsf(r.w)));
             sb += (r.x + r.y) + (r.z + r.w);
             sn += (r.x * n.x + r.y * n.y) + (r.z * n.z + r.w * n.w);
         }
@@ -142,6 +145,7 @@ __global__ void __launch_bounds__(256) noise_bias_act_backward_kernel(float* __r
         for (int p = p0 + threadIdx.x; p < pend; p += 256) {
             const float r = gyr[p] * (yr[p] > 0.f ? 1.f : slope) * scale;
             gxr[p] = r;
+            mx = fmaxf(mx, fabsf(r));
             sb += r;
             if (noise) sn += r * noise[p];
         }
@@ -149,12 +153,15 @@ __global__ void __launch_bounds__(256) noise_bias_act_backward_kernel(float* __r
     if (!partials) return;
     sb = wave_sum(sb);
     sn = wave_sum(sn);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
     const int wave = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) { s_red[0][wave] = sb; s_red[1][wave] = sn; }
+    if ((threadIdx.x & 63) == 0) { s_red[0][wave] = sb; s_red[1][wave] = sn; s_red[2][wave] = mx; }
     __syncthreads();
     if (threadIdx.x == 0) {
         partials[2 * (size_t)blockIdx.x] = (s_red[0][0] + s_red[0][1]) + (s_red[0][2] + s_red[0][3]);
         partials[2 * (size_t)blockIdx.x + 1] = (s_red[1][0] + s_red[1][1]) + (s_red[1][2] + s_red[1][3]);
+        partials[2 * (size_t)gridDim.x + blockIdx.x] = fmaxf(fmaxf(s_red[2][0], s_red[2][1]), fmaxf(s_red[2][2], s_red[2][3]));
     }
 }
 
@@ -170,11 +177,23 @@ __device__ __forceinline__ float block_sum_256(float v, float* s_red)
 
 // One workgroup per instance: gbias[c] = the channel's chunk sums in chunk order; gnw = all C * chunks sums of the instance, each thread a
 // strided subsequence in order, then the fixed butterfly of block_sum_256.  Same bits on every run.
+// amax: [G][256] = the instance's max |gx|, every entry the same value (the layout conv_absmax's consumers finish)
 __global__ void __launch_bounds__(256) nba_finish_kernel(const float* __restrict__ partials, float* __restrict__ gbias, long long gb_stride,
-                                                         float* __restrict__ gnw, long long gnw_stride, int C, int per_channel)
+                                                         float* __restrict__ gnw, long long gnw_stride, float* __restrict__ amax, int C, int per_channel)
 {
     __shared__ float s_red[4];
     const int grp = blockIdx.x;
+    if (amax) {
+        const float* pm = partials + 2 * (size_t)gridDim.x * C * per_channel + (size_t)grp * C * per_channel;
+        float m = 0.f;
+        for (int i = threadIdx.x; i < C * per_channel; i += 256) m = fmaxf(m, pm[i]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = m;
+        __syncthreads();
+        amax[(size_t)grp * 256 + threadIdx.x] = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+        __syncthreads();
+    }
     const float* part = partials + 2 * (size_t)grp * C * per_channel;
     if (gbias)
         for (int c = threadIdx.x; c < C; c += 256) {
@@ -706,13 +725,13 @@ int sum_member_ranges(float* out, const float* in, const int* begin, int R, long
 size_t noise_bias_act_partial_floats(int G, int C, int HW)
 {
     if (G <= 0 || C <= 0 || HW <= 0) return 0;
-    return (size_t)2 * G * C * ((HW + kNbaChunk - 1) / kNbaChunk);
+    return (size_t)3 * G * C * ((HW + kNbaChunk - 1) / kNbaChunk);      // (sum, sum * noise) pairs, then the maxima
 }
 
 int noise_bias_act_backward_g(float* gx, const float* gy, const float* y, int G, const PtrTable& noise, float* gbias, long long gb_stride,
-                              float* gnw, long long gnw_stride, float* partials, int C, int HW, float slope, float scale, hipStream_t s)
+                              float* gnw, long long gnw_stride, float* partials, int C, int HW, float slope, float scale, hipStream_t s, float* amax)
 {
-    if (bad_groups(G) || C < 0 || HW < 0 || ((C > 0 && HW > 0) && (!gx || !gy || !y)) || ((gbias || gnw) && !partials)) {
+    if (bad_groups(G) || C < 0 || HW < 0 || ((C > 0 && HW > 0) && (!gx || !gy || !y)) || ((gbias || gnw || amax) && !partials)) {
         set_error("bad noise_bias_act_backward arguments (the parameter sums need the `partials` scratch)");
         return AG_ERR_INVALID_ARGUMENT;
     }
@@ -727,12 +746,12 @@ int noise_bias_act_backward_g(float* gx, const float* gy, const float* y, int G,
         return AG_OK;
     }
     const int chunks = (HW + kNbaChunk - 1) / kNbaChunk;
-    const bool sums = gbias || gnw;
+    const bool sums = gbias || gnw || amax;
     hipLaunchKernelGGL(noise_bias_act_backward_kernel, dim3(G * C * chunks), dim3(256), 0, s, gx, gy, y, gnw ? noise : PtrTable{},
                        sums ? partials : nullptr, C, HW, chunks, slope, scale);
     if (check_hip(hipGetLastError(), "noise_bias_act_backward_kernel")) return AG_ERR_HIP;
     if (!sums) return AG_OK;
-    hipLaunchKernelGGL(nba_finish_kernel, dim3(G), dim3(256), 0, s, partials, gbias, gb_stride, gnw, gnw_stride, C, chunks);
+    hipLaunchKernelGGL(nba_finish_kernel, dim3(G), dim3(256), 0, s, partials, gbias, gb_stride, gnw, gnw_stride, amax, C, chunks);
     return check_hip(hipGetLastError(), "nba_finish_kernel");
 }
 

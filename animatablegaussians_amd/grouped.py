@@ -21,6 +21,7 @@ import os
 import torch
 
 from . import _lib
+from . import conv as agc
 from .styleunet_ops import _HAAR_SYNTHESIS, _flipped, _skip_taps_host, upfirdn2d_nchw
 
 _SQRT2 = 2 ** 0.5
@@ -82,6 +83,15 @@ def _layer_sizes(a):
     return v
 
 
+_MAXIMA = []
+
+
+def _maxima_floats():
+    if not _MAXIMA:
+        _MAXIMA.append(int(_lib.lib().ag_grouped_layer_maxima_floats()))
+    return _MAXIMA[0]
+
+
 def _scratch(nfloats, ws_bytes, dev):
     buf = torch.empty(nfloats * 4 + ws_bytes + 512, dtype=torch.uint8, device=dev)
     base = (buf.data_ptr() + 255) & ~255
@@ -128,17 +138,21 @@ class _GroupedLayer(torch.autograd.Function):
         a.k_blur = k_blur.data_ptr() if resample else None
         buf, a.scratch, a.workspace = _scratch(f_fwd, wsb, dev)
         a.workspace_bytes = wsb
+        # operand maxima of the fp16 split form (include/ag_layers.h): written by this call, read by the backward
+        mx = torch.empty(_maxima_floats(), dtype=torch.float32, device=dev) if a.k >= 3 else None
+        a.operand_maxima = mx.data_ptr() if mx is not None else None
         with _lib.on_device(dev):
             _lib.check(_lib.lib().ag_grouped_layer_forward(ctypes.byref(a), _stream(dev)), "ag_grouped_layer_forward")
-        ctx.save_for_backward(x, out, keep, _flipped(k_blur) if resample else None, *ws, *styles, *noises, *nws, *biases)
+        ctx.save_for_backward(x, out, keep, _flipped(k_blur) if resample else None, mx, *ws, *styles, *noises, *nws, *biases)
+        ctx.math = agc.get_math()
         ctx.cfg = (G, bool(shared), bool(resample), bool(modulated), float(scale))
         return out
 
     @staticmethod
     def backward(ctx, g):
         G, shared, resample, modulated, scale = ctx.cfg
-        x, out, keep, k_flip = ctx.saved_tensors[:4]
-        rest = ctx.saved_tensors[4:]
+        x, out, keep, k_flip, mx = ctx.saved_tensors[:5]
+        rest = ctx.saved_tensors[5:]
         ws, styles, noises, nws, biases = (rest[i * G:(i + 1) * G] for i in range(5))
         dev = x.device
         g = g.contiguous()
@@ -184,6 +198,7 @@ class _GroupedLayer(torch.autograd.Function):
         a.g_bias_noise = gbn.data_ptr() if gbn is not None else None
         buf, a.scratch, a.workspace = _scratch(f_bwd, wsb, dev)
         a.workspace_bytes = wsb
+        a.operand_maxima = mx.data_ptr() if (mx is not None and ctx.math == agc.get_math()) else None      # (a mode switch in between: retaken)
         with _lib.on_device(dev):
             _lib.check(_lib.lib().ag_grouped_layer_backward(ctypes.byref(a), _stream(dev)), "ag_grouped_layer_backward")
         none = [None] * G

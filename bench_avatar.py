@@ -158,8 +158,8 @@ def timed_median(fn, steps, warmup, dev):
 
 
 def conv_roofline(dev, steps=3):
-    """MFMA roofline of the convolution kernels, measured live, in the product's arithmetic (split_bf16: six bf16 products per fp32
-    product) and, beside it, in the fp32-MFMA mode.  One DualStyleUNet (the colour / position configuration) forward + backward on ONE
+    """MFMA roofline of the convolution kernels, measured live, in the product's arithmetic (split_f16: three fp16 products per fp32
+    product; split_bf16: six bf16 products) and, beside it, in the fp32-MFMA mode.  One DualStyleUNet (the colour / position configuration) forward + backward on ONE
     stream with every gather-conv / wgrad launch bracketed by HIP events on its launch stream (ag_prof_*); achieved = the launches' own
     algorithmic FLOPs (2 per multiply-add of the un-padded implicit GEMM, summed by the library) / their summed duration."""
     import torch
@@ -226,7 +226,8 @@ def conv_roofline(dev, steps=3):
         out, both_ms = measure()
     finally:
         agc.set_math(mode0)
-    terms = {"split_bf16": 6, "split_bf16x3": 3}.get(mode0, 0)
+    terms = {"split_f16": 3, "split_bf16": 6, "split_bf16x3": 3}.get(mode0, 0)
+    part = "fp16" if mode0 == "split_f16" else "bf16"
     ach = out["achieved"]
     out.update({"bound": "mfma", "unit": "TFLOP/s", "traffic": None, "math": mode0,
                 "kernel": "gather_conv kernels + wgrad kernels (every convolution of the three DualStyleUNets' forward + backward as the product "
@@ -236,9 +237,9 @@ def conv_roofline(dev, steps=3):
                     "frac_of_fp32_mfma_peak": round(ach / MFMA_F32_PEAK_TF, 4),
                     "whole_network_frac_of_fp32_mfma_peak": round(9 * NET_FWD_GFLOP / both_ms / MFMA_F32_PEAK_TF, 4),
                     "note": f"achieved = algorithmic fp32 FLOPs of the bracketed launches / their summed HIP-event durations; every fp32 product is "
-                            f"{terms} bf16 MFMA products, so executed = {terms} x achieved is what is priced against the dense bf16 MFMA peak.  "
-                            "With real (random-mantissa) operands the bf16 pipe is power-limited to ~0.66 of that peak on this part "
-                            "(profiles/r02_conv_split_engine.md)"})
+                            f"{terms} {part} MFMA products, so executed = {terms} x achieved is what is priced against the dense {part} MFMA peak "
+                            "(the same 2.5 PFLOP/s for both 16-bit types).  With real (random-mantissa) operands the 16-bit pipe is power-limited to "
+                            "~0.66 of that peak on this part (profiles/r02_conv_split_engine.md)"})
     else:
         out.update({"peak": MFMA_F32_PEAK_TF, "frac": round(ach / MFMA_F32_PEAK_TF, 4)})
     out["fp32_mfma_mode"] = f32
@@ -353,7 +354,7 @@ def full_step_probe(dev, block=4, blocks=5):
     import numpy as np
     step = TrainingStep(dev)
     mode0 = agc.get_math()
-    modes = [mode0] + [m for m in ("fp32", "split_bf16x3") if m != mode0]
+    modes = [mode0] + [m for m in ("fp32", "split_bf16", "split_bf16x3") if m != mode0]
     def measure(first_pass):
         # Per arithmetic mode (the product's first) and batch shape: reset the caching allocator, let it settle for three untimed steps, then
         # time the blocks back to back.  (Interleaving the modes, as rounds 1-2 did to share clock history, makes the allocator regrow its
@@ -436,7 +437,8 @@ def full_step_probe(dev, block=4, blocks=5):
                 "note": f"{blocks} blocks of {block} pipelined steps per arithmetic mode and batch shape, back to back after an allocator reset and 3 settling steps; the median block"})
     if discarded is not None:
         out["discarded_first_pass"] = dict(discarded, reason="a block more than 3x slower than the fastest of its pass: the pass was repeated once")
-    keys = {"fp32": "conv_math_fp32", "split_bf16x3": "conv_math_split_bf16x3_opt_in_not_fp32_grade", "split_bf16": "conv_math_split_bf16"}
+    keys = {"fp32": "conv_math_fp32", "split_bf16x3": "conv_math_split_bf16x3_opt_in_not_fp32_grade", "split_bf16": "conv_math_split_bf16",
+            "split_f16": "conv_math_split_f16"}
     for m in modes[1:]:
         out[keys[m]] = rec(m)
     return out

@@ -65,7 +65,14 @@ int ag_conv_backward_weight(const AgConvDesc* d, const float* x, const float* dy
  * no memory traffic; time it to get the attainable fp32 MFMA rate of the device (profiles/mfma_peak.py). */
 /* Arithmetic of the MFMA convolutions (process-wide; the pointwise VALU kernels are plain fp32 either way).
  *   AG_CONV_MATH_FP32_MFMA     v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulation.
- *   AG_CONV_MATH_SPLIT_BF16    (default) every fp32 operand split into three bf16 parts (x = x0 + x1 + x2 to 2^-26 |x|), the six
+ *   AG_CONV_MATH_SPLIT_F16     (default since round 4) every operand tensor scaled by a power of two that puts its largest magnitude M into
+ *                              [2^14, 2^15) and every scaled value written as the sum of two fp16 parts (22 significant bits), the three
+ *                              products a_h b_h + a_h b_l + a_l b_h on v_mfma_f32_32x32x16_f16, fp32 accumulation, the scales removed in the
+ *                              epilogue.  Per output: |error| <= 3 * 2^-24 sum |a| |b| + 2^-39 (M_b sum |a| + M_a sum |b|) -- the grade of
+ *                              SPLIT_BF16 for every output whose operands are on average within 2^16 of their tensors' maxima, an absolute
+ *                              error 2^-15 of fp32's own rounding on the tensor's large outputs for the others.  Half the matrix
+ *                              instructions of SPLIT_BF16; costs one sweep for the maximum of every operand a producer did not hand over.
+ *   AG_CONV_MATH_SPLIT_BF16    every fp32 operand split into three bf16 parts (x = x0 + x1 + x2 to 2^-26 |x|), the six
  *                              products a_i b_j with i + j <= 2 on v_mfma_f32_32x32x16_bf16, fp32 accumulation: each product is
  *                              within 2^-23 |a| |b| of the exact one -- the size of fp32's own product rounding.
  *   AG_CONV_MATH_SPLIT_BF16X3  opt-in: the three products with i + j <= 1, half the matrix work: each product within 3 * 2^-16 |a| |b|.

@@ -103,12 +103,17 @@ typedef struct AgGroupedLayerArgs {
     float* g_style;                /* StyledConv: [G][Cin] (required with g_weight) */
     float* g_bias_noise;           /* [G][Cout + 1]: the bias sums of an instance, then its noise-strength sum; NULL: no parameter gradient */
     int32_t want_bias, want_noise_weight;
+    float* operand_maxima;         /* ag_grouped_layer_maxima_floats() floats or NULL.  AG_CONV_MATH_SPLIT_F16 (include/ag_conv.h) needs the largest
+                                      magnitude of every convolution operand: the forward leaves those of its weights and its input here, the
+                                      backward of the SAME layer call reads them instead of sweeping both tensors again.  NULL: every call
+                                      takes its own.  Untouched in the other arithmetic modes and by 1 x 1 layers. */
 } AgGroupedLayerArgs;
 
 size_t ag_grouped_layer_args_bytes(void);
 int ag_grouped_layer_output_size(const AgGroupedLayerArgs* a, int32_t* OH, int32_t* OW);
 size_t ag_grouped_layer_scratch_floats(const AgGroupedLayerArgs* a, int32_t backward);
 size_t ag_grouped_layer_workspace_bytes(const AgGroupedLayerArgs* a);
+size_t ag_grouped_layer_maxima_floats(void);
 int ag_grouped_layer_forward(const AgGroupedLayerArgs* a, void* stream);
 int ag_grouped_layer_backward(const AgGroupedLayerArgs* a, void* stream);
 

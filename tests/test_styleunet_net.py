@@ -100,7 +100,8 @@ def test_dual_styleunet_forward_backward_vs_reference_golden(math):
 def test_grouped_chain_forward_backward_vs_reference_golden():
     """The PRODUCT path -- the grouped launch chain of grouped.py (here over one network: one encoder instance, its two decoders as a
     group of two, the comb convolutions without the concatenation) -- against the same fixture of the reference module, same bars."""
-    _golden_body("split_bf16", grouped=True)
+    from animatablegaussians_amd import conv as agc
+    _golden_body(agc.get_math(), grouped=True)
 
 
 def _golden_body(math, grouped=False):
@@ -154,8 +155,14 @@ def _golden_body(math, grouped=False):
                 f.write(f"ours {o:.3e} ref32 {r:.3e} {n}\n")
     # Round 4 (bias / noise-strength / style reductions deterministic, two-stage): measured ours / reference-fp32 = 2.7, 1.7-2.2, 1.6-2.1,
     # 1.7-2.3, 1.5-1.6 at the 50/75/90/95/99th percentiles (profiles/r04_styleunet_grad_report_*.txt, all three paths): bar 3x (was 4x)
-    for q in (50, 75, 90, 95, 99):
+    for q in (50, 75, 90, 95):
         assert np.percentile(ours, q) <= 3 * np.percentile(ref, q), (q, np.percentile(ours, q), np.percentile(ref, q))
+    # the 99th percentile of ~250 rows is the third largest one, and the largest rows are the one-number quantities with their own caps below
+    # (noise strengths: the reference's fp32 run itself is off by 6.1e-2 on one of them; the pose-map gradient): taken over the parameter TENSORS
+    # on both sides (measured 1.5-2.3x in the three arithmetic modes and on the grouped chain, profiles/r04_styleunet_grad_report_*.txt)
+    tens = [(o, r) for o, r, n in rows if not n.endswith("noise.weight") and n != "pose"]
+    o99, r99 = np.percentile([o for o, _ in tens], 99), np.percentile([r for _, r in tens], 99)
+    assert o99 <= 3 * r99, (o99, r99)
     # per-tensor caps (fraction of the tensor's largest gradient; were 3e-2 / 0.12 with the atomically summed scalars): 1e-2 for
     # parameter tensors (measured worst 5.4e-3); 5e-2 for the twelve noise-strength scalars -- one number each, a sum over a whole
     # feature map of products with mixed signs, where the reference's OWN fp32 run is off by 6.1e-2 (convs2.5; ours 3.0e-2 there, every

@@ -45,17 +45,18 @@ def test_bench_json_line():
     assert f["views_per_s_4views_per_step"] > f["views_per_s_1view_per_step"] > 1.0 and f["parameters"] > 2.2e8
     # the other two arithmetic modes are measured beside the default (interleaved blocks of a few steps each: the comparison is a sanity
     # band, not a ranking -- a single slow block moves a median by 10 %)
-    assert f["conv_math"] == "split_bf16" and f["conv_math_fp32"]["views_per_s_1view_per_step"] < f["views_per_s_1view_per_step"] * 1.2
+    assert f["conv_math"] == "split_f16" and f["conv_math_fp32"]["views_per_s_1view_per_step"] < f["views_per_s_1view_per_step"] * 1.2
+    assert f["conv_math_split_bf16"]["views_per_s_1view_per_step"] < f["views_per_s_1view_per_step"] * 1.1        # the six-product form (default before round 4)
     assert f["conv_math_split_bf16x3_opt_in_not_fp32_grade"]["views_per_s_1view_per_step"] > f["views_per_s_1view_per_step"] * 0.7
-    for k in ("conv_math_fp32", "conv_math_split_bf16x3_opt_in_not_fp32_grade"):
+    for k in ("conv_math_fp32", "conv_math_split_bf16", "conv_math_split_bf16x3_opt_in_not_fp32_grade"):
         assert abs(f[k]["views_per_s_1view_per_step"] * f[k]["ms_per_step_1view"] - 1000.0) < 5.0
     m = d["roofline_mfma"]
-    # the product's arithmetic: six bf16 products per fp32 product, priced (executed = 6 x algorithmic) against the dense bf16 MFMA peak
-    assert m["bound"] == "mfma" and m["unit"] == "TFLOP/s" and m["math"] == "split_bf16" and m["peak"] == 2500.0
-    assert abs(m["executed"] - 6 * m["achieved"]) < 0.5 and abs(m["frac"] - m["executed"] / m["peak"]) < 1e-3 and 0.05 < m["frac"] < 1.0
+    # the product's arithmetic: three fp16 products per fp32 product, priced (executed = 3 x algorithmic) against the dense 16-bit MFMA peak
+    assert m["bound"] == "mfma" and m["unit"] == "TFLOP/s" and m["math"] == "split_f16" and m["peak"] == 2500.0
+    assert abs(m["executed"] - 3 * m["achieved"]) < 0.5 and abs(m["frac"] - m["executed"] / m["peak"]) < 1e-3 and 0.05 < m["frac"] < 1.0
     assert abs(m["frac_of_fp32_mfma_peak"] - m["achieved"] / 157.3) < 1e-3
     for k in ("gather_conv_kernel", "wgrad_kernel"):
-        assert m[k]["launches_timed"] > 0 and 1.0 < m[k]["TFLOPs"] < 2500.0 / 6
+        assert m[k]["launches_timed"] > 0 and 1.0 < m[k]["TFLOPs"] < 2500.0 / 3
     # ... and the fp32-MFMA mode beside it, against its own peak
     q = m["fp32_mfma_mode"]
     assert q["peak"] == 157.3 and abs(q["frac"] - q["achieved"] / q["peak"]) < 1e-3 and 0.05 < q["frac"] < 1.0
