@@ -185,6 +185,40 @@ def test_split_products_are_fp32_grade(kind, Cin, Cout, hw, k, stride, padding):
         assert rms[("split_bf16x3", name)] > 4.0 * rms[("split_bf16", name)], (name, rms)
 
 
+def test_split_f16_bound_beyond_the_full_precision_range():
+    """include/ag_conv.h, AG_CONV_MATH_SPLIT_F16: |error| <= 3 * 2^-24 sum |a| |b| + 2^-39 (M_b sum |a| + M_a sum |b|) per output (plus the
+    fp32 accumulation bound 2^-19 sum |a| |b| every mode is held to).  Operands spread over 40 binades (far more than the 17 below a
+    tensor's maximum in which the low parts are normal fp16 numbers), and one output channel whose weights are 2^-24 of the tensor's
+    largest: the bound holds everywhere, the outputs fed by in-range operands keep the fp32 grade, and the tiny channel degrades in
+    RELATIVE terms only (its absolute error stays 2^-15 of the rounding fp32 commits on the large outputs)."""
+    import torch
+    import torch.nn.functional as F
+    from animatablegaussians_amd import conv as agc
+    g = torch.Generator().manual_seed(23)
+    Cin, Cout, hw = 64, 128, 24
+    x = torch.randn(1, Cin, hw, hw, generator=g) * torch.exp2(torch.randint(-40, 1, (1, Cin, hw, hw), generator=g).float())
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * torch.exp2(torch.randint(-12, 1, (Cout, Cin, 3, 3), generator=g).float())
+    w[5] *= 2.0 ** -24
+    ref = F.conv2d(x.double(), w.double(), None, padding=1)
+    mag = F.conv2d(x.abs().double(), w.abs().double(), None, padding=1)                              # sum |a| |b|
+    sum_x = F.conv2d(x.abs().double(), torch.ones(1, Cin, 3, 3, dtype=torch.float64), None, padding=1)  # sum |x| over the receptive field
+    sum_w = w.abs().double().sum(dim=(1, 2, 3)).view(1, Cout, 1, 1)
+    Mx, Mw = float(x.abs().max()), float(w.abs().max())
+    prev = agc.set_math("split_f16")
+    try:
+        out = agc.conv2d(x.cuda(), w.cuda(), None, padding=1).cpu().double()
+    finally:
+        agc.set_math(prev)
+    dev = (out - ref).abs()
+    bound = (2.0 ** -19 + 3 * 2.0 ** -24) * mag + 2.0 ** -39 * (Mw * sum_x + Mx * sum_w)
+    assert bool((dev <= bound).all()), float((dev / bound).max())
+    big = mag >= 2.0 ** -10 * float(mag.max())                 # outputs fed by operands near their tensors' maxima: the fp32 grade
+    assert float((dev[big] / mag[big]).max()) <= 2.0 ** -19
+    tiny = dev[:, 5] / (mag[:, 5] + 1e-300)                    # the 2^-24 channel: relative error degraded, as documented ...
+    assert float(dev[:, 5].max()) <= 2.0 ** -38 * Mw * float(sum_x.max())      # ... absolute error far below fp32's rounding of the large outputs
+    print(f"split_f16 wide range: worst dev / bound {float((dev / bound).max()):.3f}; tiny channel worst relative error 2^{np.log2(float(tiny.max()) + 1e-300):.1f}")
+
+
 def test_three_product_mode_vs_torch():
     """split_bf16x3 (opt-in) on the reference comparison of test_conv_forward_backward, at ITS contract: deviation from the fp32 CPU
     convolution <= 1e-4 |ref| + 1e-4 max|ref| (products within 3 * 2^-16)."""
