@@ -314,20 +314,35 @@ __global__ void __launch_bounds__(256) modulate_weight_backward_kernel(float* __
     }
 }
 
-// dstyle[grp][ci] = sum_co partials[grp][co][ci]: a workgroup owns 64 channels, its four waves a quarter of the rows each, in order
-__global__ void __launch_bounds__(256) modulate_finish_kernel(float* __restrict__ dstyle, const float* __restrict__ partials, int Co, int Ci)
+// dstyle[grp][ci] = sum_co partials[grp][co][ci]: a workgroup owns 64 channels, its sixteen waves a sixteenth of the rows each (four
+// independent partial sums per thread: the loop is a chain of dependent loads otherwise), combined in a fixed order
+constexpr int kModFinishWaves = 16;
+__global__ void __launch_bounds__(64 * kModFinishWaves) modulate_finish_kernel(float* __restrict__ dstyle, const float* __restrict__ partials, int Co, int Ci)
 {
-    __shared__ float s_q[4][64];
+    __shared__ float s_q[kModFinishWaves][64];
     const int grp = blockIdx.y, lane = threadIdx.x & 63, q = threadIdx.x >> 6;
     const int ci = blockIdx.x * 64 + lane;
     const float* part = partials + (size_t)grp * Co * Ci;
-    const int per = (Co + 3) / 4, r0 = q * per, r1 = min(Co, r0 + per);
-    float s = 0.f;
-    if (ci < Ci)
-        for (int co = r0; co < r1; co++) s += part[(size_t)co * Ci + ci];
-    s_q[q][lane] = s;
+    const int per = (Co + kModFinishWaves - 1) / kModFinishWaves, r0 = min(Co, q * per), r1 = min(Co, r0 + per);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (ci < Ci) {
+        int co = r0;
+        for (; co + 3 < r1; co += 4) {
+            s0 += part[(size_t)co * Ci + ci];
+            s1 += part[(size_t)(co + 1) * Ci + ci];
+            s2 += part[(size_t)(co + 2) * Ci + ci];
+            s3 += part[(size_t)(co + 3) * Ci + ci];
+        }
+        for (; co < r1; co++) s0 += part[(size_t)co * Ci + ci];
+    }
+    s_q[q][lane] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (q == 0 && ci < Ci) dstyle[(size_t)grp * Ci + ci] = (s_q[0][lane] + s_q[1][lane]) + (s_q[2][lane] + s_q[3][lane]);
+    if (q == 0 && ci < Ci) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < kModFinishWaves; i++) t += s_q[i][lane];
+        dstyle[(size_t)grp * Ci + ci] = t;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -783,7 +798,7 @@ int modulate_weight_backward_g(float* dW, float* dstyle, float* partials, const 
     hipLaunchKernelGGL(modulate_weight_backward_kernel, dim3(G * Co), dim3(256), 0, s, dW, partials, g, W, style, dcoef, scale, demod, Co, Ci, K2,
                        transposed);
     if (check_hip(hipGetLastError(), "modulate_weight_backward_kernel")) return AG_ERR_HIP;
-    hipLaunchKernelGGL(modulate_finish_kernel, dim3((Ci + 63) / 64, G), dim3(256), 0, s, dstyle, partials, Co, Ci);
+    hipLaunchKernelGGL(modulate_finish_kernel, dim3((Ci + 63) / 64, G), dim3(64 * kModFinishWaves), 0, s, dstyle, partials, Co, Ci);
     return check_hip(hipGetLastError(), "modulate_finish_kernel");
 }
 
