@@ -55,6 +55,8 @@ int ag_noise_bias_act_forward(float* y, const float* x, const float* noise, cons
  * gbias / gnoise_weight may be NULL (not needed); they are overwritten.  DETERMINISTIC since round 4: every workgroup stores its partial
  * sums in `partials` (ag_noise_bias_act_partial_floats(C, HW) floats of caller-owned scratch, required when either sum is wanted) and a
  * one-workgroup finish adds them in a fixed order -- bit-identical from run to run given the same inputs (float atomics before).
+ * `partials` holds (sum, sum * noise) per workgroup, then one float per workgroup: the largest |gx| it wrote (used by the grouped layer
+ * calls, include/ag_layers.h: the fp16-split convolutions that consume gx need its largest magnitude and do not sweep it again).
  */
 size_t ag_noise_bias_act_partial_floats(int32_t C, int32_t HW);
 int ag_noise_bias_act_backward(float* gx, const float* gy, const float* y, const float* noise, float* gbias, float* gnoise_weight,
