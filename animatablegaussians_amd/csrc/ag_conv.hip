@@ -153,6 +153,7 @@ struct GatherProblem {
     float slope, act_scale;
     PtrTable noise_t;      // act 1: per-instance noise [OHf * OWf] (null: no noise); act 2: per-instance addend [M][OHf * OWf]
     PtrTable nw_t;         // act 1: per-instance noise weight [1]
+    float* out_amax;       // act != 0: zeroed [G][kAmaxParts] slots for the largest magnitude of the activated output (ConvAct::out_amax), or null
     // fp16 split form: partial maxima (absmax_kernel) of the packed weights' source tensors [G][kAmaxParts] and of the gathered tensor
     // ([G][kAmaxParts], or one row when the instances share their input); amax_a_mult = |weight_scale| (the packed values are w * scale)
     const float* amax_a;
@@ -183,6 +184,20 @@ __device__ __forceinline__ GroupView group_view(const GatherProblem& p)
     v.noise = p.act ? p.noise_t.p[v.grp] : nullptr;
     v.nw = (p.act == 1 && v.noise) ? p.nw_t.p[v.grp][0] : 1.0f;
     return v;
+}
+
+// Largest magnitude a wave stored -> one of the kAmaxParts zeroed slots of its instance: an unsigned atomic maximum of the float bits
+// (order-independent, hence deterministic), skipped when the slot already holds a larger value (a stale read only costs an atomic).
+// Every lane of the wave must arrive here.
+__device__ __forceinline__ void emit_amax(float* slots, float mx, int salt)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((threadIdx.x & 63) == 0) {
+        unsigned int* slot = reinterpret_cast<unsigned int*>(slots) + ((unsigned)salt & (kAmaxParts - 1));
+        const unsigned int bits = __float_as_uint(mx);
+        if (bits > __builtin_nontemporal_load(slot)) atomicMax(slot, bits);
+    }
 }
 
 // Epilogue shared by the gather kernels.  C/D layout of the 32 x 32 MFMAs: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
@@ -218,6 +233,7 @@ __device__ __forceinline__ void gather_epilogue(const GatherProblem& p, const Gr
         opix[j] = (size_t)(cl.y0 + oy * p.os) * p.OWf + (cl.x0 + ox * p.os);
     }
     const bool has_scale = p.out_scale != nullptr, has_bias = gv.bias != nullptr;
+    float mx = 0.f;
 #pragma unroll
     for (int i = 0; i < WMB; i++)
 #pragma unroll
@@ -233,7 +249,9 @@ __device__ __forceinline__ void gather_epilogue(const GatherProblem& p, const Gr
                 for (int j = 0; j < WNB; j++)
                     if (nn[j] < N) {
                         const float t = fmaf(gv.nw, nz ? nz[opix[j]] : 0.f, acc[i][j][r]) + bi;
-                        row[opix[j]] = (t > 0.f ? t : t * p.slope) * p.act_scale;
+                        const float y = (t > 0.f ? t : t * p.slope) * p.act_scale;
+                        row[opix[j]] = y;
+                        mx = fmaxf(mx, fabsf(y));
                     }
                 continue;
             }
@@ -241,6 +259,7 @@ __device__ __forceinline__ void gather_epilogue(const GatherProblem& p, const Gr
             for (int j = 0; j < WNB; j++)
                 if (nn[j] < N) row[opix[j]] = acc[i][j][r] * sc + bi;
         }
+    if (p.act && p.out_amax) emit_amax(p.out_amax + (size_t)gv.grp * kAmaxParts, mx, (int)blockIdx.x * 8 + (int)(threadIdx.x >> 6));
 }
 
 // K is ordered (channel block of 16, tap, channel in block), so the 16 rows of a K tile are 16 consecutive channels of ONE tap:
@@ -489,8 +508,9 @@ __device__ __forceinline__ TensorScale tensor_scale(const float* __restrict__ pa
 struct AmaxJobs {
     const float* ptr[2 * kMaxGroups];
     long long len[2 * kMaxGroups], stride[2 * kMaxGroups];
-    int rows[2 * kMaxGroups], slot[2 * kMaxGroups];
-    float* out;                         // job j writes out[slot[j]][kAmaxParts]
+    int rows[2 * kMaxGroups];
+    float* outp[2 * kMaxGroups];        // job j writes outp[j][kAmaxParts] (a job of length 0 zeroes them: the slots a producer kernel will
+                                        // raise with atomic maxima, ConvAct::out_amax)
 };
 constexpr int kAmaxThreads = 1024;      // 16 waves per workgroup: 256 workgroups per tensor have to keep HBM busy on their own
 __global__ void __launch_bounds__(kAmaxThreads) absmax_kernel(AmaxJobs J)
@@ -527,7 +547,7 @@ __global__ void __launch_bounds__(kAmaxThreads) absmax_kernel(AmaxJobs J)
     if (threadIdx.x == 0) {
 #pragma unroll
         for (int i = 1; i < kAmaxThreads / 64; i++) m = fmaxf(m, wm[i]);
-        J.out[(size_t)J.slot[job] * kAmaxParts + blockIdx.x] = m;
+        J.outp[job][blockIdx.x] = m;
     }
 }
 
@@ -811,6 +831,7 @@ __global__ void __launch_bounds__(256) reduce_splits_kernel(GatherProblem p, int
     float* __restrict__ yout = p.yout + (size_t)grp * p.y_gs;
     const float* __restrict__ noise = p.act ? p.noise_t.p[grp] : nullptr;
     const float nw = (p.act == 1 && noise) ? p.nw_t.p[grp][0] : 1.0f;
+    float mx = 0.f;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int m = (int)(i / Nc), colg = (int)(i - (long long)m * Nc);
         float v = 0.f;
@@ -818,7 +839,9 @@ __global__ void __launch_bounds__(256) reduce_splits_kernel(GatherProblem p, int
         if (p.act) {        // plain gather (one class, os = 1): column = output pixel
             const float nv = noise ? (p.act == 2 ? noise[(size_t)m * Nc + colg] : noise[colg]) : 0.f;
             const float t = fmaf(nw, nv, v) + (bias ? bias[m] : 0.f);
-            yout[(size_t)m * Nc + colg] = (t > 0.f ? t : t * p.slope) * p.act_scale;
+            const float y = (t > 0.f ? t : t * p.slope) * p.act_scale;
+            yout[(size_t)m * Nc + colg] = y;
+            mx = fmaxf(mx, fabsf(y));
             continue;
         }
         if (p.out_scale) v *= p.out_scale[m];
@@ -830,6 +853,16 @@ __global__ void __launch_bounds__(256) reduce_splits_kernel(GatherProblem p, int
         const int nn = colg - p.cls[ci].col_begin;
         const int oy = nn / p.cls[ci].gw, ox = nn - oy * p.cls[ci].gw;
         yout[(size_t)m * p.OHf * p.OWf + (size_t)(p.cls[ci].y0 + oy * p.os) * p.OWf + (p.cls[ci].x0 + ox * p.os)] = v;
+    }
+    if (p.act && p.out_amax) {        // one non-returning atomic per workgroup (these workgroups are short: nothing may wait at their end)
+        __shared__ float s_mx[4];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        if ((threadIdx.x & 63) == 0) s_mx[threadIdx.x >> 6] = mx;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            atomicMax(reinterpret_cast<unsigned int*>(p.out_amax) + (size_t)grp * kAmaxParts + (blockIdx.x & (kAmaxParts - 1)),
+                      __float_as_uint(fmaxf(fmaxf(s_mx[0], s_mx[1]), fmaxf(s_mx[2], s_mx[3]))));
     }
 }
 
@@ -954,6 +987,7 @@ struct WgradProblem {
     float wscale;          // the forward convolved with w * wscale: dL/dw = wscale * dL/d(w * wscale)
     int G, mtiles;         // grouped launch: gridDim.y = G * mtiles
     long long a_gs, xin_gs, c_gs;     // floats between the instances' operands / outputs
+    PtrTable c_t;          // p[0] != null: instance g writes to c_t.p[g] instead of c + g * c_gs (ConvOpts::dw_table)
     const float* amax_a;   // fp16 split form: partial maxima of `a` and of `xin` ([G][kAmaxParts], one row where the instances share the tensor)
     const float* amax_b;
     int c_row_stride, c_chan_stride;  // element (m, nn = (channel, tap)) of the output sits at m * c_row_stride + channel * c_chan_stride + tap:
@@ -982,7 +1016,7 @@ __global__ void __launch_bounds__(64 * WVM * WVN, AG_CONV_WAVES_PER_SIMD) wgrad_
     const int Kp = p.gh * p.gw, Nw = p.Cg * p.ntaps;
     const int grp = (int)blockIdx.y / p.mtiles, my = (int)blockIdx.y - grp * p.mtiles;      // grouped launch (ag_groups.h)
     const float* __restrict__ xin_g = p.xin + (size_t)grp * p.xin_gs;
-    float* __restrict__ c_g = p.c + (size_t)grp * p.c_gs;
+    float* __restrict__ c_g = p.c_t.p[0] ? const_cast<float*>(p.c_t.p[grp]) : p.c + (size_t)grp * p.c_gs;
     const int m0 = my * BM, n0 = blockIdx.x * BN;
     const int kbeg = blockIdx.z * p.ksplit_len, kend = min(Kp, kbeg + p.ksplit_len);
     if (kbeg >= kend) return;
@@ -1161,7 +1195,7 @@ __global__ void __launch_bounds__(64 * WVM * WVN, AG_CONV_WAVES_PER_SIMD) wgrad_
     const int Kp = p.gh * p.gw, Nw = p.Cg * p.ntaps;
     const int grp = (int)blockIdx.y / p.mtiles, my = (int)blockIdx.y - grp * p.mtiles;      // grouped launch (ag_groups.h)
     const float* __restrict__ xin_g = p.xin + (size_t)grp * p.xin_gs;
-    float* __restrict__ c_g = p.c + (size_t)grp * p.c_gs;
+    float* __restrict__ c_g = p.c_t.p[0] ? const_cast<float*>(p.c_t.p[grp]) : p.c + (size_t)grp * p.c_gs;
     const int m0 = my * BM, n0 = blockIdx.x * BN;
     const int kbeg = blockIdx.z * p.ksplit_len, kend = min(Kp, kbeg + p.ksplit_len);
     if (kbeg >= kend) return;
@@ -1465,28 +1499,34 @@ static bool split_math() { return split_terms() != 0; }
 constexpr size_t kAmaxBytes = 2 * (size_t)kMaxGroups * kAmaxParts * sizeof(float);
 // one launch for the partial maxima of up to three operand tensors (instances: `table` entries, or `ptr + g * gs`, or ONE shared instance
 // when gs == 0 and there is no table); tensor i's instance g goes to out[(i * kMaxGroups + g) * kAmaxParts ...]
-int conv_absmax(const AmaxTensor* t, int n, int G, float* out, hipStream_t s)
+int conv_absmax(const AmaxTensor* t, int n, int G, float* out, hipStream_t s, float* zero, int zero_inst)
 {
     AmaxJobs J;
     int jobs = 0;
+    auto flush = [&]() {
+        hipLaunchKernelGGL(absmax_kernel, dim3(kAmaxParts, jobs), dim3(kAmaxThreads), 0, s, J);
+        jobs = 0;
+    };
     for (int i = 0; i < n; i++) {
         if (!t[i].ptr && !t[i].table) continue;
         const int n_i = t[i].inst ? t[i].inst : G;
         const int inst = t[i].table ? n_i : (t[i].gs ? n_i : 1);
         for (int g = 0; g < inst; g++) {
-            if (jobs == 2 * kMaxGroups) {         // three full stacks of more than 10 instances: a second launch
-                J.out = out;
-                hipLaunchKernelGGL(absmax_kernel, dim3(kAmaxParts, jobs), dim3(kAmaxThreads), 0, s, J);
-                jobs = 0;
-            }
+            if (jobs == 2 * kMaxGroups) flush();          // three full stacks of more than 10 instances: a second launch
             J.ptr[jobs] = t[i].table ? t[i].table->p[g] : t[i].ptr + (size_t)g * t[i].gs;
-            J.len[jobs] = t[i].len; J.stride[jobs] = t[i].stride; J.rows[jobs] = t[i].rows; J.slot[jobs] = i * kMaxGroups + g;
+            J.len[jobs] = t[i].len; J.stride[jobs] = t[i].stride; J.rows[jobs] = t[i].rows;
+            J.outp[jobs] = out + (size_t)(i * kMaxGroups + g) * kAmaxParts;
             jobs++;
         }
     }
+    for (int g = 0; zero && g < zero_inst; g++) {          // slots to be zeroed for a producer's atomic maxima
+        if (jobs == 2 * kMaxGroups) flush();
+        J.ptr[jobs] = zero; J.len[jobs] = 0; J.stride[jobs] = 0; J.rows[jobs] = 1;
+        J.outp[jobs] = zero + (size_t)g * kAmaxParts;
+        jobs++;
+    }
     if (jobs == 0) return AG_OK;
-    J.out = out;
-    hipLaunchKernelGGL(absmax_kernel, dim3(kAmaxParts, jobs), dim3(kAmaxThreads), 0, s, J);
+    flush();
     return check_hip(hipGetLastError(), "absmax_kernel");
 }
 size_t conv_absmax_floats(int tensors) { return (size_t)tensors * kMaxGroups * kAmaxParts; }
@@ -1657,6 +1697,7 @@ static int pack_and_launch(GatherProblem& gp, const TapSet* taps, int bm, const 
     const long long total = (long long)gp.M * cols;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
+    if (gp.act && gp.out_amax && blocks * G > 2048) blocks = std::max(1, 2048 / G);      // each workgroup ends with an atomic into its instance's 16 lines of slots
     hipLaunchKernelGGL(reduce_splits_kernel, dim3(blocks, G), dim3(256), 0, s, gp, splits);
     return check_hip(hipGetLastError(), "reduce_splits_kernel");
 }
@@ -1726,6 +1767,7 @@ static int run_gather_family(const AgConvDesc* d, bool backward_input, int G, co
     gp.act = opt.act ? opt.act->kind : 0;
     gp.slope = opt.act ? opt.act->slope : 0.f; gp.act_scale = opt.act ? opt.act->scale : 1.f;
     gp.noise_t = opt.act ? opt.act->noise : PtrTable{}; gp.nw_t = opt.act ? opt.act->nw : PtrTable{};
+    gp.out_amax = opt.act ? opt.act->out_amax : nullptr;
     if (gp.act && (out_scale || backward_input)) { set_error("conv: the fused activation is a forward option without out_scale"); return AG_ERR_INVALID_ARGUMENT; }
     const bool conv = d->kind == AG_CONV;
     // input of the GEMM / output of the GEMM in tensor terms
@@ -1842,8 +1884,9 @@ int conv_backward_weight_g(const AgConvDesc* d, int G, const float* x, long long
 {
     int rc = validate(d);
     if (rc) return rc;
-    if (G < 1 || G > kMaxGroups || !x || !dy || !dw) { set_error("null conv tensor / bad group count"); return AG_ERR_INVALID_ARGUMENT; }
-    if ((rc = pointwise_backward_weight(d, G, x, x_gs, dy, dy_gs, dw, dw_gs, workspace, workspace_bytes, s)) != 0) return rc < 0 ? rc : AG_OK;
+    if (G < 1 || G > kMaxGroups || !x || !dy || (!dw && !o.dw_table)) { set_error("null conv tensor / bad group count"); return AG_ERR_INVALID_ARGUMENT; }
+    if (o.dw_table && (!table_complete(*o.dw_table, G) || o.dw_row_stride <= 0 || d->k == 1)) { set_error("conv: bad weight-gradient table"); return AG_ERR_INVALID_ARGUMENT; }
+    if (!o.dw_table && (rc = pointwise_backward_weight(d, G, x, x_gs, dy, dy_gs, dw, dw_gs, workspace, workspace_bytes, s)) != 0) return rc < 0 ? rc : AG_OK;
     int OH, OW;
     out_size(d, OH, OW);
     const int k = d->k, k2 = k * k;
@@ -1860,6 +1903,8 @@ int conv_backward_weight_g(const AgConvDesc* d, int G, const float* x, long long
     wp.c = dw; wp.c_gs = dw_gs; wp.G = G; wp.ntaps = k2; wp.wscale = wscale_of(d);
     wp.c_row_stride = wp.Cg * k2; wp.c_chan_stride = k2;                         // [Mw][Cg][taps]
     if (o.wt_oihw && d->kind == AG_CONV_TRANSPOSE) { wp.c_row_stride = k2; wp.c_chan_stride = wp.Mw * k2; }   // rows = Cin: [Cout][Cin][taps]
+    wp.c_t = PtrTable{};
+    if (o.dw_table) { wp.c_t = *o.dw_table; wp.c_row_stride = (int)o.dw_row_stride; }
     const int Kp = wp.gh * wp.gw, Nw = wp.Cg * k2;
     const int bm = pick_bm(wp.Mw), BN = bn_of(bm);
     const int tiles = ((Nw + BN - 1) / BN) * ((wp.Mw + bm - 1) / bm) * G;
@@ -1882,7 +1927,9 @@ int conv_backward_weight_g(const AgConvDesc* d, int G, const float* x, long long
     }
     wp.ksplit_len = round_up((Kp + splits - 1) / splits, BK);
     splits = (Kp + wp.ksplit_len - 1) / wp.ksplit_len;
-    if (dw_gs == (long long)wp.Mw * Nw || G == 1) {
+    if (o.dw_table) {
+        // the caller zeroed the target
+    } else if (dw_gs == (long long)wp.Mw * Nw || G == 1) {
         if ((rc = check_hip(hipMemsetAsync(dw, 0, (size_t)G * wp.Mw * Nw * sizeof(float), s), "memset dw"))) return rc;
     } else {
         for (int g = 0; g < G; g++)

@@ -54,8 +54,10 @@ int sum_member_ranges(float* out, const float* in, const int* begin, int R, long
 size_t noise_bias_act_partial_floats(int G, int C, int HW);
 // gbias: instance g writes C sums at gbias + g * gb_stride (null: not wanted); gnw: one sum at gnw + g * gnw_stride (null: not wanted).
 // Deterministic: per-workgroup partial sums + a fixed-order finish (no float atomics).
+int fir4x4_amax_g(float* out, const float* in, const float* taps, int planes, int in_h, int in_w, int pad, float* amax, int planes_per_group,
+                  hipStream_t s);
 int blur_act_forward_g(float* y, const float* x, const float* taps, int G, const PtrTable& noise, const PtrTable& nw, const PtrTable& bias,
-                       int C, int H, int W, float slope, float scale, hipStream_t s);
+                       int C, int H, int W, float slope, float scale, hipStream_t s, float* out_amax = nullptr);
 int noise_bias_act_backward_g(float* gx, const float* gy, const float* y, int G, const PtrTable& noise, float* gbias, long long gb_stride,
                               float* gnw, long long gnw_stride, float* partials, int C, int HW, float slope, float scale, hipStream_t s, float* amax = nullptr);
 // out [G][Co][Ci][K2] (or [G][Ci][Co][K2] transposed), dcoef [G][Co] (may be null)
@@ -84,6 +86,8 @@ struct ConvAct {
     float slope, scale;
     PtrTable noise;          // kind 1: noise maps; kind 2: addends
     PtrTable nw;             // kind 1: noise weights
+    float* out_amax = nullptr;   // [G][kAmaxParts] zeroed slots or null: the largest magnitude of the activated output of every instance is left there
+                                 // (unsigned atomic maxima of the float bits) -- the operand maximum of the NEXT convolution's fp16 split form
 };
 
 // fp16 split form of the convolutions (AG_CONV_MATH_SPLIT_F16): every operand tensor's largest magnitude as kAmaxParts partial maxima per
@@ -98,7 +102,8 @@ struct AmaxTensor {                 // instances: `table` entries, or ptr + g * 
     int inst;                       // instances of this tensor when it differs from the call's G (0: G)
 };
 // tensor i's instance g -> out[(i * kMaxGroups + g) * kAmaxParts ...]; one launch
-int conv_absmax(const AmaxTensor* t, int n, int G, float* out, hipStream_t s);
+// zero / zero_inst: additionally zeroes zero[0 .. zero_inst)[kAmaxParts] in the same launch (slots a producer kernel then raises, ConvAct::out_amax)
+int conv_absmax(const AmaxTensor* t, int n, int G, float* out, hipStream_t s, float* zero = nullptr, int zero_inst = 0);
 size_t conv_absmax_floats(int tensors);
 bool conv_math_needs_absmax();
 
@@ -115,6 +120,11 @@ struct ConvOpts {
     const float* amax_w = nullptr;
     const float* amax_x = nullptr;
     const float* amax_dy = nullptr;
+    // weight gradient written into a wider tensor (the comb convolutions: a channel slice of the parameter's own gradient): instance g goes to
+    // dw_table->p[g] with rows dw_row_stride floats apart; entries may repeat -- those instances ACCUMULATE (the split-K atomics do that anyway);
+    // the call does not zero the target
+    const PtrTable* dw_table = nullptr;
+    long long dw_row_stride = 0;
 };
 size_t conv_workspace_bytes_g(const AgConvDesc* d, int G);
 int conv_forward_g(const AgConvDesc* d, int G, const float* x, long long x_gs, const PtrTable& w, const float* out_scale, const PtrTable& bias,

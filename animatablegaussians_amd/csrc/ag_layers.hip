@@ -146,17 +146,33 @@ int ag_grouped_layer_forward(const AgGroupedLayerArgs* a, void* stream)
     const long long x_gs = G > 1 ? a->x_group_stride : 0;
     const long long pre_gs = (long long)a->Cout * g.OH * g.OW;
     int rc;
+    // the largest magnitudes of this call's output for the NEXT call: from the kernel that writes `out` where it can emit them
+    float* const omax = (conv_math_needs_absmax() && a->out_maxima) ? a->out_maxima : nullptr;
+    bool omax_zeroed = false;
     // fp16 split form of the MFMA convolutions: the maxima of the forward's operands (weights as convolved, input as convolved) go to
     // a->operand_maxima, where the backward finds them -- its convolutions have the same operands
     const long long w_len = (long long)a->Cout * a->Cin * a->k * a->k;
     auto keep_maxima = [&](const PtrTable& w, const float* x, long long xgs, long long x_len, ConvOpts& o) -> int {
         if (!conv_math_needs_absmax() || a->k < 3 || !a->operand_maxima) return AG_OK;
-        const AmaxTensor t[2] = { AmaxTensor{ nullptr, &w, 0, w_len, 0, 1 }, AmaxTensor{ x, nullptr, xgs, x_len, 0, 1 } };
-        const int rc1 = conv_absmax(t, 2, G, a->operand_maxima, s);
+        AmaxTensor t[2] = { AmaxTensor{ nullptr, &w, 0, w_len, 0, 1 }, AmaxTensor{ x, nullptr, xgs, x_len, 0, 1 } };
+        const bool x_known = a->x_maxima && x == a->x;        // handed over by the call that produced x
+        if (x_known) t[1] = AmaxTensor{};
+        const int rc1 = conv_absmax(t, 2, G, a->operand_maxima, s, omax, G);       // (and zeroes the slots of this call's own output maxima)
         if (rc1) return rc1;
+        omax_zeroed = true;
         o.amax_w = a->operand_maxima;
-        o.amax_x = a->operand_maxima + (size_t)kMaxGroups * kAmaxParts;
+        o.amax_x = x_known ? a->x_maxima : a->operand_maxima + (size_t)kMaxGroups * kAmaxParts;
         return AG_OK;
+    };
+    auto zero_omax = [&]() -> int {       // the slots a producer kernel raises must start at zero: by the maxima launch above, or here
+        if (!omax || omax_zeroed) return AG_OK;
+        omax_zeroed = true;
+        return check_hip(hipMemsetAsync(omax, 0, (size_t)G * kAmaxParts * sizeof(float), s), "memset out_maxima");
+    };
+    auto sweep_out = [&]() -> int {       // ... by a sweep where no kernel can emit them
+        if (!omax) return AG_OK;
+        const AmaxTensor t{ a->out, nullptr, pre_gs, pre_gs, 0, 1 };
+        return conv_absmax(&t, 1, G, omax, s);
     };
     if (!a->modulated) {
         const float* cx = a->x;
@@ -172,11 +188,14 @@ int ag_grouped_layer_forward(const AgGroupedLayerArgs* a, void* stream)
         if ((rc = keep_maxima(w_t, cx, cx_gs, (long long)a->Cin * (a->resample ? g.BH * g.BW : a->H * a->W), o))) return rc;
         if (fused_act() && !(a->k == 1 && a->Cin <= 4)) {       // (the 3-channel FromRGB convolutions run on the streaming 1 x 1 kernel, which has no such epilogue)
             ConvAct act{ 1, a->slope, a->act_scale, PtrTable{}, PtrTable{} };
+            if ((rc = zero_omax())) return rc;
+            act.out_amax = omax;
             o.act = &act;
             return conv_forward_g(&g.d, G, cx, cx_gs, w_t, nullptr, bias_t, a->out, pre_gs, a->workspace, a->workspace_bytes, s, o);
         }
         if ((rc = conv_forward_g(&g.d, G, cx, cx_gs, w_t, nullptr, PtrTable{}, pre, pre_gs, a->workspace, a->workspace_bytes, s, o))) return rc;
-        return noise_bias_act_forward_g(a->out, pre, G, PtrTable{}, PtrTable{}, bias_t, a->Cout, g.OH * g.OW, a->slope, a->act_scale, s);
+        if ((rc = noise_bias_act_forward_g(a->out, pre, G, PtrTable{}, PtrTable{}, bias_t, a->Cout, g.OH * g.OW, a->slope, a->act_scale, s))) return rc;
+        return sweep_out();
     }
     const PtrTable style_t = table_of(a->style, G);
     if (!table_complete(style_t, G) || !a->w_mod || !a->demod) { set_error("ag_layer_forward: StyledConv needs style, w_mod and demod"); return AG_ERR_INVALID_ARGUMENT; }
@@ -196,17 +215,22 @@ int ag_grouped_layer_forward(const AgGroupedLayerArgs* a, void* stream)
         if (!a->k_blur) { set_error("ag_layer_forward: resampling layer without FIR taps"); return AG_ERR_INVALID_ARGUMENT; }
         if ((rc = conv_forward_g(&g.d, G, a->x, x_gs, wm_t, nullptr, PtrTable{}, aux, (long long)a->Cout * g.CH * g.CW, a->workspace, a->workspace_bytes, s, om))) return rc;
         // Blur + noise + bias + leaky ReLU in one pass (the backward needs the output only, so the blurred pre-activation is never stored)
-        if (fused_act()) return blur_act_forward_g(a->out, aux, a->k_blur, G, noise_t, nw_t, bias_t, a->Cout, g.CH, g.CW, a->slope, a->act_scale, s);
+        if (fused_act() && G * a->Cout <= 65535 && (rc = zero_omax())) return rc;
+        if (fused_act() && G * a->Cout <= 65535)
+            return blur_act_forward_g(a->out, aux, a->k_blur, G, noise_t, nw_t, bias_t, a->Cout, g.CH, g.CW, a->slope, a->act_scale, s, omax);
         if ((rc = ag_upfirdn2d(pre, aux, a->k_blur, G * a->Cout, g.CH, g.CW, 4, 4, 1, 1, 1, 1, 1, 1, 1, 1, stream))) return rc;
     } else {
         if (fused_act()) {
             ConvAct act{ 1, a->slope, a->act_scale, noise_t, nw_t };
+            if ((rc = zero_omax())) return rc;
+            act.out_amax = omax;
             om.act = &act;
             return conv_forward_g(&g.d, G, a->x, x_gs, wm_t, nullptr, bias_t, a->out, pre_gs, a->workspace, a->workspace_bytes, s, om);
         }
         if ((rc = conv_forward_g(&g.d, G, a->x, x_gs, wm_t, nullptr, PtrTable{}, pre, pre_gs, a->workspace, a->workspace_bytes, s, om))) return rc;
     }
-    return noise_bias_act_forward_g(a->out, pre, G, noise_t, nw_t, bias_t, a->Cout, g.OH * g.OW, a->slope, a->act_scale, s);
+    if ((rc = noise_bias_act_forward_g(a->out, pre, G, noise_t, nw_t, bias_t, a->Cout, g.OH * g.OW, a->slope, a->act_scale, s))) return rc;
+    return sweep_out();
 }
 
 int ag_grouped_layer_backward(const AgGroupedLayerArgs* a, void* stream)
@@ -239,17 +263,19 @@ int ag_grouped_layer_backward(const AgGroupedLayerArgs* a, void* stream)
                                         g.OH * g.OW, a->slope, a->act_scale, s, want_maxima ? am : nullptr))) return rc;
     // fp16 split form of the MFMA convolutions: dL/dx and dL/dw share dy, so the three operand maxima are taken once, in one launch
     const long long w_len = (long long)a->Cout * a->Cin * a->k * a->k;
+    bool dy_maxima_ready = true;       // `am` holds the maxima of g_pre (noise_bias_act_backward_g above); the Blur adjoint below replaces them by its output's
     auto shared_maxima = [&](const float* dy, long long dy_gs, const PtrTable& w, const float* x, long long xgs, long long x_len, ConvOpts& o) -> int {
         if (!want_maxima) return AG_OK;
         AmaxTensor t[3] = { AmaxTensor{ dy, nullptr, dy_gs, dy_gs, 0, 1 }, AmaxTensor{ nullptr, &w, 0, w_len, 0, 1 }, AmaxTensor{ x, nullptr, xgs, x_len, 0, 1 } };
-        if (dy == g_pre) t[0] = AmaxTensor{};          // already in `am` (noise_bias_act_backward_g above)
+        if (dy_maxima_ready) t[0] = AmaxTensor{};
+        const bool x_known = a->x_maxima && x == a->x;                  // handed over by the call that produced x
         if (!a->g_x || a->operand_maxima) t[1] = AmaxTensor{};          // kept by the forward
-        if (!a->g_weight || a->operand_maxima) t[2] = AmaxTensor{};
+        if (!a->g_weight || a->operand_maxima || x_known) t[2] = AmaxTensor{};
         const int rc1 = conv_absmax(t, 3, G, am, s);
         if (rc1) return rc1;
         o.amax_dy = am;
         if (a->g_x) o.amax_w = a->operand_maxima ? a->operand_maxima : am + (size_t)kMaxGroups * kAmaxParts;
-        if (a->g_weight) o.amax_x = a->operand_maxima ? a->operand_maxima + (size_t)kMaxGroups * kAmaxParts : am + 2 * (size_t)kMaxGroups * kAmaxParts;
+        if (a->g_weight) o.amax_x = x_known ? a->x_maxima : a->operand_maxima ? a->operand_maxima + (size_t)kMaxGroups * kAmaxParts : am + 2 * (size_t)kMaxGroups * kAmaxParts;
         return AG_OK;
     };
     if (!a->modulated) {
@@ -283,8 +309,15 @@ int ag_grouped_layer_backward(const AgGroupedLayerArgs* a, void* stream)
     const float* g_conv = g_pre;
     long long gconv_gs = pre_gs;
     if (a->resample) {
-        // adjoint of Blur pad (1,1): pads (2,2) with the flipped taps, [2H] -> [2H + 1]
-        if ((rc = ag_upfirdn2d(aux, g_pre, a->k_blur, G * a->Cout, g.OH, g.OW, 4, 4, 1, 1, 1, 1, 2, 2, 2, 2, stream))) return rc;
+        // adjoint of Blur pad (1,1): pads (2,2) with the flipped taps, [2H] -> [2H + 1]; fp16 split form: the kernel leaves the largest
+        // magnitude of what it writes in `am` (atomic maxima into zeroed slots) -- the convolutions below do not sweep `aux` for it
+        if (want_maxima && G * a->Cout <= 65535) {
+            if ((rc = check_hip(hipMemsetAsync(am, 0, (size_t)G * kAmaxParts * sizeof(float), s), "memset maxima"))) return rc;
+            if ((rc = fir4x4_amax_g(aux, g_pre, a->k_blur, G * a->Cout, g.OH, g.OW, 2, am, a->Cout, s))) return rc;
+        } else {
+            if ((rc = ag_upfirdn2d(aux, g_pre, a->k_blur, G * a->Cout, g.OH, g.OW, 4, 4, 1, 1, 1, 1, 2, 2, 2, 2, stream))) return rc;
+            dy_maxima_ready = false;
+        }
         g_conv = aux;
         gconv_gs = (long long)a->Cout * g.CH * g.CW;
     }
@@ -426,6 +459,7 @@ static AgConvDesc comb_desc(const AgGroupedCombArgs* a, int cin)
 }
 
 size_t ag_grouped_comb_args_bytes(void) { return sizeof(AgGroupedCombArgs); }
+size_t ag_grouped_comb_maxima_floats(void) { return conv_absmax_floats(4); }
 
 size_t ag_grouped_comb_workspace_bytes(const AgGroupedCombArgs* a)
 {
@@ -462,30 +496,39 @@ int ag_grouped_comb_forward(const AgGroupedCombArgs* a, void* stream)
     const AgConvDesc d1 = comb_desc(a, a->C1), d2 = comb_desc(a, a->C2);
     int rc;
     ConvOpts o1 = o, o2 = o;
-    if (conv_math_needs_absmax()) {           // the operand maxima of both convolutions in one launch
-        float* am = t + pad64((size_t)a->N * a->Cout * hw);
+    if (conv_math_needs_absmax()) {           // the operand maxima of both convolutions in one launch; kept for the backward when the caller has room
+        float* am = a->operand_maxima ? a->operand_maxima : t + pad64((size_t)a->N * a->Cout * hw);
         const long long wrow = (long long)(a->C1 + a->C2) * 9;
-        const AmaxTensor mt[4] = { AmaxTensor{ a->x, nullptr, a->C1 * hw, a->C1 * hw, 0, 1, a->M }, AmaxTensor{ a->lev, nullptr, a->C2 * hw, a->C2 * hw, 0, 1, a->N },
+        AmaxTensor mt[4] = { AmaxTensor{ a->x, nullptr, a->C1 * hw, a->C1 * hw, 0, 1, a->M }, AmaxTensor{ a->lev, nullptr, a->C2 * hw, a->C2 * hw, 0, 1, a->N },
                                    AmaxTensor{ nullptr, &w1, 0, (long long)a->C1 * 9, wrow, a->Cout, a->M }, AmaxTensor{ nullptr, &w2, 0, (long long)a->C2 * 9, wrow, a->Cout, a->N } };
-        if ((rc = conv_absmax(mt, 4, a->M, am, s))) return rc;
+        if (a->x_maxima) mt[0] = AmaxTensor{};                 // handed over by the call that produced x
+        if ((rc = conv_absmax(mt, 4, a->M, am, s, a->out_maxima, a->M))) return rc;      // (and zeroes the slots of this call's own output maxima)
         const size_t slot = (size_t)kMaxGroups * kAmaxParts;
-        o1.amax_x = am; o2.amax_x = am + slot; o1.amax_w = am + 2 * slot; o2.amax_w = am + 3 * slot;
+        o1.amax_x = a->x_maxima ? a->x_maxima : am; o2.amax_x = am + slot; o1.amax_w = am + 2 * slot; o2.amax_w = am + 3 * slot;
     }
+    float* const omax = (conv_math_needs_absmax() && a->out_maxima) ? a->out_maxima : nullptr;
     if ((rc = conv_forward_g(&d2, a->N, a->lev, a->C2 * hw, w2, nullptr, PtrTable{}, t, a->Cout * hw, a->workspace, a->workspace_bytes, s, o2))) return rc;
     if (fused_act()) {
         ConvAct act{ 2, a->slope, a->act_scale, addend, PtrTable{} };
+        act.out_amax = omax;
         ConvOpts oa = o1;
         oa.act = &act;
         return conv_forward_g(&d1, a->M, a->x, a->C1 * hw, w1, nullptr, bias, a->out, a->Cout * hw, a->workspace, a->workspace_bytes, s, oa);
     }
     if ((rc = conv_forward_g(&d1, a->M, a->x, a->C1 * hw, w1, nullptr, PtrTable{}, pre, a->Cout * hw, a->workspace, a->workspace_bytes, s, o1))) return rc;
-    return bias_act_forward_addend_g(a->out, pre, a->M, addend, bias, a->Cout, (int)hw, a->slope, a->act_scale, s);
+    if ((rc = bias_act_forward_addend_g(a->out, pre, a->M, addend, bias, a->Cout, (int)hw, a->slope, a->act_scale, s))) return rc;
+    if (omax) {
+        const AmaxTensor to{ a->out, nullptr, a->Cout * hw, a->Cout * hw, 0, 1 };
+        return conv_absmax(&to, 1, a->M, omax, s);
+    }
+    return AG_OK;
 }
 
 int ag_grouped_comb_backward(const AgGroupedCombArgs* a, void* stream)
 {
     if (!comb_ok(a) || !a->x || !a->lev || !a->out || !a->scratch || !a->g_out) { set_error("ag_grouped_comb_backward: bad arguments"); return AG_ERR_INVALID_ARGUMENT; }
-    if ((a->g_weight_x == nullptr) != (a->g_weight_lev == nullptr)) { set_error("ag_grouped_comb_backward: both weight gradients or none"); return AG_ERR_INVALID_ARGUMENT; }
+    if (!a->g_weight && (a->g_weight_x == nullptr) != (a->g_weight_lev == nullptr)) { set_error("ag_grouped_comb_backward: both weight gradients or none"); return AG_ERR_INVALID_ARGUMENT; }
+    const bool want_w = a->g_weight || a->g_weight_x;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const long long hw = (long long)a->H * a->W;
     float* g_pre = a->scratch;
@@ -505,7 +548,7 @@ int ag_grouped_comb_backward(const AgGroupedCombArgs* a, void* stream)
     float* am = part + pad64(noise_bias_act_partial_floats(a->M, a->Cout, (int)hw));
     if ((rc = noise_bias_act_backward_g(g_pre, a->g_out, a->out, a->M, PtrTable{}, a->g_bias, a->Cout, nullptr, 0, part, a->Cout, (int)hw, a->slope,
                                         a->act_scale, s, maxima ? am : nullptr))) return rc;            // (slot 0: max |g_pre| per member)
-    const bool need_t = a->g_lev || a->g_weight_lev;
+    const bool need_t = a->g_lev || want_w;
     if (need_t && (rc = sum_member_ranges(g_t, g_pre, a->member_begin, a->N, a->Cout * hw, s))) return rc;       // the level half sees the SUM of its members' gradients
     ConvOpts o1 = o, o2 = o, ow1, ow2;
     if (maxima) {       // the other operands of the four convolutions below, one launch
@@ -513,18 +556,37 @@ int ag_grouped_comb_backward(const AgGroupedCombArgs* a, void* stream)
         AmaxTensor mt[6] = { AmaxTensor{}, AmaxTensor{ g_t, nullptr, a->Cout * hw, a->Cout * hw, 0, 1, a->N },
                              AmaxTensor{ a->x, nullptr, a->C1 * hw, a->C1 * hw, 0, 1, a->M }, AmaxTensor{ a->lev, nullptr, a->C2 * hw, a->C2 * hw, 0, 1, a->N },
                              AmaxTensor{ nullptr, &w1, 0, (long long)a->C1 * 9, wrow, a->Cout, a->M }, AmaxTensor{ nullptr, &w2, 0, (long long)a->C2 * 9, wrow, a->Cout, a->N } };
+        const bool kept = a->operand_maxima != nullptr;        // x, lev, w1, w2 in the forward's order
         if (!need_t) mt[1] = AmaxTensor{};
-        if (!a->g_weight_x) mt[2] = mt[3] = AmaxTensor{};
-        if (!a->g_x) mt[4] = AmaxTensor{};
-        if (!a->g_lev) mt[5] = AmaxTensor{};
+        if (!want_w || kept) mt[2] = mt[3] = AmaxTensor{};
+        if (a->x_maxima) mt[2] = AmaxTensor{};
+        if (!a->g_x || kept) mt[4] = AmaxTensor{};
+        if (!a->g_lev || kept) mt[5] = AmaxTensor{};
         if ((rc = conv_absmax(mt, 6, a->M, am, s))) return rc;
         const size_t slot = (size_t)kMaxGroups * kAmaxParts;
         o1.amax_dy = ow1.amax_dy = am; o2.amax_dy = ow2.amax_dy = am + slot;
-        ow1.amax_x = am + 2 * slot; ow2.amax_x = am + 3 * slot; o1.amax_w = am + 4 * slot; o2.amax_w = am + 5 * slot;
+        ow1.amax_x = a->x_maxima ? a->x_maxima : kept ? a->operand_maxima : am + 2 * slot;
+        ow2.amax_x = kept ? a->operand_maxima + slot : am + 3 * slot;
+        o1.amax_w = kept ? a->operand_maxima + 2 * slot : am + 4 * slot;
+        o2.amax_w = kept ? a->operand_maxima + 3 * slot : am + 5 * slot;
     }
     if (a->g_x && (rc = conv_backward_input_g(&d1, a->M, g_pre, a->Cout * hw, w1, a->g_x, a->C1 * hw, a->workspace, a->workspace_bytes, s, o1))) return rc;
     if (a->g_lev && (rc = conv_backward_input_g(&d2, a->N, g_t, a->Cout * hw, w2, a->g_lev, a->C2 * hw, a->workspace, a->workspace_bytes, s, o2))) return rc;
-    if (a->g_weight_x) {
+    if (a->g_weight) {
+        // both halves straight into the parameters' gradients [N][Cout][C1 + C2][3][3]: the members of a network accumulate into its tensor's first
+        // C1 channels (the split-K atomics of the weight gradient do not care whose slice they add), the level half fills the other C2
+        const long long wrow = (long long)(a->C1 + a->C2) * 9, wnet = (long long)a->Cout * wrow;
+        if ((rc = check_hip(hipMemsetAsync(a->g_weight, 0, (size_t)a->N * wnet * sizeof(float), s), "memset g_weight"))) return rc;
+        PtrTable t1{}, t2{};
+        for (int r = 0; r < a->N; r++) {
+            t2.p[r] = a->g_weight + (size_t)r * wnet + (size_t)a->C1 * 9;
+            for (int m = a->member_begin[r]; m < a->member_begin[r + 1]; m++) t1.p[m] = a->g_weight + (size_t)r * wnet;
+        }
+        ow1.dw_table = &t1; ow2.dw_table = &t2;
+        ow1.dw_row_stride = ow2.dw_row_stride = wrow;
+        if ((rc = conv_backward_weight_g(&d1, a->M, a->x, a->C1 * hw, g_pre, a->Cout * hw, nullptr, 0, a->workspace, a->workspace_bytes, s, ow1))) return rc;
+        if ((rc = conv_backward_weight_g(&d2, a->N, a->lev, a->C2 * hw, g_t, a->Cout * hw, nullptr, 0, a->workspace, a->workspace_bytes, s, ow2))) return rc;
+    } else if (a->g_weight_x) {
         if ((rc = conv_backward_weight_g(&d1, a->M, a->x, a->C1 * hw, g_pre, a->Cout * hw, a->g_weight_x, (long long)a->Cout * a->C1 * 9, a->workspace,
                                          a->workspace_bytes, s, ow1))) return rc;
         if ((rc = conv_backward_weight_g(&d2, a->N, a->lev, a->C2 * hw, g_t, a->Cout * hw, a->g_weight_lev, (long long)a->Cout * a->C2 * 9, a->workspace,

@@ -572,20 +572,28 @@ __global__ void __launch_bounds__(256) upfirdn2d_kernel(float* __restrict__ out,
 // ACT: NoiseInjection + FusedLeakyReLU applied to the filtered value before it is stored (the activation pass of an up-sampling
 // StyledConv, ag_layers.hip), the same expression as noise_bias_act_forward_kernel, hence the same bits as the two passes.
 constexpr int kFirRows = 8;
-struct FirAct { PtrTable noise, nw, bias; int C; float slope, scale; };
+// amax: [G][256] zero-initialised slots that receive the largest magnitude the kernel stores, per group of amax_C planes (unsigned atomic
+// maxima of the float bits: order-independent, hence deterministic) -- the operand maximum the fp16-split convolutions consuming the output
+// need (ag_groups.h), taken while the data is in registers instead of by another sweep
+struct FirAct { PtrTable noise, nw, bias; int C; float slope, scale; float* amax; int amax_C; };
 
 template <bool ACT>
 __global__ void __launch_bounds__(256) fir4x4_kernel(float* __restrict__ out, const float* __restrict__ input,
-                                                     const float* __restrict__ kernel, UpfirdnParams p, int quads, int strips,
+                                                     const float* __restrict__ kernel, UpfirdnParams p, int quads, int strips, int nblocks,
                                                      long long total, const FirAct act)
 {
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    const int strip = t / quads, quad = t - strip * quads;
-    if (strip >= strips) return;
+    float mx = 0.f;
     float taps[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) taps[i] = kernel[i];                    // uniform address: scalar loads
     const int plane = blockIdx.y;
+    // a workgroup walks the plane's thread blocks gridDim.x apart (the launcher caps gridDim.x when `amax` is wanted: one atomic per
+    // workgroup at the end, and few workgroups per cache line of slots)
+    for (int bx = blockIdx.x; bx < nblocks; bx += gridDim.x) {
+    const int t = bx * 256 + threadIdx.x;
+    const int strip_t = t / quads, quad = t - strip_t * quads;
+    const bool live = strip_t < strips;                                  // (no early exit: the wave reduction of `amax` wants every lane)
+    const int strip = live ? strip_t : 0;
     const int ox0 = quad * 4, oy0 = strip * kFirRows;
     const long long plane0 = (long long)plane * p.in_h * p.in_w;
     const int cx = ox0 - p.pad_x0, cy = oy0 - p.pad_y0;                 // window origin: columns cx .. cx + 6, rows cy .. cy + kFirRows + 2
@@ -645,23 +653,43 @@ __global__ void __launch_bounds__(256) fir4x4_kernel(float* __restrict__ out, co
                 v[q] = (tv > 0.f ? tv : tv * act.slope) * act.scale;
             }
         }
+        if (!live) continue;
         if (ox0 + 4 <= p.out_w && (((size_t)o) & 15) == 0) {
             *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+            mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
         } else {
 #pragma unroll
             for (int q = 0; q < 4; q++)
-                if (ox0 + q < p.out_w) o[q] = v[q];
+                if (ox0 + q < p.out_w) { o[q] = v[q]; mx = fmaxf(mx, fabsf(v[q])); }
         }
+    }
+    }   // bx
+    if (act.amax) {      // one non-returning atomic per workgroup
+        __shared__ float s_mx[4];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        if ((threadIdx.x & 63) == 0) s_mx[threadIdx.x >> 6] = mx;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            atomicMax(reinterpret_cast<unsigned int*>(act.amax) + (size_t)(plane / act.amax_C) * 256 + ((blockIdx.x + 37u * (unsigned)plane) & 255u),
+                      __float_as_uint(fmaxf(fmaxf(s_mx[0], s_mx[1]), fmaxf(s_mx[2], s_mx[3]))));
     }
 }
 
-static int launch_fir4x4(float* out, const float* input, const float* kernel, const UpfirdnParams& p, int major, const FirAct* act, hipStream_t s)
+static int launch_fir4x4(float* out, const float* input, const float* kernel, const UpfirdnParams& p, int major, const FirAct* act, hipStream_t s,
+                         float* amax = nullptr, int amax_C = 1)
 {
     const int quads = (p.out_w + 3) / 4, strips = (p.out_h + kFirRows - 1) / kFirRows;
     const long long threads = (long long)quads * strips, total = (long long)major * p.in_h * p.in_w;
-    dim3 grid((unsigned)((threads + 255) / 256), major);
-    if (act) hipLaunchKernelGGL(fir4x4_kernel<true>, grid, dim3(256), 0, s, out, input, kernel, p, quads, strips, total, *act);
-    else     hipLaunchKernelGGL(fir4x4_kernel<false>, grid, dim3(256), 0, s, out, input, kernel, p, quads, strips, total, FirAct{});
+    const int nblocks = (int)((threads + 255) / 256);
+    // with `amax`: at most ~4096 workgroups in all (each ends with one atomic into its group's 16 cache lines of slots)
+    int gx = nblocks;
+    if (amax) gx = std::max(1, std::min(nblocks, 4096 / std::max(1, major)));
+    dim3 grid((unsigned)gx, major);
+    FirAct a = act ? *act : FirAct{};
+    a.amax = amax; a.amax_C = amax_C > 0 ? amax_C : 1;
+    if (act) hipLaunchKernelGGL(fir4x4_kernel<true>, grid, dim3(256), 0, s, out, input, kernel, p, quads, strips, nblocks, total, a);
+    else     hipLaunchKernelGGL(fir4x4_kernel<false>, grid, dim3(256), 0, s, out, input, kernel, p, quads, strips, nblocks, total, a);
     return check_hip(hipGetLastError(), "fir4x4_kernel");
 }
 
@@ -672,7 +700,7 @@ static bool bad_groups(int G) { return G < 1 || G > kMaxGroups; }
 
 // Blur pad (1, 1) of a [G][C][H][W] stack followed by the activation pass, one kernel (the tail of an up-sampling StyledConv)
 int blur_act_forward_g(float* y, const float* x, const float* taps, int G, const PtrTable& noise, const PtrTable& nw, const PtrTable& bias,
-                       int C, int H, int W, float slope, float scale, hipStream_t s)
+                       int C, int H, int W, float slope, float scale, hipStream_t s, float* out_amax)
 {
     if (bad_groups(G) || C < 1 || H < 3 || W < 3 || !y || !x || !taps || (long long)G * C > 65535) { set_error("bad blur_act arguments"); return AG_ERR_INVALID_ARGUMENT; }
     for (int g = 0; g < G; g++)
@@ -682,7 +710,23 @@ int blur_act_forward_g(float* y, const float* x, const float* taps, int G, const
     p.major = G * C; p.in_h = H; p.in_w = W; p.kernel_h = p.kernel_w = 4;
     p.out_h = H - 1; p.out_w = W - 1;
     FirAct act{ noise, nw, bias, C, slope, scale };
-    return launch_fir4x4(y, x, taps, p, G * C, &act, s);
+    return launch_fir4x4(y, x, taps, p, G * C, &act, s, out_amax, C);
+}
+
+// 4 x 4 FIR with pads (pad, pad) of `planes` planes, leaving the largest magnitude of the output of every group of planes_per_group planes
+// in amax[group][256] (zeroed by the caller): the Blur adjoint in front of an up-sampling StyledConv's backward convolutions
+int fir4x4_amax_g(float* out, const float* in, const float* taps, int planes, int in_h, int in_w, int pad, float* amax, int planes_per_group,
+                  hipStream_t s)
+{
+    if (planes < 1 || planes > 65535 || in_h < 1 || in_w < 1 || pad < 0 || !out || !in || !taps || in_h + 2 * pad < 4 || in_w + 2 * pad < 4) {
+        set_error("bad fir4x4 arguments");
+        return AG_ERR_INVALID_ARGUMENT;
+    }
+    UpfirdnParams p;
+    p.up_x = p.up_y = p.down_x = p.down_y = 1; p.pad_x0 = p.pad_y0 = pad;
+    p.major = planes; p.in_h = in_h; p.in_w = in_w; p.kernel_h = p.kernel_w = 4;
+    p.out_h = in_h + 2 * pad - 3; p.out_w = in_w + 2 * pad - 3;
+    return launch_fir4x4(out, in, taps, p, planes, nullptr, s, amax, planes_per_group);
 }
 
 int noise_bias_act_forward_g(float* y, const float* x, int G, const PtrTable& noise, const PtrTable& nw, const PtrTable& bias, int C, int HW,

@@ -88,8 +88,31 @@ _MAXIMA = []
 
 def _maxima_floats():
     if not _MAXIMA:
-        _MAXIMA.append(int(_lib.lib().ag_grouped_layer_maxima_floats()))
+        _MAXIMA.extend([int(_lib.lib().ag_grouped_layer_maxima_floats()), int(_lib.lib().ag_grouped_comb_maxima_floats())])
     return _MAXIMA[0]
+
+
+def _comb_maxima_floats():
+    _maxima_floats()
+    return _MAXIMA[1]
+
+
+_OUT_MAXIMA_FLOATS = _lib.AG_MAX_GROUPS * 256
+
+
+def _handed_maxima(x):
+    """The largest magnitudes of ``x`` as the grouped call that produced it left them (``out_maxima`` of include/ag_layers.h), or None.
+    They travel as an attribute of the very tensor the producer returned: any operation in between yields another tensor without it."""
+    m = getattr(x, "_ag_maxima", None)
+    return m if (m is not None and agc.get_math() == "split_f16" and x.is_contiguous()) else None
+
+
+def _new_out_maxima(out):
+    if agc.get_math() != "split_f16":
+        return None
+    m = torch.empty(_OUT_MAXIMA_FLOATS, dtype=torch.float32, device=out.device)
+    out._ag_maxima = m
+    return m
 
 
 def _scratch(nfloats, ws_bytes, dev):
@@ -104,6 +127,7 @@ class _GroupedLayer(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, G, shared, resample, modulated, scale, k_blur, x, *params):
+        xm = _handed_maxima(x)
         x = x.contiguous()
         ws = [p.contiguous() for p in params[:G]]
         if modulated:
@@ -141,9 +165,12 @@ class _GroupedLayer(torch.autograd.Function):
         # operand maxima of the fp16 split form (include/ag_layers.h): written by this call, read by the backward
         mx = torch.empty(_maxima_floats(), dtype=torch.float32, device=dev) if a.k >= 3 else None
         a.operand_maxima = mx.data_ptr() if mx is not None else None
+        a.x_maxima = xm.data_ptr() if xm is not None else None
+        om = _new_out_maxima(out)
+        a.out_maxima = om.data_ptr() if om is not None else None
         with _lib.on_device(dev):
             _lib.check(_lib.lib().ag_grouped_layer_forward(ctypes.byref(a), _stream(dev)), "ag_grouped_layer_forward")
-        ctx.save_for_backward(x, out, keep, _flipped(k_blur) if resample else None, mx, *ws, *styles, *noises, *nws, *biases)
+        ctx.save_for_backward(x, out, keep, _flipped(k_blur) if resample else None, mx, xm, *ws, *styles, *noises, *nws, *biases)
         ctx.math = agc.get_math()
         ctx.cfg = (G, bool(shared), bool(resample), bool(modulated), float(scale))
         return out
@@ -151,8 +178,8 @@ class _GroupedLayer(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         G, shared, resample, modulated, scale = ctx.cfg
-        x, out, keep, k_flip, mx = ctx.saved_tensors[:5]
-        rest = ctx.saved_tensors[5:]
+        x, out, keep, k_flip, mx, xm = ctx.saved_tensors[:6]
+        rest = ctx.saved_tensors[6:]
         ws, styles, noises, nws, biases = (rest[i * G:(i + 1) * G] for i in range(5))
         dev = x.device
         g = g.contiguous()
@@ -198,7 +225,9 @@ class _GroupedLayer(torch.autograd.Function):
         a.g_bias_noise = gbn.data_ptr() if gbn is not None else None
         buf, a.scratch, a.workspace = _scratch(f_bwd, wsb, dev)
         a.workspace_bytes = wsb
-        a.operand_maxima = mx.data_ptr() if (mx is not None and ctx.math == agc.get_math()) else None      # (a mode switch in between: retaken)
+        same_math = ctx.math == agc.get_math()                                                         # (a mode switch in between: retaken)
+        a.operand_maxima = mx.data_ptr() if (mx is not None and same_math) else None
+        a.x_maxima = xm.data_ptr() if (xm is not None and same_math) else None
         with _lib.on_device(dev):
             _lib.check(_lib.lib().ag_grouped_layer_backward(ctypes.byref(a), _stream(dev)), "ag_grouped_layer_backward")
         none = [None] * G
@@ -377,6 +406,7 @@ class _GroupedComb(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, begin, scale, x, lev, *rest):
+        xm = _handed_maxima(x)
         x, lev = x.contiguous(), lev.contiguous()
         N, M = int(lev.shape[0]), int(x.shape[0])
         ws = [p.contiguous() for p in rest[:N]]
@@ -390,18 +420,24 @@ class _GroupedComb(torch.autograd.Function):
         a.x, a.lev, a.out = x.data_ptr(), lev.data_ptr(), out.data_ptr()
         buf, a.scratch, a.workspace = _scratch(f_fwd, wsb, dev)
         a.workspace_bytes = wsb
+        mx = torch.empty(_comb_maxima_floats(), dtype=torch.float32, device=dev)      # operand maxima of the fp16 split form, kept for the backward
+        a.operand_maxima = mx.data_ptr()
+        a.x_maxima = xm.data_ptr() if xm is not None else None
+        om = _new_out_maxima(out)
+        a.out_maxima = om.data_ptr() if om is not None else None
         with _lib.on_device(dev):
             _lib.check(_lib.lib().ag_grouped_comb_forward(ctypes.byref(a), _stream(dev)), "ag_grouped_comb_forward")
-        ctx.save_for_backward(x, lev, out, *ws, *bs)
+        ctx.save_for_backward(x, lev, out, mx, xm, *ws, *bs)
         ctx.cfg = (tuple(begin), float(scale))
+        ctx.math = agc.get_math()
         return out
 
     @staticmethod
     def backward(ctx, g):
         begin, scale = ctx.cfg
-        x, lev, out = ctx.saved_tensors[:3]
+        x, lev, out, mx, xm = ctx.saved_tensors[:5]
         N, M = int(lev.shape[0]), int(x.shape[0])
-        ws, bs = ctx.saved_tensors[3:3 + N], ctx.saved_tensors[3 + N:3 + N + M]
+        ws, bs = ctx.saved_tensors[5:5 + N], ctx.saved_tensors[5 + N:5 + N + M]
         dev = x.device
         g = g.contiguous()
         a = _comb_args(begin, x, lev, ws[0], scale)
@@ -411,28 +447,25 @@ class _GroupedComb(torch.autograd.Function):
         need_w, need_b = any(pn[:N]), any(pn[N:N + M])
         gx = torch.empty_like(x) if nx else None
         glev = torch.empty_like(lev) if nlev else None
-        gw1 = torch.empty((M, a.Cout, a.C1, 3, 3), dtype=torch.float32, device=dev) if need_w else None
-        gw2 = torch.empty((N, a.Cout, a.C2, 3, 3), dtype=torch.float32, device=dev) if need_w else None
+        # the weight gradients come back in the parameters' own layout: the members of a network accumulate into its tensor's first C1 channels,
+        # the level half fills the rest (the native call zeroes it) -- no sum over the members, no concatenation
+        gW = torch.empty((N, a.Cout, a.C1 + a.C2, 3, 3), dtype=torch.float32, device=dev) if need_w else None
         gb = torch.empty((M, a.Cout), dtype=torch.float32, device=dev) if need_b else None
         _fill(a.weight, ws)
         _fill(a.act_bias, bs)
         a.x, a.lev, a.out, a.g_out = x.data_ptr(), lev.data_ptr(), out.data_ptr(), g.data_ptr()
         a.g_x = gx.data_ptr() if gx is not None else None
         a.g_lev = glev.data_ptr() if glev is not None else None
-        a.g_weight_x = gw1.data_ptr() if gw1 is not None else None
-        a.g_weight_lev = gw2.data_ptr() if gw2 is not None else None
+        a.g_weight = gW.data_ptr() if gW is not None else None
+        same_math = ctx.math == agc.get_math()
+        a.operand_maxima = mx.data_ptr() if same_math else None
+        a.x_maxima = xm.data_ptr() if (xm is not None and same_math) else None
         a.g_bias = gb.data_ptr() if gb is not None else None
         buf, a.scratch, a.workspace = _scratch(f_bwd, wsb, dev)
         a.workspace_bytes = wsb
         with _lib.on_device(dev):
             _lib.check(_lib.lib().ag_grouped_comb_backward(ctypes.byref(a), _stream(dev)), "ag_grouped_comb_backward")
-        g_ws = [None] * N
-        if need_w:
-            for r in range(N):
-                if pn[r]:
-                    m0, m1 = begin[r], begin[r + 1]
-                    half = gw1[m0] if m1 - m0 == 1 else gw1[m0:m1].sum(0)
-                    g_ws[r] = torch.cat([half, gw2[r]], 1)
+        g_ws = [gW[r] if (need_w and pn[r]) else None for r in range(N)]
         g_bs = [gb[m] if (gb is not None and pn[N + m]) else None for m in range(M)]
         return (None, None, gx, glev, *g_ws, *g_bs)
 

@@ -107,6 +107,11 @@ typedef struct AgGroupedLayerArgs {
                                       magnitude of every convolution operand: the forward leaves those of its weights and its input here, the
                                       backward of the SAME layer call reads them instead of sweeping both tensors again.  NULL: every call
                                       takes its own.  Untouched in the other arithmetic modes and by 1 x 1 layers. */
+    const float* x_maxima;         /* AG_MAX_GROUPS * 256 floats or NULL: the largest magnitudes of `x` as a previous call's out_maxima left them (instance
+                                      g at g * 256; a shared input at 0) -- forward and backward then do not sweep x (ignored by the down-sampling
+                                      ConvLayer, whose convolution reads the blurred input, and outside AG_CONV_MATH_SPLIT_F16) */
+    float* out_maxima;             /* forward: AG_MAX_GROUPS * 256 floats or NULL: receives the largest magnitudes of `out` (from the kernel that writes
+                                      it wherever that kernel can, by a sweep otherwise; untouched outside AG_CONV_MATH_SPLIT_F16) */
 } AgGroupedLayerArgs;
 
 size_t ag_grouped_layer_args_bytes(void);
@@ -180,11 +185,18 @@ typedef struct AgGroupedCombArgs {
     float* g_weight_x;             /* [M][Cout][C1][3][3]: per member, w.r.t. W_r[:, :C1] (NULL: no weight gradients) */
     float* g_weight_lev;           /* [N][Cout][C2][3][3]: per network, w.r.t. W_r[:, C1:] (required with g_weight_x) */
     float* g_bias;                 /* [M][Cout] or NULL */
+    float* g_weight;               /* [N][Cout][C1 + C2][3][3] or NULL: the weight gradients in the PARAMETERS' own layout (zeroed by the call; the
+                                      members of a network accumulate into its tensor).  When given, g_weight_x / g_weight_lev are not used */
+    float* operand_maxima;         /* ag_grouped_comb_maxima_floats() floats or NULL: as AgGroupedLayerArgs.operand_maxima (written by the forward,
+                                      read by the backward of the same call) */
+    const float* x_maxima;         /* as AgGroupedLayerArgs.x_maxima, for the members' input `x` */
+    float* out_maxima;             /* as AgGroupedLayerArgs.out_maxima */
 } AgGroupedCombArgs;
 
 size_t ag_grouped_comb_args_bytes(void);
 size_t ag_grouped_comb_scratch_floats(const AgGroupedCombArgs* a, int32_t backward);
 size_t ag_grouped_comb_workspace_bytes(const AgGroupedCombArgs* a);
+size_t ag_grouped_comb_maxima_floats(void);
 int ag_grouped_comb_forward(const AgGroupedCombArgs* a, void* stream);
 int ag_grouped_comb_backward(const AgGroupedCombArgs* a, void* stream);
 
