@@ -78,6 +78,60 @@ def test_grouped_styled_conv_equals_the_layers_one_by_one(G, Cin, Cout, H, up):
         _close(a, b, n, tol=5e-5 if n.startswith(("style", "nw")) else TOL)
 
 
+@pytest.mark.parametrize("up_first", [True, False])
+def test_maxima_handed_over_by_the_producer_equal_the_swept_ones(up_first):
+    """AgGroupedLayerArgs.out_maxima / x_maxima (fp16 split form): the kernel that writes a layer's output (Blur + activation, the convolution
+    epilogue, the split-K finish) leaves its largest magnitudes for the next grouped call, which then does not sweep its input.  The maxima
+    themselves are exact (a maximum does not depend on who takes it), so a chain of two StyledConvs and a comb convolution gives the SAME BITS,
+    forward and backward, whether the second and third call take the maxima from the tensor they are handed or sweep it (attribute removed)."""
+    import torch
+    from animatablegaussians_amd import conv as agc, grouped as gr
+    if agc.get_math() != "split_f16":
+        pytest.skip("operand maxima exist in the fp16 split form only")
+    g = torch.Generator().manual_seed(77)
+    G, C, H = 4, 32, 16
+    kb = torch.tensor([1., 3., 3., 1.])
+    kb = (kb[None] * kb[:, None] / 16).cuda()
+
+    def params(cin, cout):
+        return ([torch.randn(1, cout, cin, 3, 3, generator=g).cuda().requires_grad_(True) for _ in range(G)],
+                [(torch.randn(1, cin, generator=g) + 1).cuda().requires_grad_(True) for _ in range(G)],
+                [torch.randn(1, generator=g).cuda().requires_grad_(True) for _ in range(G)],
+                [(torch.randn(cout, generator=g) * 0.1).cuda().requires_grad_(True) for _ in range(G)])
+    p1, p2 = params(C, C), params(C, C)
+    OH = 2 * H if up_first else H
+    nz1 = [torch.randn(1, 1, OH, OH, generator=g).cuda() for _ in range(G)]
+    nz2 = [torch.randn(1, 1, OH, OH, generator=g).cuda() for _ in range(G)]
+    wc = [torch.randn(C, 2 * C, 3, 3, generator=g).cuda().requires_grad_(True) for _ in range(2)]
+    bc = [(torch.randn(C, generator=g) * 0.1).cuda().requires_grad_(True) for _ in range(2)]
+    lev = torch.randn(2, C, OH, OH, generator=g).cuda()
+    x0 = torch.randn(G, C, H, H, generator=g).cuda()
+    up = torch.randn(G, C, OH, OH, generator=g).cuda()
+    leaves = p1[0] + p1[1] + p1[2] + p1[3] + p2[0] + p2[1] + p2[2] + p2[3] + wc + bc
+
+    def run(hand_over):
+        for t in leaves:
+            t.grad = None
+        x = x0.clone().requires_grad_(True)
+        a = gr.grouped_styled_conv(x, p1[0], p1[1], nz1, p1[2], p1[3], kb, 1 / (C * 9) ** 0.5, up_first)
+        assert getattr(a, "_ag_maxima", None) is not None            # the producer left them
+        if not hand_over:
+            del a._ag_maxima
+        b = gr.grouped_styled_conv(a, p2[0], p2[1], nz2, p2[2], p2[3], None, 1 / (C * 9) ** 0.5, False)
+        if not hand_over:
+            del b._ag_maxima
+        c = gr._GroupedComb.apply((0, 2, 4), 1 / (2 * C * 9) ** 0.5, b, lev, wc[0], wc[1], bc[0], bc[0], bc[1], bc[1])
+        c.backward(up)
+        return [c.detach().clone(), x.grad.clone()] + [t.grad.clone() for t in leaves]
+
+    with_h, without = run(True), run(False)
+    for i, (u, v) in enumerate(zip(with_h, without)):
+        if i < 2:                                # the output and the input gradient: deterministic kernels all the way
+            assert torch.equal(u, v), (i, float((u - v).abs().max()))
+        else:                                    # parameter gradients: the weight gradients (and the style gradients derived from them) go through
+            _close(u, v, i, tol=1e-5)            # split-K float atomics -- equal up to their summation order, as two runs of ONE path are
+
+
 @pytest.mark.parametrize("G,Cin,Cout,H,with_skip", [(4, 64, 12, 32, True), (2, 32, 32, 16, True), (3, 16, 12, 8, False), (4, 64, 12, 128, True)])
 def test_grouped_to_rgb_equals_the_heads_one_by_one(G, Cin, Cout, H, with_skip):
     import torch
