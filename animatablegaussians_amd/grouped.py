@@ -104,7 +104,11 @@ def _handed_maxima(x):
     """The largest magnitudes of ``x`` as the grouped call that produced it left them (``out_maxima`` of include/ag_layers.h), or None.
     They travel as an attribute of the very tensor the producer returned: any operation in between yields another tensor without it."""
     m = getattr(x, "_ag_maxima", None)
-    return m if (m is not None and agc.get_math() == "split_f16" and x.is_contiguous()) else None
+    if m is None or agc.get_math() != "split_f16" or not x.is_contiguous():
+        return None
+    if x._version != getattr(x, "_ag_maxima_version", -1):      # written in place since: the maxima are stale (too small a maximum would overflow fp16)
+        return None
+    return m
 
 
 def _new_out_maxima(out):
@@ -112,6 +116,7 @@ def _new_out_maxima(out):
         return None
     m = torch.empty(_OUT_MAXIMA_FLOATS, dtype=torch.float32, device=out.device)
     out._ag_maxima = m
+    out._ag_maxima_version = out._version
     return m
 
 
