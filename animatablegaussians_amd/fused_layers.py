@@ -2,7 +2,7 @@
 ONE ``torch.autograd.Function`` that runs the same kernels, in the same order, as the chain of per-kernel Functions in
 ``styleunet_ops`` / ``conv`` -- so the results are bit-identical -- but costs autograd one node instead of three to six.
 
-Why: after the convolutions moved to the bf16 matrix pipe the training step was bound by the host (profiles/host_op_times.py: 1300
+Why: after the convolutions moved to the 16-bit matrix pipe (round 2) the training step was bound by the host (profiles/host_op_times.py: 1300
 custom-op calls per step, 13-32 us each inside their bodies plus autograd's own per-node bookkeeping).  The per-kernel Functions stay
 the single implementation of every kernel call: a fused node calls their ``forward`` / ``backward`` static methods as plain functions
 with a stand-in for autograd's ``ctx`` (``_Sub``), it does not duplicate them.

@@ -25,11 +25,11 @@ The JSON line also carries
   cpu_baseline : the CPU oracle (a restatement of the reference's CUDA kernels -- the reference has no CPU
                  rasterizer) timed on this box's host cores on a bounded sample of the same workload;
   full_step    : BASELINE configs[2], the whole training iteration (three StyleUNets + assembly + LBS + raster, loss, backward,
-                 fused Adam) at 1 and at 4 views per step, in the product's convolution arithmetic and, interleaved in the same
-                 process, in the other two modes of include/ag_conv.h;
-  roofline_mfma: the convolution kernels' own rate (HIP events around every launch of one network forward + backward), in the
-                 product's arithmetic against the dense bf16 MFMA peak (executed = 6 x algorithmic FLOPs) and in the fp32-MFMA
-                 mode against the fp32 MFMA peak;
+                 fused Adam) at 1 and at 4 views per step, in the product's convolution arithmetic (split_f16) and, in the same
+                 process, in the other three modes of include/ag_conv.h;
+  roofline_mfma: the convolution kernels' own rate (HIP events around every launch of the three networks' forward + backward), in the
+                 product's arithmetic against the dense 16-bit MFMA peak (executed = 3 x algorithmic FLOPs: three fp16 products per fp32
+                 product) and in the fp32-MFMA mode against the fp32 MFMA peak;
   stress_1m_2048: BASELINE configs[4] on one GPU (1.07 M Gaussians, 2048^2): views/s, blend-backward us, algorithmic GB/s;
   cpu_baseline_styleunet / cpu_baseline_lbs: SURVEY.md 8(d)(i)(ii) -- the reference's DualStyleUNet forward and forward + backward
                  (oracle/dual_styleunet_oracle.py: the same torch CPU ops in the same order, pinned against the reference module's
