@@ -153,6 +153,7 @@ struct GatherProblem {
     float slope, act_scale;
     PtrTable noise_t;      // act 1: per-instance noise [OHf * OWf] (null: no noise); act 2: per-instance addend [M][OHf * OWf]
     PtrTable nw_t;         // act 1: per-instance noise weight [1]
+    int xcd_order;         // 1: workgroups take their (N tile, instance * M tile) in the XCD-aware order of tile_of_workgroup() (host: gridDim.x * gridDim.y % 8 == 0)
     float* out_amax;       // act != 0: zeroed [G][kAmaxParts] slots for the largest magnitude of the activated output (ConvAct::out_amax), or null
     // fp16 split form: partial maxima (absmax_kernel) of the packed weights' source tensors [G][kAmaxParts] and of the gathered tensor
     // ([G][kAmaxParts], or one row when the instances share their input); amax_a_mult = |weight_scale| (the packed values are w * scale)
@@ -172,11 +173,28 @@ struct GroupView {
     const float* noise;          // activation operands of the instance (GatherProblem::act)
     float nw;
 };
-__device__ __forceinline__ GroupView group_view(const GatherProblem& p)
+// XCD-aware order (round 4).  The hardware deals workgroups to the 8 XCDs round-robin by linear id, so neighbouring N tiles -- neighbouring
+// image rows, whose 3 x 3 gathers read the same input rows -- and the M tiles of one N tile (which gather the SAME input) landed on eight
+// different L2s: PMC on a 256 -> 256 layer at 256^2 showed 523 MB fetched by L2 per launch for 69.5 MB of unique input
+// (profiles/r04_pmc_traffic_gather_conv_f16_256_256_256.txt).  Here XCD j takes the j-th eighth of the (N tile, instance x M tile) pairs,
+// M tiles and instances of one N tile back to back, N tiles in image order.
+struct TileId { int bx, by; };
+__device__ __forceinline__ TileId tile_of_workgroup(const GatherProblem& p)
+{
+    TileId t{ (int)blockIdx.x, (int)blockIdx.y };
+    if (p.xcd_order) {
+        const int L = (int)blockIdx.x + (int)gridDim.x * (int)blockIdx.y;
+        const int Lg = (L & 7) * (((int)gridDim.x * (int)gridDim.y) >> 3) + (L >> 3);
+        t.bx = Lg / (int)gridDim.y;
+        t.by = Lg - t.bx * (int)gridDim.y;
+    }
+    return t;
+}
+__device__ __forceinline__ GroupView group_view(const GatherProblem& p, int by)
 {
     GroupView v;
-    v.grp = (int)blockIdx.y / p.mtiles;
-    v.my = (int)blockIdx.y - v.grp * p.mtiles;
+    v.grp = by / p.mtiles;
+    v.my = by - v.grp * p.mtiles;
     v.xin = p.xin + (size_t)v.grp * p.x_gs;
     v.yout = p.yout + (size_t)v.grp * p.y_gs;
     v.partial = p.partial ? p.partial + (size_t)v.grp * p.part_gs : nullptr;
@@ -286,15 +304,16 @@ __global__ void __launch_bounds__(64 * WVM * WVN, AG_CONV_WAVES_PER_SIMD) gather
     const int wm = wave / WVN, wn = wave % WVN;
 
     // class of this workgroup (wave-uniform)
+    const TileId tw = tile_of_workgroup(p);
     int ci = 0;
 #pragma unroll
     for (int c = 1; c < kMaxClasses; c++)
-        if (c < p.nclasses && (int)blockIdx.x >= p.cls[c].tile_begin) ci = c;
+        if (c < p.nclasses && tw.bx >= p.cls[c].tile_begin) ci = c;
     const GatherClass& cl = p.cls[ci];
     const int gw = cl.gw, ntaps = cl.ntaps;
     const int N = cl.gh * gw;
-    const GroupView gv = group_view(p);
-    const int m0 = gv.my * BM, n0 = ((int)blockIdx.x - cl.tile_begin) * BN;
+    const GroupView gv = group_view(p, tw.by);
+    const int m0 = gv.my * BM, n0 = (tw.bx - cl.tile_begin) * BN;
 
     const int n_loc = tid % BN, g = (wave * 64) / BN;   // g is wave-uniform (BN >= 64)
     const int n = n0 + n_loc;
@@ -656,15 +675,16 @@ __global__ void __launch_bounds__(64 * WVM * WVN, AG_CONV_WAVES_PER_SIMD) gather
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WVN, wn = wave % WVN;
 
+    const TileId tw = tile_of_workgroup(p);
     int ci = 0;
 #pragma unroll
     for (int c = 1; c < kMaxClasses; c++)
-        if (c < p.nclasses && (int)blockIdx.x >= p.cls[c].tile_begin) ci = c;
+        if (c < p.nclasses && tw.bx >= p.cls[c].tile_begin) ci = c;
     const GatherClass& cl = p.cls[ci];
     const int gw = cl.gw, ntaps = cl.ntaps;
     const int N = cl.gh * gw;
-    const GroupView gv = group_view(p);
-    const int m0 = gv.my * BM, n0 = ((int)blockIdx.x - cl.tile_begin) * BN;
+    const GroupView gv = group_view(p, tw.by);
+    const int m0 = gv.my * BM, n0 = (tw.bx - cl.tile_begin) * BN;
 
     const int n_loc = tid % BN, g = (wave * 64) / BN;
     const int n = n0 + n_loc;
@@ -1672,6 +1692,11 @@ static int pack_and_launch(GatherProblem& gp, const TapSet* taps, int bm, const 
     gp.part_gs = (long long)splits * gp.Mpad * cols;
     gp.At = At;
     dim3 grid((unsigned)tiles, (gp.Mpad / bm) * G, splits);
+    // XCD-aware tile order (tile_of_workgroup), opt-in with AG_CONV_XCD=1: 4.2x less L2-miss traffic (PMC: 524 -> 124 MB per launch on a
+    // 256 -> 256 layer at 256^2) and no time gained (ABBA same-box: 33.37 vs 33.45 ms per step) -- the kernel does not wait for those misses
+    // (profiles/r04_conv_xcd_order_ab.txt).  Needs whole eighths.
+    static const bool xcd_on = [] { const char* e = getenv("AG_CONV_XCD"); return e && e[0] == '1'; }();
+    gp.xcd_order = (xcd_on && ((long long)grid.x * grid.y) % 8 == 0 && (long long)grid.x * grid.y >= 64) ? 1 : 0;
     double flops = 0.0;
     for (int c = 0; c < gp.nclasses; c++)
         if (!gp.cls[c].zero_weights) flops += 2.0 * G * gp.M * (double)gp.cls[c].gh * gp.cls[c].gw * gp.cls[c].ntaps * gp.Cg;
