@@ -15,14 +15,17 @@ import torch
 from . import _lib
 
 AG_CONV, AG_CONV_TRANSPOSE = 0, 1
-MATH_MODES = {"fp32": 0, "split_bf16": 1, "split_bf16x3": 2, "split_f16": 3}      # include/ag_conv.h AgConvMath
+MATH_MODES = {"fp32": 0, "split_bf16": 1, "split_bf16x3": 2, "split_f16": 3, "f16": 4}      # include/ag_conv.h AgConvMath
+SCALED_MODES = ("split_f16", "f16")          # the forms that need every operand tensor's largest magnitude (per-tensor power-of-two scale)
 
 
 def set_math(mode: str) -> str:
     """Arithmetic of the MFMA convolutions, process-wide: ``"split_f16"`` (default: fp32 operands as two fp16 parts under a per-tensor
     power-of-two scale, three products on the fp16 matrix pipe, fp32 accumulation), ``"split_bf16"`` (three bf16 parts, six products) --
     both with products within 2^-23 of the exact ones --, ``"fp32"`` (v_mfma_f32_32x32x2_f32) or the opt-in ``"split_bf16x3"`` (three
-    products, 3 * 2^-16 per product: not fp32-grade).  include/ag_conv.h has the contracts.  Returns the previous mode."""
+    products, 3 * 2^-16 per product: not fp32-grade) or the opt-in ``"f16"`` (one fp16 part per operand under the same scale: 11 significant bits,
+    the operand grade of the cuDNN TF32 path the reference's convolutions take on its own hardware).  include/ag_conv.h has the contracts.
+    Returns the previous mode."""
     if mode not in MATH_MODES:
         raise ValueError(f"conv math mode must be one of {sorted(MATH_MODES)}")
     prev = get_math()
@@ -33,6 +36,11 @@ def set_math(mode: str) -> str:
 def get_math() -> str:
     m = _lib.lib().ag_conv_get_math()
     return next(k for k, v in MATH_MODES.items() if v == m)
+
+
+def needs_maxima() -> bool:
+    """True in the arithmetic modes that scale every operand tensor by its largest magnitude (fp16 forms)."""
+    return get_math() in SCALED_MODES
 
 
 if os.environ.get("AG_CONV_MATH"):          # A/B hook for the profiles/ scripts: initial mode of the process

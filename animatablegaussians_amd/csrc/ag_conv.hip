@@ -489,6 +489,13 @@ __device__ __forceinline__ void split_pair(float x0, float x1, uint32_t& p0, uin
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 constexpr int kF16 = 2;                 // value of the kernels' NTERMS parameter that selects this form (6 / 3: the bf16 forms)
+// ONE fp16 part under the same per-tensor scale (round 5, AG_CONV_MATH_F16): h = rn_f16(s x), one product a_h b_h per fp32 product.  11
+// significant bits per operand = the operand grade of cuDNN's TF32 path (10 explicit mantissa bits, fp32 accumulation), which is what the
+// reference's convolutions run on its own hardware (network/styleunet/conv2d_gradfix.py:185-189 hands torch.backends.cudnn.allow_tf32 --
+// True by default -- to cuDNN and nothing in the repository clears it).  Per product <= (2^-11 + 2^-22) |a| |b| wherever both scaled operands
+// are normal fp16 numbers (|x| >= 2^-29 M); one plane in LDS and in the packed weights, a third of the matrix instructions.
+constexpr int kF16S = 1;
+constexpr bool is_f16_form(int nterms) { return nterms == kF16 || nterms == kF16S; }
 
 __device__ __forceinline__ uint32_t pack_f16(float lo, float hi)        // round to nearest even
 {
@@ -574,7 +581,7 @@ __global__ void __launch_bounds__(kAmaxThreads) absmax_kernel(AmaxJobs J)
 // pitch) on different halves, so the ds_read_b128 of 16 consecutive rows covers all 64 banks once.
 __device__ __forceinline__ int chunk_off(int row, int kh) { return row * kRowB + ((kh ^ ((row >> 3) & 1)) << 4); }
 
-constexpr int planes_of(int nterms) { return nterms == 6 ? 3 : 2; }      // parts per operand that the form stores and reads
+constexpr int planes_of(int nterms) { return nterms == 6 ? 3 : (nterms == kF16S ? 1 : 2); }      // parts per operand that the form stores and reads
 
 template <int WMB, int WNB, int WVM, int WVN, int NPL>
 struct SplitTile {
@@ -622,11 +629,11 @@ __device__ __forceinline__ void mma_split(const SplitOperands<WMB, WNB>& o, f32x
 }
 
 // the fp16 form: smallest terms first, like mma_split
-template <int WMB, int WNB>
+template <int WMB, int WNB, int NTERMS = kF16>
 __device__ __forceinline__ void mma_split_h(const SplitOperands<WMB, WNB>& o, f32x16 (&acc)[WMB][WNB])
 {
 #pragma unroll
-    for (int t = 0; t < 3; t++)
+    for (int t = (NTERMS == kF16S ? 2 : 0); t < 3; t++)
 #pragma unroll
         for (int i = 0; i < WMB; i++)
 #pragma unroll
@@ -661,7 +668,7 @@ template <int WMB, int WNB, int WVM, int WVN, bool CEXACT, int NTERMS>
 __global__ void __launch_bounds__(64 * WVM * WVN, AG_CONV_WAVES_PER_SIMD) gather_conv_split_kernel(GatherProblem p)
 {
     constexpr int NPL = planes_of(NTERMS);
-    constexpr bool F16 = NTERMS == kF16;
+    constexpr bool F16 = is_f16_form(NTERMS);
     using T = SplitTile<WMB, WNB, WVM, WVN, NPL>;
     constexpr int BM = T::BM, BN = T::BN, NT = T::NT;
     constexpr int G = NT / BN, KG = BK / G;           // B loader: G thread groups, each KG consecutive k's of a pixel
@@ -781,13 +788,14 @@ __global__ void __launch_bounds__(64 * WVM * WVN, AG_CONV_WAVES_PER_SIMD) gather
 #pragma unroll
             for (int e = 0; e < 2; e++) {
                 const float x0 = st.tap_ok ? st.rb[4 * q + 2 * e] : 0.f, x1 = st.tap_ok ? st.rb[4 * q + 2 * e + 1] : 0.f;
-                uint32_t a, b, c = 0;
-                if constexpr (F16) split_pair_h(x0 * sb.s, x1 * sb.s, a, b);
-                else               split_pair(x0, x1, a, b, c);
+                uint32_t a, b = 0, c = 0;
+                if constexpr (NTERMS == kF16S) a = pack_f16(x0 * sb.s, x1 * sb.s);
+                else if constexpr (F16)        split_pair_h(x0 * sb.s, x1 * sb.s, a, b);
+                else                           split_pair(x0, x1, a, b, c);
                 w0[e] = a; w1[e] = b; w2[e] = c;
             }
             *reinterpret_cast<u32x2*>(Bs + 0 * BN * kRowB + b_woff + 8 * q) = w0;
-            *reinterpret_cast<u32x2*>(Bs + 1 * BN * kRowB + b_woff + 8 * q) = w1;
+            if constexpr (NPL >= 2) *reinterpret_cast<u32x2*>(Bs + 1 * BN * kRowB + b_woff + 8 * q) = w1;
             if constexpr (NPL == 3) *reinterpret_cast<u32x2*>(Bs + 2 * BN * kRowB + b_woff + 8 * q) = w2;
         }
     };
@@ -795,7 +803,7 @@ __global__ void __launch_bounds__(64 * WVM * WVN, AG_CONV_WAVES_PER_SIMD) gather
         read_split_operands<WMB, WNB, BM, BN, NTERMS>(As0 + buf * T::a_bytes, Bs0 + buf * T::b_bytes, wm, wn, lane, O);
     };
     auto mma = [&]() {
-        if constexpr (F16) mma_split_h<WMB, WNB>(O, acc);
+        if constexpr (F16) mma_split_h<WMB, WNB, NTERMS>(O, acc);
         else               mma_split<WMB, WNB, NTERMS>(O, acc);
     };
 
@@ -984,12 +992,13 @@ __global__ void __launch_bounds__(256) pack_weights_split_kernel(PackProblem p)
         for (int t = th; t < ntaps; t += 2) {
             const int to = p.tapoff[ci][t];
             const float v0 = zero ? 0.f : blk[o0][i0 + to], v1 = zero ? 0.f : blk[o1][i1 + to];
-            uint32_t a, b, c = 0;
-            if (f16) split_pair_h(v0 * sc, v1 * sc, a, b);
-            else     split_pair(v0, v1, a, b, c);
+            uint32_t a, b = 0, c = 0;
+            if (f16 && npl == 1) a = pack_f16(v0 * sc, v1 * sc);
+            else if (f16)        split_pair_h(v0 * sc, v1 * sc, a, b);
+            else                 split_pair(v0, v1, a, b, c);
             char* d = base + (size_t)t * (npl * plane);
             *reinterpret_cast<uint32_t*>(d) = a;
-            *reinterpret_cast<uint32_t*>(d + plane) = b;
+            if (npl >= 2) *reinterpret_cast<uint32_t*>(d + plane) = b;
             if (npl == 3) *reinterpret_cast<uint32_t*>(d + 2 * plane) = c;
         }
     }
@@ -1199,7 +1208,7 @@ template <int WMB, int WNB, int WVM, int WVN, bool AVEC, int NTERMS, bool BVEC =
 __global__ void __launch_bounds__(64 * WVM * WVN, AG_CONV_WAVES_PER_SIMD) wgrad_split_kernel(WgradProblem p)
 {
     constexpr int NPL = planes_of(NTERMS);
-    constexpr bool F16 = NTERMS == kF16;
+    constexpr bool F16 = is_f16_form(NTERMS);
     using T = SplitTile<WMB, WNB, WVM, WVN, NPL>;
     constexpr int BM = T::BM, BN = T::BN, NT = T::NT;
     constexpr int BSTEP = NT / 16;
@@ -1277,9 +1286,10 @@ __global__ void __launch_bounds__(64 * WVM * WVN, AG_CONV_WAVES_PER_SIMD) wgrad_
     }
     // one pair of fp32 values -> its words in the planes (w2 unused by the two-plane forms)
     auto split2 = [&](float x0, float x1, float sc, uint32_t& a, uint32_t& b, uint32_t& c) {
-        c = 0;
-        if constexpr (F16) split_pair_h(x0 * sc, x1 * sc, a, b);
-        else               split_pair(x0, x1, a, b, c);
+        b = 0; c = 0;
+        if constexpr (NTERMS == kF16S) a = pack_f16(x0 * sc, x1 * sc);
+        else if constexpr (F16)        split_pair_h(x0 * sc, x1 * sc, a, b);
+        else                           split_pair(x0, x1, a, b, c);
     };
 
     struct Stage {
@@ -1354,7 +1364,7 @@ __global__ void __launch_bounds__(64 * WVM * WVN, AG_CONV_WAVES_PER_SIMD) wgrad_
                 w0[e] = a; w1[e] = b; w2[e] = c;
             }
             *reinterpret_cast<u32x2*>(As + 0 * BM * kRowB + a_woff) = w0;
-            *reinterpret_cast<u32x2*>(As + 1 * BM * kRowB + a_woff) = w1;
+            if constexpr (NPL >= 2) *reinterpret_cast<u32x2*>(As + 1 * BM * kRowB + a_woff) = w1;
             if constexpr (NPL == 3) *reinterpret_cast<u32x2*>(As + 2 * BM * kRowB + a_woff) = w2;
         }
         if constexpr (BVEC) {
@@ -1374,7 +1384,7 @@ __global__ void __launch_bounds__(64 * WVM * WVN, AG_CONV_WAVES_PER_SIMD) wgrad_
                     w0[e] = a; w1[e] = b; w2[e] = c;
                 }
                 *reinterpret_cast<u32x2*>(Bs + 0 * BN * kRowB + vb_woff[j]) = w0;
-                *reinterpret_cast<u32x2*>(Bs + 1 * BN * kRowB + vb_woff[j]) = w1;
+                if constexpr (NPL >= 2) *reinterpret_cast<u32x2*>(Bs + 1 * BN * kRowB + vb_woff[j]) = w1;
                 if constexpr (NPL == 3) *reinterpret_cast<u32x2*>(Bs + 2 * BN * kRowB + vb_woff[j]) = w2;
             }
             return;
@@ -1388,7 +1398,7 @@ __global__ void __launch_bounds__(64 * WVM * WVN, AG_CONV_WAVES_PER_SIMD) wgrad_
             uint32_t a, b, c;
             split2(odd ? got : keep, odd ? keep : got, sb.s, a, b, c);        // (pixel k & ~1, pixel (k & ~1) + 1)
             *reinterpret_cast<uint32_t*>(Bs + 0 * BN * kRowB + b_woff[h]) = a;
-            *reinterpret_cast<uint32_t*>(Bs + 1 * BN * kRowB + b_woff[h]) = b;
+            if constexpr (NPL >= 2) *reinterpret_cast<uint32_t*>(Bs + 1 * BN * kRowB + b_woff[h]) = b;
             if constexpr (NPL == 3) *reinterpret_cast<uint32_t*>(Bs + 2 * BN * kRowB + b_woff[h]) = c;
         }
     };
@@ -1397,7 +1407,7 @@ __global__ void __launch_bounds__(64 * WVM * WVN, AG_CONV_WAVES_PER_SIMD) wgrad_
     };
 
     auto mma = [&]() {
-        if constexpr (F16) mma_split_h<WMB, WNB>(O, acc);
+        if constexpr (F16) mma_split_h<WMB, WNB, NTERMS>(O, acc);
         else               mma_split<WMB, WNB, NTERMS>(O, acc);
     };
 
@@ -1508,10 +1518,10 @@ static int round_up(int v, int a) { return (v + a - 1) / a * a; }
 
 // arithmetic of the MFMA convolutions (ag_conv_set_math): process-wide, read at every call
 static std::atomic<int> g_conv_math{ AG_CONV_MATH_SPLIT_F16 };
-static int split_terms()        // 0: fp32 MFMA engine; 6 / 3: bf16 products per fp32 product; kF16 (2): the two-part fp16 form
+static int split_terms()        // 0: fp32 MFMA engine; 6 / 3: bf16 products per fp32 product; kF16 (2): the two-part fp16 form; kF16S (1): one fp16 part
 {
     const int m = g_conv_math.load(std::memory_order_relaxed);
-    return m == AG_CONV_MATH_SPLIT_BF16 ? 6 : m == AG_CONV_MATH_SPLIT_BF16X3 ? 3 : m == AG_CONV_MATH_SPLIT_F16 ? kF16 : 0;
+    return m == AG_CONV_MATH_SPLIT_BF16 ? 6 : m == AG_CONV_MATH_SPLIT_BF16X3 ? 3 : m == AG_CONV_MATH_SPLIT_F16 ? kF16 : m == AG_CONV_MATH_F16 ? kF16S : 0;
 }
 static bool split_math() { return split_terms() != 0; }
 
@@ -1550,7 +1560,7 @@ int conv_absmax(const AmaxTensor* t, int n, int G, float* out, hipStream_t s, fl
     return check_hip(hipGetLastError(), "absmax_kernel");
 }
 size_t conv_absmax_floats(int tensors) { return (size_t)tensors * kMaxGroups * kAmaxParts; }
-bool conv_math_needs_absmax() { return split_terms() == kF16; }
+bool conv_math_needs_absmax() { return is_f16_form(split_terms()); }
 
 static int validate(const AgConvDesc* d)
 {
@@ -1631,7 +1641,7 @@ static int pack_and_launch(GatherProblem& gp, const TapSet* taps, int bm, const 
 {
     const bool split = split_math();
     const int terms = split_terms();
-    const bool f16 = terms == kF16;
+    const bool f16 = is_f16_form(terms);
     const int BN = bn_of(bm);
     const int G = gp.G;
     PackProblem pp;
@@ -1705,7 +1715,7 @@ static int pack_and_launch(GatherProblem& gp, const TapSet* taps, int bm, const 
         const bool cexact = gp.Cg % BK == 0 && (size_t)gp.Cg * gp.Hg * gp.Wg * sizeof(float) < (size_t(1) << 32);
 #define AG_LAUNCH_SPLIT_T(WMB, WNB, CE, NTM) hipLaunchKernelGGL((gather_conv_split_kernel<WMB, WNB, 2, 4, CE, NTM>), grid, dim3(512), 0, s, gp)
 #define AG_LAUNCH_SPLIT(WMB, WNB, CE) do { if (terms == 6) AG_LAUNCH_SPLIT_T(WMB, WNB, CE, 6); else if (terms == 3) AG_LAUNCH_SPLIT_T(WMB, WNB, CE, 3); \
-                                           else AG_LAUNCH_SPLIT_T(WMB, WNB, CE, kF16); } while (0)
+                                           else if (terms == kF16S) AG_LAUNCH_SPLIT_T(WMB, WNB, CE, kF16S); else AG_LAUNCH_SPLIT_T(WMB, WNB, CE, kF16); } while (0)
         if (bm == 64) {
             if (cexact) AG_LAUNCH_SPLIT(1, 2, true); else AG_LAUNCH_SPLIT(1, 2, false);
         } else {
@@ -1966,7 +1976,7 @@ int conv_backward_weight_g(const AgConvDesc* d, int G, const float* x, long long
     wp.amax_a = wp.amax_b = nullptr;
     if (split_math()) {
         const int terms = split_terms();
-        if (terms == kF16) {
+        if (is_f16_form(terms)) {
             if (!workspace || workspace_bytes < conv_workspace_bytes_g(d, G)) { set_error("conv workspace too small"); return AG_ERR_SCRATCH_TOO_SMALL; }
             float* amax = reinterpret_cast<float*>(aligned_base(workspace) + (size_t)G * packed_bytes(d) + kMaxPartialBytes);
             const bool conv = d->kind == AG_CONV;
@@ -1982,9 +1992,9 @@ int conv_backward_weight_g(const AgConvDesc* d, int G, const float* x, long long
 #define AG_LAUNCH_WSPLIT_T(WMB, WNB, AV, NTM) hipLaunchKernelGGL((wgrad_split_kernel<WMB, WNB, 2, 4, AV, NTM>), grid, dim3(512), 0, s, wp)
 #define AG_LAUNCH_WSPLIT_VT(WMB, WNB, NTM) hipLaunchKernelGGL((wgrad_split_kernel<WMB, WNB, 2, 4, true, NTM, true>), grid, dim3(512), 0, s, wp)
 #define AG_LAUNCH_WSPLIT(WMB, WNB, AV) do { if (terms == 6) AG_LAUNCH_WSPLIT_T(WMB, WNB, AV, 6); else if (terms == 3) AG_LAUNCH_WSPLIT_T(WMB, WNB, AV, 3); \
-                                            else AG_LAUNCH_WSPLIT_T(WMB, WNB, AV, kF16); } while (0)
+                                            else if (terms == kF16S) AG_LAUNCH_WSPLIT_T(WMB, WNB, AV, kF16S); else AG_LAUNCH_WSPLIT_T(WMB, WNB, AV, kF16); } while (0)
 #define AG_LAUNCH_WSPLIT_V(WMB, WNB) do { if (terms == 6) AG_LAUNCH_WSPLIT_VT(WMB, WNB, 6); else if (terms == 3) AG_LAUNCH_WSPLIT_VT(WMB, WNB, 3); \
-                                          else AG_LAUNCH_WSPLIT_VT(WMB, WNB, kF16); } while (0)
+                                          else if (terms == kF16S) AG_LAUNCH_WSPLIT_VT(WMB, WNB, kF16S); else AG_LAUNCH_WSPLIT_VT(WMB, WNB, kF16); } while (0)
         // the K-vectorised loader of the gathered operand: stride-1 "same" convolutions with rows of a multiple of 16 pixels (every 3 x 3 stride-1
         // layer of the product), whole K tiles per slice; AG_WGRAD_BVEC=0 keeps the scalar gathers (A/B)
         static const bool bvec_on = [] { const char* e = getenv("AG_WGRAD_BVEC"); return !(e && e[0] == '0'); }();
@@ -2036,7 +2046,7 @@ int ag_conv_backward_weight(const AgConvDesc* d, const float* x, const float* dy
 
 int ag_conv_set_math(int mode)
 {
-    if (mode != AG_CONV_MATH_FP32_MFMA && mode != AG_CONV_MATH_SPLIT_BF16 && mode != AG_CONV_MATH_SPLIT_BF16X3 && mode != AG_CONV_MATH_SPLIT_F16) { set_error("unknown conv math mode"); return AG_ERR_INVALID_ARGUMENT; }
+    if (mode != AG_CONV_MATH_FP32_MFMA && mode != AG_CONV_MATH_SPLIT_BF16 && mode != AG_CONV_MATH_SPLIT_BF16X3 && mode != AG_CONV_MATH_SPLIT_F16 && mode != AG_CONV_MATH_F16) { set_error("unknown conv math mode"); return AG_ERR_INVALID_ARGUMENT; }
     g_conv_math.store(mode, std::memory_order_relaxed);
     return AG_OK;
 }

@@ -104,7 +104,7 @@ def _handed_maxima(x):
     """The largest magnitudes of ``x`` as the grouped call that produced it left them (``out_maxima`` of include/ag_layers.h), or None.
     They travel as an attribute of the very tensor the producer returned: any operation in between yields another tensor without it."""
     m = getattr(x, "_ag_maxima", None)
-    if m is None or agc.get_math() != "split_f16" or not x.is_contiguous():
+    if m is None or not agc.needs_maxima() or not x.is_contiguous():
         return None
     if x._version != getattr(x, "_ag_maxima_version", -1):      # written in place since: the maxima are stale (too small a maximum would overflow fp16)
         return None
@@ -112,7 +112,7 @@ def _handed_maxima(x):
 
 
 def _new_out_maxima(out):
-    if agc.get_math() != "split_f16":
+    if not agc.needs_maxima():
         return None
     m = torch.empty(_OUT_MAXIMA_FLOATS, dtype=torch.float32, device=out.device)
     out._ag_maxima = m

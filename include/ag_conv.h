@@ -78,8 +78,16 @@ int ag_conv_backward_weight(const AgConvDesc* d, const float* x, const float* dy
  *   AG_CONV_MATH_SPLIT_BF16X3  opt-in: the three products with i + j <= 1, half the matrix work: each product within 3 * 2^-16 |a| |b|.
  *                              Not fp32-grade; for scale, the reference's cuDNN path runs TF32 (2^-11 per operand) by default --
  *                              conv2d_gradfix.py never disables it.
+ *   AG_CONV_MATH_F16           opt-in (round 5): ONE fp16 part per operand under SPLIT_F16's per-tensor scale, one product per fp32 product on
+ *                              v_mfma_f32_32x32x16_f16, fp32 accumulation.  Operands carry 11 significant bits, rounded to nearest: the operand
+ *                              grade of cuDNN's TF32 path (10 explicit mantissa bits), i.e. the arithmetic the reference's own convolutions
+ *                              run on its hardware (network/styleunet/conv2d_gradfix.py:185-189 passes torch.backends.cudnn.allow_tf32,
+ *                              True by default, and nothing clears it).  Contract: the result equals the convolution of the operands
+ *                              ROUNDED to 11 significant bits (exact products, fp32 accumulation) wherever |x| >= 2^-29 of its tensor's
+ *                              largest magnitude; below that fp16's gradual underflow applies (absolute error <= 2^-40 M per operand).
+ *                              A third of SPLIT_F16's matrix instructions.  Not fp32-grade; no fp32 parity claim is made in this mode.
  * Returns AG_OK / AG_ERR_INVALID_ARGUMENT. */
-typedef enum AgConvMath { AG_CONV_MATH_FP32_MFMA = 0, AG_CONV_MATH_SPLIT_BF16 = 1, AG_CONV_MATH_SPLIT_BF16X3 = 2, AG_CONV_MATH_SPLIT_F16 = 3 } AgConvMath;
+typedef enum AgConvMath { AG_CONV_MATH_FP32_MFMA = 0, AG_CONV_MATH_SPLIT_BF16 = 1, AG_CONV_MATH_SPLIT_BF16X3 = 2, AG_CONV_MATH_SPLIT_F16 = 3, AG_CONV_MATH_F16 = 4 } AgConvMath;
 int ag_conv_set_math(int mode);
 int ag_conv_get_math(void);
 

@@ -244,4 +244,76 @@ def test_three_product_mode_vs_torch():
         d = np.abs(a - b)
         assert (d <= 1e-4 * np.abs(b) + 1e-4 * np.abs(b).max()).all(), (name, d.max(), np.abs(b).max())
     with pytest.raises(ValueError):
-        agc.set_math("tf32")
+        agc.set_math("tf32")      # the opt-in 11-bit mode is spelled "f16"
+
+
+def _round11(t, mult=1.0):
+    """Oracle of AG_CONV_MATH_F16's operand rounding (include/ag_conv.h): the tensor scaled by the power of two that puts its largest
+    magnitude (times ``mult``) into [2^14, 2^15), rounded to fp16 (nearest even), scaled back -- 11 significant bits wherever the scaled
+    value is a normal fp16 number.  Returns float64."""
+    import torch
+    m = float(t.abs().max()) * mult
+    e = int(np.floor(np.log2(m))) if m > 0 else 0
+    s = 2.0 ** (14 - e)
+    return (t.double() * s).to(torch.float16).double() / s
+
+
+def _tf32_rne(t):
+    """A float32 tensor rounded to TF32's 10 explicit mantissa bits, nearest even (cuDNN converts with ties away: differs on exact ties only)."""
+    import torch
+    b = t.contiguous().view(torch.int32)
+    b = (b + 0xFFF + ((b >> 13) & 1)) & ~0x1FFF
+    return b.view(torch.float32)
+
+
+@pytest.mark.parametrize("kind,Cin,Cout,H,W,k,stride,padding", [("conv", 64, 96, 40, 36, 3, 1, 1), ("conv", 256, 64, 32, 32, 3, 1, 1), ("conv", 48, 130, 33, 35, 3, 2, 0),
+                                                               ("convT", 128, 64, 16, 16, 3, 2, 0), ("conv", 64, 160, 64, 64, 1, 1, 0), ("conv", 512, 512, 16, 16, 3, 1, 1)])
+def test_f16_mode_is_the_convolution_of_operands_rounded_to_11_bits(kind, Cin, Cout, H, W, k, stride, padding):
+    """AG_CONV_MATH_F16 (opt-in, round 5) against ITS contract: forward, input gradient and weight gradient equal the fp64 convolution of the
+    operands ROUNDED to 11 significant bits (exact products), up to the fp32 accumulation bound 2^-19 sum |a| |b| every mode is held to --
+    i.e. the only error of the mode is the operand rounding, which is TF32's (asserted bit for bit on the in-range values).  Against the
+    UNROUNDED fp64 convolution the deviation is then the rounding's: <= (2^-11 + 2^-19) sum |a| |b|."""
+    import torch
+    import torch.nn.functional as F
+    from animatablegaussians_amd import conv as agc
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(1, Cin, H, W, generator=g) * torch.exp2(torch.randint(-6, 1, (1, Cin, H, W), generator=g).float())
+    w = torch.randn(*((Cout, Cin, k, k) if kind == "conv" else (Cin, Cout, k, k)), generator=g) / np.sqrt(Cin * k * k)
+    f = (lambda a, b: F.conv2d(a, b, None, stride=stride, padding=padding)) if kind == "conv" else (lambda a, b: F.conv_transpose2d(a, b, None, stride=2))
+    gy = torch.randn(f(x, w).shape, generator=g) * torch.exp2(torch.randint(-6, 1, f(x, w).shape, generator=g).float())
+    xr, wr, gr = _round11(x), _round11(w), _round11(gy)
+    # the rounding IS TF32's on every value whose scaled magnitude is a normal fp16 number
+    for t, r in ((x, xr), (w, wr), (gy, gr)):
+        inr = t.abs() >= 2.0 ** -28 * float(t.abs().max())
+        assert torch.equal(r.float()[inr], _tf32_rne(t)[inr])
+
+    def grads(xo, wo, go):
+        xo, wo = xo.clone().requires_grad_(True), wo.clone().requires_grad_(True)
+        out = f(xo, wo)
+        out.backward(go)
+        return out.detach(), xo.grad, wo.grad
+    # forward: round(x) * round(w); dL/dx: round(gy) * round(w); dL/dw: round(gy) * round(x)
+    ref_f = f(xr, wr)
+    ref_dx = grads(x.double(), wr, gr)[1]
+    ref_dw = grads(xr, w.double(), gr)[2]
+    exact = grads(x.double(), w.double(), gy.double())
+    mags = grads(x.abs().double(), w.abs().double(), gy.abs().double())
+    prev = agc.set_math("f16")
+    try:
+        assert agc.get_math() == "f16" and agc.needs_maxima()
+        xg, wg = (t.clone().cuda().requires_grad_(True) for t in (x, w))
+        fn = agc.conv2d if kind == "conv" else agc.conv_transpose2d
+        out = fn(xg, wg, None, stride=stride, padding=padding)
+        out.backward(gy.cuda())
+        got = (out.detach(), xg.grad, wg.grad)
+    finally:
+        agc.set_math(prev)
+    for name, a, r, ex, m in zip(("forward", "dL/dx", "dL/dw"), got, (ref_f, ref_dx, ref_dw), exact, mags):
+        a = a.cpu().double()
+        assert bool(torch.isfinite(a).all()), name
+        d = (a - r).abs()
+        worst = float((d / (m + 1e-300)).max())
+        dev_exact = float(((a - ex).abs() / (m + 1e-300)).max())
+        print(f"{kind} {Cin}->{Cout} f16 {name:8s}: vs rounded-operand oracle 2^{np.log2(worst + 1e-300):6.2f} of sum|a||b|; vs exact fp64 2^{np.log2(dev_exact + 1e-300):6.2f}")
+        assert worst <= 2.0 ** -19, (name, worst)
+        assert dev_exact <= 2.0 ** -11 + 2.0 ** -19, (name, dev_exact)
