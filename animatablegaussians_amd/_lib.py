@@ -149,6 +149,7 @@ SYMBOLS = [
     ("ag_prof_kernel_name", ctypes.c_char_p, [c_i32]),
     ("ag_prof_enable", ctypes.c_int, [ctypes.c_uint32]),
     ("ag_prof_collect", ctypes.c_int, [ctypes.POINTER(c_i32), ctypes.POINTER(c_f), ctypes.POINTER(ctypes.c_double)]),
+    ("ag_prof_collect_to", ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(c_i32), ctypes.POINTER(c_f), ctypes.POINTER(ctypes.c_double)]),
     ("ag_debug_atomic_rate", ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
     ("ag_noise_bias_act_forward", ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_float,
                                                ctypes.c_float, c_vp]),
@@ -266,12 +267,16 @@ def prof_collect():
     return {k: (n[k], ms[k]) for k in n}
 
 
-def prof_collect_work():
-    """({name: launches}, {name: total ms}, {name: declared work (FLOPs for the convolution kernels)})."""
+def prof_collect_work(records_path=None):
+    """({name: launches}, {name: total ms}, {name: declared work (FLOPs for the convolution kernels)}); ``records_path``: also one CSV line
+    per bracketed launch (kernel,tag,work,ms) into that file."""
     n = (c_i32 * AG_K_COUNT)()
     ms = (c_f * AG_K_COUNT)()
     wk = (ctypes.c_double * AG_K_COUNT)()
-    check(lib().ag_prof_collect(n, ms, wk), "ag_prof_collect")
+    if records_path is not None:
+        check(lib().ag_prof_collect_to(str(records_path).encode(), n, ms, wk), "ag_prof_collect_to")
+    else:
+        check(lib().ag_prof_collect(n, ms, wk), "ag_prof_collect")
     names = [lib().ag_prof_kernel_name(i).decode() for i in range(AG_K_COUNT)]
     return ({k: int(n[i]) for i, k in enumerate(names)}, {k: float(ms[i]) for i, k in enumerate(names)},
             {k: float(wk[i]) for i, k in enumerate(names)})

@@ -3,6 +3,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <mutex>
+#include <cstring>
 #include <vector>
 
 #include "ag_common.h"
@@ -31,7 +32,7 @@ int check_hip(hipError_t e, const char* what)
 // and the work the caller declared for it.  A ProfScope keeps the index of ITS record, so launches of the same kernel
 // from several threads / streams / devices never pair each other's events.
 static uint32_t g_prof_mask = 0;
-struct ProfRec { int id, dev; hipEvent_t a, b; double work; bool ended; };
+struct ProfRec { int id, dev; hipEvent_t a, b; double work; bool ended; char tag[64]; };
 static std::vector<ProfRec> g_prof_log;
 static int g_prof_gen = 0;       // bumped by every ag_prof_collect: a handle taken before a collect must not touch the refilled log
 static std::vector<std::pair<int, hipEvent_t>> g_prof_pool;   // (device, event)
@@ -50,14 +51,15 @@ static hipEvent_t prof_event(int dev)
     return e;
 }
 
-int prof_begin(int id, hipStream_t s, double work)
+int prof_begin(int id, hipStream_t s, double work, const char* tag)
 {
     if (!(g_prof_mask & (1u << id))) return -1;
     int dev = 0;
     (void)hipGetDevice(&dev);
     std::lock_guard<std::mutex> lk(g_prof_mu);
     if (g_prof_log.size() >= (1u << 20)) return -1;
-    ProfRec r{ id, dev, prof_event(dev), prof_event(dev), work, false };
+    ProfRec r{ id, dev, prof_event(dev), prof_event(dev), work, false, { 0 } };
+    if (tag) { strncpy(r.tag, tag, sizeof(r.tag) - 1); r.tag[sizeof(r.tag) - 1] = 0; }
     (void)hipEventRecord(r.a, s);
     g_prof_log.push_back(r);
     return ((g_prof_gen & 0x3ff) << 20) | (int)(g_prof_log.size() - 1);      // generation in the upper bits
@@ -363,6 +365,8 @@ int ag_prof_enable(uint32_t mask)
     return AG_OK;
 }
 
+static FILE* g_prof_dump = nullptr;      // ag_prof_collect_to: one line per record (kernel, tag, work, ms) while collecting
+
 int ag_prof_collect(int32_t* launches, float* total_ms, double* work)
 {
     if (!launches || !total_ms) return AG_ERR_INVALID_ARGUMENT;
@@ -375,7 +379,10 @@ int ag_prof_collect(int32_t* launches, float* total_ms, double* work)
         (void)hipSetDevice(r.dev);
         if (!r.ended) { /* begun on another thread, not ended yet: not measured */ }
         else if (hipEventSynchronize(r.b) != hipSuccess || hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) rc = AG_ERR_HIP;
-        else { launches[r.id]++; total_ms[r.id] += ms; if (work) work[r.id] += r.work; }
+        else {
+            launches[r.id]++; total_ms[r.id] += ms; if (work) work[r.id] += r.work;
+            if (g_prof_dump) fprintf(g_prof_dump, "%s,%s,%.0f,%.5f\n", ag_prof_kernel_name(r.id), r.tag, r.work, ms);
+        }
         g_prof_pool.push_back({ r.dev, r.a });
         g_prof_pool.push_back({ r.dev, r.b });
     }
@@ -385,6 +392,20 @@ int ag_prof_collect(int32_t* launches, float* total_ms, double* work)
     return rc;
 }
 
+/* ag_prof_collect that also writes one CSV line per bracketed launch, in launch order: kernel,tag,work,ms (the tag is whatever the launcher
+ * declared: the convolutions put their shape there).  Diagnostic (profiles/conv_launch_table.py). */
+int ag_prof_collect_to(const char* path, int32_t* launches, float* total_ms, double* work)
+{
+    if (!path) return AG_ERR_INVALID_ARGUMENT;
+    FILE* f = fopen(path, "w");
+    if (!f) { set_error("ag_prof_collect_to: cannot open %s", path); return AG_ERR_INVALID_ARGUMENT; }
+    fprintf(f, "kernel,tag,work,ms\n");
+    g_prof_dump = f;
+    const int rc = ag_prof_collect(launches, total_ms, work);
+    g_prof_dump = nullptr;
+    fclose(f);
+    return rc;
+}
 
 int ag_debug_atomic_rate(float* accum, int32_t lines, int32_t blocks, int32_t iters, int32_t comps, void* stream)
 {

@@ -159,11 +159,11 @@ void set_error(const char* fmt, ...);
 
 // Optional event bracketing of kernel launches (ag_prof_* in the ABI).  Usage: { ProfScope ps(AG_K_X, stream); launch; }
 // `work` = what the launch computes in the kernel's roofline unit (FLOPs for the convolutions), summed by ag_prof_collect.
-int prof_begin(int kernel_id, hipStream_t s, double work);
+int prof_begin(int kernel_id, hipStream_t s, double work, const char* tag = nullptr);
 void prof_end(int handle, hipStream_t s);
 struct ProfScope {
     int handle; hipStream_t s;
-    ProfScope(int id, hipStream_t s_, double work = 0.0) : handle(prof_begin(id, s_, work)), s(s_) {}
+    ProfScope(int id, hipStream_t s_, double work = 0.0, const char* tag = nullptr) : handle(prof_begin(id, s_, work, tag)), s(s_) {}
     ~ProfScope() { prof_end(handle, s); }
     ProfScope(const ProfScope&) = delete;
     ProfScope& operator=(const ProfScope&) = delete;

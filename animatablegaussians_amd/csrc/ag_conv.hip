@@ -27,6 +27,7 @@
 // after them (one LDS-only barrier per K step).
 #include <algorithm>
 #include <atomic>
+#include <cstdio>
 #include <cstdlib>
 
 #include "ag_common.h"
@@ -1710,7 +1711,10 @@ static int pack_and_launch(GatherProblem& gp, const TapSet* taps, int bm, const 
     double flops = 0.0;
     for (int c = 0; c < gp.nclasses; c++)
         if (!gp.cls[c].zero_weights) flops += 2.0 * G * gp.M * (double)gp.cls[c].gh * gp.cls[c].gw * gp.cls[c].ntaps * gp.Cg;
-    ProfScope ps(AG_K_GATHER_CONV, s, flops);      // covers the split-K finish too
+    char tag[64];
+    snprintf(tag, sizeof(tag), "g bm%d G%d M%d C%d N%d cls%d nkt%d sp%d wg%lld", bm, G, gp.M, gp.Cg, cols, gp.nclasses, nkt_max, splits,
+             (long long)grid.x * grid.y * grid.z);
+    ProfScope ps(AG_K_GATHER_CONV, s, flops, tag);      // covers the split-K finish too
     if (split) {
         const bool cexact = gp.Cg % BK == 0 && (size_t)gp.Cg * gp.Hg * gp.Wg * sizeof(float) < (size_t(1) << 32);
 #define AG_LAUNCH_SPLIT_T(WMB, WNB, CE, NTM) hipLaunchKernelGGL((gather_conv_split_kernel<WMB, WNB, 2, 4, CE, NTM>), grid, dim3(512), 0, s, gp)
@@ -1971,7 +1975,10 @@ int conv_backward_weight_g(const AgConvDesc* d, int G, const float* x, long long
             if ((rc = check_hip(hipMemsetAsync(dw + (size_t)g * dw_gs, 0, (size_t)wp.Mw * Nw * sizeof(float), s), "memset dw"))) return rc;
     }
     dim3 grid((Nw + BN - 1) / BN, wp.mtiles * G, splits);
-    ProfScope ps(AG_K_WGRAD, s, 2.0 * G * wp.Mw * (double)Kp * Nw);
+    char tag[64];
+    snprintf(tag, sizeof(tag), "w bm%d G%d M%d C%d Kp%d t%d sp%d wg%lld %s", bm, G, wp.Mw, wp.Cg, Kp, k2, splits, (long long)grid.x * grid.y * grid.z,
+             d->kind == AG_CONV ? (d->stride == 1 ? "s1" : "s2") : "T");
+    ProfScope ps(AG_K_WGRAD, s, 2.0 * G * wp.Mw * (double)Kp * Nw, tag);
     const bool avec = (Kp & 3) == 0;      // rows of A 16-byte aligned
     wp.amax_a = wp.amax_b = nullptr;
     if (split_math()) {

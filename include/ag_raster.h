@@ -221,6 +221,9 @@ enum AgKernelId {
 const char* ag_prof_kernel_name(int32_t kernel_id);
 int ag_prof_enable(uint32_t kernel_mask);
 int ag_prof_collect(int32_t* launches /*[AG_K_COUNT]*/, float* total_ms /*[AG_K_COUNT]*/, double* work /*[AG_K_COUNT] or NULL*/);
+/* The same, and one CSV line per bracketed launch in launch order into `path`: kernel,tag,work,ms -- the tag is what the launcher declared
+ * (the convolutions put their shape, tile and split-K count there).  Diagnostic: profiles/conv_launch_table.py. */
+int ag_prof_collect_to(const char* path, int32_t* launches, float* total_ms, double* work);
 
 /*
  * Calibration hook (profiles/atomic_rate.py): `blocks` workgroups of 8 waves; every wave issues `iters` instructions, each adding
