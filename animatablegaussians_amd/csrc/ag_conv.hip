@@ -1011,13 +1011,16 @@ __global__ void __launch_bounds__(256) pack_weights_split_kernel(PackProblem p)
 struct WgradProblem {
     const float* a;        // [Mw][gh * gw]
     const float* xin;      // [Cg][Hg][Wg]
-    float* c;              // [Mw][Cg * ntaps], zero-initialised
+    float* c;              // [Mw][Cg * ntaps]; every element is written (round 5: no zero fill, no atomics)
     int Mw, Cg, Hg, Wg, gh, gw, sy, sx, ntaps;
     int ksplit_len;        // pixels per split (multiple of BK)
     float wscale;          // the forward convolved with w * wscale: dL/dw = wscale * dL/d(w * wscale)
     int G, mtiles;         // grouped launch: gridDim.y = G * mtiles
     long long a_gs, xin_gs, c_gs;     // floats between the instances' operands / outputs
     PtrTable c_t;          // p[0] != null: instance g writes to c_t.p[g] instead of c + g * c_gs (ConvOpts::dw_table)
+    float* partial;        // non-null: every workgroup stores its slice's tile to partial[z][instance][Mpad][Npad] and wgrad_reduce_kernel adds the
+                           // slices (and the instances that share a destination) in a fixed order; null: one slice, stored straight to the destination
+    int Mpad, Npad;
     const float* amax_a;   // fp16 split form: partial maxima of `a` and of `xin` ([G][kAmaxParts], one row where the instances share the tensor)
     const float* amax_b;
     int c_row_stride, c_chan_stride;  // element (m, nn = (channel, tap)) of the output sits at m * c_row_stride + channel * c_chan_stride + tap:
@@ -1025,6 +1028,73 @@ struct WgradProblem {
                                       // weight gradient written in the [Cout][Cin][k][k] layout its modulated weight is kept in)
     int dy[kMaxTaps], dx[kMaxTaps];
 };
+
+// Epilogue of the weight-gradient kernels (round 5: deterministic).  Rounds 1-4 added every pixel slice's tile to a zeroed dw with float
+// atomics: the sum's order was the slices' arrival order, so a weight gradient differed from run to run in its last bits (and through the
+// leaky-ReLU slope selections downstream, occasionally in much more).  Now a slice stores its tile -- the only slice straight into dw, several
+// into partial[z][instance][Mpad][Npad] -- and wgrad_reduce_kernel adds them in slice order.  No zero fill of dw, no atomics, same bits every run.
+template <int WMB, int WNB>
+__device__ __forceinline__ void wgrad_store(const WgradProblem& p, const f32x16 (&acc)[WMB][WNB], float unscale, int grp, float* __restrict__ c_g, int m0,
+                                            int n0, int Nw, int wm, int wn, int lane)
+{
+    const int col = lane & 31, rbase = 4 * (lane >> 5);
+    const float f = unscale * p.wscale;
+    if (p.partial) {
+        float* __restrict__ part = p.partial + ((size_t)blockIdx.z * p.G + grp) * p.Mpad * p.Npad;
+#pragma unroll
+        for (int i = 0; i < WMB; i++)
+#pragma unroll
+            for (int j = 0; j < WNB; j++) {
+                const int nn = n0 + (wn * WNB + j) * 32 + col;           // < Npad by construction
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int m = m0 + (wm * WMB + i) * 32 + (r & 3) + 8 * (r >> 2) + rbase;
+                    part[(size_t)m * p.Npad + nn] = acc[i][j][r] * f;
+                }
+            }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < WMB; i++)
+#pragma unroll
+        for (int j = 0; j < WNB; j++) {
+            const int nn = n0 + (wn * WNB + j) * 32 + col;
+            if (nn >= Nw) continue;
+            const int ch = nn / p.ntaps;
+            float* cn = c_g + (size_t)ch * p.c_chan_stride + (nn - ch * p.ntaps);
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int m = m0 + (wm * WMB + i) * 32 + (r & 3) + 8 * (r >> 2) + rbase;
+                if (m < p.Mw) cn[(size_t)m * p.c_row_stride] = acc[i][j][r] * f;     // natural layout: 32 lanes = 128 contiguous bytes
+            }
+        }
+}
+
+// dw = the sum of the slices' tiles, and of the instances that share a destination (ConvOpts::dw_table with repeated entries: the members of a
+// network in the comb convolutions), in a fixed order.  grid (blocks, runs); run r = instances [begin[r], begin[r + 1]) -> dst.p[r].
+struct WgradReduce {
+    const float* partial;
+    PtrTable dst;
+    int begin[kMaxGroups + 1];
+    int G, splits, Mw, Nw, Mpad, Npad, ntaps, c_row_stride, c_chan_stride;
+};
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(WgradReduce r)
+{
+    const int run = blockIdx.y;
+    const int g0 = r.begin[run], g1 = r.begin[run + 1];
+    float* __restrict__ dst = const_cast<float*>(r.dst.p[run]);
+    const size_t inst = (size_t)r.Mpad * r.Npad, zstride = inst * r.G;
+    const long long total = (long long)r.Mw * r.Nw;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int m = (int)(i / r.Nw), nn = (int)(i - (long long)m * r.Nw);
+        const float* __restrict__ src = r.partial + (size_t)m * r.Npad + nn;
+        float v = 0.f;
+        for (int g = g0; g < g1; g++)
+            for (int z = 0; z < r.splits; z++) v += src[(size_t)z * zstride + (size_t)g * inst];
+        const int ch = nn / r.ntaps;
+        dst[(size_t)m * r.c_row_stride + (size_t)ch * r.c_chan_stride + (nn - ch * r.ntaps)] = v;
+    }
+}
 
 // AVEC: the rows of A are 16-byte aligned (pixel count a multiple of 4, always true in the product): one dwordx4 per thread and
 // tile; the scalar form is kept for arbitrary sizes.  Everything in the K loop is branch-free: loads are unconditional from clamped
@@ -1176,21 +1246,7 @@ __global__ void __launch_bounds__(64 * WVM * WVN, AG_CONV_WAVES_PER_SIMD) wgrad_
         step_tail(kt, S[1], O[0], O[1], false);
     }
 
-    const int col = lane & 31, rbase = 4 * (lane >> 5);
-#pragma unroll
-    for (int i = 0; i < WMB; i++)
-#pragma unroll
-        for (int j = 0; j < WNB; j++) {
-            const int nn = n0 + (wn * WNB + j) * 32 + col;
-            if (nn >= Nw) continue;
-            const int ch = nn / p.ntaps;
-            float* cn = c_g + (size_t)ch * p.c_chan_stride + (nn - ch * p.ntaps);
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int m = m0 + (wm * WMB + i) * 32 + (r & 3) + 8 * (r >> 2) + rbase;
-                if (m < p.Mw) atomicAdd(cn + (size_t)m * p.c_row_stride, acc[i][j][r] * p.wscale);   // natural layout: 32 lanes = 128 contiguous bytes
-            }
-        }
+    wgrad_store<WMB, WNB>(p, acc, 1.f, grp, c_g, m0, n0, Nw, wm, wn, lane);
 }
 
 // wgrad_kernel on the split engine: both operands are activations, so both are split by their loader threads.  A: four consecutive
@@ -1447,23 +1503,7 @@ __global__ void __launch_bounds__(64 * WVM * WVN, AG_CONV_WAVES_PER_SIMD) wgrad_
         step_tail(kt, S[1], false);
     }
 
-    const int col = lane & 31, rbase = 4 * (lane >> 5);
-#pragma unroll
-    for (int i = 0; i < WMB; i++)
-#pragma unroll
-        for (int j = 0; j < WNB; j++) {
-            const int nn = n0 + (wn * WNB + j) * 32 + col;
-            if (nn >= Nw) continue;
-            const int ch = nn / p.ntaps;
-            float* cn = c_g + (size_t)ch * p.c_chan_stride + (nn - ch * p.ntaps);
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int m = m0 + (wm * WMB + i) * 32 + (r & 3) + 8 * (r >> 2) + rbase;
-                float v = acc[i][j][r];
-                if constexpr (F16) v = v * sa.inv * sb.inv;
-                if (m < p.Mw) atomicAdd(cn + (size_t)m * p.c_row_stride, v * p.wscale);
-            }
-        }
+    wgrad_store<WMB, WNB>(p, acc, F16 ? sa.inv * sb.inv : 1.f, grp, c_g, m0, n0, Nw, wm, wn, lane);
 }
 
 // Matrix-pipe calibration: every wave issues `iters` x 4 independent v_mfma_f32_32x32x2_f32 back to back, no memory.
@@ -1964,16 +2004,29 @@ int conv_backward_weight_g(const AgConvDesc* d, int G, const float* x, long long
         const int f = atoi(forced);
         if (f >= 1) splits = std::min(f, std::max(1, nkt_all));
     }
+    // destinations: instance g -> its own gradient, or (dw_table) possibly the same tensor as its neighbours: those instances are added up
+    WgradReduce wr;
+    wr.begin[0] = 0;
+    int nruns = 0, longest_run = 1;
+    for (int g = 0; g < G; g++) {
+        const float* dst = o.dw_table ? o.dw_table->p[g] : dw + (size_t)g * dw_gs;
+        if (nruns == 0 || dst != wr.dst.p[nruns - 1]) { wr.dst.p[nruns] = dst; wr.begin[nruns] = g; nruns++; }
+        wr.begin[nruns] = g + 1;
+        longest_run = std::max(longest_run, wr.begin[nruns] - wr.begin[nruns - 1]);
+    }
+    wp.Mpad = wp.mtiles * bm;
+    wp.Npad = round_up(Nw, BN);
+    // the slices' tiles live in the call's workspace (nothing else of it is in use by a weight gradient except the operand maxima behind it)
+    const size_t tile_set = (size_t)G * wp.Mpad * wp.Npad * sizeof(float);
+    const size_t part_room = workspace ? (size_t)G * packed_bytes(d) + kMaxPartialBytes : 0;
+    if (workspace && workspace_bytes < conv_workspace_bytes_g(d, G)) { set_error("conv workspace too small"); return AG_ERR_SCRATCH_TOO_SMALL; }
+    const int max_splits = (int)std::min<size_t>(4096, part_room / tile_set);
+    if (splits > max_splits) splits = std::max(1, max_splits);
     wp.ksplit_len = round_up((Kp + splits - 1) / splits, BK);
     splits = (Kp + wp.ksplit_len - 1) / wp.ksplit_len;
-    if (o.dw_table) {
-        // the caller zeroed the target
-    } else if (dw_gs == (long long)wp.Mw * Nw || G == 1) {
-        if ((rc = check_hip(hipMemsetAsync(dw, 0, (size_t)G * wp.Mw * Nw * sizeof(float), s), "memset dw"))) return rc;
-    } else {
-        for (int g = 0; g < G; g++)
-            if ((rc = check_hip(hipMemsetAsync(dw + (size_t)g * dw_gs, 0, (size_t)wp.Mw * Nw * sizeof(float), s), "memset dw"))) return rc;
-    }
+    const bool via_partial = splits > 1 || longest_run > 1;
+    if (via_partial && max_splits < 1) { set_error("conv workspace too small for the weight gradient's slices"); return AG_ERR_SCRATCH_TOO_SMALL; }
+    wp.partial = via_partial ? reinterpret_cast<float*>(aligned_base(workspace)) : nullptr;
     dim3 grid((Nw + BN - 1) / BN, wp.mtiles * G, splits);
     char tag[64];
     snprintf(tag, sizeof(tag), "w bm%d G%d M%d C%d Kp%d t%d sp%d wg%lld %s", bm, G, wp.Mw, wp.Cg, Kp, k2, splits, (long long)grid.x * grid.y * grid.z,
@@ -2026,7 +2079,12 @@ int conv_backward_weight_g(const AgConvDesc* d, int G, const float* x, long long
         if (avec) hipLaunchKernelGGL((wgrad_kernel<2, 1, 2, 4, true>), grid, dim3(512), 0, s, wp);
         else      hipLaunchKernelGGL((wgrad_kernel<2, 1, 2, 4, false>), grid, dim3(512), 0, s, wp);
     }
-    return check_hip(hipGetLastError(), "wgrad_kernel");
+    if ((rc = check_hip(hipGetLastError(), "wgrad_kernel")) || !via_partial) return rc;
+    wr.partial = wp.partial; wr.G = G; wr.splits = splits; wr.Mw = wp.Mw; wr.Nw = Nw; wr.Mpad = wp.Mpad; wr.Npad = wp.Npad; wr.ntaps = k2;
+    wr.c_row_stride = wp.c_row_stride; wr.c_chan_stride = wp.c_chan_stride;
+    const long long total = (long long)wp.Mw * Nw;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 2048), nruns), dim3(256), 0, s, wr);
+    return check_hip(hipGetLastError(), "wgrad_reduce_kernel");
 }
 
 }  // namespace ag

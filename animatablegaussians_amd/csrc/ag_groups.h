@@ -121,8 +121,8 @@ struct ConvOpts {
     const float* amax_x = nullptr;
     const float* amax_dy = nullptr;
     // weight gradient written into a wider tensor (the comb convolutions: a channel slice of the parameter's own gradient): instance g goes to
-    // dw_table->p[g] with rows dw_row_stride floats apart; entries may repeat -- those instances ACCUMULATE (the split-K atomics do that anyway);
-    // the call does not zero the target
+    // dw_table->p[g] with rows dw_row_stride floats apart; CONSECUTIVE instances with the same entry are summed into it (in instance order, by the
+    // weight gradient's slice reduction); the slice is overwritten
     const PtrTable* dw_table = nullptr;
     long long dw_row_stride = 0;
 };

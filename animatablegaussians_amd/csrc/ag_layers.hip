@@ -573,10 +573,10 @@ int ag_grouped_comb_backward(const AgGroupedCombArgs* a, void* stream)
     if (a->g_x && (rc = conv_backward_input_g(&d1, a->M, g_pre, a->Cout * hw, w1, a->g_x, a->C1 * hw, a->workspace, a->workspace_bytes, s, o1))) return rc;
     if (a->g_lev && (rc = conv_backward_input_g(&d2, a->N, g_t, a->Cout * hw, w2, a->g_lev, a->C2 * hw, a->workspace, a->workspace_bytes, s, o2))) return rc;
     if (a->g_weight) {
-        // both halves straight into the parameters' gradients [N][Cout][C1 + C2][3][3]: the members of a network accumulate into its tensor's first
-        // C1 channels (the split-K atomics of the weight gradient do not care whose slice they add), the level half fills the other C2
+        // both halves straight into the parameters' gradients [N][Cout][C1 + C2][3][3]: the members of a network are summed into its tensor's first
+        // C1 channels (consecutive instances with one destination: the weight gradient's fixed-order slice reduction adds them), the level half
+        // fills the other C2; every element is written, nothing is zeroed first
         const long long wrow = (long long)(a->C1 + a->C2) * 9, wnet = (long long)a->Cout * wrow;
-        if ((rc = check_hip(hipMemsetAsync(a->g_weight, 0, (size_t)a->N * wnet * sizeof(float), s), "memset g_weight"))) return rc;
         PtrTable t1{}, t2{};
         for (int r = 0; r < a->N; r++) {
             t2.p[r] = a->g_weight + (size_t)r * wnet + (size_t)a->C1 * 9;

@@ -317,3 +317,24 @@ def test_f16_mode_is_the_convolution_of_operands_rounded_to_11_bits(kind, Cin, C
         print(f"{kind} {Cin}->{Cout} f16 {name:8s}: vs rounded-operand oracle 2^{np.log2(worst + 1e-300):6.2f} of sum|a||b|; vs exact fp64 2^{np.log2(dev_exact + 1e-300):6.2f}")
         assert worst <= 2.0 ** -19, (name, worst)
         assert dev_exact <= 2.0 ** -11 + 2.0 ** -19, (name, dev_exact)
+
+
+@pytest.mark.parametrize("kind,Cin,Cout,hw,k,stride,padding", [("conv", 64, 64, 128, 3, 1, 1), ("conv", 32, 48, 97, 3, 2, 0), ("convT", 64, 32, 48, 3, 2, 0)])
+def test_weight_gradient_is_deterministic_and_needs_no_zeroed_target(kind, Cin, Cout, hw, k, stride, padding, math_mode):
+    """Round 5: many pixel slices (the 64-channel layers at 512^2 use 28), summed in slice order by wgrad_reduce_kernel: the same bits on every
+    call, and the target is overwritten, not accumulated into (the call used to zero it and add with float atomics)."""
+    import torch
+    from animatablegaussians_amd import conv as agc
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(1, Cin, hw, hw, generator=g).cuda()
+    w = (torch.randn(*((Cout, Cin, k, k) if kind == "conv" else (Cin, Cout, k, k)), generator=g) / np.sqrt(Cin * k * k)).cuda()
+    fn = agc.conv2d if kind == "conv" else agc.conv_transpose2d
+    grads = []
+    for rep in range(3):
+        xg, wg = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        out = fn(xg, wg, None, stride=stride, padding=padding)
+        if rep == 0:
+            gy = torch.randn(out.shape, generator=torch.Generator().manual_seed(10)).cuda()
+        out.backward(gy)
+        grads.append(wg.grad.clone())
+    assert torch.equal(grads[0], grads[1]) and torch.equal(grads[0], grads[2])

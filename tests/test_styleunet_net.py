@@ -173,6 +173,41 @@ def _golden_body(math, grouped=False):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("grouped", [True, False])
+def test_styleunet_gradients_are_bit_reproducible(grouped):
+    """Round 5: the weight gradient's pixel slices are added in a fixed order (csrc/ag_conv.hip wgrad_reduce_kernel; float atomics in arrival
+    order before), which was the last non-deterministic sum of the StyleUNet path: two forward + backward passes from the same state give
+    BIT-equal images, pose-map gradient and all parameter gradients -- on the product's grouped chain and one network at a time."""
+    import torch
+    from animatablegaussians_amd import synth
+    from animatablegaussians_amd.styleunet import DualStyleUNet
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(11)
+    net = DualStyleUNet(inp_size=512, inp_ch=3, out_ch=3, out_size=1024, style_dim=512, n_mlp=2).to(dev)
+    pose0 = synth.pose_map(512).to(dev)
+    style = (torch.ones(1, 512) / np.sqrt(512)).to(dev)
+    G = torch.randn(1, 6, 1024, 1024, generator=torch.Generator().manual_seed(4242)).to(dev)
+    runs = []
+    for _ in range(3):
+        for p in net.parameters():
+            p.grad = None
+        pose = pose0.clone().requires_grad_(True)
+        if grouped:
+            from animatablegaussians_amd.grouped import GroupedStyleUNets
+            images = GroupedStyleUNets([net]).forward([style], pose)[0]
+        else:
+            images, _ = net([style], pose, randomize_noise=False)
+        (images * G).sum().backward()
+        torch.cuda.synchronize()
+        runs.append((images.detach().clone(), pose.grad.clone(), {n: net._p(n).grad.clone() for n in net._learnable}))
+    for im, pg, gr in runs[1:]:
+        assert torch.equal(im, runs[0][0]) and torch.equal(pg, runs[0][1])
+        for n, g in gr.items():
+            assert torch.equal(g, runs[0][2][n]), (n, float((g - runs[0][2][n]).abs().max()))
+
+
+@pytest.mark.gpu
 def test_layer_level_autograd_nodes_equal_the_per_kernel_chain():
     """fused_layers.py: ConvLayer / StyledConv / ToRGB as one autograd node each run the same kernels in the same order as the chain of
     per-kernel Functions -- images bit-equal; gradients equal up to the order in which float atomics sum (weight gradients of the
