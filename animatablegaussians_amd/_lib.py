@@ -171,6 +171,7 @@ SYMBOLS = [
     ("ag_lpips_level_backward", ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_int32, ctypes.c_int32, c_vp]),
     ("ag_conv_set_math", ctypes.c_int, [ctypes.c_int]),
     ("ag_conv_get_math", ctypes.c_int, []),
+    ("ag_conv_status", ctypes.c_int, [ctypes.c_int]),
     ("ag_debug_mfma_rate", ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_vp, c_vp]),
     ("ag_debug_mfma_rate_bf16", ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_vp, c_vp]),
     # include/ag_smplx.h

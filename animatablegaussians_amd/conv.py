@@ -38,6 +38,13 @@ def get_math() -> str:
     return next(k for k, v in MATH_MODES.items() if v == m)
 
 
+def check_status(clear: bool = True) -> None:
+    """Raises ``AgNativeError`` if a convolution enqueued so far met a non-finite accumulator (include/ag_conv.h ``ag_conv_status``: an operand
+    beyond the maximum its fp16 scale was taken from -- a stale handed-over maximum -- or non-finite inputs).  Does not synchronise: call it after
+    ``torch.cuda.synchronize()`` for a definitive answer.  The next convolution call raises by itself otherwise."""
+    _lib.check(_lib.lib().ag_conv_status(int(bool(clear))), "ag_conv_status")
+
+
 def needs_maxima() -> bool:
     """True in the arithmetic modes that scale every operand tensor by its largest magnitude (fp16 forms)."""
     return get_math() in SCALED_MODES

@@ -156,6 +156,7 @@ struct GatherProblem {
     PtrTable nw_t;         // act 1: per-instance noise weight [1]
     int xcd_order;         // 1: workgroups take their (N tile, instance * M tile) in the XCD-aware order of tile_of_workgroup() (host: gridDim.x * gridDim.y % 8 == 0)
     float* out_amax;       // act != 0: zeroed [G][kAmaxParts] slots for the largest magnitude of the activated output (ConvAct::out_amax), or null
+    int* status;           // host-visible sticky flag raised on a non-finite accumulator (ag_conv_status), or null
     // fp16 split form: partial maxima (absmax_kernel) of the packed weights' source tensors [G][kAmaxParts] and of the gathered tensor
     // ([G][kAmaxParts], or one row when the instances share their input); amax_a_mult = |weight_scale| (the packed values are w * scale)
     const float* amax_a;
@@ -219,6 +220,22 @@ __device__ __forceinline__ void emit_amax(float* slots, float mx, int salt)
     }
 }
 
+// Range guard (ag_conv_status): a lane that holds a non-finite accumulator raises the host-visible flag.  Runs once per tile; the store is
+// executed by offending lanes only, so a healthy launch never touches the word.
+template <int WMB, int WNB>
+__device__ __forceinline__ void flag_non_finite(int* status, const f32x16 (&acc)[WMB][WNB])
+{
+    if (!status) return;
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i < WMB; i++)
+#pragma unroll
+        for (int j = 0; j < WNB; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) bad |= !(fabsf(acc[i][j][r]) <= 3.4028234664e38f);      // inf or NaN
+    if (bad) __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // Epilogue shared by the gather kernels.  C/D layout of the 32 x 32 MFMAs: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
 template <int WMB, int WNB>
 __device__ __forceinline__ void gather_epilogue(const GatherProblem& p, const GroupView& gv, const GatherClass& cl, f32x16 (&acc)[WMB][WNB], int m0,
@@ -226,6 +243,7 @@ __device__ __forceinline__ void gather_epilogue(const GatherProblem& p, const Gr
 {
     const int gw = cl.gw;
     const int col = lane & 31, rbase = 4 * (lane >> 5);
+    flag_non_finite<WMB, WNB>(p.status, acc);
     if (gridDim.z > 1) {
         float* part = gv.partial + (size_t)blockIdx.z * p.Mpad * p.Ncols + cl.col_begin;
 #pragma unroll
@@ -1021,6 +1039,7 @@ struct WgradProblem {
     float* partial;        // non-null: every workgroup stores its slice's tile to partial[z][instance][Mpad][Npad] and wgrad_reduce_kernel adds the
                            // slices (and the instances that share a destination) in a fixed order; null: one slice, stored straight to the destination
     int Mpad, Npad;
+    int* status;           // host-visible sticky flag raised on a non-finite accumulator (ag_conv_status), or null
     const float* amax_a;   // fp16 split form: partial maxima of `a` and of `xin` ([G][kAmaxParts], one row where the instances share the tensor)
     const float* amax_b;
     int c_row_stride, c_chan_stride;  // element (m, nn = (channel, tap)) of the output sits at m * c_row_stride + channel * c_chan_stride + tap:
@@ -1039,6 +1058,7 @@ __device__ __forceinline__ void wgrad_store(const WgradProblem& p, const f32x16 
 {
     const int col = lane & 31, rbase = 4 * (lane >> 5);
     const float f = unscale * p.wscale;
+    flag_non_finite<WMB, WNB>(p.status, acc);
     if (p.partial) {
         float* __restrict__ part = p.partial + ((size_t)blockIdx.z * p.G + grp) * p.Mpad * p.Npad;
 #pragma unroll
@@ -1603,6 +1623,28 @@ int conv_absmax(const AmaxTensor* t, int n, int G, float* out, hipStream_t s, fl
 size_t conv_absmax_floats(int tensors) { return (size_t)tensors * kMaxGroups * kAmaxParts; }
 bool conv_math_needs_absmax() { return is_f16_form(split_terms()); }
 
+// ag_conv_status: one pinned, mapped word per process (portable across devices); kernels store 1 into it, the host reads it without synchronising
+static int* status_word()
+{
+    static int* w = [] {
+        int* p = nullptr;
+        if (hipHostMalloc(reinterpret_cast<void**>(&p), 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) return (int*)nullptr;
+        *p = 0;
+        return p;
+    }();
+    return w;
+}
+static int take_status(bool clear)
+{
+    int* w = status_word();
+    if (!w) return AG_OK;
+    const int v = __atomic_load_n(w, __ATOMIC_RELAXED);
+    if (v && clear) __atomic_store_n(w, 0, __ATOMIC_RELAXED);
+    if (!v) return AG_OK;
+    set_error("a convolution produced a non-finite accumulator: an operand exceeded the maximum its fp16 scale was taken from (a stale handed-over maximum?) or was not finite");
+    return AG_ERR_RANGE;
+}
+
 static int validate(const AgConvDesc* d)
 {
     if (!d) { set_error("null conv descriptor"); return AG_ERR_INVALID_ARGUMENT; }
@@ -1841,6 +1883,7 @@ static int run_gather_family(const AgConvDesc* d, bool backward_input, int G, co
     float* amax = reinterpret_cast<float*>(aligned_base(workspace) + (size_t)G * packed_bytes(d) + kMaxPartialBytes);
 
     GatherProblem gp;
+    gp.status = status_word();
     gp.out_scale = out_scale; gp.bias_t = bias; gp.yout = yout; gp.xin = xin;
     gp.G = G; gp.x_gs = x_gs; gp.y_gs = y_gs;
     gp.act = opt.act ? opt.act->kind : 0;
@@ -1941,7 +1984,7 @@ int conv_forward_g(const AgConvDesc* d, int G, const float* x, long long x_gs, c
                    float* y, long long y_gs, void* workspace, size_t workspace_bytes, hipStream_t s, const ConvOpts& o)
 {
     int rc = validate(d);
-    if (rc) return rc;
+    if (rc || (rc = take_status(true))) return rc;
     if (G < 1 || G > kMaxGroups || !x || !table_complete(w, G) || !y) { set_error("null conv tensor / bad group count"); return AG_ERR_INVALID_ARGUMENT; }
     if (!o.w_cin_total && !o.act && (rc = pointwise_forward(d, G, x, x_gs, w, out_scale, bias, y, y_gs, s)) != 0) return rc < 0 ? rc : AG_OK;
     return run_gather_family(d, false, G, x, x_gs, w, out_scale, bias, y, y_gs, workspace, workspace_bytes, s, o);
@@ -1951,7 +1994,7 @@ int conv_backward_input_g(const AgConvDesc* d, int G, const float* dy, long long
                           void* workspace, size_t workspace_bytes, hipStream_t s, const ConvOpts& o)
 {
     int rc = validate(d);
-    if (rc) return rc;
+    if (rc || (rc = take_status(true))) return rc;
     if (G < 1 || G > kMaxGroups || !dy || !table_complete(w, G) || !dx) { set_error("null conv tensor / bad group count"); return AG_ERR_INVALID_ARGUMENT; }
     if (!o.w_cin_total && (rc = pointwise_backward_input(d, G, dy, dy_gs, w, dx, dx_gs, s)) != 0) return rc < 0 ? rc : AG_OK;
     return run_gather_family(d, true, G, dy, dy_gs, w, nullptr, PtrTable{}, dx, dx_gs, workspace, workspace_bytes, s, o);
@@ -1962,7 +2005,7 @@ int conv_backward_weight_g(const AgConvDesc* d, int G, const float* x, long long
                            void* workspace, size_t workspace_bytes, hipStream_t s, const ConvOpts& o)
 {
     int rc = validate(d);
-    if (rc) return rc;
+    if (rc || (rc = take_status(true))) return rc;
     if (G < 1 || G > kMaxGroups || !x || !dy || (!dw && !o.dw_table)) { set_error("null conv tensor / bad group count"); return AG_ERR_INVALID_ARGUMENT; }
     if (o.dw_table && (!table_complete(*o.dw_table, G) || o.dw_row_stride <= 0 || d->k == 1)) { set_error("conv: bad weight-gradient table"); return AG_ERR_INVALID_ARGUMENT; }
     if (!o.dw_table && (rc = pointwise_backward_weight(d, G, x, x_gs, dy, dy_gs, dw, dw_gs, workspace, workspace_bytes, s)) != 0) return rc < 0 ? rc : AG_OK;
@@ -1979,6 +2022,7 @@ int conv_backward_weight_g(const AgConvDesc* d, int G, const float* x, long long
         wp.sy = wp.sx = 2;
         for (int t = 0; t < k2; t++) { wp.dy[t] = t / k; wp.dx[t] = t % k; }
     }
+    wp.status = status_word();
     wp.c = dw; wp.c_gs = dw_gs; wp.G = G; wp.ntaps = k2; wp.wscale = wscale_of(d);
     wp.c_row_stride = wp.Cg * k2; wp.c_chan_stride = k2;                         // [Mw][Cg][taps]
     if (o.wt_oihw && d->kind == AG_CONV_TRANSPOSE) { wp.c_row_stride = k2; wp.c_chan_stride = wp.Mw * k2; }   // rows = Cin: [Cout][Cin][taps]
@@ -2117,6 +2161,8 @@ int ag_conv_set_math(int mode)
 }
 
 int ag_conv_get_math(void) { return g_conv_math.load(std::memory_order_relaxed); }
+
+int ag_conv_status(int clear) { return take_status(clear != 0); }
 
 
 

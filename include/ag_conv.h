@@ -91,6 +91,16 @@ typedef enum AgConvMath { AG_CONV_MATH_FP32_MFMA = 0, AG_CONV_MATH_SPLIT_BF16 = 
 int ag_conv_set_math(int mode);
 int ag_conv_get_math(void);
 
+/* Range guard of the scaled fp16 forms (round 5).  SPLIT_F16 / F16 scale every operand tensor by its largest magnitude, which may be HANDED to a
+ * call (ag_layers.h x_maxima / operand_maxima, ConvOpts) instead of swept: a maximum that is too small (stale after an in-place write the caller
+ * did not account for) overflows fp16 and would silently put inf / NaN into the outputs.  Every MFMA convolution kernel therefore tests its
+ * accumulators in the epilogue (32 class tests per lane, once per tile) and raises a sticky flag in host-visible memory when one is not finite
+ * (the same happens for operands that were not finite to begin with).  The flag is read WITHOUT synchronising:
+ *   - the NEXT convolution call on any stream returns AG_ERR_RANGE (and clears the flag) instead of launching,
+ *   - ag_conv_status(clear) returns AG_ERR_RANGE / AG_OK on demand (after a stream synchronisation it covers everything enqueued before).
+ * A kernel that raised the flag still wrote its (non-finite) outputs; nothing is repaired. */
+int ag_conv_status(int clear);
+
 int ag_debug_mfma_rate(int blocks, int iters, float* out, void* stream);
 /* Same for v_mfma_f32_32x32x16_bf16 (calibration of the bf16-split option; not used by the product). */
 int ag_debug_mfma_rate_bf16(int blocks, int iters, float* out, void* stream);

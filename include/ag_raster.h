@@ -38,6 +38,7 @@ extern "C" {
 #define AG_ERR_SCRATCH_TOO_SMALL (-2)
 #define AG_ERR_HIP (-3)
 #define AG_ERR_UNSUPPORTED (-4)
+#define AG_ERR_RANGE (-5)          /* a convolution met a non-finite accumulator: include/ag_conv.h ag_conv_status */
 
 #define AG_TILE_X 16 /* cuda_rasterizer/config.h:16-17 — baked into the bit-exact tile/sort indices */
 #define AG_TILE_Y 16

@@ -318,3 +318,46 @@ def test_grouped_chain_without_view_directions_and_under_no_grad():
         multi = net.render_views(items, views)
         single = net.render({**items, **views[1]})
         _close(multi[1]['cano_tex_map'], single['cano_tex_map'], "colour map of view 1", tol=2e-5)
+
+
+def test_a_stale_handed_over_maximum_is_reported_not_silent():
+    """Range guard of the scaled fp16 forms (include/ag_conv.h ag_conv_status, round 5): a producer's maxima travel with the tensor
+    (grouped._handed_maxima); writes that bypass the version counter leave them stale.  A maximum too small by 2^8 overflows fp16 in the
+    consumer's loader: the kernel raises the host-visible flag, ``check_status`` (and the next convolution call) raise AgNativeError with
+    AG_ERR_RANGE instead of inf / NaN travelling on silently; after that the library works as before."""
+    import torch
+    from animatablegaussians_amd import _lib, conv as agc, grouped as gr
+    if not agc.needs_maxima():
+        pytest.skip("the arithmetic mode of this process does not scale its operands")
+    g = torch.Generator().manual_seed(3)
+    G, Cin, Cout, H = 3, 32, 32, 24
+    x = torch.randn(G, Cin, H, H, generator=g).cuda()
+    ws = [torch.randn(Cout, Cin, 3, 3, generator=g).cuda() for _ in range(G)]
+    bs = [torch.zeros(Cout).cuda() for _ in range(G)]
+    kb = torch.ones(4, 4).cuda() / 16
+    agc.check_status()                                           # clean before
+    good = gr.grouped_conv_layer(x, ws, bs, kb, 0.05, False)
+    torch.cuda.synchronize()
+    agc.check_status()
+    assert bool(torch.isfinite(good).all())
+    stale = torch.zeros(gr._OUT_MAXIMA_FLOATS, device="cuda")
+    stale.view(-1, 256)[:G] = float(x.abs().max()) / 256.0       # as if x had grown by 2^8 since its producer measured it
+    x._ag_maxima, x._ag_maxima_version = stale, x._version
+    bad = gr.grouped_conv_layer(x, ws, bs, kb, 0.05, False)
+    torch.cuda.synchronize()
+    assert not bool(torch.isfinite(bad).all())                   # the overflow happened ...
+    with pytest.raises(_lib.AgNativeError, match="code -5"):     # ... and is reported
+        agc.check_status()
+    del x._ag_maxima
+    again = gr.grouped_conv_layer(x, ws, bs, kb, 0.05, False)    # flag cleared: business as usual, same bits as before
+    torch.cuda.synchronize()
+    agc.check_status()
+    assert torch.equal(again, good)
+    # the NEXT convolution call reports by itself when nobody asked in between
+    x._ag_maxima, x._ag_maxima_version = stale, x._version
+    gr.grouped_conv_layer(x, ws, bs, kb, 0.05, False)
+    torch.cuda.synchronize()
+    with pytest.raises(_lib.AgNativeError, match="code -5"):
+        gr.grouped_conv_layer(x, ws, bs, kb, 0.05, False)
+    del x._ag_maxima
+    agc.check_status()
