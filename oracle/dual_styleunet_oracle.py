@@ -65,8 +65,11 @@ def haar_merge(x):
 
 
 class DualStyleUNetOracle:
-    def __init__(self, sd, inp_size=512, out_size=1024, middle_size=8, n_mlp=2, lr_mlp=0.01):
+    def __init__(self, sd, inp_size=512, out_size=1024, middle_size=8, n_mlp=2, lr_mlp=0.01, comb_as_two_halves=False):
         self.sd = sd
+        # conditioning probe (tests/test_styleunet_oracle_cpu.py): the decoders' comb convolutions summed as conv(out, W[:, :C1]) + conv(level, W[:, C1:])
+        # -- the same expression re-associated, as ag_grouped_comb_* evaluates it -- instead of one convolution of the concatenation
+        self.comb_as_two_halves = comb_as_two_halves
         self.n_mlp, self.lr_mlp = n_mlp, lr_mlp
         self.log_in, self.log_mid, self.log_out = int(math.log2(inp_size)), int(math.log2(middle_size)), int(math.log2(out_size)) - 1
         self.n_enc = self.log_in - 2 - self.log_mid + 1
@@ -144,6 +147,11 @@ class DualStyleUNetOracle:
             for n in range(self.n_dec):
                 if n == 0:
                     out = self.conv_layer(levels[-1], f"comb_convs.{n_comb - 1}")
+                elif n < n_comb and self.comb_as_two_halves:
+                    w = self.p(f"comb_convs.{n_comb - 1 - n}.0.weight")
+                    c1, sc = out.shape[1], 1 / math.sqrt(w.shape[1] * 9)
+                    y = F.conv2d(out, w[:, :c1] * sc, padding=1) + F.conv2d(levels[-1 - n], w[:, c1:] * sc, padding=1)
+                    out = fused_leaky_relu(y, self.p(f"comb_convs.{n_comb - 1 - n}.1.bias"))
                 elif n < n_comb:
                     out = self.conv_layer(torch.cat([out, levels[-1 - n]], 1), f"comb_convs.{n_comb - 1 - n}")
                 out = self.styled_conv(out, f"convs{b}.{2 * n}", w_latent, self.p(f"noises.noise_{2 * n}"), True)

@@ -161,12 +161,22 @@ def _golden_body(math, grouped=False):
     # 1.7-2.3, 1.5-1.6 at the 50/75/90/95/99th percentiles (profiles/r04_styleunet_grad_report_*.txt, all three paths): bar 3x (was 4x)
     for q in (50, 75, 90, 95):
         assert np.percentile(ours, q) <= 3 * np.percentile(ref, q), (q, np.percentile(ours, q), np.percentile(ref, q))
-    # the 99th percentile of ~250 rows is the third largest one, and the largest rows are the one-number quantities with their own caps below
-    # (noise strengths: the reference's fp32 run itself is off by 6.1e-2 on one of them; the pose-map gradient): taken over the parameter TENSORS
-    # on both sides (measured 1.5-2.3x in the three arithmetic modes and on the grouped chain, profiles/r04_styleunet_grad_report_*.txt)
+    # 99th percentile.  Over the parameter TENSORS on both sides: 3x (measured 1.5-2.3x in every mode and on the grouped chain).  Over ALL rows
+    # (round 5: asserted again) it is the third largest of ~230 rows, and the largest rows are the thirteen one-number quantities -- twelve noise
+    # strengths and the pose-map gradient's maximum --, which are heavy-tailed: re-associating the comb convolutions moves single noise strengths by
+    # 4-15x in the REFERENCE'S OWN fp32 arithmetic (tests/test_styleunet_oracle_cpu.py::test_the_one_number_gradients_move_by_factors...), and the
+    # bisect of round 5 (profiles/r05_grad_bisect/, r05_comb_split_flip_diag.txt) shows that the product chain's comb convolutions as two halves are
+    # exactly such a re-association: forward 1.4e-6 apart, pose-gradient deviations identical at the 50 / 90 / 99th percentile of the SAMPLES
+    # (1.2e-5 / 1.0e-4 / 6.3e-4 with the split and without, in fp16 and in exact-product fp32), differences above 5e-3 confined to 219 pixels in 6
+    # spots.  Measured all-rows p99 / reference: 1.13 (comb off) .. 3.35 (product chain), 2.35 in exact-product fp32 with the split: bar 4x; the
+    # results are deterministic since round 5 (fixed-order weight-gradient sums), so these are the same numbers on every run and box.
     tens = [(o, r) for o, r, n in rows if not n.endswith("noise.weight") and n != "pose"]
     o99, r99 = np.percentile([o for o, _ in tens], 99), np.percentile([r for _, r in tens], 99)
     assert o99 <= 3 * r99, (o99, r99)
+    assert np.percentile(ours, 99) <= 4 * np.percentile(ref, 99), (np.percentile(ours, 99), np.percentile(ref, 99))
+    # the pose-map gradient by DISTRIBUTION over its 12 288 stored samples (deviation / max|grad|): the bulk is what an arithmetic error would move,
+    # the maximum is what a single slope flip moves.  Measured 6.3e-4 / 2.0-2.9e-3 at the 99th / 99.9th percentile on every path and mode.
+    assert np.percentile(pose_dev, 99) <= 1.5e-3 and np.percentile(pose_dev, 99.9) <= 6e-3, (np.percentile(pose_dev, 99), np.percentile(pose_dev, 99.9))
     # per-tensor caps (fraction of the tensor's largest gradient; were 3e-2 / 0.12 with the atomically summed scalars): 1e-2 for
     # parameter tensors (measured worst 5.4e-3); 5e-2 for the twelve noise-strength scalars -- one number each, a sum over a whole
     # feature map of products with mixed signs, where the reference's OWN fp32 run is off by 6.1e-2 (convs2.5; ours 3.0e-2 there, every
