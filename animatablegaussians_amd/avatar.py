@@ -391,6 +391,8 @@ class AvatarNet(nn.Module):
         self._graphs = {}
 
     def _graphs_active(self):
+        # eval mode only: the captures bake ``self.color_style`` in, and ``random_style`` (a fresh colour style per call, :469) applies in training
+        # mode only -- so a captured pass and an eager one of the same mode always use the same style
         return getattr(self, "_use_graphs", False) and not self.training and not torch.is_grad_enabled()
 
     def _graphed(self, key, fn, inputs):

@@ -156,7 +156,9 @@ int ag_grouped_layer_forward(const AgGroupedLayerArgs* a, void* stream)
         if (!conv_math_needs_absmax() || a->k < 3 || !a->operand_maxima) return AG_OK;
         AmaxTensor t[2] = { AmaxTensor{ nullptr, &w, 0, w_len, 0, 1 }, AmaxTensor{ x, nullptr, xgs, x_len, 0, 1 } };
         const bool x_known = a->x_maxima && x == a->x;        // handed over by the call that produced x
-        if (x_known) t[1] = AmaxTensor{};
+        // ... then the x slot of operand_maxima gets the handed maxima themselves ("maxima of the 256 partial maxima": the same largest magnitude, inside
+        // the same launch), so that a backward call that is given operand_maxima WITHOUT x_maxima never reads a slot nobody wrote (round-4 advice)
+        if (x_known) t[1] = AmaxTensor{ a->x_maxima, nullptr, xgs ? (long long)kAmaxParts : 0, kAmaxParts, 0, 1 };
         const int rc1 = conv_absmax(t, 2, G, a->operand_maxima, s, omax, G);       // (and zeroes the slots of this call's own output maxima)
         if (rc1) return rc1;
         omax_zeroed = true;
@@ -501,7 +503,8 @@ int ag_grouped_comb_forward(const AgGroupedCombArgs* a, void* stream)
         const long long wrow = (long long)(a->C1 + a->C2) * 9;
         AmaxTensor mt[4] = { AmaxTensor{ a->x, nullptr, a->C1 * hw, a->C1 * hw, 0, 1, a->M }, AmaxTensor{ a->lev, nullptr, a->C2 * hw, a->C2 * hw, 0, 1, a->N },
                                    AmaxTensor{ nullptr, &w1, 0, (long long)a->C1 * 9, wrow, a->Cout, a->M }, AmaxTensor{ nullptr, &w2, 0, (long long)a->C2 * 9, wrow, a->Cout, a->N } };
-        if (a->x_maxima) mt[0] = AmaxTensor{};                 // handed over by the call that produced x
+        if (a->x_maxima) mt[0] = AmaxTensor{ a->x_maxima, nullptr, kAmaxParts, kAmaxParts, 0, 1, a->M };   // handed over by the call that produced x: the slot
+                                                                                                       // gets the handed maxima (as in ag_grouped_layer_forward)
         if ((rc = conv_absmax(mt, 4, a->M, am, s, a->out_maxima, a->M))) return rc;      // (and zeroes the slots of this call's own output maxima)
         const size_t slot = (size_t)kMaxGroups * kAmaxParts;
         o1.amax_x = a->x_maxima ? a->x_maxima : am; o2.amax_x = am + slot; o1.amax_w = am + 2 * slot; o2.amax_w = am + 3 * slot;

@@ -703,6 +703,9 @@ class GroupedStyleUNets:
         view_features = dict(view_features or {})
         lat, noises = zip(*(n._latent_and_noise([s], False, None, False) for n, s in zip(nets, styles)))
         levels = self._encode(x)
+        for i, v in view_features.items():
+            if isinstance(v, (list, tuple)) and len(v) == 0:
+                raise ValueError(f"grouped networks: network {i} was given an empty list of views (pass None / omit it for no view features)")
         multi = {i: isinstance(v, (list, tuple)) and len(v) > 0 and isinstance(v[0], (list, tuple)) for i, v in view_features.items()}
         views = {i: (list(view_features[i]) if multi[i] else [view_features[i]]) for i in view_features}
         # AG_GROUPED_STREAMS=2: the decoders as two chains (branch 1 / branch 2 of every network, G = 3 each) on two HIP streams
@@ -765,11 +768,13 @@ class GroupedStyleUNets:
                     tail.append((i, bb, mm, v))
         results = {}
         step = max(2, min(_lib.AG_MAX_GROUPS, int(os.environ.get("AG_GROUPED_TAIL_CHUNK", _lib.AG_MAX_GROUPS))))
+        # the tail stages' styles depend on (network, branch) only: one modulation GEMM per pair, shared by all views and chunks
+        tail_styles = {ib: nets[ib[0]]._stage_styles(ib[1], tail_stages, lat[ib[0]]) for ib in dict.fromkeys((i, b) for i, b, _, _ in tail)}
         for c0 in range(0, len(tail), step):
             chunk = tail[c0:c0 + step]
             tm = [(i, b) for i, b, _, _ in chunk]
             src = [m for _, _, m, _ in chunk]
-            tst = [nets[i]._stage_styles(b, tail_stages, lat[i]) for i, b in tm]
+            tst = [tail_styles[ib] for ib in tm]
             # view features: the members that have one must be one contiguous run (they are: members are ordered by network)
             rows = [r for r, (i, b, _, v) in enumerate(chunk) if views.get(i) and views[i][v] is not None and views[i][v][b - 1] is not None]
             vf = None

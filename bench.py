@@ -366,6 +366,7 @@ def main() -> None:
                            "through the library-owned step (ag_raster_forward_backward, one native call per view; per-camera argument structures and "
                            "output images prepared once, FusedRasterStep.prepare / run)"),
             "gaussians": P, "instances_per_view": int(R_mean), "tiles": T_tiles, "views": len(settings), "streams": args.streams,
+            "prewarm": max(0, args.prewarm),      # untimed steps BEFORE the --warmup steps (round 4: the first region of a process is cold)
             "parallelism": "1 process" if world == 1 else f"view-sharded x{world}, RCCL all-reduce of per-Gaussian grads (14 f32 each)",
             "backend": None if world == 1 else (backend if backend == "nccl" else f"{backend}: fewer GPUs than ranks, ranks share devices -- a "
                                                 "functional run of the N > 1 control flow, NOT a measurement"),

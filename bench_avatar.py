@@ -226,8 +226,8 @@ def conv_roofline(dev, steps=3):
         out, both_ms = measure()
     finally:
         agc.set_math(mode0)
-    terms = {"split_f16": 3, "split_bf16": 6, "split_bf16x3": 3}.get(mode0, 0)
-    part = "fp16" if mode0 == "split_f16" else "bf16"
+    terms = {"split_f16": 3, "split_bf16": 6, "split_bf16x3": 3, "f16": 1}.get(mode0, 0)
+    part = "fp16" if mode0 in ("split_f16", "f16") else "bf16"
     ach = out["achieved"]
     out.update({"bound": "mfma", "unit": "TFLOP/s", "traffic": None, "math": mode0,
                 "kernel": "gather_conv kernels + wgrad kernels (every convolution of the three DualStyleUNets' forward + backward as the product "
@@ -239,7 +239,12 @@ def conv_roofline(dev, steps=3):
                     "note": f"achieved = algorithmic fp32 FLOPs of the bracketed launches / their summed HIP-event durations; every fp32 product is "
                             f"{terms} {part} MFMA products, so executed = {terms} x achieved is what is priced against the dense {part} MFMA peak "
                             "(the same 2.5 PFLOP/s for both 16-bit types).  With real (random-mantissa) operands the 16-bit pipe is power-limited to "
-                            "~0.66 of that peak on this part (profiles/r02_conv_split_engine.md)"})
+                            "~0.66 of that peak on this part (profiles/r02_conv_split_engine.md)",
+                    "matrix_pipe_power_floor": {"ns_per_mfma_per_simd_real_operands": 20.7, "ns_per_mfma_per_simd_constant_operands": 13.6,
+                                                "executed_TFLOPs_at_the_floor": 1618.0,
+                                                "frac_of_the_floor": round(terms * ach / 1618.0, 4),
+                                                "source": "profiles/r05_mfma_floor_f16.txt (profiles/ub/mfma_floor_f16.hip: a pure v_mfma_f32_32x32x16_f16 stream on "
+                                                          "operands with random mantissas, any occupancy): no kernel on real data can execute more"}})
     else:
         out.update({"peak": MFMA_F32_PEAK_TF, "frac": round(ach / MFMA_F32_PEAK_TF, 4)})
     out["fp32_mfma_mode"] = f32
@@ -354,7 +359,7 @@ def full_step_probe(dev, block=4, blocks=5):
     import numpy as np
     step = TrainingStep(dev)
     mode0 = agc.get_math()
-    modes = [mode0] + [m for m in ("fp32", "split_bf16", "split_bf16x3") if m != mode0]
+    modes = [mode0] + [m for m in ("f16", "fp32", "split_bf16", "split_bf16x3") if m != mode0]
     def measure(first_pass):
         # Per arithmetic mode (the product's first) and batch shape: reset the caching allocator, let it settle for three untimed steps, then
         # time the blocks back to back.  (Interleaving the modes, as rounds 1-2 did to share clock history, makes the allocator regrow its
@@ -392,7 +397,9 @@ def full_step_probe(dev, block=4, blocks=5):
                 "ms_per_step_4views_min_max": [round(float(np.min(t4[m])), 2), round(float(np.max(t4[m])), 2)]}
 
     out = {"workload": "BASELINE configs[2]: StyleUNet x3 + LBS + raster fwd+bwd + L1/offset loss + fused Adam, 268 k Gaussians @1024^2",
-           "conv_math": mode0}
+           "conv_math": mode0, "adam_lr": step.lr,
+           "adam_lr_note": "the trainer's 5e-4 (configs/avatarrex_zzr/avatar.yaml) on this random-noise target inflates the Gaussians while the step is being "
+                           "timed (profiles/r04_fullstep_degrade.txt); Adam's kernel does the same work at any learning rate (AG_BENCH_LR overrides)"}
     out.update(rec(mode0))
     # BASELINE configs[3] at N = 1 (the anchor of the 8-GPU curve: 16 views of one pose per step, which 8 ranks render 2 each) and the
     # reference's WHOLE loss in the step (main_avatar.py:197-246: boundary compositing, L1, mask loss, 512^2 crop, 0.1 x LPIPS-VGG16),
@@ -438,7 +445,7 @@ def full_step_probe(dev, block=4, blocks=5):
     if discarded is not None:
         out["discarded_first_pass"] = dict(discarded, reason="a block more than 3x slower than the fastest of its pass: the pass was repeated once")
     keys = {"fp32": "conv_math_fp32", "split_bf16x3": "conv_math_split_bf16x3_opt_in_not_fp32_grade", "split_bf16": "conv_math_split_bf16",
-            "split_f16": "conv_math_split_f16"}
+            "split_f16": "conv_math_split_f16", "f16": "conv_math_f16_opt_in_the_references_cudnn_tf32_operand_grade"}
     for m in modes[1:]:
         out[keys[m]] = rec(m)
     return out

@@ -109,7 +109,9 @@ typedef struct AgGroupedLayerArgs {
                                       takes its own.  Untouched in the other arithmetic modes and by 1 x 1 layers. */
     const float* x_maxima;         /* AG_MAX_GROUPS * 256 floats or NULL: the largest magnitudes of `x` as a previous call's out_maxima left them (instance
                                       g at g * 256; a shared input at 0) -- forward and backward then do not sweep x (ignored by the down-sampling
-                                      ConvLayer, whose convolution reads the blurred input, and outside AG_CONV_MATH_SPLIT_F16) */
+                                      ConvLayer, whose convolution reads the blurred input, and outside the scaled fp16 modes).  The forward also copies
+                                      them into operand_maxima's input slot, so a backward call may pass operand_maxima with or without x_maxima.
+                                      They MUST be current: a maximum that is too small overflows fp16 (reported through ag_conv_status, AG_ERR_RANGE) */
     float* out_maxima;             /* forward: AG_MAX_GROUPS * 256 floats or NULL: receives the largest magnitudes of `out` (from the kernel that writes
                                       it wherever that kernel can, by a sweep otherwise; untouched outside AG_CONV_MATH_SPLIT_F16) */
 } AgGroupedLayerArgs;
