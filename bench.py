@@ -247,9 +247,9 @@ def main() -> None:
     R_mean = float(np.mean([R_seen[v] for v in views_of_rank]))
 
     breakdown = None
-    if args.breakdown and rank == 0:
-        _lib.prof_enable(range(_lib.AG_K_COUNT))
-        for i in range(min(args.steps, 64)):
+    if rank == 0 and (args.breakdown or world == 1):      # round 5: always at N = 1 (64 one-stream steps = ~20 ms), so that the driver's record carries
+        _lib.prof_enable(range(_lib.AG_K_COUNT))          # every raster kernel's fraction (`roofline_raster_kernels`), not the dominant one's only
+        for i in range(64 if not args.breakdown else min(args.steps, 64)):
             step_on(i)            # one stream: per-kernel times without the overlap of the pipelined timed region
         sync_all() if world == 1 else torch.cuda.synchronize(dev)
         bd = _lib.prof_collect()
@@ -381,11 +381,37 @@ def main() -> None:
         },
     }
     if breakdown is not None:
-        out["kernels_us"] = breakdown
         # algorithmic bytes per launch of every raster kernel (DESIGN.md section 4 / SURVEY.md 8d) against its one-stream duration
         alg = {"preprocess_kernel": 112 * P, "tile_scan_kernel": 8 * T_tiles, "scatter_kernel": 20 * P + 12 * R_mean,
                "tile_sort_kernel": 24 * R_mean, "blend_forward_kernel": 8 * T_tiles + 44 * R_mean + 24 * W * H,
                "blend_backward_kernel": alg_dom, "preprocess_backward_kernel": 220 * P}
+        pmc = {}
+        try:
+            import json as _json
+            with open(os.path.join(ROOT, "profiles", "traffic_head.json")) as f:
+                tj = _json.load(f).get("kernels", {})
+            frag = {"preprocess_kernel": "::preprocess_kernel", "tile_scan_kernel": "tile_scan_kernel", "scatter_kernel": "scatter_kernel",
+                    "tile_sort_kernel": "tile_sort_kernel", "blend_forward_kernel": "blend_forward_kernel",
+                    "blend_backward_kernel": "blend_backward_wave_kernel", "preprocess_backward_kernel": "preprocess_backward_kernel"}
+            for k, fr in frag.items():
+                hit = [v["hbm_bytes"] for kk, v in tj.items() if fr in kk]
+                if hit:
+                    pmc[k] = float(sum(hit))
+        except (OSError, ValueError, KeyError):
+            pass
+        rk = {"what": "every raster kernel of ONE view on ONE stream (64 dependent steps, HIP events around every launch): average launch, "
+                      "SURVEY 8(d) algorithmic bytes, achieved = bytes / time against the 8 TB/s HBM peak; pmc_ratio = HBM bytes per launch from the "
+                      "PMC counters (profiles/traffic_head.json, separate rocprofv3 --pmc passes, not this run) / algorithmic bytes",
+              "one_stream_sum_us": round(sum(breakdown.get(k, 0.0) for k in alg), 2)}
+        for k in alg:
+            us = breakdown.get(k, 0.0)
+            if us > 0:
+                gbs = alg[k] / (us * 1e-6) / 1e9
+                rk[k] = {"avg_launch_us": us, "algorithmic_MB": round(alg[k] / 1e6, 2), "achieved_GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4),
+                         "pmc_ratio": round(pmc[k] / alg[k], 2) if k in pmc else None}
+        out["roofline_raster_kernels"] = rk
+    if breakdown is not None and args.breakdown:
+        out["kernels_us"] = breakdown
         out["kernels_algorithmic_GBps"] = {k: round(alg[k] / (breakdown[k] * 1e-6) / 1e9, 1) for k in alg if breakdown.get(k, 0) > 0}
         out["kernels_algorithmic_MB"] = {k: round(alg[k] / 1e6, 2) for k in alg}
         # what a pure streaming kernel achieves at the same footprints on this box: a device copy moving as many bytes (half read, half
