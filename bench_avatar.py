@@ -57,7 +57,7 @@ class TrainingStep:
     """The training iteration of config 3 as a callable: ``step(i, V)`` renders V cameras of one pose, takes the loss, back-propagates,
     exchanges gradients (N > 1) and applies fused Adam.  Shared by this script and by bench.py's ``full_step`` leg."""
 
-    def __init__(self, dev, viewdirs=True, lpips=False, world=1, rank=0, lr=None):
+    def __init__(self, dev, viewdirs=True, lpips=False, world=1, rank=0, lr=None, pose_per_rank=False):
         import numpy as np
         import torch
         from animatablegaussians_amd import synth
@@ -67,7 +67,10 @@ class TrainingStep:
         self.dev, self.world, self.rank = dev, world, rank
         self.net = net = AvatarNet.synthetic({'with_viewdirs': viewdirs}, device=dev)
         self.n_params = sum(p.numel() for p in net.parameters())
-        A = joint_transforms(net.lbs.shape[1], dev)
+        # pose_per_rank (round 5, DESIGN section 6 mode (b)): every rank trains on ITS OWN pose (another frame of the sequence, as a data-parallel
+        # trainer would deal them) -- nothing of the step is replicated across ranks, so the job scales weakly; the default shards the views of ONE pose
+        self.pose_per_rank = bool(pose_per_rank)
+        A = joint_transforms(net.lbs.shape[1], dev, seed=7 + (rank if pose_per_rank else 0))
         W = H = 1024
         cams = synth.free_view_cameras(8, img=W)
         self.views = [{'cano2live_jnt_mats': A, 'cano2live_jnt_mats_woRoot': A,
@@ -103,6 +106,8 @@ class TrainingStep:
         return (out['rgb_map'] - self.target).abs().mean() + 0.005 * torch.linalg.norm(out['offset'], dim=-1).mean()
 
     def cameras(self, i, V):
+        if self.pose_per_rank:          # every rank its own pose: the cameras need not differ between ranks
+            return [self.views[(i * V + j + self.rank) % len(self.views)] for j in range(V)]
         return [self.views[((i * self.world + self.rank) * V + j) % len(self.views)] for j in range(V)]
 
     def infer(self, i, V=1):
@@ -464,6 +469,8 @@ def main() -> None:
     ap.add_argument("--views", type=int, default=1, help="cameras of the same pose per step (multi-view step: "
                     "pose-dependent work shared through AvatarNet.render_views)")
     ap.add_argument("--conv-roofline", action="store_true", help="only print the in-run MFMA roofline of the convolution kernels")
+    ap.add_argument("--pose-per-rank", action="store_true", help="N > 1: every rank trains on its own pose (x --views cameras of it) instead of sharding the "
+                    "views of one pose: no pose-shared work is replicated, the job scales weakly (DESIGN.md section 6, mode (b))")
     args = ap.parse_args()
 
     import torch
@@ -483,7 +490,7 @@ def main() -> None:
         print(json.dumps({"roofline_mfma": conv_roofline(dev)}), flush=True)
         return
 
-    ts = TrainingStep(dev, viewdirs=not args.no_viewdirs, lpips=args.lpips and not args.infer, world=world, rank=rank)
+    ts = TrainingStep(dev, viewdirs=not args.no_viewdirs, lpips=args.lpips and not args.infer, world=world, rank=rank, pose_per_rank=args.pose_per_rank)
     net, n_params, lp = ts.net, ts.n_params, ts.lp
     V = args.views
     if args.infer:
@@ -535,7 +542,12 @@ def main() -> None:
             "config": {"workload": f"SURVEY 8d config 3: {V} view(s) of one pose per step, whole render path"
                                    + (" (eval)" if args.infer else " + loss + backward + Adam"),
                        "gaussians": int(net.lbs.shape[0]), "parameters": int(n_params), "with_viewdirs": bool(net.with_viewdirs), "views_per_step": V, "lpips_loss_tail": lp is not None, "hip_graphs": bool(args.infer and args.graphs),
-                       "parallelism": "1 process" if world == 1 else f"view-sharded x{world}, bucketed RCCL all-reduce of {n_params * 4 >> 20} MB grads",
+                       "parallelism": "1 process" if world == 1 else
+                                      (f"one pose per rank x{world} ({V} view(s) each)" if args.pose_per_rank else f"view-sharded x{world} (the views of ONE pose)")
+                                      + f", bucketed RCCL all-reduce of {n_params * 4 >> 20} MB grads",
+                       "scaling_mode": None if world == 1 else ("(b) one pose per rank: weak scaling, nothing replicated" if args.pose_per_rank else
+                                                                "(a) views of one pose sharded: the pose-shared StyleUNet work is replicated on every rank "
+                                                                "(ceiling = t(all views, 1 GPU) / t(views per rank, 1 GPU): DESIGN.md section 6)"),
                        "backend": None if world == 1 else (backend if backend == "nccl" else f"{backend}: fewer GPUs than ranks, ranks share "
                                                            "devices -- a functional run, NOT a measurement"),
                        "replicas_identical_after_run": replicas_identical},

@@ -131,3 +131,25 @@ def test_training_replicas_stay_identical_over_two_adam_steps_two_ranks_one_gpu(
     assert len(lines) == 1, p.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["replicas_identical_after_run"] is True, d["config"]
+
+
+def test_pose_per_rank_mode_keeps_replicas_identical_two_ranks_one_gpu():
+    """DESIGN.md section 6 mode (b), `bench_avatar.py --gpus 2 --pose-per-rank --views 2`: every rank renders two cameras of ITS OWN pose (different joint
+    transforms per rank, so different pose maps, Gaussians and gradients), the bucketed exchange averages the gradients, fused Adam steps: after two
+    iterations both ranks hold bit-identical parameters, and the line says which scaling mode it reports.  Functional only (ranks share this GPU over gloo)."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench_avatar.py"), "--gpus", "2", "--steps", "2", "--warmup", "0", "--views", "2",
+                        "--pose-per-rank"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["views_per_step"] == 2
+    assert d["config"]["replicas_identical_after_run"] is True, d["config"]
+    assert d["config"]["scaling_mode"].startswith("(b)") and "one pose per rank x2" in d["config"]["parallelism"]
+    assert abs(d["value"] * d["ms_per_step"] - 2 * 2 * 1000.0) < 40.0          # whole-job aggregate: 2 ranks x 2 views per step
