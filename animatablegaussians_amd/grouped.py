@@ -120,6 +120,33 @@ def _new_out_maxima(out):
     return m
 
 
+def _merge_shared(stacked, owners, needs, view_shape=None):
+    """Gradients of stacked members -> one gradient per DISTINCT parameter.  ``stacked`` [G, ...]: member g's gradient; ``owners[g]``: the parameter
+    tensor it belongs to (several views of a pose run the colour network's tail once per view, all on the same parameters); ``needs[g]``.
+    Returns G entries: the SUM over a parameter's members at its first member, None at the others (autograd then has nothing to accumulate: it
+    used to add the members' gradients pairwise, 41 small additions per extra view of a training step, profiles/r05_per_view_breakdown_*.txt)."""
+    G = len(owners)
+    if stacked is None:
+        return [None] * G
+    slot, first = [], {}
+    for g, t in enumerate(owners):
+        slot.append(first.setdefault(t if isinstance(t, int) else t.data_ptr(), len(first)))
+    def shaped(t):
+        return t.view(view_shape) if view_shape is not None else t
+    if len(first) == G:
+        return [shaped(stacked[g]) if needs[g] else None for g in range(G)]
+    summed = torch.zeros((len(first),) + tuple(stacked.shape[1:]), dtype=stacked.dtype, device=stacked.device)
+    summed.index_add_(0, _index(slot, stacked.device), stacked)
+    seen, out = set(), []
+    for g in range(G):
+        if slot[g] in seen or not needs[g]:
+            out.append(None)
+        else:
+            out.append(shaped(summed[slot[g]]))
+        seen.add(slot[g])
+    return out
+
+
 def _scratch(nfloats, ws_bytes, dev):
     buf = torch.empty(nfloats * 4 + ws_bytes + 512, dtype=torch.uint8, device=dev)
     base = (buf.data_ptr() + 255) & ~255
@@ -236,12 +263,14 @@ class _GroupedLayer(torch.autograd.Function):
         with _lib.on_device(dev):
             _lib.check(_lib.lib().ag_grouped_layer_backward(ctypes.byref(a), _stream(dev)), "ag_grouped_layer_backward")
         none = [None] * G
-        g_ws = [gw[i] if (gw is not None and pn[i]) else None for i in range(G)]
-        g_bs = [gbn[i, :a.Cout] if a.want_bias else None for i in range(G)]
+        # one gradient per distinct parameter (members that share a parameter -- the views of a pose -- are summed here, not by autograd)
+        g_ws = _merge_shared(gw, ws, pn[:G])
         if not modulated:
+            g_bs = _merge_shared(gbn[:, :a.Cout] if a.want_bias else None, biases, pn[G:2 * G])
             return (None, None, None, None, None, None, gx, *g_ws, *g_bs)
-        g_ss = [gs[i] if (gs is not None and pn[G + i]) else None for i in range(G)]
-        g_nws = [gbn[i, a.Cout:].view(nws[i].shape) if a.want_noise_weight else None for i in range(G)]
+        g_bs = _merge_shared(gbn[:, :a.Cout] if a.want_bias else None, biases, pn[4 * G:5 * G])
+        g_ss = _merge_shared(gs, styles, pn[G:2 * G])
+        g_nws = _merge_shared(gbn[:, a.Cout:] if a.want_noise_weight else None, nws, pn[3 * G:4 * G], view_shape=tuple(nws[0].shape)) if has_noise else none
         return (None, None, None, None, None, None, gx, *g_ws, *g_ss, *none, *g_nws, *g_bs)
 
 
@@ -320,6 +349,7 @@ class _GroupedToRGB(torch.autograd.Function):
             outs.append(out)
             wms.append(wm)
         ctx.save_for_backward(x, *wms, *ws, *styles)
+        ctx.bias_owners = [b.data_ptr() for b in biases]      # the parameters' identity, for the backward's sums over shared heads
         ctx.cfg = (tuple(runs), float(scale), tuple(t is not None for t in skips), tuple(tuple(b.shape) for b in biases))
         ctx.k_up = k_up                       # a module buffer, not an output of this node
         return tuple(outs)
@@ -361,10 +391,10 @@ class _GroupedToRGB(torch.autograd.Function):
             with _lib.on_device(dev):
                 _lib.check(_lib.lib().ag_grouped_to_rgb_backward(ctypes.byref(a), _stream(dev)), "ag_grouped_to_rgb_backward")
             g_skips[r] = gskip
-            for i in range(G):
-                g_ws[s + i] = gw[i] if (gw is not None and pn[s + i]) else None
-                g_ss[s + i] = gst[i] if (gst is not None and pn[M + s + i]) else None
-                g_bs[s + i] = gb[i].view(bshapes[s + i]) if (gb is not None and pn[2 * M + s + i]) else None
+            # one gradient per distinct parameter of the run (the views of a pose share the heads' parameters)
+            g_ws[s:e] = _merge_shared(gw, ws[s:e], pn[s:e])
+            g_ss[s:e] = _merge_shared(gst, styles[s:e], pn[M + s:M + e])
+            g_bs[s:e] = _merge_shared(gb, ctx.bias_owners[s:e], pn[2 * M + s:2 * M + e], view_shape=bshapes[s])
         return (None, None, None, gx, *g_skips, *g_ws, *g_ss, *g_bs)
 
 
@@ -471,7 +501,7 @@ class _GroupedComb(torch.autograd.Function):
         with _lib.on_device(dev):
             _lib.check(_lib.lib().ag_grouped_comb_backward(ctypes.byref(a), _stream(dev)), "ag_grouped_comb_backward")
         g_ws = [gW[r] if (need_w and pn[r]) else None for r in range(N)]
-        g_bs = [gb[m] if (gb is not None and pn[N + m]) else None for m in range(M)]
+        g_bs = _merge_shared(gb, bs, pn[N:N + M])                   # the views of a pose share the members' biases
         return (None, None, gx, glev, *g_ws, *g_bs)
 
 

@@ -361,3 +361,48 @@ def test_a_stale_handed_over_maximum_is_reported_not_silent():
         gr.grouped_conv_layer(x, ws, bs, kb, 0.05, False)
     del x._ag_maxima
     agc.check_status()
+
+
+def test_multi_view_gradients_are_the_sum_over_the_views(net):
+    """Three views of one pose through the grouped chain (the colour network's view-dependent tail runs once per view ON THE SAME PARAMETERS; round 5:
+    grouped._merge_shared sums the members' parameter gradients inside the layer's backward instead of leaving ~40 pairwise additions per extra
+    view to autograd): every probed parameter gradient equals the sum of the three single-view passes' gradients, up to summation order."""
+    import torch
+    items = _items(net)
+    net.get_pose_map(items)
+    net.eval()
+    G = net._grouped_nets()
+    assert G is not None
+    pose = items['smpl_pos_map'][:3][None].contiguous()
+    styles = [net.position_style, net.color_style, net.other_style]
+    gen = torch.Generator().manual_seed(21)
+    feats = [tuple((torch.randn(1, 128, 128, 128, generator=gen) * 0.1).cuda() for _ in range(2)) for _ in range(3)]
+    ups_c = [torch.randn(1, 6, 1024, 1024, generator=gen).cuda() for _ in range(3)]
+    ups_p, ups_o = torch.randn(1, 6, 1024, 1024, generator=gen).cuda(), torch.randn(1, 16, 1024, 1024, generator=gen).cuda()
+    probe = ["convs1.10.conv.weight", "convs2.11.conv.weight", "convs1.11.conv.modulation.weight", "convs2.10.noise.weight", "convs1.11.activate.bias",
+             "to_rgbs1.5.conv.weight", "to_rgbs2.5.bias", "to_rgbs1.5.conv.modulation.bias", "comb_convs.0.0.weight", "comb_convs.0.1.bias",
+             "convs1.8.conv.weight", "comb_convs.2.0.weight", "cond_convs.1.conv1.0.weight", "style.1.weight"]
+
+    def grads():
+        return {k: net.color_net._p(k).grad.clone() for k in probe}
+    net.zero_grad(set_to_none=True)
+    pm, cms, om = G.forward(styles, pose, {1: feats})
+    assert isinstance(cms, list) and len(cms) == 3
+    torch.autograd.backward([pm, om] + cms, [ups_p, ups_o] + ups_c)
+    multi = grads()
+    net.zero_grad(set_to_none=True)
+    for v in range(3):
+        pm1, cm1, om1 = G.forward(styles, pose, {1: feats[v]})
+        if v == 0:
+            torch.autograd.backward([pm1, om1, cm1], [ups_p, ups_o, ups_c[v]])
+        else:
+            cm1.backward(ups_c[v])
+    single = grads()
+    net.zero_grad(set_to_none=True)
+    worst = 0.0
+    for k in probe:
+        scale = float(single[k].abs().max())
+        err = float((multi[k] - single[k]).abs().max()) / max(scale, 1e-30)
+        worst = max(worst, err)
+        assert err <= (2e-2 if k.endswith("noise.weight") else 5e-3), (k, err)
+    print(f"three views at once vs three single-view passes: worst relative parameter-gradient deviation {worst:.2e} over {len(probe)} probes")
