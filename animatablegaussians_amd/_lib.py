@@ -122,6 +122,15 @@ class AgGroupedCombArgs(ctypes.Structure):    # include/ag_layers.h
                 + [(n, c_vp) for n in ("g_out", "g_x", "g_lev", "g_weight_x", "g_weight_lev", "g_bias", "g_weight", "operand_maxima", "x_maxima", "out_maxima")])
 
 
+AG_ADAM_MAX_TENSORS = 48
+
+
+class AgAdamArgs(ctypes.Structure):           # include/ag_optim.h
+    _fields_ = ([("n", c_i32), ("maximize", c_i32)] + [(n, c_vp * AG_ADAM_MAX_TENSORS) for n in ("param", "grad", "exp_avg", "exp_avg_sq")]
+                + [("numel", ctypes.c_int64 * AG_ADAM_MAX_TENSORS)]
+                + [(n, c_f) for n in ("lr", "beta1", "beta2", "eps", "weight_decay", "bias_correction1", "bias_correction2_sqrt")])
+
+
 class AgSmplxModel(ctypes.Structure):
     _fields_ = [("V", c_i32), ("J", c_i32), ("NB", c_i32), ("reserved", c_i32)] + [(n, c_vp) for n in (
         "v_template", "shapedirs", "posedirs", "J_regressor", "parents", "lbs_weights", "joint_template", "joint_dirs")]
@@ -172,6 +181,8 @@ SYMBOLS = [
     ("ag_conv_set_math", ctypes.c_int, [ctypes.c_int]),
     ("ag_conv_get_math", ctypes.c_int, []),
     ("ag_conv_status", ctypes.c_int, [ctypes.c_int]),
+    ("ag_adam_args_bytes", c_sz, []),
+    ("ag_adam_step", ctypes.c_int, [ctypes.POINTER(AgAdamArgs), c_vp]),
     ("ag_debug_mfma_rate", ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_vp, c_vp]),
     ("ag_debug_mfma_rate_bf16", ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_vp, c_vp]),
     # include/ag_smplx.h

@@ -135,8 +135,14 @@ def _merge_shared(stacked, owners, needs, view_shape=None):
         return t.view(view_shape) if view_shape is not None else t
     if len(first) == G:
         return [shaped(stacked[g]) if needs[g] else None for g in range(G)]
-    summed = torch.zeros((len(first),) + tuple(stacked.shape[1:]), dtype=stacked.dtype, device=stacked.device)
-    summed.index_add_(0, _index(slot, stacked.device), stacked)
+    R = len(first)
+    if G % R == 0 and all(slot[g] == g % R for g in range(G)):            # view-major order (view, branch): one strided reduction
+        summed = stacked.reshape((G // R, R) + tuple(stacked.shape[1:])).sum(0)
+    elif G % R == 0 and all(slot[g] == g // (G // R) for g in range(G)):   # runs of equal length
+        summed = stacked.reshape((R, G // R) + tuple(stacked.shape[1:])).sum(1)
+    else:
+        summed = torch.zeros((R,) + tuple(stacked.shape[1:]), dtype=stacked.dtype, device=stacked.device)
+        summed.index_add_(0, _index(slot, stacked.device), stacked)
     seen, out = set(), []
     for g in range(G):
         if slot[g] in seen or not needs[g]:

@@ -86,7 +86,14 @@ class TrainingStep:
         if lr is None:
             lr = float(os.environ.get("AG_BENCH_LR", "1e-7"))
         self.lr = lr
-        self.opt = torch.optim.Adam(net.parameters(), lr=lr, fused=True)
+        # the optimizer step: FusedAdam = torch.optim.Adam's update as this library's streaming kernel (include/ag_optim.h; same state layout);
+        # AG_BENCH_ADAM=torch: torch's own fused multi-tensor kernel (the A/B)
+        self.adam = os.environ.get("AG_BENCH_ADAM", "ag")
+        if self.adam == "torch":
+            self.opt = torch.optim.Adam(net.parameters(), lr=lr, fused=True)
+        else:
+            from animatablegaussians_amd.optim import FusedAdam
+            self.opt = FusedAdam(net.parameters(), lr=lr)
         self.lp = None
         if lpips:
             from animatablegaussians_amd import losses
@@ -402,7 +409,7 @@ def full_step_probe(dev, block=4, blocks=5):
                 "ms_per_step_4views_min_max": [round(float(np.min(t4[m])), 2), round(float(np.max(t4[m])), 2)]}
 
     out = {"workload": "BASELINE configs[2]: StyleUNet x3 + LBS + raster fwd+bwd + L1/offset loss + fused Adam, 268 k Gaussians @1024^2",
-           "conv_math": mode0, "adam_lr": step.lr,
+           "conv_math": mode0, "adam_lr": step.lr, "adam": "animatablegaussians_amd.optim.FusedAdam (include/ag_optim.h)" if step.adam != "torch" else "torch.optim.Adam(fused=True)",
            "adam_lr_note": "the trainer's 5e-4 (configs/avatarrex_zzr/avatar.yaml) on this random-noise target inflates the Gaussians while the step is being "
                            "timed (profiles/r04_fullstep_degrade.txt); Adam's kernel does the same work at any learning rate (AG_BENCH_LR overrides)"}
     out.update(rec(mode0))

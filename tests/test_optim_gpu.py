@@ -1,0 +1,61 @@
+"""FusedAdam (include/ag_optim.h) against torch.optim.Adam: the same parameters after several steps, the same state_dict layout."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("wd,maximize", [(0.0, False), (0.01, False), (0.0, True)])
+def test_fused_adam_equals_torch_adam(wd, maximize):
+    """Tensors of awkward lengths (1, 3, a prime, > one chunk, a view offset that breaks 16-byte alignment), 5 steps with fresh gradients:
+    parameters and both moments agree with torch.optim.Adam to fp32 rounding (different association of the same expression)."""
+    import torch
+    from animatablegaussians_amd.optim import FusedAdam
+    g = torch.Generator().manual_seed(1)
+    shapes = [(1,), (3,), (4099,), (64, 64, 3, 3), (512, 512), (7, 13)] + [(17,)] * 60        # > 48 tensors: two native calls
+    base = [torch.randn(*s, generator=g) for s in shapes]
+    pool = torch.randn(1003, generator=g).cuda()
+    mis = torch.nn.Parameter(pool[1:1001])                      # data pointer 4 bytes off a 16-byte boundary
+    ours = [torch.nn.Parameter(t.clone().cuda()) for t in base] + [mis]
+    ref = [torch.nn.Parameter(t.clone().cuda()) for t in base] + [torch.nn.Parameter(pool[1:1001].clone())]
+    kw = dict(lr=3e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=wd, maximize=maximize)
+    oa, ob = FusedAdam(ours, **kw), torch.optim.Adam(ref, **kw)
+    for step in range(5):
+        for a, b in zip(ours, ref):
+            gr = torch.randn(a.shape, generator=g).cuda() * (10.0 ** (step - 2))
+            a.grad, b.grad = gr.clone(), gr.clone()
+        oa.step()
+        ob.step()
+    torch.cuda.synchronize()
+    for a, b in zip(ours, ref):
+        assert torch.allclose(a, b, rtol=2e-6, atol=1e-7), float((a - b).abs().max())
+        sa, sb = oa.state[a], ob.state[b]
+        assert float(sa["step"]) == float(sb["step"]) == 5.0
+        assert torch.allclose(sa["exp_avg"], sb["exp_avg"], rtol=2e-6, atol=1e-9) and torch.allclose(sa["exp_avg_sq"], sb["exp_avg_sq"], rtol=2e-6, atol=1e-12)
+
+
+def test_fused_adam_state_dict_loads_into_torch_adam_and_back():
+    import torch
+    from animatablegaussians_amd.optim import FusedAdam
+    ps = [torch.nn.Parameter(torch.randn(33, 5).cuda()), torch.nn.Parameter(torch.randn(100).cuda())]
+    qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    a, b = FusedAdam(ps, lr=1e-2), torch.optim.Adam(qs, lr=1e-2, fused=True)
+    for p in ps + qs:
+        p.grad = torch.ones_like(p)
+    a.step()
+    b.load_state_dict(a.state_dict())            # ours -> torch
+    for p, q in zip(ps, qs):
+        q.data.copy_(p.data)
+    for p in ps + qs:
+        p.grad = torch.full_like(p, 0.5)
+    a.step()
+    b.step()
+    for p, q in zip(ps, qs):
+        assert torch.allclose(p, q, rtol=2e-6, atol=1e-7)
+    a2 = FusedAdam(ps, lr=1e-2)
+    a2.load_state_dict(b.state_dict())           # torch (device-resident step counter) -> ours
+    assert float(a2.state[ps[0]]["step"]) == 2.0 and a2.state[ps[0]]["step"].device.type == "cpu"
+    h = torch.nn.Parameter(torch.randn(4).cuda().half())
+    h.grad = torch.ones_like(h)
+    with pytest.raises(RuntimeError):           # no fallback: anything but dense fp32 on one GPU is refused
+        FusedAdam([h]).step()
