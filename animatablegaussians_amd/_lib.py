@@ -154,6 +154,7 @@ SYMBOLS = [
     ("ag_raster_forward_backward_enqueue", ctypes.c_int, [ctypes.POINTER(AgRasterForwardArgs), ctypes.POINTER(AgRasterBackwardArgs), c_i32, c_vp,
                                                           ctypes.POINTER(c_i32)]),
     ("ag_raster_collect", ctypes.c_int, [c_i32, ctypes.POINTER(c_i32)]),
+    ("ag_raster_large_tile_sort", ctypes.c_int, [c_i32]),
     ("ag_raster_mark_visible", ctypes.c_int, [c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
     ("ag_prof_kernel_name", ctypes.c_char_p, [c_i32]),
     ("ag_prof_enable", ctypes.c_int, [ctypes.c_uint32]),

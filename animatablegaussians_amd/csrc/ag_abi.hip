@@ -1,5 +1,6 @@
 // C-ABI entry points of libag_hip.so (declared in include/ag_raster.h): argument validation, scratch sizing,
 // stage orchestration.  Host code only; the kernels live in the other translation units.
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <mutex>
@@ -150,6 +151,12 @@ int ag_raster_describe_scratch(int32_t P, int32_t W, int32_t H, int32_t R, AgRas
     return AG_OK;
 }
 
+// Large-class sort launch (ag_binning.hip launch_bin_sort): enqueued behind a frame only once some frame of the process has had a tile of >= 2048
+// instances.  The paths that enqueue everything before the host knows the counts (optimistic, enqueue + collect) consult this flag; a frame that
+// needed the launch although it was skipped comes back as AG_ERR_SCRATCH_TOO_SMALL (untouched outputs, like an overflow) with the flag raised, and
+// the caller's redo then gets the launch.  The host-synchronised path (plan + render) always launches it.
+static std::atomic<int> g_large_tiles_seen{ 0 };
+
 int ag_raster_forward_plan(const AgRasterForwardArgs* a, void* stream, int32_t* num_rendered_host)
 {
     if (!num_rendered_host) { set_error("null num_rendered_host"); return AG_ERR_INVALID_ARGUMENT; }
@@ -182,19 +189,22 @@ int ag_raster_forward_optimistic(const AgRasterForwardArgs* a, int32_t capacity,
     int32_t* w = pinned_word();
     hipEvent_t ev = plan_event();
     if (!w || !ev) { set_error("hipHostMalloc / hipEventCreate failed"); return AG_ERR_HIP; }
+    const bool skip_large = g_large_tiles_seen.load(std::memory_order_relaxed) == 0;
     if ((rc = launch_preprocess(*a, s))) return rc;
-    if ((rc = launch_tile_scan(*a, s, (uint32_t)capacity))) return rc;
+    if ((rc = launch_tile_scan(*a, s, (uint32_t)capacity, skip_large))) return rc;
     ImageLayout il((size_t)a->W, (size_t)a->H);
     const char* ib = aligned_base(a->image_buffer);
-    if ((rc = check_hip(hipMemcpyAsync(w, ib + il.num_rendered, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, s), "read num_rendered"))) return rc;
+    if ((rc = check_hip(hipMemcpyAsync(w, ib + il.num_rendered, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, s), "read num_rendered"))) return rc;
     if ((rc = check_hip(hipEventRecord(ev, s), "record plan event"))) return rc;
     // everything else is enqueued BEFORE the host learns the count: the GPU never waits for the host round trip
-    if ((rc = launch_bin_sort(*a, capacity, s))) return rc;
+    if ((rc = launch_bin_sort(*a, capacity, s, skip_large))) return rc;
     if ((rc = launch_blend_forward(*a, capacity, s))) return rc;
     if ((rc = check_hip(hipEventSynchronize(ev), "wait for the instance count"))) return rc;
     *num_rendered_host = w[0];
+    if (w[3] > 0) g_large_tiles_seen.store(1, std::memory_order_relaxed);
     if (w[2]) {
-        set_error("optimistic forward: %d instances exceed the capacity of %d; redo with ag_raster_forward_plan + _render", w[0], capacity);
+        if (w[0] <= capacity) set_error("optimistic forward: %d tiles of >= 2048 instances and the large-class sort was not enqueued for this frame; redo it", w[3]);
+        else set_error("optimistic forward: %d instances exceed the capacity of %d; redo with ag_raster_forward_plan + _render", w[0], capacity);
         return AG_ERR_SCRATCH_TOO_SMALL;
     }
     return AG_OK;
@@ -307,13 +317,14 @@ int ag_raster_forward_backward_enqueue(const AgRasterForwardArgs* f, AgRasterBac
     if (tk < 0) { set_error("no free read-back ticket (64 views pending) or hipHostMalloc / hipEventCreate failed"); return AG_ERR_HIP; }
     Ticket& t = g_tk[tk];
     auto fail = [&](int code) { std::lock_guard<std::mutex> lk(g_tk_mu); t.busy = false; return code; };
+    const bool skip_large = g_large_tiles_seen.load(std::memory_order_relaxed) == 0;
     if ((rc = launch_preprocess(*f, s))) return fail(rc);
-    if ((rc = launch_tile_scan(*f, s, (uint32_t)capacity))) return fail(rc);
+    if ((rc = launch_tile_scan(*f, s, (uint32_t)capacity, skip_large))) return fail(rc);
     ImageLayout il((size_t)f->W, (size_t)f->H);
     const char* ib = aligned_base(f->image_buffer);
-    if ((rc = check_hip(hipMemcpyAsync(t.w, ib + il.num_rendered, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, s), "read num_rendered"))) return fail(rc);
+    if ((rc = check_hip(hipMemcpyAsync(t.w, ib + il.num_rendered, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, s), "read num_rendered"))) return fail(rc);
     if ((rc = check_hip(hipEventRecord(t.ev, s), "record plan event"))) return fail(rc);
-    if ((rc = launch_bin_sort(*f, capacity, s))) return fail(rc);
+    if ((rc = launch_bin_sort(*f, capacity, s, skip_large))) return fail(rc);
     if ((rc = launch_blend_forward(*f, capacity, s))) return fail(rc);
     if ((rc = launch_blend_backward(*b, s))) return fail(rc);
     if ((rc = launch_preprocess_backward(*b, s))) return fail(rc);
@@ -328,15 +339,24 @@ int ag_raster_collect(int32_t ticket, int32_t* num_rendered_host)
     if (ticket < 0 || ticket >= kTickets || !g_tk[ticket].busy) { set_error("ag_raster_collect: no such pending view (%d)", ticket); return AG_ERR_INVALID_ARGUMENT; }
     Ticket& t = g_tk[ticket];
     const int rc = check_hip(hipEventSynchronize(t.ev), "wait for the instance count");
-    const int32_t n = t.w[0], over = t.w[2], cap = t.capacity;
+    const int32_t n = t.w[0], over = t.w[2], n_large = t.w[3], cap = t.capacity;
     { std::lock_guard<std::mutex> lk(g_tk_mu); t.busy = false; }
     if (rc) return rc;
     *num_rendered_host = n;
+    if (n_large > 0) g_large_tiles_seen.store(1, std::memory_order_relaxed);
     if (over) {
-        set_error("forward+backward: %d instances exceed the capacity of %d; redo the view with a larger capacity", n, cap);
+        if (n <= cap) set_error("forward+backward: %d tiles of >= 2048 instances and the large-class sort was not enqueued for this view; redo it", n_large);
+        else set_error("forward+backward: %d instances exceed the capacity of %d; redo the view with a larger capacity", n, cap);
         return AG_ERR_SCRATCH_TOO_SMALL;
     }
     return AG_OK;
+}
+
+int ag_raster_large_tile_sort(int32_t mode)
+{
+    if (mode == 0 || mode == 1) g_large_tiles_seen.store(mode, std::memory_order_relaxed);
+    else if (mode != -1) { set_error("ag_raster_large_tile_sort: mode must be -1 (query), 0 or 1"); return AG_ERR_INVALID_ARGUMENT; }
+    return g_large_tiles_seen.load(std::memory_order_relaxed);
 }
 
 int ag_raster_forward_backward(const AgRasterForwardArgs* f, AgRasterBackwardArgs* b, int32_t capacity, void* stream,

@@ -26,7 +26,7 @@ namespace ag {
 __global__ void __launch_bounds__(1024) tile_scan_kernel(int T, const uint32_t* __restrict__ tile_count,
                                                         uint32_t* __restrict__ cursor, uint2* __restrict__ ranges,
                                                         uint32_t* __restrict__ num_rendered,
-                                                        uint4* __restrict__ tile_order, uint32_t capacity)
+                                                        uint4* __restrict__ tile_order, uint32_t capacity, uint32_t skip_large)
 {
     // Four consecutive tiles per thread and pass (one 16-byte load, one 16-byte cursor store, two 16-byte range stores): the
     // kernel is one workgroup deep, so its time is the number of dependent global round trips -- 2 per 4096 tiles this way,
@@ -103,11 +103,18 @@ __global__ void __launch_bounds__(1024) tile_scan_kernel(int T, const uint32_t* 
     // instances, non-empty tiles, overflow flag.  `capacity` = instances the binning buffer was sized for when the later stages
     // were enqueued before this count was known (ag_raster_forward_optimistic): on overflow they must not touch it -- the
     // scatter returns on the flag, and with zero active tiles the sort and blend kernels have nothing to walk.
+    // Round 5: num_rendered[3] = tiles of the large size classes (>= 2048 instances: bit length >= 12).  `skip_large`: the caller did NOT
+    // enqueue the large-class sort launch behind this frame (no frame of the process has had such a tile so far: launch_bin_sort) -- if this
+    // frame has one after all, it is refused exactly like an overflow (nothing downstream touches it; the host sees the flag and redoes the
+    // frame, from then on with the launch).
     if (tid == 0) {
-        const bool over = carry_s > capacity;
+        uint32_t n_large = 0;
+        for (int cls = 12; cls < 34; cls++) n_large += cls_hist[cls];
+        const bool over = carry_s > capacity || (skip_large && n_large > 0u);
         num_rendered[0] = carry_s;
         num_rendered[1] = over ? 0u : carry_ne;
         num_rendered[2] = over ? 1u : 0u;
+        num_rendered[3] = n_large;
     }
     // Work order for the persistent blend kernels: tiles by descending size class (longest-processing-time first),
     // empty tiles last.  Order inside a class is arbitrary.
@@ -139,7 +146,7 @@ __global__ void __launch_bounds__(1024) tile_scan_kernel(int T, const uint32_t* 
     }
 }
 
-int launch_tile_scan(const AgRasterForwardArgs& a, hipStream_t s, uint32_t capacity)
+int launch_tile_scan(const AgRasterForwardArgs& a, hipStream_t s, uint32_t capacity, bool skip_large)
 {
     const int gx = (a.W + kTileX - 1) / kTileX, gy = (a.H + kTileY - 1) / kTileY;
     char* ib = aligned_base(a.image_buffer);
@@ -149,7 +156,7 @@ int launch_tile_scan(const AgRasterForwardArgs& a, hipStream_t s, uint32_t capac
                        reinterpret_cast<uint32_t*>(ib + il.cursor),
                        reinterpret_cast<uint2*>(ib + il.ranges),
                        reinterpret_cast<uint32_t*>(ib + il.num_rendered),
-                       reinterpret_cast<uint4*>(ib + il.tile_order), capacity); }
+                       reinterpret_cast<uint4*>(ib + il.tile_order), capacity, skip_large ? 1u : 0u); }
     return check_hip(hipGetLastError(), "tile_scan_kernel");
 }
 
@@ -472,7 +479,7 @@ __global__ void __launch_bounds__(NT) tile_sort_kernel(const uint4* __restrict__
     }
 }
 
-int launch_bin_sort(const AgRasterForwardArgs& a, int R, hipStream_t s)
+int launch_bin_sort(const AgRasterForwardArgs& a, int R, hipStream_t s, bool skip_large)
 {
     const int gx = (a.W + kTileX - 1) / kTileX, gy = (a.H + kTileY - 1) / kTileY;
     if (R <= 0) return AG_OK;
@@ -509,7 +516,12 @@ int launch_bin_sort(const AgRasterForwardArgs& a, int R, hipStream_t s)
         const uint32_t* counts = reinterpret_cast<const uint32_t*>(ib + il.num_rendered);
         const int T = gx * gy;
         hipLaunchKernelGGL((tile_sort_kernel<512, false, 4>), dim3(T < 1280 ? T : 1280), dim3(512), kSmallLds, s, order, counts, keys, point_list);
-        hipLaunchKernelGGL((tile_sort_kernel<1024, true, 8>), dim3(T < 256 ? T : 256), dim3(1024), kLargeLds, s, order, counts, keys, point_list);
+        // the large class (tiles of 2049 .. 8192 instances merged from their sorted chunks, longer ones sorted in global memory): 256 workgroups
+        // that each need a whole CU's LDS.  On avatar views no tile is that long and the launch was 4 us of the one-stream view and a 27-us slot
+        // in the overlapped pipeline for nothing (round-4 review): skipped until a frame of the process has had such a tile (tile_scan_kernel
+        // refuses a frame that needs it when it was skipped; ag_abi.hip keeps the sticky flag)
+        if (!skip_large)
+            hipLaunchKernelGGL((tile_sort_kernel<1024, true, 8>), dim3(T < 256 ? T : 256), dim3(1024), kLargeLds, s, order, counts, keys, point_list);
     }
     return check_hip(hipGetLastError(), "tile_sort_kernel");
 }

@@ -172,8 +172,8 @@ int check_hip(hipError_t e, const char* what);
 
 // launchers (one per translation unit)
 int launch_preprocess(const AgRasterForwardArgs& a, hipStream_t s);
-int launch_tile_scan(const AgRasterForwardArgs& a, hipStream_t s, uint32_t capacity = 0xffffffffu);
-int launch_bin_sort(const AgRasterForwardArgs& a, int R, hipStream_t s);
+int launch_tile_scan(const AgRasterForwardArgs& a, hipStream_t s, uint32_t capacity = 0xffffffffu, bool skip_large = false);
+int launch_bin_sort(const AgRasterForwardArgs& a, int R, hipStream_t s, bool skip_large = false);
 int launch_blend_forward(const AgRasterForwardArgs& a, int R, hipStream_t s);
 int launch_blend_backward(const AgRasterBackwardArgs& a, hipStream_t s);
 int launch_preprocess_backward(const AgRasterBackwardArgs& a, hipStream_t s);

@@ -219,6 +219,16 @@ enum AgKernelId {
     AG_K_WGRAD = 8,             /* ag_conv.h: weight-gradient implicit GEMM */
     AG_K_COUNT = 9
 };
+/*
+ * The large-class launch of the tile sort (tiles of >= 2048 instances: 256 workgroups that each take a whole CU's LDS).  The paths that enqueue a
+ * whole frame before the host knows its counts (ag_raster_forward_optimistic, ag_raster_forward_backward_enqueue) skip that launch until some
+ * frame of the process has had such a tile: avatar views never have one, and the empty launch cost 4 us per view and a 27-us slot of the
+ * overlapped pipeline.  A frame that needs the launch although it was skipped is REFUSED like an overflow (AG_ERR_SCRATCH_TOO_SMALL, outputs and
+ * sums untouched): the caller's redo -- the same code path it has for an outgrown capacity -- then gets the launch, and so does every later frame.
+ * mode -1: query; 0: forget (skip again until seen); 1: always launch.  Returns the state after the call (0 / 1) or an error code.
+ */
+int ag_raster_large_tile_sort(int32_t mode);
+
 const char* ag_prof_kernel_name(int32_t kernel_id);
 int ag_prof_enable(uint32_t kernel_mask);
 int ag_prof_collect(int32_t* launches /*[AG_K_COUNT]*/, float* total_ms /*[AG_K_COUNT]*/, double* work /*[AG_K_COUNT] or NULL*/);

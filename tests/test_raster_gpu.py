@@ -701,3 +701,69 @@ def test_optimistic_path_edge_cases_through_autograd():
     assert radii.numel() == 0 and not color.any() and not alpha.any()
     rz._capacity.pop(key, None)
     rz._capacity.pop((0, 96, 96, rs.bg.device.index), None)
+
+
+def test_the_large_class_sort_is_enqueued_only_once_a_frame_needed_it():
+    """Round 5 (include/ag_raster.h ag_raster_large_tile_sort): the enqueue-everything paths skip the tile sort's large-class launch until a frame
+    of the process has had a tile of >= 2048 instances.  From a forgotten state: a scene with short lists leaves the flag down; the first
+    OPTIMISTIC frame with such a tile is refused inside the library, redone by the caller's overflow path and comes out bit-identical to the
+    host-synchronised path (which always launches the large class and is itself bit-exact against the oracle) -- through the operator
+    (GaussianRasterizer) and through the library-owned step (enqueue + collect, gradients included); the flag is up afterwards."""
+    import torch
+    from animatablegaussians_amd import _lib, rasterizer as rz
+    from animatablegaussians_amd.rasterizer import FusedRasterStep, GaussianRasterizer
+    L = _lib.lib()
+    small = synth.random_gaussians(4000, seed=3, img=256, focal=275.0)
+    rs = np.random.RandomState(7)
+    P = 9000
+    big = synth.random_gaussians(P=P)
+    big["means3D"] = (rs.normal(0, 0.004, (P, 3))).astype(np.float32)
+    big["scales"] = np.full((P, 3), 0.002, np.float32)
+    big["opacities"] = np.full((P, 1), 0.02, np.float32)
+
+    def operator(scene, cam):
+        inp = h.gpu_inputs(scene)
+        with torch.no_grad():
+            color, radii, depth, alpha = GaussianRasterizer(h.gpu_settings(scene, cam))(means3D=inp["means3D"], means2D=torch.zeros_like(inp["means3D"]), opacities=inp["opacities"],
+                                                                                        colors_precomp=inp["colors"], scales=inp["scales"], rotations=inp["rotations"])
+        torch.cuda.synchronize()
+        return color.cpu().numpy(), alpha.cpu().numpy(), radii.cpu().numpy()
+
+    def same(got, ref):
+        assert np.array_equal(got[0], ref["color"]) and np.array_equal(got[1], ref["alpha"]) and np.array_equal(got[2], ref["radii"])
+    try:
+        assert L.ag_raster_large_tile_sort(0) == 0
+        cam_s, cam_b = h.cam_of(small), h.cam_of(big)
+        ref_s, ref_b = h.gpu_native_forward(small, cam_s), h.gpu_native_forward(big, cam_b)          # plan + render: always the full sort
+        _bitexact(ref_b, h.oracle_forward(big, cam_b))
+        assert (h.oracle_forward(big, cam_b)["ranges"][:, 1] - h.oracle_forward(big, cam_b)["ranges"][:, 0]).max() > 4096
+        for _ in range(3):
+            same(operator(small, cam_s), ref_s)
+        assert L.ag_raster_large_tile_sort(-1) == 0                       # nothing long: the launch is still skipped
+        same(operator(big, cam_b), ref_b)                                 # first frame of this configuration: plan + render
+        same(operator(big, cam_b), ref_b)                                 # optimistic, launch skipped -> refused -> redone
+        assert L.ag_raster_large_tile_sort(-1) == 1
+        same(operator(big, cam_b), ref_b)                                 # optimistic with the launch
+        # the library-owned step: forward + backward of the view against the operator path, from a forgotten state
+        inp = h.gpu_inputs(big, requires_grad=True)
+        rset = h.gpu_settings(big, cam_b)
+        up = synth.upstream_grads(rset.image_width, rset.image_height, 5)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+        m2d = torch.zeros_like(inp["means3D"], requires_grad=True)
+        color, radii, depth, alpha = GaussianRasterizer(rset)(means3D=inp["means3D"], means2D=m2d, opacities=inp["opacities"], colors_precomp=inp["colors"],
+                                                              scales=inp["scales"], rotations=inp["rotations"])
+        torch.autograd.backward([color, depth, alpha], [t(up["dL_dcolor"]), t(up["dL_ddepth"]), t(up["dL_dalpha"])])
+        det = {k: v.detach() for k, v in inp.items() if v is not None}
+        assert L.ag_raster_large_tile_sort(0) == 0
+        step = FusedRasterStep(P, rset.image_height, rset.image_width, "cuda", n_streams=1)
+        c2, d2, a2, r2, _ = step.view(rset, det["means3D"], det["colors"], det["opacities"], det["scales"], det["rotations"],
+                                      t(up["dL_dcolor"]), t(up["dL_ddepth"]), t(up["dL_dalpha"]), accumulate=True)
+        got = step.join()
+        torch.cuda.synchronize()
+        assert L.ag_raster_large_tile_sort(-1) == 1
+        assert torch.equal(c2, color.detach()) and torch.equal(a2, alpha.detach()) and torch.equal(r2, radii)
+        for k, w in (("dL_dmeans3D", inp["means3D"].grad), ("dL_dcolors", inp["colors"].grad), ("dL_dopacity", inp["opacities"].grad)):
+            scale = float(w.abs().max())
+            assert float((got[k] - w.reshape(got[k].shape)).abs().max()) <= 5e-5 * scale + 1e-9, k
+    finally:
+        L.ag_raster_large_tile_sort(0)
