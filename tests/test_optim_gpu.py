@@ -36,6 +36,7 @@ def test_fused_adam_equals_torch_adam(wd, maximize):
 
 
 def test_fused_adam_state_dict_loads_into_torch_adam_and_back():
+    import copy
     import torch
     from animatablegaussians_amd.optim import FusedAdam
     ps = [torch.nn.Parameter(torch.randn(33, 5).cuda()), torch.nn.Parameter(torch.randn(100).cuda())]
@@ -44,7 +45,7 @@ def test_fused_adam_state_dict_loads_into_torch_adam_and_back():
     for p in ps + qs:
         p.grad = torch.ones_like(p)
     a.step()
-    b.load_state_dict(a.state_dict())            # ours -> torch
+    b.load_state_dict(copy.deepcopy(a.state_dict()))      # ours -> torch (a copy: load_state_dict keeps tensors that already have the right device and type)
     for p, q in zip(ps, qs):
         q.data.copy_(p.data)
     for p in ps + qs:
@@ -54,7 +55,7 @@ def test_fused_adam_state_dict_loads_into_torch_adam_and_back():
     for p, q in zip(ps, qs):
         assert torch.allclose(p, q, rtol=2e-6, atol=1e-7)
     a2 = FusedAdam(ps, lr=1e-2)
-    a2.load_state_dict(b.state_dict())           # torch (device-resident step counter) -> ours
+    a2.load_state_dict(copy.deepcopy(b.state_dict()))     # torch -> ours
     assert float(a2.state[ps[0]]["step"]) == 2.0 and a2.state[ps[0]]["step"].device.type == "cpu"
     h = torch.nn.Parameter(torch.randn(4).cuda().half())
     h.grad = torch.ones_like(h)
