@@ -15,13 +15,13 @@ struct AdamLaunch {
     int32_t chunk_begin[AG_ADAM_MAX_TENSORS + 1];
 };
 
-__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, const AgAdamArgs& a, float step_size)
+__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, const AgAdamArgs& a, float step_size, float bc2_sqrt)
 {
     if (a.maximize) g = -g;
     if (a.weight_decay != 0.f) g = fmaf(a.weight_decay, p, g);
     m = fmaf(1.f - a.beta1, g - m, m);
     v = fmaf(a.beta2, v, (1.f - a.beta2) * g * g);
-    const float denom = sqrtf(v) / a.bias_correction2_sqrt + a.eps;
+    const float denom = sqrtf(v) / bc2_sqrt + a.eps;
     p -= step_size * (m / denom);
 }
 
@@ -38,7 +38,7 @@ __global__ void __launch_bounds__(256) adam_kernel(AdamLaunch L)
     const float* __restrict__ Gr = a.grad[t];
     float* __restrict__ M = a.exp_avg[t];
     float* __restrict__ V = a.exp_avg_sq[t];
-    const float step_size = a.lr / a.bias_correction1;
+    const float step_size = a.lr / a.bias_correction1[t], bc2 = a.bias_correction2_sqrt[t];
     const bool vec = ((((size_t)P) | ((size_t)Gr) | ((size_t)M) | ((size_t)V)) & 15) == 0;
     int64_t i = e0 + (int64_t)threadIdx.x * 4;
     if (vec) {
@@ -48,7 +48,7 @@ __global__ void __launch_bounds__(256) adam_kernel(AdamLaunch L)
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 float pe = p[e], me = m[e], ve = v[e];
-                adam_one(pe, g[e], me, ve, a, step_size);
+                adam_one(pe, g[e], me, ve, a, step_size, bc2);
                 p[e] = pe; m[e] = me; v[e] = ve;
             }
             *reinterpret_cast<f32x4*>(P + i) = p;
@@ -59,14 +59,14 @@ __global__ void __launch_bounds__(256) adam_kernel(AdamLaunch L)
         const int64_t done = e0 + ((e1 - e0) & ~(int64_t)3);
         for (int64_t j = done + threadIdx.x; j < e1; j += 256) {
             float p = P[j], m = M[j], v = V[j];
-            adam_one(p, Gr[j], m, v, a, step_size);
+            adam_one(p, Gr[j], m, v, a, step_size, bc2);
             P[j] = p; M[j] = m; V[j] = v;
         }
         return;
     }
     for (int64_t j = e0 + threadIdx.x; j < e1; j += 256) {
         float p = P[j], m = M[j], v = V[j];
-        adam_one(p, Gr[j], m, v, a, step_size);
+        adam_one(p, Gr[j], m, v, a, step_size, bc2);
         P[j] = p; M[j] = m; V[j] = v;
     }
 }
@@ -82,12 +82,12 @@ size_t ag_adam_args_bytes(void) { return sizeof(AgAdamArgs); }
 int ag_adam_step(const AgAdamArgs* a, void* stream)
 {
     if (!a || a->n < 1 || a->n > AG_ADAM_MAX_TENSORS) { set_error("ag_adam_step: bad tensor count"); return AG_ERR_INVALID_ARGUMENT; }
-    if (!(a->bias_correction1 > 0.f) || !(a->bias_correction2_sqrt > 0.f)) { set_error("ag_adam_step: bias corrections must be positive"); return AG_ERR_INVALID_ARGUMENT; }
     AdamLaunch L;
     L.a = *a;
     long long chunks = 0;
     for (int i = 0; i < a->n; i++) {
         if (!a->param[i] || !a->grad[i] || !a->exp_avg[i] || !a->exp_avg_sq[i] || a->numel[i] < 0) { set_error("ag_adam_step: null tensor / negative length"); return AG_ERR_INVALID_ARGUMENT; }
+        if (!(a->bias_correction1[i] > 0.f) || !(a->bias_correction2_sqrt[i] > 0.f)) { set_error("ag_adam_step: bias corrections must be positive"); return AG_ERR_INVALID_ARGUMENT; }
         L.chunk_begin[i] = (int32_t)chunks;
         chunks += (a->numel[i] + kAdamChunk - 1) / kAdamChunk;
         if (chunks > 0x7fffffffLL) { set_error("ag_adam_step: too many elements in one call"); return AG_ERR_INVALID_ARGUMENT; }

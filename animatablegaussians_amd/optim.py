@@ -47,11 +47,13 @@ class FusedAdam(torch.optim.Optimizer):
                 if not p.is_contiguous():
                     raise RuntimeError("FusedAdam: parameters must be contiguous")
             states = [self._state(p) for p in ps]
-            t = float(states[0]["step"]) + 1.0
-            for st in states:
-                if float(st["step"]) + 1.0 != t:
-                    raise RuntimeError("FusedAdam: the parameters of a group must have taken the same number of steps")
             b1, b2 = group["betas"]
+            # steps are counted per parameter, as torch.optim.Adam does (the reference's pretraining pass leaves the colour network without gradients)
+            bcs = {}
+            for st in states:
+                t = float(st["step"]) + 1.0
+                if t not in bcs:
+                    bcs[t] = (1.0 - b1 ** t, math.sqrt(1.0 - b2 ** t))
             key = (gi, tuple(id(p) for p in ps))
             calls = self._calls.get(key)
             if calls is None:
@@ -64,19 +66,21 @@ class FusedAdam(torch.optim.Optimizer):
                         if not (st["exp_avg"].is_contiguous() and st["exp_avg_sq"].is_contiguous() and st["exp_avg"].device == dev):
                             raise RuntimeError("FusedAdam: optimizer state must be contiguous and on the parameters' device")
                         a.param[i], a.exp_avg[i], a.exp_avg_sq[i], a.numel[i] = p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel()
-                    calls.append((a, [p for p, _ in chunk]))
+                    calls.append((a, [p for p, _ in chunk], [st for _, st in chunk]))
                 self._calls = {key: calls}          # one cached layout per optimizer (a changed parameter set rebuilds it)
             stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-            bc1, bc2 = 1.0 - b1 ** t, math.sqrt(1.0 - b2 ** t)
             with _lib.on_device(dev):
-                for a, chunk in calls:
+                for a, chunk, sts in calls:
                     a.maximize = int(bool(group["maximize"]))
                     a.lr, a.beta1, a.beta2, a.eps, a.weight_decay = float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"])
-                    a.bias_correction1, a.bias_correction2_sqrt = bc1, bc2
+                    keep = []                       # contiguous copies must outlive the launch (the allocator would hand their block to the next copy)
                     for i, p in enumerate(chunk):
+                        a.bias_correction1[i], a.bias_correction2_sqrt[i] = bcs[float(sts[i]["step"]) + 1.0]
                         g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                        keep.append(g)
                         a.grad[i] = g.data_ptr()
                     _lib.check(L.ag_adam_step(ctypes.byref(a), stream), "ag_adam_step")
+                    del keep
             for st in states:
                 st["step"] += 1.0
         return loss

@@ -9,7 +9,8 @@
  *     m      = m + (1 - beta1) * (g - m)
  *     v      = beta2 * v + (1 - beta2) * g * g
  *     param -= (lr / (1 - beta1^t)) * m / (sqrt(v) / sqrt(1 - beta2^t) + eps)
- * in fp32; the two bias corrections are computed by the caller in double and passed in.
+ * in fp32; the two bias corrections are computed by the caller in double, per tensor (a parameter that received no gradient in some iterations --
+ * the reference's pretraining pass leaves the colour network out -- has taken fewer steps), and passed in.
  */
 #ifndef AG_OPTIM_H
 #define AG_OPTIM_H
@@ -29,8 +30,8 @@ typedef struct AgAdamArgs {
     float* exp_avg_sq[AG_ADAM_MAX_TENSORS];       /* updated in place */
     int64_t numel[AG_ADAM_MAX_TENSORS];
     float lr, beta1, beta2, eps, weight_decay;
-    float bias_correction1;                       /* 1 - beta1^t */
-    float bias_correction2_sqrt;                  /* sqrt(1 - beta2^t) */
+    float bias_correction1[AG_ADAM_MAX_TENSORS];        /* per tensor: 1 - beta1^t (t = the steps THAT tensor has taken, this one included:   */
+    float bias_correction2_sqrt[AG_ADAM_MAX_TENSORS];   /* sqrt(1 - beta2^t)        torch.optim.Adam counts steps per parameter)              */
 } AgAdamArgs;
 
 size_t ag_adam_args_bytes(void);

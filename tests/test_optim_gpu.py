@@ -61,3 +61,28 @@ def test_fused_adam_state_dict_loads_into_torch_adam_and_back():
     h.grad = torch.ones_like(h)
     with pytest.raises(RuntimeError):           # no fallback: anything but dense fp32 on one GPU is refused
         FusedAdam([h]).step()
+
+
+def test_fused_adam_counts_steps_per_parameter_like_torch():
+    """The reference pretrains position / other networks first (main_avatar.py:126-160: the colour network gets no gradient), then trains all three:
+    parameters of one optimizer have then taken different numbers of steps, and Adam's bias corrections are per parameter.  Two steps in which only
+    half the tensors have gradients, then two with all: identical to torch.optim.Adam."""
+    import torch
+    from animatablegaussians_amd.optim import FusedAdam
+    g = torch.Generator().manual_seed(4)
+    base = [torch.randn(257, generator=g) for _ in range(6)]
+    ours = [torch.nn.Parameter(t.clone().cuda()) for t in base]
+    ref = [torch.nn.Parameter(t.clone().cuda()) for t in base]
+    oa, ob = FusedAdam(ours, lr=1e-2), torch.optim.Adam(ref, lr=1e-2)
+    for step in range(4):
+        for i, (a, b) in enumerate(zip(ours, ref)):
+            if step < 2 and i % 2:
+                a.grad = b.grad = None
+                continue
+            gr = torch.randn(a.shape, generator=g).cuda()
+            a.grad, b.grad = gr.clone(), gr.clone()
+        oa.step()
+        ob.step()
+    for i, (a, b) in enumerate(zip(ours, ref)):
+        assert float(oa.state[a]["step"]) == float(ob.state[b]["step"]) == (2.0 if i % 2 else 4.0)
+        assert torch.allclose(a, b, rtol=2e-6, atol=1e-7), (i, float((a - b).abs().max()))
