@@ -128,7 +128,7 @@ AG_ADAM_MAX_TENSORS = 48
 class AgAdamArgs(ctypes.Structure):           # include/ag_optim.h
     _fields_ = ([("n", c_i32), ("maximize", c_i32)] + [(n, c_vp * AG_ADAM_MAX_TENSORS) for n in ("param", "grad", "exp_avg", "exp_avg_sq")]
                 + [("numel", ctypes.c_int64 * AG_ADAM_MAX_TENSORS)]
-                + [(n, c_f) for n in ("lr", "beta1", "beta2", "eps", "weight_decay")]
+                + [(n, c_f) for n in ("lr", "beta1", "beta2", "eps", "weight_decay", "one_minus_beta1", "one_minus_beta2")]
                 + [(n, c_f * AG_ADAM_MAX_TENSORS) for n in ("bias_correction1", "bias_correction2_sqrt")])
 
 

@@ -19,8 +19,8 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
 {
     if (a.maximize) g = -g;
     if (a.weight_decay != 0.f) g = fmaf(a.weight_decay, p, g);
-    m = fmaf(1.f - a.beta1, g - m, m);
-    v = fmaf(a.beta2, v, (1.f - a.beta2) * g * g);
+    m = fmaf(a.one_minus_beta1, g - m, m);
+    v = fmaf(a.beta2, v, a.one_minus_beta2 * g * g);
     const float denom = sqrtf(v) / bc2_sqrt + a.eps;
     p -= step_size * (m / denom);
 }

@@ -73,6 +73,7 @@ class FusedAdam(torch.optim.Optimizer):
                 for a, chunk, sts in calls:
                     a.maximize = int(bool(group["maximize"]))
                     a.lr, a.beta1, a.beta2, a.eps, a.weight_decay = float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"])
+                    a.one_minus_beta1, a.one_minus_beta2 = 1.0 - float(b1), 1.0 - float(b2)          # in double, rounded once
                     keep = []                       # contiguous copies must outlive the launch (the allocator would hand their block to the next copy)
                     for i, p in enumerate(chunk):
                         a.bias_correction1[i], a.bias_correction2_sqrt[i] = bcs[float(sts[i]["step"]) + 1.0]

@@ -30,6 +30,7 @@ typedef struct AgAdamArgs {
     float* exp_avg_sq[AG_ADAM_MAX_TENSORS];       /* updated in place */
     int64_t numel[AG_ADAM_MAX_TENSORS];
     float lr, beta1, beta2, eps, weight_decay;
+    float one_minus_beta1, one_minus_beta2;       /* formed by the caller in double: 1 - 0.999f in fp32 is off by 1.3e-5 of its value */
     float bias_correction1[AG_ADAM_MAX_TENSORS];        /* per tensor: 1 - beta1^t (t = the steps THAT tensor has taken, this one included:   */
     float bias_correction2_sqrt[AG_ADAM_MAX_TENSORS];   /* sqrt(1 - beta2^t)        torch.optim.Adam counts steps per parameter)              */
 } AgAdamArgs;
