@@ -858,11 +858,15 @@ class GroupedStyleUNets:
                     else:
                         sk = {}
                         for (s, e) in _runs([nets[i].out_ch for i, _ in tm]):
-                            parts = []
-                            for r in range(s, e):
-                                m = src[r]
-                                (ks, ke) = next(k for k in skips if k[0] <= m < k[1])
-                                parts.append(skips[(ks, ke)][m - ks:m - ks + 1])
+                            keys = [next(k for k in skips if k[0] <= src[r] < k[1]) for r in range(s, e)]
+                            if all(k == keys[0] for k in keys):
+                                # all members of the run continue rows of ONE stacked skip tensor: a row selection whose backward sums the views'
+                                # gradients per row in one pass (slices + cat left a zero fill, a copy and an addition per member to autograd)
+                                rows_sel = tuple(src[r] - keys[0][0] for r in range(s, e))
+                                src_t = skips[keys[0]]
+                                sk[(s, e)] = src_t if rows_sel == tuple(range(src_t.shape[0])) else _SelectAddRows.apply(src_t, None, rows_sel, None)
+                                continue
+                            parts = [skips[k][src[r] - k[0]:src[r] - k[0] + 1] for r, k in zip(range(s, e), keys)]
                             sk[(s, e)] = torch.cat(parts, 0) if len(parts) > 1 else parts[0]
                     o, sk = self._stage(n, tm, tst, noises, o, sk, levels, src=src, vf=vf, vf_rows=(rows[0], rows[-1] + 1) if rows else None)
                 else:
