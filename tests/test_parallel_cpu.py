@@ -221,3 +221,35 @@ def test_world_size_one_pass_through_surface():
     assert kept.flat.numel() == 15 and all(p.grad.data_ptr() >= kept.flat.data_ptr() for p in net.parameters())
     assert float(kept.flat.abs().sum()) > 0
     kept.close()
+
+
+def test_pose_per_rank_dealing_of_the_training_step():
+    """bench_avatar.TrainingStep's two sharding modes, host logic only: (a) the views of ONE pose are dealt round-robin over the
+    ranks -- every rank has the same joint transforms and the ranks' cameras of a step are disjoint; (b) ``pose_per_rank``: every rank has its own pose
+    (its own joint transforms) and needs no disjoint cameras."""
+    import numpy as np
+    import torch
+    import bench_avatar as ba
+    J = 55
+    same = [ba.joint_transforms(J, "cpu", seed=7 + 0) for _ in range(2)]
+    assert torch.equal(same[0], same[1])
+    a, b = ba.joint_transforms(J, "cpu", seed=7), ba.joint_transforms(J, "cpu", seed=8)
+    assert not torch.equal(a, b)
+    for A in (a, b):                                                  # rigid: rotation blocks orthonormal
+        R = A[:, :3, :3]
+        assert float((R @ R.transpose(1, 2) - torch.eye(3)).abs().max()) < 1e-5
+
+    class _Step:                                                      # the camera dealing without a GPU: the method only reads these attributes
+        cameras = ba.TrainingStep.cameras
+    world, V, n_cam = 4, 2, 8
+    for mode in (False, True):
+        per_rank = []
+        for rank in range(world):
+            s = _Step()
+            s.world, s.rank, s.pose_per_rank, s.views = world, rank, mode, list(range(n_cam))
+            per_rank.append([s.cameras(i, V) for i in range(3)])
+        for i in range(3):
+            dealt = [c for r in range(world) for c in per_rank[r][i]]
+            if not mode:
+                assert sorted(dealt) == sorted(set(dealt)) and len(dealt) == world * V          # one pose: no camera rendered twice in a step
+            assert all(len(per_rank[r][i]) == V for r in range(world))
