@@ -22,7 +22,7 @@ struct __attribute__((aligned(16))) GaussRec {
     float r, g;        // colour
     float b, depth;    // colour, view-space depth
     float r2cut;       // conservative squared pixel distance beyond which alpha < 1/255 (wave-level cull)
-    float pad;
+    float qcut;        // the same bound on q = a dx^2 + 2 b dx dy + c dy^2 = -2 power itself: 2 ln(255 op) with the same slack (exact cull of the blend backward)
 };
 static_assert(sizeof(GaussRec) == 48, "GaussRec must be 48 bytes");
 

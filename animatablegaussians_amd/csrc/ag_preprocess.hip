@@ -99,6 +99,8 @@ __global__ void __launch_bounds__(256) preprocess_kernel(PreParams p)
     // The 48-byte records and the 24-byte covariances leave through LDS: a thread's own record would be 12 + 6 dword stores at a
     // 48 / 24-byte lane stride (every store instruction touches 24 cache lines); staged, the workgroup writes its 12 + 6 KB as 16-byte
     // stores, lanes along addresses.  Round 2: 14.8 -> see DESIGN.md section 5.
+    // (Round 5: the INPUT rows through LDS the same way -- 13 strided load instructions -> 4 contiguous ones + LDS reads, two more barriers --
+    // measured 14.0 -> 15.3 us, profiles/r05b_ab_stage.txt: the loads are latency the 4 resident workgroups already overlap; not kept.)
     __shared__ __attribute__((aligned(16))) float s_rec[256 * 12];
     __shared__ __attribute__((aligned(16))) float s_cov[256 * 6];
     const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -203,13 +205,18 @@ __global__ void __launch_bounds__(256) preprocess_kernel(PreParams p)
                 // alpha = op*exp(power) < 1/255  <=>  power < -ln(255*op); lambda1 >= lambda_max (0.1 floor above).
                 // 1 % + 0.01 slack in log space dwarfs every fp32 rounding of conic/power; huge or degenerate
                 // splats are never culled.
-                float r2 = 3.0e38f;
+                // qcut (round 5): the same threshold on the quadratic form itself, q = a dx^2 + 2 b dx dy + c dy^2 = -2 power: alpha < 1 / 255
+                // wherever q > 2 ln(255 op).  The blend backward minimises q over its 4 x 4 pixels' rectangle exactly (ag_blend_backward.hip), which
+                // needs a positive definite conic; any other conic is never culled by it.
+                float r2 = 3.0e38f, qc = 3.0e38f;
                 if (lambda1 < 1.0e4f && lambda1 > 0.f && op >= 0.f) {
                     const float lg = __logf(255.0f * op) + 0.01f;   // -inf for op == 0
                     r2 = (lg > 0.f) ? 2.0f * lambda1 * lg * 1.01f : -1.0f;
+                    const bool pd = ca > 0.f && cc > 0.f && (ca * cc - cb * cb) > 0.f;
+                    qc = (lg > 0.f) ? (pd ? 2.0f * lg * 1.01f : 3.0e38f) : -1.0f;
                 }
                 g.r2cut = r2;
-                g.pad = 0.f;
+                g.qcut = qc;
                 *reinterpret_cast<GaussRec*>(s_rec + 12 * threadIdx.x) = g;
                 rec_set = true;
                 rx0 = x0; ry0 = y0; rx1 = x1; ry1 = y1;

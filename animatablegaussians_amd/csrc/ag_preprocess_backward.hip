@@ -6,6 +6,10 @@
 // rasterize_points.cu:158-167 (every output element is written here, zeros for culled Gaussians).
 // One thread per Gaussian: reads its 64-byte accumulator line (blend backward), 12+24+12+16 B of inputs, writes
 // the 8 output rows.  HBM-bound: ~128 B in + ~104 B out per Gaussian.
+// Round 5: the rows enter and leave through LDS.  A thread's own rows are 3 / 6 / 4 floats at a 12 / 24 / 16-byte lane stride -- 17 load
+// and 23 store instructions that each touch 12-24 cache lines a third or a sixth at a time; staged, the workgroup moves every array
+// of its 256 Gaussians as one contiguous run of 16-byte accesses, lanes along addresses (8 store instructions per thread), exactly as
+// the forward preprocess writes its records.
 //
 // Semantics kept from the reference: the 1.3*tanfov clamp zeroes dL/dt.x, dL/dt.y outside the frustum guard
 // (:168-176), denom2inv = 1/(denom^2 + 1e-7) (:203), p_w = 1/(w + 1e-7) (:376), the depth gradient enters through
@@ -75,16 +79,65 @@ struct PreBwdParams {
     int accumulate;                          // 1: add into the outputs (sum over the views of a step) instead of overwriting them
 };
 
+typedef float pb_f4 __attribute__((ext_vector_type(4)));
+
+// rows [first, first + nv) of a [P][K] array <-> LDS, lanes along addresses.  first is a multiple of 256, so the run starts 16-byte
+// aligned whenever the array itself is (torch allocations are; an unaligned base takes the scalar path).
+template <int K>
+__device__ __forceinline__ void stage_in(float* __restrict__ s, const float* __restrict__ src, int first, int nv)
+{
+    const float* g = src + (size_t)first * K;
+    const int nf = nv * K;
+    if ((reinterpret_cast<uintptr_t>(g) & 15) == 0) {
+        const int nf4 = nf >> 2;
+        for (int i = threadIdx.x; i < nf4; i += 256) reinterpret_cast<pb_f4*>(s)[i] = reinterpret_cast<const pb_f4*>(g)[i];
+        if ((int)threadIdx.x < (nf & 3)) s[4 * nf4 + threadIdx.x] = g[4 * nf4 + threadIdx.x];
+    } else {
+        for (int i = threadIdx.x; i < nf; i += 256) s[i] = g[i];
+    }
+}
+
+template <int K>
+__device__ __forceinline__ void stage_out(float* __restrict__ dst, const float* __restrict__ s, int first, int nv, bool accumulate)
+{
+    float* g = dst + (size_t)first * K;
+    const int nf = nv * K;
+    if ((reinterpret_cast<uintptr_t>(g) & 15) == 0) {
+        const int nf4 = nf >> 2;
+        for (int i = threadIdx.x; i < nf4; i += 256) {
+            pb_f4 v = reinterpret_cast<const pb_f4*>(s)[i];
+            if (accumulate) v += reinterpret_cast<const pb_f4*>(g)[i];
+            reinterpret_cast<pb_f4*>(g)[i] = v;
+        }
+        if ((int)threadIdx.x < (nf & 3)) {
+            const int i = 4 * nf4 + threadIdx.x;
+            g[i] = accumulate ? g[i] + s[i] : s[i];
+        }
+    } else {
+        for (int i = threadIdx.x; i < nf; i += 256) g[i] = accumulate ? g[i] + s[i] : s[i];
+    }
+}
+
 __global__ void __launch_bounds__(256) preprocess_backward_kernel(PreBwdParams p)
 {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= p.P) return;
+    // staging buffer: first the inputs [means3D 3][cov3D 6][scales 3][rotations 4] x 256, then (after a barrier) the outputs
+    // [means2D 3][colors 3][means3D 3][scales 3][opacity 1][cov3D 6][rotations 4] x 256
+    __shared__ __attribute__((aligned(16))) float s_io[256 * 23];
+    const int first = blockIdx.x * 256, nv = min(256, p.P - first);          // Gaussians of this workgroup
+    const int tid = threadIdx.x, idx = first + tid;
+    const bool valid = tid < nv;
+    float* const s_mean = s_io, * const s_c3 = s_io + 256 * 3, * const s_sc = s_io + 256 * 9, * const s_rot = s_io + 256 * 12;
+    stage_in<3>(s_mean, p.means3D, first, nv);
+    stage_in<6>(s_c3, p.cov3Ds, first, nv);
+    if (p.scales) { stage_in<3>(s_sc, p.scales, first, nv); stage_in<4>(s_rot, p.rotations, first, nv); }
+    const int my_radius = valid ? p.radii[idx] : 0;
+    __syncthreads();
 
     float g_m2[3] = { 0.f, 0.f, 0.f }, g_col[3] = { 0.f, 0.f, 0.f }, g_op = 0.f;
     float g_mean[3] = { 0.f, 0.f, 0.f }, g_cov[6] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
     float g_scale[3] = { 0.f, 0.f, 0.f }, g_rot[4] = { 0.f, 0.f, 0.f, 0.f };
 
-    if (p.radii[idx] > 0) {
+    if (my_radius > 0) {
         float V[16], Pm[16];
 #pragma unroll
         for (int i = 0; i < 16; i++) { V[i] = p.view[i]; Pm[i] = p.proj[i]; }
@@ -101,10 +154,10 @@ __global__ void __launch_bounds__(256) preprocess_backward_kernel(PreBwdParams p
         g_col[0] = a1.z; g_col[1] = a1.w; g_col[2] = a2.x;
         const float g_depth = a2.y;
 
-        const float mx = p.means3D[3 * idx + 0], my = p.means3D[3 * idx + 1], mz = p.means3D[3 * idx + 2];
+        const float mx = s_mean[3 * tid + 0], my = s_mean[3 * tid + 1], mz = s_mean[3 * tid + 2];
         float c3[6];
 #pragma unroll
-        for (int k = 0; k < 6; k++) c3[k] = p.cov3Ds[6 * idx + k];
+        for (int k = 0; k < 6; k++) c3[k] = s_c3[6 * tid + k];
 
         // ---- cov2D backward (backward.cu:144-274) ----
         float tx = V[0] * mx + V[4] * my + V[8] * mz + V[12];
@@ -195,15 +248,15 @@ __global__ void __launch_bounds__(256) preprocess_backward_kernel(PreBwdParams p
 
         // ---- cov3D -> scale / raw quaternion (backward.cu:278-341) ----
         if (p.scales) {
-            const float r = p.rotations[4 * idx + 0], x = p.rotations[4 * idx + 1];
-            const float y = p.rotations[4 * idx + 2], z = p.rotations[4 * idx + 3];
+            const float r = s_rot[4 * tid + 0], x = s_rot[4 * tid + 1];
+            const float y = s_rot[4 * tid + 2], z = s_rot[4 * tid + 3];
             const M3b R = mb_cols(
                 1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y),
                 2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x),
                 2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y));
-            const float s0 = p.scale_modifier * p.scales[3 * idx + 0];
-            const float s1 = p.scale_modifier * p.scales[3 * idx + 1];
-            const float s2 = p.scale_modifier * p.scales[3 * idx + 2];
+            const float s0 = p.scale_modifier * s_sc[3 * tid + 0];
+            const float s1 = p.scale_modifier * s_sc[3 * tid + 1];
+            const float s2 = p.scale_modifier * s_sc[3 * tid + 2];
             M3b S = mb_cols(1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f);
             S.m[0][0] = s0; S.m[1][1] = s1; S.m[2][2] = s2;
             M3b M = mb_mul(S, R);
@@ -229,37 +282,36 @@ __global__ void __launch_bounds__(256) preprocess_backward_kernel(PreBwdParams p
         }
     }
 
-    if (p.shs) {    // coefficients the active degree does not use, and every coefficient of a culled Gaussian: zero
-        const int first = (p.radii[idx] > 0) ? 3 * (p.sh_degree + 1) * (p.sh_degree + 1) : 0;
+    if (p.shs && valid) {    // coefficients the active degree does not use, and every coefficient of a culled Gaussian: zero
+        const int first_unused = (my_radius > 0) ? 3 * (p.sh_degree + 1) * (p.sh_degree + 1) : 0;
         float* row = p.dL_dsh + (size_t)idx * p.sh_coeffs * 3;
-        for (int i = first; i < 3 * p.sh_coeffs; i++) row[i] = 0.f;
+        for (int i = first_unused; i < 3 * p.sh_coeffs; i++) row[i] = 0.f;
     }
-    if (p.accumulate) {     // multi-view step: every Gaussian is owned by this thread, so plain read-modify-write sums the views
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            g_m2[k] += p.dL_dmeans2D[3 * idx + k];
-            g_col[k] += p.dL_dcolors[3 * idx + k];
-            g_mean[k] += p.dL_dmeans3D[3 * idx + k];
-            g_scale[k] += p.dL_dscales[3 * idx + k];
-        }
-        g_op += p.dL_dopacity[idx];
-#pragma unroll
-        for (int k = 0; k < 6; k++) g_cov[k] += p.dL_dcov3D[6 * idx + k];
-#pragma unroll
-        for (int k = 0; k < 4; k++) g_rot[k] += p.dL_drotations[4 * idx + k];
-    }
+    __syncthreads();            // every thread has read its inputs: the buffer now takes the outputs
+    float* const o_m2 = s_io, * const o_col = s_io + 256 * 3, * const o_mean = s_io + 256 * 6, * const o_sc = s_io + 256 * 9;
+    float* const o_op = s_io + 256 * 12, * const o_cov = s_io + 256 * 13, * const o_rot = s_io + 256 * 19;
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-        p.dL_dmeans2D[3 * idx + k] = g_m2[k];
-        p.dL_dcolors[3 * idx + k] = g_col[k];
-        p.dL_dmeans3D[3 * idx + k] = g_mean[k];
-        p.dL_dscales[3 * idx + k] = g_scale[k];
+        o_m2[3 * tid + k] = g_m2[k];
+        o_col[3 * tid + k] = g_col[k];
+        o_mean[3 * tid + k] = g_mean[k];
+        o_sc[3 * tid + k] = g_scale[k];
     }
-    p.dL_dopacity[idx] = g_op;
+    o_op[tid] = g_op;
 #pragma unroll
-    for (int k = 0; k < 6; k++) p.dL_dcov3D[6 * idx + k] = g_cov[k];
+    for (int k = 0; k < 6; k++) o_cov[6 * tid + k] = g_cov[k];
 #pragma unroll
-    for (int k = 0; k < 4; k++) p.dL_drotations[4 * idx + k] = g_rot[k];
+    for (int k = 0; k < 4; k++) o_rot[4 * tid + k] = g_rot[k];
+    __syncthreads();
+    // (accumulate: multi-view step -- every Gaussian's rows are owned by this workgroup, so plain read-modify-write sums the views)
+    const bool acc = p.accumulate != 0;
+    stage_out<3>(p.dL_dmeans2D, o_m2, first, nv, acc);
+    stage_out<3>(p.dL_dcolors, o_col, first, nv, acc);
+    stage_out<3>(p.dL_dmeans3D, o_mean, first, nv, acc);
+    stage_out<3>(p.dL_dscales, o_sc, first, nv, acc);
+    stage_out<1>(p.dL_dopacity, o_op, first, nv, acc);
+    stage_out<6>(p.dL_dcov3D, o_cov, first, nv, acc);
+    stage_out<4>(p.dL_drotations, o_rot, first, nv, acc);
 }
 
 int launch_preprocess_backward(const AgRasterBackwardArgs& a, hipStream_t s)

@@ -120,7 +120,7 @@ typedef struct AgRasterBackwardArgs {
 /* Byte offsets of the private scratch sub-arrays, for the parity tests (tests/ only). */
 typedef struct AgRasterScratchLayout {
     /* geom_buffer */
-    size_t geom_rec_off;      size_t geom_rec_stride;   /* per-Gaussian record: x,y,conic a,b,c,opacity,r,g,b,depth,r2cut,pad (floats) */
+    size_t geom_rec_off;      size_t geom_rec_stride;   /* per-Gaussian record: x,y,conic a,b,c,opacity,r,g,b,depth,r2cut,qcut (floats) */
     size_t geom_cov3d_off;                               /* [P,6] float */
     size_t geom_tiles_touched_off;                       /* [P] u32 */
     /* image_buffer */
