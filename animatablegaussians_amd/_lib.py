@@ -132,6 +132,17 @@ class AgAdamArgs(ctypes.Structure):           # include/ag_optim.h
                 + [(n, c_f * AG_ADAM_MAX_TENSORS) for n in ("bias_correction1", "bias_correction2_sqrt")])
 
 
+AG_LINEAR_MAX_JOBS = 32
+_LPTRS = c_vp * AG_LINEAR_MAX_JOBS
+
+
+class AgEqualLinearArgs(ctypes.Structure):    # include/ag_linear.h
+    _fields_ = ([(n, c_i32) for n in ("n_jobs", "B", "in_features", "act", "normalize_input", "reserved")]
+                + [("x", _LPTRS), ("weight", _LPTRS), ("bias", _LPTRS), ("out_features", c_i32 * AG_LINEAR_MAX_JOBS),
+                   ("alpha", c_f * AG_LINEAR_MAX_JOBS), ("bias_mul", c_f * AG_LINEAR_MAX_JOBS), ("y", c_vp), ("g_y", c_vp),
+                   ("g_x", _LPTRS), ("g_weight", _LPTRS), ("g_bias", _LPTRS), ("scratch", c_vp)])
+
+
 class AgSmplxModel(ctypes.Structure):
     _fields_ = [("V", c_i32), ("J", c_i32), ("NB", c_i32), ("reserved", c_i32)] + [(n, c_vp) for n in (
         "v_template", "shapedirs", "posedirs", "J_regressor", "parents", "lbs_weights", "joint_template", "joint_dirs")]
@@ -185,6 +196,13 @@ SYMBOLS = [
     ("ag_conv_status", ctypes.c_int, [ctypes.c_int]),
     ("ag_adam_args_bytes", c_sz, []),
     ("ag_adam_step", ctypes.c_int, [ctypes.POINTER(AgAdamArgs), c_vp]),
+    # include/ag_linear.h
+    ("ag_equal_linear_args_bytes", c_sz, []),
+    ("ag_equal_linear_scratch_floats", c_sz, [ctypes.POINTER(AgEqualLinearArgs)]),
+    ("ag_equal_linear_forward", ctypes.c_int, [ctypes.POINTER(AgEqualLinearArgs), c_vp]),
+    ("ag_equal_linear_backward", ctypes.c_int, [ctypes.POINTER(AgEqualLinearArgs), c_vp]),
+    ("ag_bilinear_resize_forward", ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    ("ag_bilinear_resize_backward", ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     ("ag_debug_mfma_rate", ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_vp, c_vp]),
     ("ag_debug_mfma_rate_bf16", ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_vp, c_vp]),
     # include/ag_smplx.h

@@ -1,0 +1,373 @@
+// EqualLinear layers on one-row inputs (the style path of the StyleUNets) and the bilinear resize of the view-direction feature
+// (include/ag_linear.h).  gfx950, wave64.  All launch-latency- or HBM-bound: the point of these kernels is that a whole group of layers is ONE
+// launch that reads the parameter tensors where they lie and writes the per-parameter gradients where autograd wants them.
+#include "ag_common.h"
+#include "../../include/ag_linear.h"
+#include "../../include/ag_raster.h"
+
+namespace ag {
+
+typedef float lf4 __attribute__((ext_vector_type(4)));
+constexpr int kLinRowsPerWave = 16;       // backward: rows of a job whose g_x contributions one wave adds up (one partial row per wave)
+constexpr float kSqrt2 = 1.41421356237309504880f;
+
+struct LinearLaunch {
+    AgEqualLinearArgs a;
+    int32_t row_begin[AG_LINEAR_MAX_JOBS + 1];       // forward: first output row (= column of y) of job j
+    int32_t chunk_begin[AG_LINEAR_MAX_JOBS + 1];     // backward: first 16-row chunk of job j
+    int32_t total_cols;
+};
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// 1 / sqrt(mean(x^2) + 1e-8) of one input row (PixelNorm, dual_styleunet.py:13-18), by the whole wave
+__device__ __forceinline__ float pixel_norm_factor(const float* __restrict__ x, int in, int lane)
+{
+    float s = 0.f;
+    for (int c = lane * 4; c < in; c += 256) {
+        const lf4 v = *reinterpret_cast<const lf4*>(x + c);
+        s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+    s = wave_sum(s);
+    return rsqrtf(s / (float)in + 1e-8f);
+}
+
+// ---- forward: one wave per output row -----------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) equal_linear_forward_kernel(LinearLaunch L)
+{
+    const AgEqualLinearArgs& a = L.a;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= L.total_cols) return;
+    int j = 0;
+    for (int i = 1; i < a.n_jobs; i++) j = (row >= L.row_begin[i]) ? i : j;
+    j = __builtin_amdgcn_readfirstlane(j);
+    const int o = row - L.row_begin[j], in = a.in_features;
+    const float* __restrict__ w = a.weight[j] + (size_t)o * in;
+    const float bias = a.bias[j] ? a.bias[j][o] * a.bias_mul[j] : 0.f;
+    for (int b = 0; b < a.B; b++) {
+        const float* __restrict__ x = a.x[j] + (size_t)b * in;
+        float s = 0.f;
+        for (int c = lane * 4; c < in; c += 256) {
+            const lf4 wv = *reinterpret_cast<const lf4*>(w + c), xv = *reinterpret_cast<const lf4*>(x + c);
+            s = fmaf(wv[0], xv[0], fmaf(wv[1], xv[1], fmaf(wv[2], xv[2], fmaf(wv[3], xv[3], s))));
+        }
+        s = wave_sum(s);
+        if (a.normalize_input) s *= pixel_norm_factor(x, in, lane);
+        float y = fmaf(a.alpha[j], s, bias);
+        if (a.act) y = (y > 0.f ? y : 0.2f * y) * kSqrt2;
+        if (lane == 0) a.y[(size_t)b * L.total_cols + row] = y;
+    }
+}
+
+// ---- backward, launch 1: one wave per 16 rows of a job -------------------------------------------------------------------------------
+// g_W rows and g_bias are final; the wave's share of g_x (sum over its rows of g' W) goes to partial[chunk][b][in].
+__global__ void __launch_bounds__(256) equal_linear_backward_kernel(LinearLaunch L, int total_chunks)
+{
+    const AgEqualLinearArgs& a = L.a;
+    const int lane = threadIdx.x & 63;
+    const int chunk = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (chunk >= total_chunks) return;
+    int j = 0;
+    for (int i = 1; i < a.n_jobs; i++) j = (chunk >= L.chunk_begin[i]) ? i : j;
+    j = __builtin_amdgcn_readfirstlane(j);
+    const int in = a.in_features, out = a.out_features[j];
+    const int o0 = (chunk - L.chunk_begin[j]) * kLinRowsPerWave, o1 = min(out, o0 + kLinRowsPerWave);
+    const int col0 = L.row_begin[j];
+    const float alpha = a.alpha[j];
+    const float* __restrict__ W = a.weight[j];
+    float* __restrict__ gW = a.g_weight[j];
+    float* __restrict__ gb = a.g_bias[j];
+    const bool want_gx = a.g_x[j] != nullptr;
+    // g' of this wave's rows: lane r < 16 holds row o0 + r (per batch row below)
+    for (int b = 0; b < a.B; b++) {
+        const float* __restrict__ x = a.x[j] + (size_t)b * in;
+        const float nf = a.normalize_input ? pixel_norm_factor(x, in, lane) : 1.f;
+        float gp = 0.f;
+        if (lane < o1 - o0) {
+            const size_t at = (size_t)b * L.total_cols + col0 + o0 + lane;
+            gp = a.g_y[at];
+            if (a.act) gp *= (a.y[at] > 0.f) ? kSqrt2 : 0.2f * kSqrt2;
+        }
+        // bias gradient: summed over the batch rows in order (b ascending)
+        if (gb && lane < o1 - o0) {
+            const float t = a.bias_mul[j] * gp;
+            gb[o0 + lane] = (b == 0) ? t : gb[o0 + lane] + t;
+        }
+        for (int c = lane * 4; c < in; c += 256) {
+            lf4 xv = *reinterpret_cast<const lf4*>(x + c);
+            xv *= nf * alpha;
+            lf4 acc = { 0.f, 0.f, 0.f, 0.f };
+            for (int r = 0; r < o1 - o0; r++) {
+                const float g = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gp), r));       // (r is wave-uniform)
+                if (want_gx) {
+                    const lf4 wv = *reinterpret_cast<const lf4*>(W + (size_t)(o0 + r) * in + c);
+                    acc += g * wv;
+                }
+                if (gW) {
+                    lf4* dst = reinterpret_cast<lf4*>(gW + (size_t)(o0 + r) * in + c);
+                    const lf4 t = g * xv;
+                    *dst = (b == 0) ? t : *dst + t;
+                }
+            }
+            if (want_gx) *reinterpret_cast<lf4*>(a.scratch + ((size_t)chunk * a.B + b) * in + c) = alpha * acc;
+        }
+    }
+}
+
+// ---- backward, launch 2: g_x = the partial rows of the jobs that share the input, added in a fixed order -----------------------------
+struct LinearReduce {
+    float* dst[AG_LINEAR_MAX_JOBS];
+    int32_t c0[AG_LINEAR_MAX_JOBS], c1[AG_LINEAR_MAX_JOBS];      // chunk range of input group g
+    const float* partial;
+    int32_t B, in;
+};
+
+__global__ void __launch_bounds__(256) equal_linear_reduce_kernel(LinearReduce R)
+{
+    // grid (ceil(in / 64), B, groups); 64 columns x 4 interleaved partitions of the chunk list, combined as (p0 + p1) + (p2 + p3)
+    __shared__ float s_part[4][64];
+    const int g = blockIdx.z, b = blockIdx.y;
+    const int cl = threadIdx.x & 63, q = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
+    float s = 0.f;
+    if (c < R.in)
+        for (int k = R.c0[g] + q; k < R.c1[g]; k += 4) s += R.partial[((size_t)k * R.B + b) * R.in + c];
+    s_part[q][cl] = s;
+    __syncthreads();
+    if (q == 0 && c < R.in) R.dst[g][(size_t)b * R.in + c] = (s_part[0][cl] + s_part[1][cl]) + (s_part[2][cl] + s_part[3][cl]);
+}
+
+// ---- bilinear resize (align_corners = False) -------------------------------------------------------------------------------------------
+struct Lerp { int i0, i1; float l0, l1; };
+__device__ __forceinline__ Lerp lerp_of(int o, float scale, int n_in)
+{
+    // torch's area_pixel_compute_source_index (align_corners false, not cubic): max(0, scale * (o + 0.5) - 0.5)
+    float src = scale * ((float)o + 0.5f) - 0.5f;
+    src = src < 0.f ? 0.f : src;
+    Lerp r;
+    r.i0 = (int)src;
+    r.i1 = r.i0 + ((r.i0 < n_in - 1) ? 1 : 0);
+    r.l1 = src - (float)r.i0;
+    r.l0 = 1.0f - r.l1;
+    return r;
+}
+
+// forward: a thread writes 4 consecutive outputs of a row (one 16-byte store when the row length allows); the two source rows and the up to 8
+// source columns come through L1
+__global__ void __launch_bounds__(256) bilinear_forward_kernel(float* __restrict__ out, const float* __restrict__ in, int N, int H, int W, int OH, int OW,
+                                                               float sy, float sx)
+{
+    // block (64, 4): threadIdx.y + 4 blockIdx.x = the output row (plane * OH + oy), threadIdx.x strides over the row's 4-output groups -- no
+    // 64-bit divisions per element (the first form spent most of its time in them: 25 us for 33 MB)
+    const int owq = (OW + 3) >> 2;
+    const bool vec = (OW & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+    const long long rows = (long long)N * OH;
+    for (long long row = (long long)blockIdx.x * 4 + threadIdx.y; row < rows; row += (long long)gridDim.x * 4) {
+    const size_t n = (size_t)((unsigned)row / (unsigned)OH);            // (the launcher refuses more than 2^31 rows); wave-uniform
+    const int oy = (int)((unsigned)row - (unsigned)n * (unsigned)OH);
+    for (int q = threadIdx.x; q < owq; q += 64) {
+        const Lerp ly = lerp_of(oy, sy, H);
+        const float* r0 = in + (n * H + ly.i0) * (size_t)W;
+        const float* r1 = in + (n * H + ly.i1) * (size_t)W;
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int ox = min(4 * q + k, OW - 1);
+            const Lerp lx = lerp_of(ox, sx, W);
+            v[k] = ly.l0 * (lx.l0 * r0[lx.i0] + lx.l1 * r0[lx.i1]) + ly.l1 * (lx.l0 * r1[lx.i0] + lx.l1 * r1[lx.i1]);
+        }
+        float* dst = out + (n * OH + oy) * (size_t)OW + 4 * q;
+        if (vec) *reinterpret_cast<lf4*>(dst) = lf4{ v[0], v[1], v[2], v[3] };
+        else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) if (4 * q + k < OW) dst[k] = v[k];
+        }
+    }
+    }
+}
+
+// weight with which output o reads input i along one axis (0 when it does not): lerp_of's two weights are the tent max(0, 1 - |src - i|) around
+// the clamped source coordinate, except at the upper border, where the clamped upper neighbour folds both weights onto the last input
+// (8 instructions per candidate against 14 for a full lerp_of and two compares; the backward is bound by these)
+__device__ __forceinline__ float axis_weight(int o, int i, float scale, int n_in)
+{
+    float src = scale * ((float)o + 0.5f) - 0.5f;
+    src = src < 0.f ? 0.f : src;
+    const float fi = (float)i;
+    const float tent = fmaxf(0.f, 1.0f - fabsf(src - fi));
+    return (i == n_in - 1 && src >= fi) ? 1.0f : tent;
+}
+
+// outputs that can read input i: source coordinates in (i - 1, i + 1), i.e. o in ((i - 0.5) / scale - 0.5, (i + 1.5) / scale - 0.5); floor / ceil of the
+// bounds keep a candidate of margin on either side of the open interval (DESIGN: a candidate outside reads nothing, its weight is 0)
+__device__ __forceinline__ void reader_range(int i, float scale, int n_out, int& lo, int& hi)
+{
+    const float inv = 1.0f / scale;
+    lo = (int)floorf(((float)i - 0.5f) * inv - 0.5f);
+    hi = (int)ceilf(((float)i + 1.5f) * inv - 0.5f);
+    lo = lo < 0 ? 0 : lo;
+    hi = hi > n_out - 1 ? n_out - 1 : hi;
+}
+
+// backward (the adjoint as a GATHER: fixed order, no atomics): a thread owns one input element and sums w_y(oy) w_x(ox) g[oy][ox] over the outputs
+// that read it.  The candidate weights of both axes are formed once (<= kBilinearTaps per axis: up-sampling factors up to 2 and every
+// down-sampling one; wider kernels take the loop form below).
+constexpr int kBilinearTaps = 6;
+__global__ void __launch_bounds__(256) bilinear_backward_kernel(float* __restrict__ g_in, const float* __restrict__ g_out, int N, int H, int W, int OH,
+                                                                int OW, float sy, float sx)
+{
+    const long long rows = (long long)N * H;
+    for (long long row = (long long)blockIdx.x * 4 + threadIdx.y; row < rows; row += (long long)gridDim.x * 4) {
+    const size_t n = (size_t)((unsigned)row / (unsigned)H);
+    const int iy = (int)((unsigned)row - (unsigned)n * (unsigned)H);
+    for (int ix = threadIdx.x; ix < W; ix += 64) {
+        const size_t e = (size_t)row * W + ix;
+        int y0, y1, x0, x1;
+        reader_range(iy, sy, OH, y0, y1);
+        reader_range(ix, sx, OW, x0, x1);
+        const float* g = g_out + n * (size_t)OH * OW;
+        float s = 0.f;
+        if (y1 - y0 < kBilinearTaps && x1 - x0 < kBilinearTaps) {
+            float wx[kBilinearTaps];
+#pragma unroll
+            for (int k = 0; k < kBilinearTaps; k++) wx[k] = (x0 + k <= x1) ? axis_weight(x0 + k, ix, sx, W) : 0.f;
+#pragma unroll
+            for (int j = 0; j < kBilinearTaps; j++) {
+                const int oy = y0 + j;
+                const float wy = (oy <= y1) ? axis_weight(oy, iy, sy, H) : 0.f;
+                if (wy == 0.f) continue;
+                const float* row = g + (size_t)oy * OW + x0;
+                float r = 0.f;
+#pragma unroll
+                for (int k = 0; k < kBilinearTaps; k++)
+                    if (wx[k] != 0.f) r = fmaf(wx[k], row[k], r);
+                s = fmaf(wy, r, s);
+            }
+        } else {
+            for (int oy = y0; oy <= y1; oy++) {
+                const float wy = axis_weight(oy, iy, sy, H);
+                if (wy == 0.f) continue;
+                float row = 0.f;
+                for (int ox = x0; ox <= x1; ox++) {
+                    const float wx = axis_weight(ox, ix, sx, W);
+                    if (wx != 0.f) row = fmaf(wx, g[(size_t)oy * OW + ox], row);
+                }
+                s = fmaf(wy, row, s);
+            }
+        }
+        g_in[e] = s;
+    }
+    }
+}
+
+}  // namespace ag
+
+using namespace ag;
+
+namespace {
+
+bool prepare(const AgEqualLinearArgs* a, LinearLaunch& L, int& total_chunks, const char* who)
+{
+    if (!a || a->n_jobs < 1 || a->n_jobs > AG_LINEAR_MAX_JOBS || a->B < 1 || a->B > 8 || a->in_features < 4 || (a->in_features & 3) || !a->y) {
+        set_error("%s: bad job count / batch / in_features (a multiple of 4)", who);
+        return false;
+    }
+    L.a = *a;
+    long long rows = 0, chunks = 0;
+    for (int j = 0; j < a->n_jobs; j++) {
+        if (!a->x[j] || !a->weight[j] || a->out_features[j] < 1) { set_error("%s: job %d without input / weight / rows", who, j); return false; }
+        if ((reinterpret_cast<uintptr_t>(a->x[j]) | reinterpret_cast<uintptr_t>(a->weight[j])) & 15) { set_error("%s: job %d: input / weight not 16-byte aligned", who, j); return false; }
+        L.row_begin[j] = (int32_t)rows;
+        L.chunk_begin[j] = (int32_t)chunks;
+        rows += a->out_features[j];
+        chunks += (a->out_features[j] + kLinRowsPerWave - 1) / kLinRowsPerWave;
+    }
+    if (rows > 0x3fffffffLL) { set_error("%s: too many rows", who); return false; }
+    for (int j = a->n_jobs; j <= AG_LINEAR_MAX_JOBS; j++) { L.row_begin[j] = (int32_t)rows; L.chunk_begin[j] = (int32_t)chunks; }
+    L.total_cols = (int32_t)rows;
+    total_chunks = (int)chunks;
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t ag_equal_linear_args_bytes(void) { return sizeof(AgEqualLinearArgs); }
+
+size_t ag_equal_linear_scratch_floats(const AgEqualLinearArgs* a)
+{
+    LinearLaunch L;
+    int chunks = 0;
+    if (!prepare(a, L, chunks, "ag_equal_linear_scratch_floats")) return 0;
+    return (size_t)chunks * a->B * a->in_features + 64;
+}
+
+int ag_equal_linear_forward(const AgEqualLinearArgs* a, void* stream)
+{
+    LinearLaunch L;
+    int chunks = 0;
+    if (!prepare(a, L, chunks, "ag_equal_linear_forward")) return AG_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(equal_linear_forward_kernel, dim3((L.total_cols + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), L);
+    return check_hip(hipGetLastError(), "equal_linear_forward_kernel");
+}
+
+int ag_equal_linear_backward(const AgEqualLinearArgs* a, void* stream)
+{
+    LinearLaunch L;
+    int chunks = 0;
+    if (!prepare(a, L, chunks, "ag_equal_linear_backward")) return AG_ERR_INVALID_ARGUMENT;
+    if (!a->g_y) { set_error("ag_equal_linear_backward: no g_y"); return AG_ERR_INVALID_ARGUMENT; }
+    // input groups: consecutive jobs with the same x share one g_x
+    LinearReduce R{};
+    int groups = 0;
+    bool any_gx = false;
+    for (int j = 0; j < a->n_jobs; j++) {
+        if (a->g_weight[j] && (reinterpret_cast<uintptr_t>(a->g_weight[j]) & 15)) { set_error("ag_equal_linear_backward: g_weight not 16-byte aligned"); return AG_ERR_INVALID_ARGUMENT; }
+        const bool cont = j > 0 && a->x[j] == a->x[j - 1];
+        if (cont && a->g_x[j] != a->g_x[j - 1]) { set_error("ag_equal_linear_backward: jobs of one input must pass one g_x"); return AG_ERR_INVALID_ARGUMENT; }
+        if (!a->g_x[j]) continue;
+        any_gx = true;
+        if (cont) { R.c1[groups - 1] = L.chunk_begin[j + 1]; continue; }
+        R.dst[groups] = a->g_x[j]; R.c0[groups] = L.chunk_begin[j]; R.c1[groups] = L.chunk_begin[j + 1];
+        groups++;
+    }
+    if (any_gx && a->normalize_input) { set_error("ag_equal_linear_backward: no input gradient through the PixelNorm option"); return AG_ERR_INVALID_ARGUMENT; }
+    if (any_gx && !a->scratch) { set_error("ag_equal_linear_backward: g_x needs scratch"); return AG_ERR_INVALID_ARGUMENT; }
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(equal_linear_backward_kernel, dim3((chunks + 3) / 4), dim3(256), 0, s, L, chunks);
+    if (check_hip(hipGetLastError(), "equal_linear_backward_kernel")) return AG_ERR_HIP;
+    if (groups) {
+        R.partial = a->scratch; R.B = a->B; R.in = a->in_features;
+        hipLaunchKernelGGL(equal_linear_reduce_kernel, dim3((a->in_features + 63) / 64, a->B, groups), dim3(256), 0, s, R);
+        if (check_hip(hipGetLastError(), "equal_linear_reduce_kernel")) return AG_ERR_HIP;
+    }
+    return AG_OK;
+}
+
+int ag_bilinear_resize_forward(float* out, const float* in, int32_t N, int32_t H, int32_t W, int32_t OH, int32_t OW, void* stream)
+{
+    if (!out || !in || N < 1 || H < 1 || W < 1 || OH < 1 || OW < 1 || (long long)N * OH > 0x7fffffffLL || (long long)N * H > 0x7fffffffLL) { set_error("ag_bilinear_resize_forward: bad arguments"); return AG_ERR_INVALID_ARGUMENT; }
+    const long long rows = (long long)N * OH;
+    const unsigned grid = (unsigned)((rows + 3) / 4 < 65536 * 16 ? (rows + 3) / 4 : 65536 * 16);
+    hipLaunchKernelGGL(bilinear_forward_kernel, dim3(grid), dim3(64, 4), 0, reinterpret_cast<hipStream_t>(stream), out, in, N, H, W, OH, OW,
+                       (float)H / (float)OH, (float)W / (float)OW);
+    return check_hip(hipGetLastError(), "bilinear_forward_kernel");
+}
+
+int ag_bilinear_resize_backward(float* g_in, const float* g_out, int32_t N, int32_t H, int32_t W, int32_t OH, int32_t OW, void* stream)
+{
+    if (!g_in || !g_out || N < 1 || H < 1 || W < 1 || OH < 1 || OW < 1 || (long long)N * OH > 0x7fffffffLL || (long long)N * H > 0x7fffffffLL) { set_error("ag_bilinear_resize_backward: bad arguments"); return AG_ERR_INVALID_ARGUMENT; }
+    const long long rows = (long long)N * H;
+    const unsigned grid = (unsigned)((rows + 3) / 4 < 65536 * 16 ? (rows + 3) / 4 : 65536 * 16);
+    hipLaunchKernelGGL(bilinear_backward_kernel, dim3(grid), dim3(64, 4), 0, reinterpret_cast<hipStream_t>(stream), g_in, g_out, N, H, W, OH, OW,
+                       (float)H / (float)OH, (float)W / (float)OW);
+    return check_hip(hipGetLastError(), "bilinear_backward_kernel");
+}
+
+}  // extern "C"

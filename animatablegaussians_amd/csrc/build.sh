@@ -19,7 +19,7 @@ FAST="-ffp-contract=fast"
 compile() { # src flags
   local src="$1"; shift
   local obj="$OBJ/$(basename "${src%.hip}").o"
-  if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ "$HERE/ag_common.h" -nt "$obj" ] || [ "$HERE/../../include/ag_raster.h" -nt "$obj" ] || [ "$HERE/../../include/ag_avatar.h" -nt "$obj" ] || [ "$HERE/../../include/ag_styleunet.h" -nt "$obj" ] || [ "$HERE/../../include/ag_conv.h" -nt "$obj" ] || [ "$HERE/../../include/ag_lpips.h" -nt "$obj" ] || [ "$HERE/../../include/ag_smplx.h" -nt "$obj" ] || [ "$HERE/ag_sh.h" -nt "$obj" ] || [ "$HERE/../../include/ag_layers.h" -nt "$obj" ] || [ "$HERE/../../include/ag_optim.h" -nt "$obj" ]; then
+  if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ "$HERE/ag_common.h" -nt "$obj" ] || [ "$HERE/../../include/ag_raster.h" -nt "$obj" ] || [ "$HERE/../../include/ag_avatar.h" -nt "$obj" ] || [ "$HERE/../../include/ag_styleunet.h" -nt "$obj" ] || [ "$HERE/../../include/ag_conv.h" -nt "$obj" ] || [ "$HERE/../../include/ag_lpips.h" -nt "$obj" ] || [ "$HERE/../../include/ag_smplx.h" -nt "$obj" ] || [ "$HERE/ag_sh.h" -nt "$obj" ] || [ "$HERE/../../include/ag_layers.h" -nt "$obj" ] || [ "$HERE/../../include/ag_optim.h" -nt "$obj" ] || [ "$HERE/../../include/ag_linear.h" -nt "$obj" ]; then
     echo "hipcc $(basename "$src") $*"
     rm -f "$obj"
     local log; log="$(mktemp)"
@@ -42,6 +42,7 @@ compile "$HERE/ag_lpips.hip" $FAST &
 compile "$HERE/ag_smplx.hip" $FAST &
 compile "$HERE/ag_layers.hip" $FAST &
 compile "$HERE/ag_optim.hip" $FAST &
+compile "$HERE/ag_linear.hip" $FAST &
 fail=0
 for job in $(jobs -p); do wait "$job" || fail=1; done
 if [ "$fail" -ne 0 ]; then echo "build.sh: compilation failed" >&2; exit 1; fi

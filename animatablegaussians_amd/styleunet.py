@@ -22,11 +22,11 @@ import math
 import os
 
 import torch
-import torch.nn.functional as F
 
 from . import conv as agc
 from . import fused_layers
-from .styleunet_ops import fused_leaky_relu, haar_merge, haar_split, modulate_weight, noise_bias_act, skip_chain, upfirdn2d_nchw
+from . import linear_ops
+from .styleunet_ops import haar_merge, haar_split, modulate_weight, noise_bias_act, skip_chain, upfirdn2d_nchw
 
 _SQRT2 = 2 ** 0.5
 # ConvLayer / StyledConv / ToRGB as one autograd node each (fused_layers.py: same kernels, same order, bit-identical results, a third of
@@ -223,17 +223,21 @@ class DualStyleUNet(torch.nn.Module):
         return noise_bias_act(x, None, None, bias)
 
     def _stage_styles(self, branch, stages, w_latent):
-        """The modulation vectors of every modulated convolution of ``stages`` (two StyledConvs and one ToRGB each) from ONE GEMM:
-        EqualLinear(w_latent) with lr_mul 1 (:152-155) is ``w_latent @ (W * c)^T + b`` per convolution; here the 3 * len(stages)
-        weight matrices are stacked and ``c`` is the GEMM's alpha (c * (w_latent @ W^T) + b: the same value up to the rounding of the
-        scaling).  Replaces three small kernels per convolution forward (scale the weight, scale the bias, GEMV) and seven backward
-        with two concatenations and one GEMM per stage group.  Returns {convolution prefix: [B, C] style}."""
+        """The modulation vectors of every modulated convolution of ``stages`` (two StyledConvs and one ToRGB each) from ONE native launch:
+        EqualLinear(w_latent) with lr_mul 1 (:152-155) is ``w_latent @ (W * c)^T + b`` per convolution; the 3 * len(stages) layers are jobs of one
+        ``ag_equal_linear_forward`` call that reads the parameter tensors where they lie (``c`` is the call's alpha: c * (w_latent @ W^T) + b, the same
+        value up to the rounding of the scaling) and, backward, writes every parameter's gradient where autograd wants it.  Rounds 3-5 stacked the
+        weights (a 12.6-MB concatenation per decoder branch and step) for one hipBLASLt GEMV forward and two backward: ~0.6 ms of a 33-ms
+        training step (profiles/r05b_glue_v1.txt).  Returns {convolution prefix: [B, C] style}."""
         prefixes = [p for n in stages for p in (f"convs{branch}.{2 * n}.conv", f"convs{branch}.{2 * n + 1}.conv", f"to_rgbs{branch}.{n}.conv")]
         ws = [self._p(f"{p}.modulation.weight") for p in prefixes]
         bs = [self._p(f"{p}.modulation.bias") for p in prefixes]
-        W = torch.cat(ws, 0)
-        s = torch.addmm(torch.cat(bs, 0)[None], w_latent, W.t(), alpha=1 / math.sqrt(W.shape[1]))
-        return dict(zip(prefixes, torch.split(s, [w.shape[0] for w in ws], dim=1)))
+        out = {}
+        for c0 in range(0, len(prefixes), linear_ops.MAX_JOBS):
+            c1 = min(len(prefixes), c0 + linear_ops.MAX_JOBS)
+            s = linear_ops.equal_linear_group(w_latent, ws[c0:c1], bs[c0:c1])
+            out.update(zip(prefixes[c0:c1], torch.split(s, [w.shape[0] for w in ws[c0:c1]], dim=1)))
+        return out
 
     def _modulated_weight(self, prefix, styles, demodulate, transposed=False):
         w = self._p(f"{prefix}.weight")                                  # [1, Cout, Cin, k, k]
@@ -286,12 +290,7 @@ class DualStyleUNet(torch.nn.Module):
 
     def get_latent(self, z):
         """Mapping network: PixelNorm + n_mlp x EqualLinear(lr_mul, fused leaky ReLU)  (:594-610)."""
-        x = z * torch.rsqrt(torch.mean(z ** 2, dim=1, keepdim=True) + 1e-8)
-        for i in range(self.n_mlp):
-            w = self._p(f"style.{i + 1}.weight")
-            x = F.linear(x, w * ((1 / math.sqrt(w.shape[1])) * self.lr_mlp))
-            x = fused_leaky_relu(x, self._p(f"style.{i + 1}.bias") * self.lr_mlp)
-        return x
+        return latents_of([self], [z])[0]
 
     def encode(self, condition_img):
         """Pose map [1, inp_ch, S, S] -> feature levels, finest first  (:854-864)."""
@@ -331,7 +330,7 @@ class DualStyleUNet(torch.nn.Module):
         """View-dependent tail of one decoder: add the view feature, run the remaining stages, inverse wavelet."""
         if view_feature is not None and len(self.dec) > self.VIEW_STAGE:
             if view_feature.shape[-2:] != out.shape[-2:]:
-                view_feature = F.interpolate(view_feature, out.shape[-2:], mode="bilinear")
+                view_feature = linear_ops.bilinear_resize(view_feature, out.shape[-2:])       # F.interpolate(..., mode="bilinear") (:881-883)
             out = out + view_feature
         out, skip = self._decode_stages(branch, levels, w_latent, noise, out, skip, range(self.VIEW_STAGE + 1, len(self.dec)))
         return self._haar_merge(skip)
@@ -418,3 +417,22 @@ class DualStyleUNet(torch.nn.Module):
         if return_latents:
             return images, w_latent.unsqueeze(1).repeat(1, self.n_latent, 1)
         return images, None
+
+
+def latents_of(nets, zs):
+    """The mapping networks (PixelNorm + n_mlp x EqualLinear(lr_mul, fused leaky ReLU), dual_styleunet.py:594-610) of several networks: layer i of
+    ALL of them is one native launch (include/ag_linear.h; the PixelNorm rides in the first).  Returns one latent [B, style_dim] per network."""
+    n0 = nets[0]
+    if any((n.n_mlp, n.style_dim, n.lr_mlp) != (n0.n_mlp, n0.style_dim, n0.lr_mlp) for n in nets):
+        return [latents_of([n], [z])[0] for n, z in zip(nets, zs)]
+    xs = list(zs)
+    norm_inside = not any(z.requires_grad for z in zs)          # (the native PixelNorm option has no input gradient: a learnable z takes the torch form)
+    if not norm_inside:
+        xs = [z * torch.rsqrt(torch.mean(z ** 2, dim=1, keepdim=True) + 1e-8) for z in zs]
+    for i in range(n0.n_mlp):
+        y = linear_ops.equal_linear_group(xs, [n._p(f"style.{i + 1}.weight") for n in nets], [n._p(f"style.{i + 1}.bias") for n in nets],
+                                          lr_mul=n0.lr_mlp, activation=True, normalize_input=norm_inside and i == 0)
+        xs = list(torch.split(y, n0.style_dim, dim=1))
+    if n0.n_mlp == 0 and norm_inside:
+        xs = [z * torch.rsqrt(torch.mean(z ** 2, dim=1, keepdim=True) + 1e-8) for z in zs]
+    return xs

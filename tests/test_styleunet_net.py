@@ -313,18 +313,20 @@ def test_layer_level_autograd_nodes_equal_the_per_kernel_chain():
     assert set(res[True][2]) == set(res[False][2])
 
 
+@pytest.mark.gpu
 def test_stacked_modulation_gemm_equals_the_per_layer_equal_linear():
     """DualStyleUNet._stage_styles: the EqualLinear modulation (dual_styleunet.py:152-155, lr_mul 1: F.linear(w, W * (1 / sqrt(512)), b)) of
-    every StyledConv / ToRGB of a stage group as one addmm on the stacked weights -- same values as the per-layer formula (CPU, fp64 as the
-    yardstick: both fp32 forms are within 2e-6 of it relative to the style scale), for both branches and both stage groups."""
+    every StyledConv / ToRGB of a stage group as ONE native launch (include/ag_linear.h; rounds 3-5: one addmm on the stacked weights) -- same
+    values as the per-layer formula (fp64 as the yardstick: both fp32 forms are within 2e-6 of it relative to the style scale), for both branches
+    and both stage groups."""
     import math
     import torch
     import torch.nn.functional as F
     from animatablegaussians_amd.styleunet import DualStyleUNet
 
     torch.manual_seed(3)
-    net = DualStyleUNet(inp_size=512, inp_ch=3, out_ch=3, out_size=1024, style_dim=512, n_mlp=2)
-    w_latent = torch.randn(1, 512)
+    net = DualStyleUNet(inp_size=512, inp_ch=3, out_ch=3, out_size=1024, style_dim=512, n_mlp=2).cuda()
+    w_latent = torch.randn(1, 512).cuda()
     n_stages = len(net.dec)
     for branch in (1, 2):
         for stages in (range(0, min(net.VIEW_STAGE + 1, n_stages)), range(net.VIEW_STAGE + 1, n_stages)):
