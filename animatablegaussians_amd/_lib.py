@@ -139,7 +139,7 @@ _LPTRS = c_vp * AG_LINEAR_MAX_JOBS
 class AgEqualLinearArgs(ctypes.Structure):    # include/ag_linear.h
     _fields_ = ([(n, c_i32) for n in ("n_jobs", "B", "in_features", "act", "normalize_input", "reserved")]
                 + [("x", _LPTRS), ("weight", _LPTRS), ("bias", _LPTRS), ("out_features", c_i32 * AG_LINEAR_MAX_JOBS),
-                   ("alpha", c_f * AG_LINEAR_MAX_JOBS), ("bias_mul", c_f * AG_LINEAR_MAX_JOBS), ("y", c_vp), ("g_y", c_vp),
+                   ("alpha", c_f * AG_LINEAR_MAX_JOBS), ("bias_mul", c_f * AG_LINEAR_MAX_JOBS), ("y", _LPTRS), ("g_y", _LPTRS),
                    ("g_x", _LPTRS), ("g_weight", _LPTRS), ("g_bias", _LPTRS), ("scratch", c_vp)])
 
 
@@ -203,6 +203,8 @@ SYMBOLS = [
     ("ag_equal_linear_backward", ctypes.c_int, [ctypes.POINTER(AgEqualLinearArgs), c_vp]),
     ("ag_bilinear_resize_forward", ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     ("ag_bilinear_resize_backward", ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    ("ag_plane_sums_scratch_floats", c_sz, [c_i32, ctypes.c_int64]),
+    ("ag_plane_sums", ctypes.c_int, [c_vp, c_vp, c_i32, ctypes.c_int64, c_vp, c_vp]),
     ("ag_debug_mfma_rate", ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_vp, c_vp]),
     ("ag_debug_mfma_rate_bf16", ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_vp, c_vp]),
     # include/ag_smplx.h

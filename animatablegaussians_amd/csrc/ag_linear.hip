@@ -61,7 +61,7 @@ __global__ void __launch_bounds__(256) equal_linear_forward_kernel(LinearLaunch 
         if (a.normalize_input) s *= pixel_norm_factor(x, in, lane);
         float y = fmaf(a.alpha[j], s, bias);
         if (a.act) y = (y > 0.f ? y : 0.2f * y) * kSqrt2;
-        if (lane == 0) a.y[(size_t)b * L.total_cols + row] = y;
+        if (lane == 0) a.y[j][(size_t)b * a.out_features[j] + o] = y;
     }
 }
 
@@ -78,7 +78,6 @@ __global__ void __launch_bounds__(256) equal_linear_backward_kernel(LinearLaunch
     j = __builtin_amdgcn_readfirstlane(j);
     const int in = a.in_features, out = a.out_features[j];
     const int o0 = (chunk - L.chunk_begin[j]) * kLinRowsPerWave, o1 = min(out, o0 + kLinRowsPerWave);
-    const int col0 = L.row_begin[j];
     const float alpha = a.alpha[j];
     const float* __restrict__ W = a.weight[j];
     float* __restrict__ gW = a.g_weight[j];
@@ -90,9 +89,9 @@ __global__ void __launch_bounds__(256) equal_linear_backward_kernel(LinearLaunch
         const float nf = a.normalize_input ? pixel_norm_factor(x, in, lane) : 1.f;
         float gp = 0.f;
         if (lane < o1 - o0) {
-            const size_t at = (size_t)b * L.total_cols + col0 + o0 + lane;
-            gp = a.g_y[at];
-            if (a.act) gp *= (a.y[at] > 0.f) ? kSqrt2 : 0.2f * kSqrt2;
+            const size_t at = (size_t)b * out + o0 + lane;
+            gp = a.g_y[j][at];
+            if (a.act) gp *= (a.y[j][at] > 0.f) ? kSqrt2 : 0.2f * kSqrt2;
         }
         // bias gradient: summed over the batch rows in order (b ascending)
         if (gb && lane < o1 - o0) {
@@ -265,6 +264,49 @@ __global__ void __launch_bounds__(256) bilinear_backward_kernel(float* __restric
     }
 }
 
+// ---- plane sums -------------------------------------------------------------------------------------------------------------------
+constexpr int kPlaneSliceMin = 4096;      // floats per slice at least (a workgroup's 256 threads x 4 float4)
+__host__ __device__ inline int plane_slices(int planes, long long len)
+{
+    long long s = (4096 + planes - 1) / planes;                   // ~4096 workgroups in all
+    const long long most = (len + kPlaneSliceMin - 1) / kPlaneSliceMin;
+    s = s > most ? most : s;
+    return (int)(s < 1 ? 1 : s);
+}
+
+__global__ void __launch_bounds__(256) plane_partial_sums_kernel(float* __restrict__ partial, const float* __restrict__ in, long long len, int S)
+{
+    __shared__ float s_w[4];
+    const int sl = blockIdx.x, p = blockIdx.y;
+    const long long per = ((len + S - 1) / S + 3) & ~3LL;          // slice length, a multiple of 4
+    const long long e0 = (long long)sl * per, e1 = e0 + per < len ? e0 + per : len;
+    const float* __restrict__ x = in + (size_t)p * len;
+    float s = 0.f;
+    if ((((uintptr_t)x) & 15) == 0) {
+        long long i = e0 + (long long)threadIdx.x * 4;
+        for (; i + 3 < e1; i += 1024) {
+            const lf4 v = *reinterpret_cast<const lf4*>(x + i);
+            s += (v[0] + v[1]) + (v[2] + v[3]);
+        }
+        for (; i < e1; i++) s += x[i];                              // the plane's ragged end (one thread)
+    } else {
+        for (long long i = e0 + threadIdx.x; i < e1; i += 256) s += x[i];
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[(size_t)p * S + sl] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+}
+
+__global__ void __launch_bounds__(256) plane_final_sums_kernel(float* __restrict__ out, const float* __restrict__ partial, int planes, int S)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= planes) return;
+    float s = 0.f;
+    for (int k = 0; k < S; k++) s += partial[(size_t)p * S + k];
+    out[p] = s;
+}
+
 }  // namespace ag
 
 using namespace ag;
@@ -273,14 +315,14 @@ namespace {
 
 bool prepare(const AgEqualLinearArgs* a, LinearLaunch& L, int& total_chunks, const char* who)
 {
-    if (!a || a->n_jobs < 1 || a->n_jobs > AG_LINEAR_MAX_JOBS || a->B < 1 || a->B > 8 || a->in_features < 4 || (a->in_features & 3) || !a->y) {
+    if (!a || a->n_jobs < 1 || a->n_jobs > AG_LINEAR_MAX_JOBS || a->B < 1 || a->B > 8 || a->in_features < 4 || (a->in_features & 3)) {
         set_error("%s: bad job count / batch / in_features (a multiple of 4)", who);
         return false;
     }
     L.a = *a;
     long long rows = 0, chunks = 0;
     for (int j = 0; j < a->n_jobs; j++) {
-        if (!a->x[j] || !a->weight[j] || a->out_features[j] < 1) { set_error("%s: job %d without input / weight / rows", who, j); return false; }
+        if (!a->x[j] || !a->weight[j] || !a->y[j] || a->out_features[j] < 1) { set_error("%s: job %d without input / weight / output / rows", who, j); return false; }
         if ((reinterpret_cast<uintptr_t>(a->x[j]) | reinterpret_cast<uintptr_t>(a->weight[j])) & 15) { set_error("%s: job %d: input / weight not 16-byte aligned", who, j); return false; }
         L.row_begin[j] = (int32_t)rows;
         L.chunk_begin[j] = (int32_t)chunks;
@@ -322,7 +364,8 @@ int ag_equal_linear_backward(const AgEqualLinearArgs* a, void* stream)
     LinearLaunch L;
     int chunks = 0;
     if (!prepare(a, L, chunks, "ag_equal_linear_backward")) return AG_ERR_INVALID_ARGUMENT;
-    if (!a->g_y) { set_error("ag_equal_linear_backward: no g_y"); return AG_ERR_INVALID_ARGUMENT; }
+    for (int j = 0; j < a->n_jobs; j++)
+        if (!a->g_y[j]) { set_error("ag_equal_linear_backward: job %d without g_y", j); return AG_ERR_INVALID_ARGUMENT; }
     // input groups: consecutive jobs with the same x share one g_x
     LinearReduce R{};
     int groups = 0;
@@ -368,6 +411,23 @@ int ag_bilinear_resize_backward(float* g_in, const float* g_out, int32_t N, int3
     hipLaunchKernelGGL(bilinear_backward_kernel, dim3(grid), dim3(64, 4), 0, reinterpret_cast<hipStream_t>(stream), g_in, g_out, N, H, W, OH, OW,
                        (float)H / (float)OH, (float)W / (float)OW);
     return check_hip(hipGetLastError(), "bilinear_backward_kernel");
+}
+
+size_t ag_plane_sums_scratch_floats(int32_t planes, int64_t len)
+{
+    if (planes < 1 || len < 1) return 0;
+    return (size_t)planes * plane_slices(planes, len) + 64;
+}
+
+int ag_plane_sums(float* out, const float* in, int32_t planes, int64_t len, float* scratch, void* stream)
+{
+    if (!out || !in || !scratch || planes < 1 || planes > 65535 || len < 1) { set_error("ag_plane_sums: bad arguments"); return AG_ERR_INVALID_ARGUMENT; }
+    const int S = plane_slices(planes, len);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(plane_partial_sums_kernel, dim3(S, planes), dim3(256), 0, s, scratch, in, (long long)len, S);
+    if (check_hip(hipGetLastError(), "plane_partial_sums_kernel")) return AG_ERR_HIP;
+    hipLaunchKernelGGL(plane_final_sums_kernel, dim3((planes + 255) / 256), dim3(256), 0, s, out, scratch, planes, S);
+    return check_hip(hipGetLastError(), "plane_final_sums_kernel");
 }
 
 }  // extern "C"

@@ -22,7 +22,7 @@ import torch
 
 from . import _lib
 from . import conv as agc
-from .linear_ops import bilinear_resize
+from .linear_ops import bilinear_resize, plane_sums
 from .styleunet import latents_of
 from .styleunet_ops import _HAAR_SYNTHESIS, _flipped, _skip_taps_host, upfirdn2d_nchw
 
@@ -397,7 +397,7 @@ class _GroupedToRGB(torch.autograd.Function):
             gw = torch.empty((G,) + tuple(ws[s].shape), dtype=torch.float32, device=dev) if want_w else None
             gst = torch.empty((G,) + tuple(styles[s].shape), dtype=torch.float32, device=dev) if want_w else None
             gskip = torch.empty((G, a.Cout, H // 2, W // 2), dtype=torch.float32, device=dev) if (has_skip[r] and nskips[r]) else None
-            gb = g.sum((2, 3)) if any(pn[2 * M + s:2 * M + e]) else None          # [G, Cout], torch's deterministic reduction
+            gb = plane_sums(g) if any(pn[2 * M + s:2 * M + e]) else None          # [G, Cout]: fixed slices, fixed order (ag_plane_sums)
             _fill(a.weight, ws[s:e])
             _fill(a.style, styles[s:e])
             a.x, a.w_mod, a.g_out = x.data_ptr() + 4 * s * Cin * H * W, wms[r].data_ptr(), g.data_ptr()

@@ -23,8 +23,21 @@ def _check_gpu(t, what):
         raise RuntimeError(f"{what}: float32 GPU tensors only (no CPU path in this package)")
 
 
+def _pad4(n):
+    return (n + 3) & ~3
+
+
+def _carve(flat, B, outs):
+    """[B, out_j] tensors inside one allocation, each starting 16-byte aligned (an output may be the next call's input)."""
+    ys, off = [], 0
+    for o in outs:
+        ys.append(flat[off:off + B * o].view(B, o))
+        off += _pad4(B * o)
+    return ys
+
+
 class _EqualLinearGroup(torch.autograd.Function):
-    """y [B, sum out_j] of n EqualLinear layers ("jobs"): job j reads xs[j] (jobs sharing an input are consecutive and pass the same tensor),
+    """(y_j [B, out_j]) of n EqualLinear layers ("jobs"): job j reads xs[j] (jobs sharing an input are consecutive and pass the same tensor),
     ``act``: the reference's fused leaky ReLU on every job; ``normalize``: PixelNorm the inputs first (they must not need a gradient)."""
 
     @staticmethod
@@ -46,18 +59,21 @@ class _EqualLinearGroup(torch.autograd.Function):
         for x, w, b in zip(xs_c, ws_c, bs_c):
             if x.dim() != 2 or tuple(x.shape) != (B, fin) or w.dim() != 2 or int(w.shape[1]) != fin or (b is not None and b.numel() != w.shape[0]):
                 raise RuntimeError("equal_linear: inputs [B, in], weights [out, in], biases [out]")
-        total = sum(int(w.shape[0]) for w in ws_c)
-        y = torch.empty((B, total), dtype=torch.float32, device=dev)
-        a = _EqualLinearGroup._args(n, B, fin, act, normalize, alphas, bias_muls, xs_c, ws_c, bs_c, y)
+        # one allocation, one tensor per job (the outputs are separate autograd tensors: a single [B, sum out_j] output that the caller splits
+        # costs a concatenation kernel per call in the backward)
+        outs = [int(w.shape[0]) for w in ws_c]
+        flat = torch.empty(sum(_pad4(B * o) for o in outs), dtype=torch.float32, device=dev)
+        ys = _carve(flat, B, outs)
+        a = _EqualLinearGroup._args(n, B, fin, act, normalize, alphas, bias_muls, xs_c, ws_c, bs_c, ys)
         with _lib.on_device(dev):
             _lib.check(_lib.lib().ag_equal_linear_forward(ctypes.byref(a), _stream(dev)), "ag_equal_linear_forward")
-        ctx.save_for_backward(y, *xs_c, *ws_c, *[b for b in bs_c if b is not None])
+        ctx.save_for_backward(flat, *xs_c, *ws_c, *[b for b in bs_c if b is not None])
         ctx.cfg = (n, bool(act), bool(normalize), tuple(alphas), tuple(bias_muls), tuple(b is not None for b in bs_c),
                    tuple(tuple(b.shape) if b is not None else None for b in bs))
-        return y
+        return tuple(ys)
 
     @staticmethod
-    def _args(n, B, fin, act, normalize, alphas, bias_muls, xs, ws, bs, y):
+    def _args(n, B, fin, act, normalize, alphas, bias_muls, xs, ws, bs, ys):
         if not 1 <= n <= MAX_JOBS:
             raise RuntimeError(f"equal_linear: 1 .. {MAX_JOBS} layers per call")
         a = _lib.AgEqualLinearArgs()
@@ -67,23 +83,25 @@ class _EqualLinearGroup(torch.autograd.Function):
             a.bias[j] = bs[j].data_ptr() if bs[j] is not None else None
             a.out_features[j] = int(ws[j].shape[0])
             a.alpha[j], a.bias_mul[j] = float(alphas[j]), float(bias_muls[j])
-        a.y = y.data_ptr()
+            a.y[j] = ys[j].data_ptr()
         return a
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, *gs):
         n, act, normalize, alphas, bias_muls, has_b, b_shapes = ctx.cfg
         saved = ctx.saved_tensors
-        y, xs, ws = saved[0], saved[1:1 + n], saved[1 + n:1 + 2 * n]
+        flat, xs, ws = saved[0], saved[1:1 + n], saved[1 + n:1 + 2 * n]
         rest = list(saved[1 + 2 * n:])
         bs = [rest.pop(0) if hb else None for hb in has_b]
-        dev = y.device
-        g = g.contiguous()
+        dev = flat.device
         B, fin = int(xs[0].shape[0]), int(xs[0].shape[1])
+        ys = _carve(flat, B, [int(w.shape[0]) for w in ws])
+        gs = [g.contiguous() if g is not None else torch.zeros_like(y) for g, y in zip(gs, ys)]
         nig = ctx.needs_input_grad[5:]
         need_x, need_w, need_b = nig[:n], nig[n:2 * n], nig[2 * n:3 * n]
-        a = _EqualLinearGroup._args(n, B, fin, act, normalize, alphas, bias_muls, xs, ws, bs, y)
-        a.g_y = g.data_ptr()
+        a = _EqualLinearGroup._args(n, B, fin, act, normalize, alphas, bias_muls, xs, ws, bs, ys)
+        for j in range(n):
+            a.g_y[j] = gs[j].data_ptr()
         gxs, gws, gbs = [None] * n, [None] * n, [None] * n
         group_gx = None
         for j in range(n):
@@ -115,9 +133,9 @@ class _EqualLinearGroup(torch.autograd.Function):
 
 
 def equal_linear_group(xs: Sequence[torch.Tensor], weights: Sequence[torch.Tensor], biases: Sequence[Optional[torch.Tensor]], lr_mul: float = 1.0,
-                       activation: bool = False, normalize_input: bool = False) -> torch.Tensor:
-    """``cat([EqualLinear_j(xs[j]) for j], dim=1)`` (dual_styleunet.py:131-165: ``F.linear(x, W * scale, b * lr_mul)``, ``scale = lr_mul /
-    sqrt(in)``; with ``activation`` the fused leaky ReLU on top) as one native launch.  ``xs``: one tensor per layer, or a single tensor for all;
+                       activation: bool = False, normalize_input: bool = False):
+    """``[EqualLinear_j(xs[j]) for j]`` (dual_styleunet.py:131-165: ``F.linear(x, W * scale, b * lr_mul)``, ``scale = lr_mul /
+    sqrt(in)``; with ``activation`` the fused leaky ReLU on top) as one native launch; a tuple of [B, out_j] tensors.  ``xs``: one tensor per layer, or a single tensor for all;
     layers that read the same tensor must be consecutive.  ``normalize_input``: PixelNorm (:13-18) the inputs first."""
     n = len(weights)
     if isinstance(xs, torch.Tensor):
@@ -159,3 +177,17 @@ def bilinear_resize(x: torch.Tensor, size) -> torch.Tensor:
     if x.dim() != 4:
         raise RuntimeError("bilinear_resize: NCHW input")
     return _BilinearResize.apply(x, int(size[0]), int(size[1]))
+
+
+def plane_sums(x: torch.Tensor) -> torch.Tensor:
+    """``x.sum((-2, -1))`` of a contiguous [..., H, W] tensor (the bias gradient of a ToRGB head), deterministic, one streaming pass
+    (include/ag_linear.h ag_plane_sums).  No autograd: used inside backward passes."""
+    _check_gpu(x, "plane_sums")
+    x = x.contiguous()
+    planes, n = int(x.numel() // (x.shape[-2] * x.shape[-1])), int(x.shape[-2] * x.shape[-1])
+    out = torch.empty(tuple(x.shape[:-2]), dtype=torch.float32, device=x.device)
+    scratch = torch.empty(int(_lib.lib().ag_plane_sums_scratch_floats(planes, n)), dtype=torch.float32, device=x.device)
+    with _lib.on_device(x.device):
+        _lib.check(_lib.lib().ag_plane_sums(ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(x.data_ptr()), planes, n, ctypes.c_void_p(scratch.data_ptr()),
+                                           _stream(x.device)), "ag_plane_sums")
+    return out

@@ -235,8 +235,7 @@ class DualStyleUNet(torch.nn.Module):
         out = {}
         for c0 in range(0, len(prefixes), linear_ops.MAX_JOBS):
             c1 = min(len(prefixes), c0 + linear_ops.MAX_JOBS)
-            s = linear_ops.equal_linear_group(w_latent, ws[c0:c1], bs[c0:c1])
-            out.update(zip(prefixes[c0:c1], torch.split(s, [w.shape[0] for w in ws[c0:c1]], dim=1)))
+            out.update(zip(prefixes[c0:c1], linear_ops.equal_linear_group(w_latent, ws[c0:c1], bs[c0:c1])))
         return out
 
     def _modulated_weight(self, prefix, styles, demodulate, transposed=False):
@@ -430,9 +429,8 @@ def latents_of(nets, zs):
     if not norm_inside:
         xs = [z * torch.rsqrt(torch.mean(z ** 2, dim=1, keepdim=True) + 1e-8) for z in zs]
     for i in range(n0.n_mlp):
-        y = linear_ops.equal_linear_group(xs, [n._p(f"style.{i + 1}.weight") for n in nets], [n._p(f"style.{i + 1}.bias") for n in nets],
-                                          lr_mul=n0.lr_mlp, activation=True, normalize_input=norm_inside and i == 0)
-        xs = list(torch.split(y, n0.style_dim, dim=1))
+        xs = list(linear_ops.equal_linear_group(xs, [n._p(f"style.{i + 1}.weight") for n in nets], [n._p(f"style.{i + 1}.bias") for n in nets],
+                                                lr_mul=n0.lr_mlp, activation=True, normalize_input=norm_inside and i == 0))
     if n0.n_mlp == 0 and norm_inside:
         xs = [z * torch.rsqrt(torch.mean(z ** 2, dim=1, keepdim=True) + 1e-8) for z in zs]
     return xs

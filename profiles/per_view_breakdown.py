@@ -11,6 +11,9 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+if os.environ.get("AG_PKG_ROOT"):      # same-box A/B against another copy of the Python package (same native library)
+    sys.path.insert(0, os.path.abspath(os.environ["AG_PKG_ROOT"]))
+    os.environ.setdefault("AG_LIB_PATH", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "animatablegaussians_amd", "lib", "libag_hip.so"))
 import bench_avatar  # noqa: E402
 from torch.profiler import ProfilerActivity, profile  # noqa: E402
 

@@ -47,8 +47,8 @@ def test_equal_linear_group_forward_backward_equals_the_reference_formula(B, act
     ref = lambda xs, W, Bi: torch.cat([_ref_equal_linear(x, w, bb, lr_mul, activation) for x, w, bb in zip(xs, W, Bi)], 1)     # noqa: E731
     want = run("cpu", torch.float64, ref)
     ref32 = run("cpu", torch.float32, ref)
-    got = run("cuda", torch.float32, lambda xs, W, Bi: equal_linear_group(xs, W, Bi, lr_mul=lr_mul, activation=activation))
-    again = run("cuda", torch.float32, lambda xs, W, Bi: equal_linear_group(xs, W, Bi, lr_mul=lr_mul, activation=activation))
+    got = run("cuda", torch.float32, lambda xs, W, Bi: torch.cat(equal_linear_group(xs, W, Bi, lr_mul=lr_mul, activation=activation), 1))
+    again = run("cuda", torch.float32, lambda xs, W, Bi: torch.cat(equal_linear_group(xs, W, Bi, lr_mul=lr_mul, activation=activation), 1))
 
     def close(a, b, r32, what):
         scale = float(b.abs().max()) + 1e-30
@@ -120,3 +120,18 @@ def test_cpu_tensors_are_refused():
         equal_linear_group([torch.randn(1, 8)], [torch.randn(4, 8)], [None])
     with pytest.raises(RuntimeError):
         bilinear_resize(torch.randn(1, 1, 4, 4), (8, 8))
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 512, 512), (4, 12, 64, 64), (3, 5, 7, 9), (1, 1, 1, 1), (6, 12, 16, 16)])
+def test_plane_sums_equal_the_float64_sums_and_are_reproducible(shape):
+    from animatablegaussians_amd.linear_ops import plane_sums
+    x = torch.randn(*shape, generator=torch.Generator().manual_seed(9))
+    want = x.double().sum((2, 3))
+    got = plane_sums(x.cuda())
+    assert got.shape == want.shape
+    n = shape[2] * shape[3]
+    assert float((got.cpu().double() - want).abs().max()) <= 2e-6 * math.sqrt(n) * 4
+    assert torch.equal(got, plane_sums(x.cuda()))
+    # a non-contiguous / unaligned view takes the scalar path
+    y = torch.randn(shape[0], shape[1], shape[2], shape[3] + 1, generator=torch.Generator().manual_seed(10)).cuda()[..., 1:]
+    assert float((plane_sums(y).cpu().double() - y.cpu().double().sum((2, 3))).abs().max()) <= 2e-6 * math.sqrt(n) * 4
