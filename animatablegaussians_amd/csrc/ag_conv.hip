@@ -2037,10 +2037,16 @@ int conv_backward_weight_g(const AgConvDesc* d, int G, const float* x, long long
     const int nkt_all = (Kp + BK - 1) / BK;
     int splits = 1;
     {
+        // Round 5 (second session): since the slices are stored and added by wgrad_reduce_kernel (no atomics), a split costs one more write and one
+        // more read of the whole [G][Mpad][Npad] tile set, at ~3 TB/s, in units of a K tile's time (0.45 us) -- 84 units per slice for the
+        // 512 x 512 x 9, G = 6 layers, whose K loop is 256 tiles: the model now knows (AG_WGRAD_SPLIT_MODEL=0: the round-2 model, for the A/B)
+        static const bool traffic_aware = [] { const char* e = getenv("AG_WGRAD_SPLIT_MODEL"); return !(e && e[0] == '0'); }();
+        const double set_bytes = (double)G * round_up(wp.Mw, bm) * round_up(Nw, BN) * sizeof(float);
+        const double per_split = traffic_aware ? 2.0 * set_bytes / 3e12 / 0.45e-6 : 0.0;
         double best_cost = 1e30;
         const int smax = std::max(1, std::min(nkt_all / 8, 4096));
         for (int sp = 1; sp <= smax; sp++) {
-            const double cost = lanes_cost((long long)tiles * sp, (nkt_all + sp - 1) / sp, 6.0);
+            const double cost = lanes_cost((long long)tiles * sp, (nkt_all + sp - 1) / sp, 6.0) + (sp > 1 ? 6.0 + per_split * sp : 0.0);
             if (cost < best_cost - 1e-9) { best_cost = cost; splits = sp; }
         }
     }
