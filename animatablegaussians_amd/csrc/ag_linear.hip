@@ -8,7 +8,7 @@
 namespace ag {
 
 typedef float lf4 __attribute__((ext_vector_type(4)));
-constexpr int kLinRowsPerWave = 16;       // backward: rows of a job whose g_x contributions one wave adds up (one partial row per wave)
+constexpr int kLinRowsPerWave = 16;       // backward: rows of a job whose g_x contributions one workgroup adds up (one partial row per chunk)
 constexpr float kSqrt2 = 1.41421356237309504880f;
 
 struct LinearLaunch {
@@ -65,56 +65,55 @@ __global__ void __launch_bounds__(256) equal_linear_forward_kernel(LinearLaunch 
     }
 }
 
-// ---- backward, launch 1: one wave per 16 rows of a job -------------------------------------------------------------------------------
-// g_W rows and g_bias are final; the wave's share of g_x (sum over its rows of g' W) goes to partial[chunk][b][in].
+// ---- backward, launch 1: one WORKGROUP per 16 rows of a job, threads along the columns -------------------------------------------------
+// g_W rows and g_bias are final; the workgroup's share of g_x (sum over its rows of g' W) goes to partial[chunk][b][in].  (First form: one WAVE
+// per 16 rows -- 384 waves for the 6144 rows of a decoder branch's modulation layers, 1.5 per CU: 22 us per launch for 25 MB.  Threads along
+// columns, two each, give every chunk four waves.)
+typedef float lf2 __attribute__((ext_vector_type(2)));
 __global__ void __launch_bounds__(256) equal_linear_backward_kernel(LinearLaunch L, int total_chunks)
 {
     const AgEqualLinearArgs& a = L.a;
-    const int lane = threadIdx.x & 63;
-    const int chunk = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (chunk >= total_chunks) return;
+    __shared__ float s_g[kLinRowsPerWave];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int chunk = blockIdx.x;
     int j = 0;
     for (int i = 1; i < a.n_jobs; i++) j = (chunk >= L.chunk_begin[i]) ? i : j;
-    j = __builtin_amdgcn_readfirstlane(j);
     const int in = a.in_features, out = a.out_features[j];
-    const int o0 = (chunk - L.chunk_begin[j]) * kLinRowsPerWave, o1 = min(out, o0 + kLinRowsPerWave);
+    const int o0 = (chunk - L.chunk_begin[j]) * kLinRowsPerWave, nr = min(out, o0 + kLinRowsPerWave) - o0;
     const float alpha = a.alpha[j];
     const float* __restrict__ W = a.weight[j];
     float* __restrict__ gW = a.g_weight[j];
     float* __restrict__ gb = a.g_bias[j];
     const bool want_gx = a.g_x[j] != nullptr;
-    // g' of this wave's rows: lane r < 16 holds row o0 + r (per batch row below)
     for (int b = 0; b < a.B; b++) {
         const float* __restrict__ x = a.x[j] + (size_t)b * in;
-        const float nf = a.normalize_input ? pixel_norm_factor(x, in, lane) : 1.f;
-        float gp = 0.f;
-        if (lane < o1 - o0) {
-            const size_t at = (size_t)b * out + o0 + lane;
-            gp = a.g_y[j][at];
+        const float nf = a.normalize_input ? pixel_norm_factor(x, in, lane) : 1.f;     // (every wave forms it: 2 KB from L2)
+        __syncthreads();                                  // s_g of the previous batch row is no longer read
+        if (tid < nr) {
+            const size_t at = (size_t)b * out + o0 + tid;
+            float gp = a.g_y[j][at];
             if (a.act) gp *= (a.y[j][at] > 0.f) ? kSqrt2 : 0.2f * kSqrt2;
+            s_g[tid] = gp;
+            if (gb) {                                     // bias gradient: summed over the batch rows in order (b ascending)
+                const float t = a.bias_mul[j] * gp;
+                gb[o0 + tid] = (b == 0) ? t : gb[o0 + tid] + t;
+            }
         }
-        // bias gradient: summed over the batch rows in order (b ascending)
-        if (gb && lane < o1 - o0) {
-            const float t = a.bias_mul[j] * gp;
-            gb[o0 + lane] = (b == 0) ? t : gb[o0 + lane] + t;
-        }
-        for (int c = lane * 4; c < in; c += 256) {
-            lf4 xv = *reinterpret_cast<const lf4*>(x + c);
+        __syncthreads();
+        for (int c = tid * 2; c < in; c += 512) {
+            lf2 xv = *reinterpret_cast<const lf2*>(x + c);
             xv *= nf * alpha;
-            lf4 acc = { 0.f, 0.f, 0.f, 0.f };
-            for (int r = 0; r < o1 - o0; r++) {
-                const float g = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gp), r));       // (r is wave-uniform)
-                if (want_gx) {
-                    const lf4 wv = *reinterpret_cast<const lf4*>(W + (size_t)(o0 + r) * in + c);
-                    acc += g * wv;
-                }
+            lf2 acc = { 0.f, 0.f };
+            for (int r = 0; r < nr; r++) {
+                const float g = s_g[r];
+                if (want_gx) acc += g * *reinterpret_cast<const lf2*>(W + (size_t)(o0 + r) * in + c);
                 if (gW) {
-                    lf4* dst = reinterpret_cast<lf4*>(gW + (size_t)(o0 + r) * in + c);
-                    const lf4 t = g * xv;
+                    lf2* dst = reinterpret_cast<lf2*>(gW + (size_t)(o0 + r) * in + c);
+                    const lf2 t = g * xv;
                     *dst = (b == 0) ? t : *dst + t;
                 }
             }
-            if (want_gx) *reinterpret_cast<lf4*>(a.scratch + ((size_t)chunk * a.B + b) * in + c) = alpha * acc;
+            if (want_gx) *reinterpret_cast<lf2*>(a.scratch + ((size_t)chunk * a.B + b) * in + c) = alpha * acc;
         }
     }
 }
@@ -127,18 +126,25 @@ struct LinearReduce {
     int32_t B, in;
 };
 
-__global__ void __launch_bounds__(256) equal_linear_reduce_kernel(LinearReduce R)
+constexpr int kLinParts = 16;
+__global__ void __launch_bounds__(64 * kLinParts) equal_linear_reduce_kernel(LinearReduce R)
 {
-    // grid (ceil(in / 64), B, groups); 64 columns x 4 interleaved partitions of the chunk list, combined as (p0 + p1) + (p2 + p3)
-    __shared__ float s_part[4][64];
+    // grid (ceil(in / 64), B, groups); 64 columns x 16 interleaved partitions of the chunk list (24 dependent loads per thread for the 384
+    // chunks of a decoder branch instead of 96 with four), combined by a fixed pairwise tree
+    __shared__ float s_part[kLinParts][64];
     const int g = blockIdx.z, b = blockIdx.y;
     const int cl = threadIdx.x & 63, q = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
     float s = 0.f;
     if (c < R.in)
-        for (int k = R.c0[g] + q; k < R.c1[g]; k += 4) s += R.partial[((size_t)k * R.B + b) * R.in + c];
+        for (int k = R.c0[g] + q; k < R.c1[g]; k += kLinParts) s += R.partial[((size_t)k * R.B + b) * R.in + c];
     s_part[q][cl] = s;
     __syncthreads();
-    if (q == 0 && c < R.in) R.dst[g][(size_t)b * R.in + c] = (s_part[0][cl] + s_part[1][cl]) + (s_part[2][cl] + s_part[3][cl]);
+#pragma unroll
+    for (int w = kLinParts / 2; w >= 1; w >>= 1) {
+        if (q < w) s_part[q][cl] += s_part[q + w][cl];
+        __syncthreads();
+    }
+    if (q == 0 && c < R.in) R.dst[g][(size_t)b * R.in + c] = s_part[0][cl];
 }
 
 // ---- bilinear resize (align_corners = False) -------------------------------------------------------------------------------------------
@@ -383,11 +389,11 @@ int ag_equal_linear_backward(const AgEqualLinearArgs* a, void* stream)
     if (any_gx && a->normalize_input) { set_error("ag_equal_linear_backward: no input gradient through the PixelNorm option"); return AG_ERR_INVALID_ARGUMENT; }
     if (any_gx && !a->scratch) { set_error("ag_equal_linear_backward: g_x needs scratch"); return AG_ERR_INVALID_ARGUMENT; }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(equal_linear_backward_kernel, dim3((chunks + 3) / 4), dim3(256), 0, s, L, chunks);
+    hipLaunchKernelGGL(equal_linear_backward_kernel, dim3(chunks), dim3(256), 0, s, L, chunks);
     if (check_hip(hipGetLastError(), "equal_linear_backward_kernel")) return AG_ERR_HIP;
     if (groups) {
         R.partial = a->scratch; R.B = a->B; R.in = a->in_features;
-        hipLaunchKernelGGL(equal_linear_reduce_kernel, dim3((a->in_features + 63) / 64, a->B, groups), dim3(256), 0, s, R);
+        hipLaunchKernelGGL(equal_linear_reduce_kernel, dim3((a->in_features + 63) / 64, a->B, groups), dim3(64 * kLinParts), 0, s, R);
         if (check_hip(hipGetLastError(), "equal_linear_reduce_kernel")) return AG_ERR_HIP;
     }
     return AG_OK;

@@ -84,7 +84,7 @@ def test_mapping_network_equals_the_reference_formula():
             b = n._p(f"style.{i + 1}.bias").detach().double().cpu().requires_grad_(True)
             x = _ref_equal_linear(x, W, b, n.lr_mlp, True)
             params.append((W, b))
-        assert float((w.detach().cpu().double() - x).abs().max()) <= 2e-6 * float(x.abs().max())
+        assert float((w.detach().cpu().double() - x.detach()).abs().max()) <= 2e-6 * float(x.detach().abs().max())
         (x * (nets.index(n) + 1)).sum().backward()
         for i, (W, b) in enumerate(params):
             gw, gb = n._p(f"style.{i + 1}.weight").grad.cpu().double(), n._p(f"style.{i + 1}.bias").grad.cpu().double()
