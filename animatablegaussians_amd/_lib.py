@@ -203,6 +203,7 @@ SYMBOLS = [
     ("ag_equal_linear_backward", ctypes.c_int, [ctypes.POINTER(AgEqualLinearArgs), c_vp]),
     ("ag_bilinear_resize_forward", ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     ("ag_bilinear_resize_backward", ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    ("ag_select_add_rows", ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
     ("ag_plane_sums_scratch_floats", c_sz, [c_i32, ctypes.c_int64]),
     ("ag_plane_sums", ctypes.c_int, [c_vp, c_vp, c_i32, ctypes.c_int64, c_vp, c_vp]),
     ("ag_debug_mfma_rate", ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_vp, c_vp]),

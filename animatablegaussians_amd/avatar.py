@@ -349,7 +349,7 @@ class AvatarNet(nn.Module):
             h = agc.conv2d(v, c0.weight, bias=c0.bias, stride=2, padding=1)
             h = fused_leaky_relu(h, None, 0.2, 1.0)
             h = agc.conv2d(h, c2.weight, bias=c2.bias, stride=2, padding=1)
-            feats.append(weight * h)
+            feats.append(h if weight == 1. else weight * h)        # (the default weight 1: no scaling pass forward or backward)
         return feats[0], feats[1]
 
     def _concurrently(self, fns, shared=()):

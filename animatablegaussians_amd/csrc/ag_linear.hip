@@ -270,6 +270,58 @@ __global__ void __launch_bounds__(256) bilinear_backward_kernel(float* __restric
     }
 }
 
+// ---- x[m] = out[src[m]] (+ bilinear resize of the member's view feature) ---------------------------------------------------------------
+struct SelectAdd {
+    float* x; const float* out; const float* vf;
+    int src[16];
+    int M, C, H, W, r0, r1, vh, vw;
+    float sy, sx;
+};
+
+__global__ void __launch_bounds__(256) select_add_rows_kernel(SelectAdd p)
+{
+    // block (64, 4): threadIdx.y + 4 blockIdx.x = row of a plane (plane = m * C + c), threadIdx.x strides over the row's 4-pixel groups
+    const int wq = (p.W + 3) >> 2;
+    const bool vec = (p.W & 3) == 0 && ((reinterpret_cast<uintptr_t>(p.x) | reinterpret_cast<uintptr_t>(p.out)) & 15) == 0;
+    const long long rows = (long long)p.M * p.C * p.H;
+    for (long long row = (long long)blockIdx.x * 4 + threadIdx.y; row < rows; row += (long long)gridDim.x * 4) {
+        const unsigned plane = (unsigned)row / (unsigned)p.H, y = (unsigned)row - plane * (unsigned)p.H;
+        const unsigned m = plane / (unsigned)p.C, c = plane - m * (unsigned)p.C;
+        const float* __restrict__ srow = p.out + (((size_t)p.src[m] * p.C + c) * p.H + y) * p.W;
+        float* __restrict__ drow = p.x + (size_t)row * p.W;
+        const bool add = p.vf && (int)m >= p.r0 && (int)m < p.r1;
+        const float* __restrict__ fplane = add ? p.vf + ((size_t)(m - p.r0) * p.C + c) * p.vh * p.vw : nullptr;
+        const bool same = p.vh == p.H && p.vw == p.W;
+        Lerp ly{};
+        if (add && !same) ly = lerp_of((int)y, p.sy, p.vh);
+        for (int q = threadIdx.x; q < wq; q += 64) {
+            float v[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int xx = min(4 * q + k, p.W - 1);
+                float a = vec ? 0.f : srow[xx];
+                if (add) {
+                    if (same) a += fplane[(size_t)y * p.vw + xx];
+                    else {
+                        const Lerp lx = lerp_of(xx, p.sx, p.vw);
+                        const float* r0p = fplane + (size_t)ly.i0 * p.vw;
+                        const float* r1p = fplane + (size_t)ly.i1 * p.vw;
+                        a += ly.l0 * (lx.l0 * r0p[lx.i0] + lx.l1 * r0p[lx.i1]) + ly.l1 * (lx.l0 * r1p[lx.i0] + lx.l1 * r1p[lx.i1]);
+                    }
+                }
+                v[k] = a;
+            }
+            if (vec) {
+                const lf4 s4 = *reinterpret_cast<const lf4*>(srow + 4 * q);
+                *reinterpret_cast<lf4*>(drow + 4 * q) = lf4{ s4[0] + v[0], s4[1] + v[1], s4[2] + v[2], s4[3] + v[3] };
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++) if (4 * q + k < p.W) drow[4 * q + k] = v[k];
+            }
+        }
+    }
+}
+
 // ---- plane sums -------------------------------------------------------------------------------------------------------------------
 constexpr int kPlaneSliceMin = 4096;      // floats per slice at least (a workgroup's 256 threads x 4 float4)
 __host__ __device__ inline int plane_slices(int planes, long long len)
@@ -434,6 +486,24 @@ int ag_plane_sums(float* out, const float* in, int32_t planes, int64_t len, floa
     if (check_hip(hipGetLastError(), "plane_partial_sums_kernel")) return AG_ERR_HIP;
     hipLaunchKernelGGL(plane_final_sums_kernel, dim3((planes + 255) / 256), dim3(256), 0, s, out, scratch, planes, S);
     return check_hip(hipGetLastError(), "plane_final_sums_kernel");
+}
+
+int ag_select_add_rows(float* x, const float* out, const int32_t* src, int32_t M, int32_t C, int32_t H, int32_t W, const float* vf, int32_t r0, int32_t r1,
+                       int32_t vh, int32_t vw, void* stream)
+{
+    if (!x || !out || !src || M < 1 || M > 16 || C < 1 || H < 1 || W < 1 || (long long)M * C * H > 0x7fffffffLL ||
+        (vf && (r0 < 0 || r1 > M || r0 >= r1 || vh < 1 || vw < 1))) { set_error("ag_select_add_rows: bad arguments"); return AG_ERR_INVALID_ARGUMENT; }
+    SelectAdd p{};
+    p.x = x; p.out = out; p.vf = vf; p.M = M; p.C = C; p.H = H; p.W = W; p.r0 = r0; p.r1 = r1; p.vh = vf ? vh : H; p.vw = vf ? vw : W;
+    for (int m = 0; m < M; m++) {
+        if (src[m] < 0) { set_error("ag_select_add_rows: negative source row"); return AG_ERR_INVALID_ARGUMENT; }
+        p.src[m] = src[m];
+    }
+    p.sy = (float)p.vh / (float)H; p.sx = (float)p.vw / (float)W;
+    const long long rows = (long long)M * C * H;
+    const unsigned grid = (unsigned)((rows + 3) / 4 < 65536 * 16 ? (rows + 3) / 4 : 65536 * 16);
+    hipLaunchKernelGGL(select_add_rows_kernel, dim3(grid), dim3(64, 4), 0, reinterpret_cast<hipStream_t>(stream), p);
+    return check_hip(hipGetLastError(), "select_add_rows_kernel");
 }
 
 }  // extern "C"

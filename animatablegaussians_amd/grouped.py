@@ -22,7 +22,7 @@ import torch
 
 from . import _lib
 from . import conv as agc
-from .linear_ops import bilinear_resize, plane_sums
+from .linear_ops import bilinear_resize, bilinear_resize_backward, plane_sums, select_add_rows
 from .styleunet import latents_of
 from .styleunet_ops import _HAAR_SYNTHESIS, _flipped, _skip_taps_host, upfirdn2d_nchw
 
@@ -532,15 +532,15 @@ class _SelectAddRows(torch.autograd.Function):
     @staticmethod
     def forward(ctx, out, vf, src, rows):
         ident = list(src) == list(range(out.shape[0]))
-        x = out.clone() if ident else out.index_select(0, _index(src, out.device))
-        if vf is not None:
-            x[rows[0]:rows[1]].add_(vf)
-        ctx.cfg = (tuple(src), rows, ident, int(out.shape[0]), vf is not None)
+        # one pass (ag_select_add_rows): the row selection, the addition and -- ``vf`` may come at its own resolution -- the bilinear resize of
+        # the members' view features (F.interpolate, dual_styleunet.py:881-883); an index_select, V resizes, a concatenation and an add_ before
+        x = select_add_rows(out, src, vf, rows)
+        ctx.cfg = (tuple(src), rows, ident, int(out.shape[0]), vf is not None, tuple(vf.shape[-2:]) if vf is not None else None)
         return x
 
     @staticmethod
     def backward(ctx, g):
-        src, rows, ident, n_out, has_vf = ctx.cfg
+        src, rows, ident, n_out, has_vf, vf_size = ctx.cfg
         g_out = g_vf = None
         if ctx.needs_input_grad[0]:
             if ident:
@@ -562,6 +562,8 @@ class _SelectAddRows(torch.autograd.Function):
                         torch.sum(g.index_select(0, _index(ms, g.device)), 0, out=g_out[r])
         if has_vf and ctx.needs_input_grad[1]:
             g_vf = g[rows[0]:rows[1]]
+            if vf_size != tuple(g.shape[-2:]):
+                g_vf = bilinear_resize_backward(g_vf, vf_size)
         return g_out, g_vf, None, None
 
 
@@ -760,6 +762,8 @@ class GroupedStyleUNets:
                 wts = [nets[r]._p(f"{prefix}.0.weight") for r in used]
                 out = _GroupedComb.apply(tuple(begin), 1 / math.sqrt(wts[0].shape[1] * 9), out, lev, *wts, *[net._p(f"{prefix}.1.bias") for net in mnets])
             else:
+                if vf is not None and vf.shape[-2:] != out.shape[-2:]:
+                    vf = bilinear_resize(vf, out.shape[-2:])
                 cat = _CatLevels.apply(out, levels[-1 - n], vf, tuple(src), tuple(net_idx), vf_rows)
                 out = self._conv_layer(cat, mnets, f"comb_convs.{n0.n_comb - 1 - n}")
         pre = [f"convs{b}.{2 * n}" for _, b in members]
@@ -875,13 +879,11 @@ class GroupedStyleUNets:
             if rows:
                 if rows != list(range(rows[0], rows[-1] + 1)):
                     raise RuntimeError("grouped networks: view features must belong to consecutive members")
-                feats = []
-                for r in rows:
-                    i, b, _, v = chunk[r]
-                    f = views[i][v][b - 1]
-                    if f.shape[-2:] != out.shape[-2:]:
-                        f = bilinear_resize(f, out.shape[-2:])        # F.interpolate(..., mode="bilinear") (dual_styleunet.py:881-883)
-                    feats.append(f)
+                # the members' view features, stacked at THEIR resolution (8 MB each at 128 planes 128^2): the stage's input kernel resizes them
+                # (F.interpolate(..., mode="bilinear"), dual_styleunet.py:881-883) while it adds them
+                feats = [views[chunk[r][0]][chunk[r][3]][chunk[r][1] - 1] for r in rows]
+                if any(f.shape != feats[0].shape for f in feats):
+                    feats = [f if f.shape[-2:] == out.shape[-2:] else bilinear_resize(f, out.shape[-2:]) for f in feats]
                 vf = torch.cat(feats, 0) if len(feats) > 1 else feats[0]
             o, sk = out, None
             for j, n in enumerate(tail_stages):

@@ -191,3 +191,37 @@ def plane_sums(x: torch.Tensor) -> torch.Tensor:
         _lib.check(_lib.lib().ag_plane_sums(ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(x.data_ptr()), planes, n, ctypes.c_void_p(scratch.data_ptr()),
                                            _stream(x.device)), "ag_plane_sums")
     return out
+
+
+def select_add_rows(out: torch.Tensor, src, vf: Optional[torch.Tensor], rows) -> torch.Tensor:
+    """``x[m] = out[src[m]]`` (+ ``vf[m - rows[0]]``, bilinearly resized to ``out``'s resolution when its own differs, for ``rows[0] <= m < rows[1]``)
+    in one pass (include/ag_linear.h ag_select_add_rows).  No autograd: the forward of grouped._SelectAddRows."""
+    _check_gpu(out, "select_add_rows")
+    out = out.contiguous()
+    M = len(src)
+    x = torch.empty((M,) + tuple(out.shape[1:]), dtype=torch.float32, device=out.device)
+    tab = (ctypes.c_int32 * M)(*[int(v) for v in src])
+    if vf is not None:
+        _check_gpu(vf, "select_add_rows")
+        vf = vf.contiguous()
+        if vf.shape[0] != rows[1] - rows[0] or vf.shape[1] != out.shape[1]:
+            raise RuntimeError("select_add_rows: one view feature [C, h, w] per member of the row range")
+    with _lib.on_device(out.device):
+        _lib.check(_lib.lib().ag_select_add_rows(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(out.data_ptr()), ctypes.cast(tab, ctypes.c_void_p), M,
+                                                int(out.shape[1]), int(out.shape[2]), int(out.shape[3]),
+                                                ctypes.c_void_p(vf.data_ptr()) if vf is not None else None, int(rows[0]) if vf is not None else 0,
+                                                int(rows[1]) if vf is not None else 0, int(vf.shape[2]) if vf is not None else 0,
+                                                int(vf.shape[3]) if vf is not None else 0, _stream(out.device)), "ag_select_add_rows")
+    return x
+
+
+def bilinear_resize_backward(g: torch.Tensor, size) -> torch.Tensor:
+    """The adjoint of ``bilinear_resize`` to ``size`` applied to ``g`` [N, C, OH, OW] (a contiguous tensor or a leading-dimension slice of one)."""
+    _check_gpu(g, "bilinear_resize_backward")
+    g = g.contiguous()
+    gx = torch.empty((g.shape[0], g.shape[1], int(size[0]), int(size[1])), dtype=torch.float32, device=g.device)
+    with _lib.on_device(g.device):
+        _lib.check(_lib.lib().ag_bilinear_resize_backward(ctypes.c_void_p(gx.data_ptr()), ctypes.c_void_p(g.data_ptr()), int(g.shape[0] * g.shape[1]),
+                                                         int(size[0]), int(size[1]), int(g.shape[2]), int(g.shape[3]), _stream(g.device)),
+                   "ag_bilinear_resize_backward")
+    return gx

@@ -70,6 +70,16 @@ int ag_bilinear_resize_forward(float* out, const float* in, int32_t N, int32_t H
 int ag_bilinear_resize_backward(float* g_in, const float* g_out, int32_t N, int32_t H, int32_t W, int32_t OH, int32_t OW, void* stream);
 
 /*
+ * Input of a view-dependent decoder stage for the stacked members (dual_styleunet.py:881-883 `out = out + F.interpolate(view_feature, size,
+ * mode="bilinear")`, for M members that continue rows of the shared state):
+ *     x[m] = out[src[m]] (+ resize(vf[m - r0]) for r0 <= m < r1)          x [M, C, H, W], out [*, C, H, W], vf [r1 - r0, C, vh, vw] or NULL
+ * one pass: a row selection, an addition and V bilinear resizes (33 MB each at 128 planes 256^2) were three passes and a concatenation before.
+ * `src`: M host integers, read at call time.  vh == H and vw == W: plain addition.
+ */
+int ag_select_add_rows(float* x, const float* out, const int32_t* src, int32_t M, int32_t C, int32_t H, int32_t W, const float* vf, int32_t r0, int32_t r1,
+                       int32_t vh, int32_t vw, void* stream);
+
+/*
  * out[p] = sum of the `len` floats of plane p, for `planes` contiguous planes: the bias gradient of a ToRGB head (dual_styleunet.py:607-633: the
  * sum of the output gradient over batch and pixels; torch's reduction ran at ~1 TB/s on these [G, 12 | 32, 512, 512] tensors, 0.2 ms per step).
  * Deterministic: every plane is cut into the same slices on every run, slice sums are added in slice order by a second launch.

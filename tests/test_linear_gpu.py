@@ -135,3 +135,32 @@ def test_plane_sums_equal_the_float64_sums_and_are_reproducible(shape):
     # a non-contiguous / unaligned view takes the scalar path
     y = torch.randn(shape[0], shape[1], shape[2], shape[3] + 1, generator=torch.Generator().manual_seed(10)).cuda()[..., 1:]
     assert float((plane_sums(y).cpu().double() - y.cpu().double().sum((2, 3))).abs().max()) <= 2e-6 * math.sqrt(n) * 4
+
+
+@pytest.mark.parametrize("vf_size", [(16, 12), (32, 24), None])
+def test_select_add_rows_equals_index_select_interpolate_add(vf_size):
+    """grouped._SelectAddRows (the input of a view-dependent decoder stage): x[m] = out[src[m]] + F.interpolate(vf[m - r0], bilinear) on the rows
+    that have a view feature, forward and both gradients, against the torch composition on the CPU."""
+    from animatablegaussians_amd.grouped import _SelectAddRows
+    g = torch.Generator().manual_seed(4)
+    out = torch.randn(3, 6, 32, 24, generator=g)
+    src, rows = (0, 1, 2, 2, 1, 2), (2, 5)
+    vf = torch.randn(3, 6, *vf_size, generator=g) if vf_size else None
+    up = torch.randn(len(src), 6, 32, 24, generator=g)
+
+    oc = out.clone().requires_grad_(True)
+    vc = vf.clone().requires_grad_(True) if vf is not None else None
+    want = oc.index_select(0, torch.tensor(src))
+    if vc is not None:
+        f = vc if vf_size == (32, 24) else F.interpolate(vc, (32, 24), mode="bilinear")
+        want = torch.cat([want[:rows[0]], want[rows[0]:rows[1]] + f, want[rows[1]:]], 0)
+    want.backward(up)
+
+    og = out.cuda().requires_grad_(True)
+    vg = vf.cuda().requires_grad_(True) if vf is not None else None
+    got = _SelectAddRows.apply(og, vg, src, rows if vf is not None else None)
+    got.backward(up.cuda())
+    np.testing.assert_allclose(got.detach().cpu().numpy(), want.detach().numpy(), rtol=0, atol=3e-6 * float(want.abs().max()))
+    np.testing.assert_allclose(og.grad.cpu().numpy(), oc.grad.numpy(), rtol=0, atol=3e-6 * float(oc.grad.abs().max()))
+    if vf is not None:
+        np.testing.assert_allclose(vg.grad.cpu().numpy(), vc.grad.numpy(), rtol=0, atol=4e-6 * float(vc.grad.abs().max()))
