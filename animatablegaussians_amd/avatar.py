@@ -588,13 +588,20 @@ class AvatarNet(nn.Module):
                 lambda: self.color_net.forward_views([color_style], x, feats, randomize_noise=False)],
                 shared=[x, color_style] + [t for fb in feats for t in fb])
         rets = []
-        live = None
+        base = offset = None
         for v, color_map in zip(views, color_maps):
-            g = self.core.assemble(position_map, other_map, color_map)
-            offset = g['positions'] - self.core.xyz
-            if live is None:                                   # camera-independent: skin once
-                live = ops.lbs_transform(g['positions'], g['rotations'], self.core.lbs, items['cano2live_jnt_mats'], self.core.lbs_sparse)
-            g['positions'], g['rotations'] = live
+            if base is None:
+                # camera-independent: positions / opacity / scales / rotations are gathered and skinned ONCE (round 5, second session: every view
+                # used to gather all three maps again -- and back-propagate a zero-filled [1, 16 | 6, 1024, 1024] map gradient each that autograd
+                # then added up: ~80 us per extra view); the views' gradients now meet on the [N, .] attribute tensors
+                base = self.core.assemble(position_map, other_map, color_map)
+                offset = base['positions'] - self.core.xyz
+                base['positions'], base['rotations'] = ops.lbs_transform(base['positions'], base['rotations'], self.core.lbs,
+                                                                        items['cano2live_jnt_mats'], self.core.lbs_sparse)
+                g = base
+            else:
+                g = dict(base)
+                g['colors'] = ops.gather_colors(color_map, self.core.pix)
             r = render3(g, bg, v['extr'], v['intr'], v['img_w'], v['img_h'])
             ret = {'rgb_map': r['render'].permute(1, 2, 0), 'mask_map': r['mask'].permute(1, 2, 0), 'offset': offset,
                    'pos_map': self._canvas(position_map)}
