@@ -103,7 +103,8 @@ class AgGroupedLayerArgs(ctypes.Structure):   # include/ag_layers.h
                 + [(n, c_vp) for n in ("k_blur", "w_mod", "demod", "x_blur", "out", "scratch", "workspace")]
                 + [("workspace_bytes", c_sz)]
                 + [(n, c_vp) for n in ("g_out", "g_x", "g_weight", "g_style", "g_bias_noise")]
-                + [("want_bias", c_i32), ("want_noise_weight", c_i32), ("operand_maxima", c_vp), ("x_maxima", c_vp), ("out_maxima", c_vp)])
+                + [("want_bias", c_i32), ("want_noise_weight", c_i32), ("operand_maxima", c_vp), ("x_maxima", c_vp), ("out_maxima", c_vp)]
+                + [("packed_weights", c_vp), ("weights_cached", c_i32), ("reserved_i", c_i32)])
 
 
 class AgGroupedToRgbArgs(ctypes.Structure):   # include/ag_layers.h
@@ -111,7 +112,8 @@ class AgGroupedToRgbArgs(ctypes.Structure):   # include/ag_layers.h
                 + [(n, _PTRS) for n in ("weight", "style", "bias")]
                 + [(n, c_vp) for n in ("skip", "skip_taps", "w_mod", "out", "scratch", "workspace")]
                 + [("workspace_bytes", c_sz)]
-                + [(n, c_vp) for n in ("g_out", "g_x", "g_weight", "g_style", "g_skip")])
+                + [(n, c_vp) for n in ("g_out", "g_x", "g_weight", "g_style", "g_skip")]
+                + [("weights_cached", c_i32), ("reserved_i", c_i32)])
 
 
 class AgGroupedCombArgs(ctypes.Structure):    # include/ag_layers.h
@@ -119,7 +121,9 @@ class AgGroupedCombArgs(ctypes.Structure):    # include/ag_layers.h
                 + [(n, c_f) for n in ("scale", "slope", "act_scale", "reserved_f")]
                 + [("x", c_vp), ("lev", c_vp), ("weight", _PTRS), ("act_bias", _PTRS)]
                 + [(n, c_vp) for n in ("out", "scratch", "workspace")] + [("workspace_bytes", c_sz)]
-                + [(n, c_vp) for n in ("g_out", "g_x", "g_lev", "g_weight_x", "g_weight_lev", "g_bias", "g_weight", "operand_maxima", "x_maxima", "out_maxima")])
+                + [(n, c_vp) for n in ("g_out", "g_x", "g_lev", "g_weight_x", "g_weight_lev", "g_bias", "g_weight", "operand_maxima", "x_maxima", "out_maxima",
+                                       "packed_x", "packed_lev")]
+                + [("weights_cached", c_i32), ("reserved_i", c_i32)])
 
 
 AG_ADAM_MAX_TENSORS = 48
@@ -235,7 +239,9 @@ SYMBOLS = [
     ("ag_grouped_layer_scratch_floats", c_sz, [ctypes.POINTER(AgGroupedLayerArgs), c_i32]),
     ("ag_grouped_layer_workspace_bytes", c_sz, [ctypes.POINTER(AgGroupedLayerArgs)]),
     ("ag_grouped_layer_maxima_floats", c_sz, []),
+    ("ag_grouped_layer_packed_bytes", c_sz, [ctypes.POINTER(AgGroupedLayerArgs)]),
     ("ag_grouped_comb_maxima_floats", c_sz, []),
+    ("ag_grouped_comb_packed_bytes", c_sz, [ctypes.POINTER(AgGroupedCombArgs), c_i32]),
     ("ag_grouped_layer_forward", ctypes.c_int, [ctypes.POINTER(AgGroupedLayerArgs), c_vp]),
     ("ag_grouped_layer_backward", ctypes.c_int, [ctypes.POINTER(AgGroupedLayerArgs), c_vp]),
     ("ag_grouped_to_rgb_args_bytes", c_sz, []),

@@ -439,7 +439,9 @@ class AvatarNet(nn.Module):
         grouped = self._grouped_nets()
         if grouped is not None:                      # the three networks as ONE launch chain (grouped.py): G = 3 encoders, G = 6 decoders
             vf = {1: (front_viewdirs, back_viewdirs)} if front_viewdirs is not None else None
-            position_map, color_map, other_map = grouped.forward([self.position_style, color_style, self.other_style], x, vf)
+            # (frozen: in eval mode the three styles are this module's buffers -- the weights' modulation / maxima / packed images persist between frames)
+            position_map, color_map, other_map = grouped.forward([self.position_style, color_style, self.other_style], x, vf,
+                                                                 frozen=color_style is self.color_style and not self.training)
             return position_map, other_map, color_map
         position_map, other_map, color_map = self._concurrently([
             lambda: self.position_net([self.position_style], x, randomize_noise=False)[0],
@@ -579,7 +581,8 @@ class AvatarNet(nn.Module):
         elif self._grouped_nets() is not None:
             color_style = torch.rand_like(self.color_style) if self.random_style and self.training else self.color_style
             vf = {1: [fb for fb in feats]} if self.with_viewdirs else {1: [(None, None)] * len(feats)}
-            position_map, color_maps, other_map = self._grouped_nets().forward([self.position_style, color_style, self.other_style], x, vf)
+            position_map, color_maps, other_map = self._grouped_nets().forward([self.position_style, color_style, self.other_style], x, vf,
+                                                                               frozen=color_style is self.color_style and not self.training)
         else:
             color_style = torch.rand_like(self.color_style) if self.random_style and self.training else self.color_style
             position_map, other_map, color_maps = self._concurrently([

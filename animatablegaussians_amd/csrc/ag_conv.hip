@@ -1720,7 +1720,7 @@ static int choose_splits(long long tiles, int Mpad, int Ncols, int nkt, int G = 
 // weights of all classes with one launch and runs them with one launch (+ one split-K finish).
 static int pack_and_launch(GatherProblem& gp, const TapSet* taps, int bm, const PtrTable& w, long long stride_c, long long stride_m,
                            float wscale, int k, float* At, float* partial, float* amax, const AmaxTensor& w_shape, const float* pre_w,
-                           const float* pre_in, hipStream_t s)
+                           const float* pre_in, hipStream_t s, bool skip_pack = false)
 {
     const bool split = split_math();
     const int terms = split_terms();
@@ -1756,6 +1756,7 @@ static int pack_and_launch(GatherProblem& gp, const TapSet* taps, int bm, const 
     pp.amax = nullptr;
     gp.amax_a = gp.amax_b = nullptr;
     gp.amax_a_mult = 1.f;
+    if (f16 && skip_pack && !pre_w) { set_error("conv: frozen packed weights need their maxima (ConvOpts::amax_w)"); return AG_ERR_INVALID_ARGUMENT; }
     if (f16) {
         AmaxTensor t[2] = { w_shape, AmaxTensor{ gp.xin, nullptr, gp.x_gs, (long long)gp.Cg * gp.Hg * gp.Wg, 0, 1 } };
         t[0].table = &w;
@@ -1768,10 +1769,13 @@ static int pack_and_launch(GatherProblem& gp, const TapSet* taps, int bm, const 
         gp.amax_b = pre_in ? pre_in : amax + (size_t)kMaxGroups * kAmaxParts;
         gp.amax_a_mult = wscale != 1.f ? fabsf(wscale) : 1.f;
     }
-    if (split) hipLaunchKernelGGL(pack_weights_split_kernel, dim3(gp.Cpad / BK, gp.Mpad / 16, G), dim3(256), 0, s, pp);
-    else       hipLaunchKernelGGL(pack_weights_kernel, dim3(gp.Cpad / BK, gp.Mpad / 16, G), dim3(256), 0, s, pp);
-    int rc = check_hip(hipGetLastError(), "pack_weights_kernel");
-    if (rc) return rc;
+    int rc = AG_OK;
+    if (!skip_pack) {                             // (frozen weights: the image a previous call left in ConvOpts::packed)
+        if (split) hipLaunchKernelGGL(pack_weights_split_kernel, dim3(gp.Cpad / BK, gp.Mpad / 16, G), dim3(256), 0, s, pp);
+        else       hipLaunchKernelGGL(pack_weights_kernel, dim3(gp.Cpad / BK, gp.Mpad / 16, G), dim3(256), 0, s, pp);
+        rc = check_hip(hipGetLastError(), "pack_weights_kernel");
+        if (rc) return rc;
+    }
 
     int splits = choose_splits(tiles * (gp.Mpad / bm) * G, gp.Mpad, cols, nkt_max, G);
     if (const char* forced = getenv("AG_CONV_SPLITS")) {       // measurement hook (profiles/conv_split_sweep.py)
@@ -1862,6 +1866,11 @@ size_t conv_workspace_bytes_g(const AgConvDesc* d, int G)
     if (validate(d) || G < 1 || G > kMaxGroups) return 0;
     return (size_t)G * packed_bytes(d) + kMaxPartialBytes + kAmaxBytes + 512;
 }
+size_t conv_packed_bytes_g(const AgConvDesc* d, int G)
+{
+    if (validate(d) || G < 1 || G > kMaxGroups) return 0;
+    return (size_t)G * packed_bytes(d) + 512;          // (+ the alignment slack of aligned_base)
+}
 }  // namespace ag
 
 extern "C" {
@@ -1878,7 +1887,7 @@ static int run_gather_family(const AgConvDesc* d, bool backward_input, int G, co
     const int k = d->k, k2 = k * k;
     if (workspace_bytes < conv_workspace_bytes_g(d, G) || !workspace) { set_error("conv workspace too small"); return AG_ERR_SCRATCH_TOO_SMALL; }
     if (G > 1 && out_scale) { set_error("grouped convolution: out_scale is a single-instance option"); return AG_ERR_UNSUPPORTED; }
-    float* At = reinterpret_cast<float*>(aligned_base(workspace));
+    float* At = opt.packed ? reinterpret_cast<float*>(aligned_base(opt.packed)) : reinterpret_cast<float*>(aligned_base(workspace));
     float* partial = reinterpret_cast<float*>(aligned_base(workspace) + (size_t)G * packed_bytes(d));
     float* amax = reinterpret_cast<float*>(aligned_base(workspace) + (size_t)G * packed_bytes(d) + kMaxPartialBytes);
 
@@ -1935,7 +1944,7 @@ static int run_gather_family(const AgConvDesc* d, bool backward_input, int G, co
             for (int t = 0; t < k2; t++) { cl.dy[t] = ts.ky[t]; cl.dx[t] = ts.kx[t]; }
         }
         for (int t = k2; t < kMaxTaps; t++) cl.dy[t] = cl.dx[t] = 0;
-        return pack_and_launch(gp, taps, bm, w, stride_c, stride_m, wscale_of(d), k, At, partial, amax, w_shape, opt.amax_w, pre_in, s);
+        return pack_and_launch(gp, taps, bm, w, stride_c, stride_m, wscale_of(d), k, At, partial, amax, w_shape, opt.amax_w, pre_in, s, opt.packed && opt.packed_valid);
     }
     // scatter with stride 2: output coordinate o = 2*i + ky - poff  (poff = padding for the conv gradient, 0 for convT).
     // Class (qy, qx) = parity of the output coordinate; it receives only taps with ky = (o + poff) mod 2, from
@@ -1973,7 +1982,7 @@ static int run_gather_family(const AgConvDesc* d, bool backward_input, int G, co
             gp.cls[pos] = cl; taps[pos] = ts;
             gp.nclasses++;
         }
-    return pack_and_launch(gp, taps, bm, w, stride_c, stride_m, wscale_of(d), k, At, partial, amax, w_shape, opt.amax_w, pre_in, s);
+    return pack_and_launch(gp, taps, bm, w, stride_c, stride_m, wscale_of(d), k, At, partial, amax, w_shape, opt.amax_w, pre_in, s, opt.packed && opt.packed_valid);
 }
 
 }  // extern "C"

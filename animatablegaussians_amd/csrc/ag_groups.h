@@ -125,8 +125,14 @@ struct ConvOpts {
     // weight gradient's slice reduction); the slice is overwritten
     const PtrTable* dw_table = nullptr;
     long long dw_row_stride = 0;
+    // Frozen weights (round 5, inference): `packed` = conv_packed_bytes_g(d, G) bytes the CALLER keeps between calls; the forward / input-gradient
+    // call packs the weights into it instead of its workspace, or -- packed_valid -- finds them there and launches no pack kernel (the weights,
+    // their scale and the arithmetic mode must be those of the call that packed them; with the scaled fp16 forms amax_w must be given too)
+    float* packed = nullptr;
+    bool packed_valid = false;
 };
 size_t conv_workspace_bytes_g(const AgConvDesc* d, int G);
+size_t conv_packed_bytes_g(const AgConvDesc* d, int G);
 int conv_forward_g(const AgConvDesc* d, int G, const float* x, long long x_gs, const PtrTable& w, const float* out_scale, const PtrTable& bias,
                    float* y, long long y_gs, void* workspace, size_t workspace_bytes, hipStream_t s, const ConvOpts& o = ConvOpts());
 int conv_backward_input_g(const AgConvDesc* d, int G, const float* dy, long long dy_gs, const PtrTable& w, float* dx, long long dx_gs,

@@ -132,6 +132,13 @@ size_t ag_grouped_layer_workspace_bytes(const AgGroupedLayerArgs* a)
 
 size_t ag_grouped_layer_maxima_floats(void) { return conv_absmax_floats(2); }
 
+size_t ag_grouped_layer_packed_bytes(const AgGroupedLayerArgs* a)
+{
+    Geo g;
+    if (!geometry(a, g)) return 0;
+    return conv_packed_bytes_g(&g.d, a->G);
+}
+
 int ag_grouped_layer_forward(const AgGroupedLayerArgs* a, void* stream)
 {
     Geo g;
@@ -155,6 +162,7 @@ int ag_grouped_layer_forward(const AgGroupedLayerArgs* a, void* stream)
     auto keep_maxima = [&](const PtrTable& w, const float* x, long long xgs, long long x_len, ConvOpts& o) -> int {
         if (!conv_math_needs_absmax() || a->k < 3 || !a->operand_maxima) return AG_OK;
         AmaxTensor t[2] = { AmaxTensor{ nullptr, &w, 0, w_len, 0, 1 }, AmaxTensor{ x, nullptr, xgs, x_len, 0, 1 } };
+        if (a->weights_cached) t[0] = AmaxTensor{};          // frozen weights: their slot of operand_maxima is a previous call's
         const bool x_known = a->x_maxima && x == a->x;        // handed over by the call that produced x
         // ... then the x slot of operand_maxima gets the handed maxima themselves ("maxima of the 256 partial maxima": the same largest magnitude, inside
         // the same launch), so that a backward call that is given operand_maxima WITHOUT x_maxima never reads a slot nobody wrote (round-4 advice)
@@ -166,6 +174,8 @@ int ag_grouped_layer_forward(const AgGroupedLayerArgs* a, void* stream)
         o.amax_x = x_known ? a->x_maxima : a->operand_maxima + (size_t)kMaxGroups * kAmaxParts;
         return AG_OK;
     };
+    // frozen weights: the packed image is reused only where its maxima are kept too (1 x 1 layers and calls without operand_maxima take their own)
+    const bool packed_frozen = a->weights_cached && a->packed_weights && (!conv_math_needs_absmax() || (a->k >= 3 && a->operand_maxima));
     auto zero_omax = [&]() -> int {       // the slots a producer kernel raises must start at zero: by the maxima launch above, or here
         if (!omax || omax_zeroed) return AG_OK;
         omax_zeroed = true;
@@ -187,6 +197,7 @@ int ag_grouped_layer_forward(const AgGroupedLayerArgs* a, void* stream)
             cx_gs = n_in == 1 ? 0 : (long long)a->Cin * g.BH * g.BW;
         }
         ConvOpts o;
+        o.packed = reinterpret_cast<float*>(a->packed_weights); o.packed_valid = packed_frozen;
         if ((rc = keep_maxima(w_t, cx, cx_gs, (long long)a->Cin * (a->resample ? g.BH * g.BW : a->H * a->W), o))) return rc;
         if (fused_act() && !(a->k == 1 && a->Cin <= 4)) {       // (the 3-channel FromRGB convolutions run on the streaming 1 x 1 kernel, which has no such epilogue)
             ConvAct act{ 1, a->slope, a->act_scale, PtrTable{}, PtrTable{} };
@@ -203,7 +214,8 @@ int ag_grouped_layer_forward(const AgGroupedLayerArgs* a, void* stream)
     if (!table_complete(style_t, G) || !a->w_mod || !a->demod) { set_error("ag_layer_forward: StyledConv needs style, w_mod and demod"); return AG_ERR_INVALID_ARGUMENT; }
     // the modulated weight is kept [Cout][Cin][k][k] for the transposed convolution too (wt_oihw below): the modulation kernels read and
     // write it coalesced both ways (conv_transpose2d's own [Cin][Cout] order made them 9x slower than their bytes, round 4)
-    if ((rc = modulate_weight_forward_g(a->w_mod, a->demod, G, w_t, style_t, a->scale, 1, a->Cout, a->Cin, a->k * a->k, 0, s))) return rc;
+    if (!a->weights_cached &&
+        (rc = modulate_weight_forward_g(a->w_mod, a->demod, G, w_t, style_t, a->scale, 1, a->Cout, a->Cin, a->k * a->k, 0, s))) return rc;
     // the modulated weights of the instances, stacked
     PtrTable wm_t{};
     const size_t wn = (size_t)a->Cout * a->Cin * a->k * a->k;
@@ -212,6 +224,7 @@ int ag_grouped_layer_forward(const AgGroupedLayerArgs* a, void* stream)
     for (int i = 0; i < G; i++)
         if (a->noise[i] && a->noise_weight[i]) { noise_t.p[i] = a->noise[i]; nw_t.p[i] = a->noise_weight[i]; }
     ConvOpts om = kOihw;          // (wt_oihw is ignored by the plain convolution of the non-resampling case)
+    om.packed = reinterpret_cast<float*>(a->packed_weights); om.packed_valid = packed_frozen;
     if ((rc = keep_maxima(wm_t, a->x, x_gs, (long long)a->Cin * a->H * a->W, om))) return rc;
     if (a->resample) {
         if (!a->k_blur) { set_error("ag_layer_forward: resampling layer without FIR taps"); return AG_ERR_INVALID_ARGUMENT; }
@@ -404,7 +417,7 @@ int ag_grouped_to_rgb_forward(const AgGroupedToRgbArgs* a, void* stream)
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const PtrTable w_t = table_of(a->weight, G), style_t = table_of(a->style, G), bias_t = table_of(a->bias, G);
     int rc;
-    if ((rc = modulate_weight_forward_g(a->w_mod, nullptr, G, w_t, style_t, a->scale, 0, a->Cout, a->Cin, 1, 0, s))) return rc;
+    if (!a->weights_cached && (rc = modulate_weight_forward_g(a->w_mod, nullptr, G, w_t, style_t, a->scale, 0, a->Cout, a->Cin, 1, 0, s))) return rc;
     PtrTable wm_t{};
     for (int i = 0; i < G; i++) wm_t.p[i] = a->w_mod + (size_t)i * a->Cout * a->Cin;
     const AgConvDesc d = rgb_desc(a);
@@ -463,6 +476,13 @@ static AgConvDesc comb_desc(const AgGroupedCombArgs* a, int cin)
 size_t ag_grouped_comb_args_bytes(void) { return sizeof(AgGroupedCombArgs); }
 size_t ag_grouped_comb_maxima_floats(void) { return conv_absmax_floats(4); }
 
+size_t ag_grouped_comb_packed_bytes(const AgGroupedCombArgs* a, int32_t level_half)
+{
+    if (!comb_ok(a)) return 0;
+    const AgConvDesc d = comb_desc(a, level_half ? a->C2 : a->C1);
+    return conv_packed_bytes_g(&d, level_half ? a->N : a->M);
+}
+
 size_t ag_grouped_comb_workspace_bytes(const AgGroupedCombArgs* a)
 {
     if (!comb_ok(a)) return 0;
@@ -503,12 +523,16 @@ int ag_grouped_comb_forward(const AgGroupedCombArgs* a, void* stream)
         const long long wrow = (long long)(a->C1 + a->C2) * 9;
         AmaxTensor mt[4] = { AmaxTensor{ a->x, nullptr, a->C1 * hw, a->C1 * hw, 0, 1, a->M }, AmaxTensor{ a->lev, nullptr, a->C2 * hw, a->C2 * hw, 0, 1, a->N },
                                    AmaxTensor{ nullptr, &w1, 0, (long long)a->C1 * 9, wrow, a->Cout, a->M }, AmaxTensor{ nullptr, &w2, 0, (long long)a->C2 * 9, wrow, a->Cout, a->N } };
+        if (a->weights_cached && a->operand_maxima) mt[2] = mt[3] = AmaxTensor{};        // frozen weights: their slots are a previous call's
         if (a->x_maxima) mt[0] = AmaxTensor{ a->x_maxima, nullptr, kAmaxParts, kAmaxParts, 0, 1, a->M };   // handed over by the call that produced x: the slot
                                                                                                        // gets the handed maxima (as in ag_grouped_layer_forward)
         if ((rc = conv_absmax(mt, 4, a->M, am, s, a->out_maxima, a->M))) return rc;      // (and zeroes the slots of this call's own output maxima)
         const size_t slot = (size_t)kMaxGroups * kAmaxParts;
         o1.amax_x = a->x_maxima ? a->x_maxima : am; o2.amax_x = am + slot; o1.amax_w = am + 2 * slot; o2.amax_w = am + 3 * slot;
     }
+    const bool frozen = a->weights_cached && (a->operand_maxima || !conv_math_needs_absmax());
+    o1.packed = reinterpret_cast<float*>(a->packed_x); o1.packed_valid = frozen;
+    o2.packed = reinterpret_cast<float*>(a->packed_lev); o2.packed_valid = frozen;
     float* const omax = (conv_math_needs_absmax() && a->out_maxima) ? a->out_maxima : nullptr;
     if ((rc = conv_forward_g(&d2, a->N, a->lev, a->C2 * hw, w2, nullptr, PtrTable{}, t, a->Cout * hw, a->workspace, a->workspace_bytes, s, o2))) return rc;
     if (fused_act()) {

@@ -102,6 +102,30 @@ def _comb_maxima_floats():
 _OUT_MAXIMA_FLOATS = _lib.AG_MAX_GROUPS * 256
 
 
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Frozen weights (round 5): inference runs the same parameters and styles frame after frame (the reference's --mode test, main_avatar.py:525-776).
+# Their modulation, maxima and tile-blocked fp16 images are a seventh of a frame's device time; under no_grad a GroupedStyleUNets keeps them
+# (include/ag_layers.h AgGroupedLayerArgs.packed_weights / weights_cached) for as long as no parameter's version counter, no style input and
+# not the arithmetic mode changes.  ``_FROZEN``: the cache of the GroupedStyleUNets whose forward is running, or None (training, captures).
+# ---------------------------------------------------------------------------------------------------------------------------------
+_FROZEN = None
+
+
+def frozen_weights_enabled() -> bool:
+    return os.environ.get("AG_FROZEN_WEIGHTS", "1") != "0"
+
+
+def _frozen_entry(site):
+    """(entry dict, hit) of the layer call identified by ``site`` in the active cache, or (None, False)."""
+    if _FROZEN is None:
+        return None, False
+    e = _FROZEN.get(site)
+    if e is not None:
+        return e, True
+    e = _FROZEN[site] = {}
+    return e, False
+
+
 def _handed_maxima(x):
     """The largest magnitudes of ``x`` as the grouped call that produced it left them (``out_maxima`` of include/ag_layers.h), or None.
     They travel as an attribute of the very tensor the producer returned: any operation in between yields another tensor without it."""
@@ -193,8 +217,10 @@ class _GroupedLayer(torch.autograd.Function):
         out = torch.empty((G, a.Cout, oh, ow), dtype=torch.float32, device=dev)
         keep = None
         wnum = ws[0].numel()
+        # frozen weights (inference): the modulated weights, the weight maxima and the packed image persist between frames
+        fz, fz_hit = _frozen_entry(("layer", tuple(w.data_ptr() for w in ws), tuple(st.data_ptr() for st in styles) if modulated else (), G, resample))
         if modulated:
-            keep = torch.empty(G * (wnum + a.Cout), dtype=torch.float32, device=dev)       # modulated weights, then the demodulation coefficients
+            keep = fz["keep"] if fz_hit else torch.empty(G * (wnum + a.Cout), dtype=torch.float32, device=dev)   # modulated weights, then the demodulation coefficients
             a.w_mod, a.demod = keep.data_ptr(), keep.data_ptr() + 4 * G * wnum
             for st in styles:
                 if st.numel() != a.Cin:
@@ -215,11 +241,15 @@ class _GroupedLayer(torch.autograd.Function):
         buf, a.scratch, a.workspace = _scratch(f_fwd, wsb, dev)
         a.workspace_bytes = wsb
         # operand maxima of the fp16 split form (include/ag_layers.h): written by this call, read by the backward
-        mx = torch.empty(_maxima_floats(), dtype=torch.float32, device=dev) if a.k >= 3 else None
+        mx = (fz["mx"] if fz_hit else torch.empty(_maxima_floats(), dtype=torch.float32, device=dev)) if a.k >= 3 else None
         a.operand_maxima = mx.data_ptr() if mx is not None else None
         a.x_maxima = xm.data_ptr() if xm is not None else None
         om = _new_out_maxima(out)
         a.out_maxima = om.data_ptr() if om is not None else None
+        if fz is not None:
+            packed = fz["packed"] if fz_hit else torch.empty(int(_lib.lib().ag_grouped_layer_packed_bytes(ctypes.byref(a))), dtype=torch.uint8, device=dev)
+            a.packed_weights, a.weights_cached = packed.data_ptr(), int(fz_hit)
+            fz.update(keep=keep if modulated else None, mx=mx, packed=packed)
         with _lib.on_device(dev):
             _lib.check(_lib.lib().ag_grouped_layer_forward(ctypes.byref(a), _stream(dev)), "ag_grouped_layer_forward")
         ctx.save_for_backward(x, out, keep, _flipped(k_blur) if resample else None, mx, xm, *ws, *styles, *noises, *nws, *biases)
@@ -353,7 +383,11 @@ class _GroupedToRGB(torch.autograd.Function):
             a = _rgb_args(G, x[s:e], ws[s], scale)
             f_fwd, _, wsb = _rgb_sizes(a)
             out = torch.empty((G, a.Cout, H, W), dtype=torch.float32, device=dev)
-            wm = torch.empty(G * a.Cout * Cin, dtype=torch.float32, device=dev)
+            fz, fz_hit = _frozen_entry(("rgb", tuple(w.data_ptr() for w in ws[s:e]), tuple(st.data_ptr() for st in styles[s:e])))
+            wm = fz["wm"] if fz_hit else torch.empty(G * a.Cout * Cin, dtype=torch.float32, device=dev)
+            if fz is not None:
+                fz["wm"] = wm
+                a.weights_cached = int(fz_hit)
             _fill(a.weight, ws[s:e])
             _fill(a.style, styles[s:e])
             _fill(a.bias, biases[s:e])
@@ -475,11 +509,17 @@ class _GroupedComb(torch.autograd.Function):
         a.x, a.lev, a.out = x.data_ptr(), lev.data_ptr(), out.data_ptr()
         buf, a.scratch, a.workspace = _scratch(f_fwd, wsb, dev)
         a.workspace_bytes = wsb
-        mx = torch.empty(_comb_maxima_floats(), dtype=torch.float32, device=dev)      # operand maxima of the fp16 split form, kept for the backward
+        fz, fz_hit = _frozen_entry(("comb", tuple(w.data_ptr() for w in ws), tuple(begin)))
+        mx = fz["mx"] if fz_hit else torch.empty(_comb_maxima_floats(), dtype=torch.float32, device=dev)      # operand maxima of the fp16 split form, kept for the backward
         a.operand_maxima = mx.data_ptr()
         a.x_maxima = xm.data_ptr() if xm is not None else None
         om = _new_out_maxima(out)
         a.out_maxima = om.data_ptr() if om is not None else None
+        if fz is not None:
+            if not fz_hit:
+                fz.update(mx=mx, px=torch.empty(int(_lib.lib().ag_grouped_comb_packed_bytes(ctypes.byref(a), 0)), dtype=torch.uint8, device=dev),
+                          pl=torch.empty(int(_lib.lib().ag_grouped_comb_packed_bytes(ctypes.byref(a), 1)), dtype=torch.uint8, device=dev))
+            a.packed_x, a.packed_lev, a.weights_cached = fz["px"].data_ptr(), fz["pl"].data_ptr(), int(fz_hit)
         with _lib.on_device(dev):
             _lib.check(_lib.lib().ag_grouped_comb_forward(ctypes.byref(a), _stream(dev)), "ag_grouped_comb_forward")
         ctx.save_for_backward(x, lev, out, mx, xm, *ws, *bs)
@@ -787,15 +827,60 @@ class GroupedStyleUNets:
         new_skips = dict(zip(runs, outs))
         return out, new_skips
 
-    def forward(self, styles, x, view_features=None):
+    def forward(self, styles, x, view_features=None, frozen=False):
         """styles[i]: the style vector [1, style_dim] of network i; x: [1, inp_ch, S, S]; view_features: {network index: (f1, f2)} or
         {network index: [(f1, f2), ...]} for several views of the pose (the view-dependent stages then run once per view).
-        Returns per network the image [1, 2 out_ch, S', S'] (= ``DualStyleUNet.forward(...)[0]``), or a list of them per view."""
+        Returns per network the image [1, 2 out_ch, S', S'] (= ``DualStyleUNet.forward(...)[0]``), or a list of them per view.
+        ``frozen``: the caller's promise that ``styles`` are PERSISTENT tensors (module buffers, not per-call temporaries whose address and version
+        a later temporary may repeat): under no_grad the weights' modulation, maxima and packed images are then kept between calls (``_FROZEN``)."""
+        global _FROZEN
+        frozen = self._frozen_cache_for(styles) if frozen else None
+        prev, _FROZEN = _FROZEN, frozen
+        try:
+            return self._forward(styles, x, view_features)
+        finally:
+            _FROZEN = prev
+
+    def _frozen_cache_for(self, styles):
+        """The frozen-weight cache of this object (a dict the layer calls fill and read, see ``_FROZEN``) when the call is an inference call --
+        no autograd, no hipGraph capture, one stream -- and None otherwise.  It is emptied whenever a parameter or buffer of the networks, a style
+        input or the arithmetic mode has changed since it was filled (version counters; ``optim.FusedAdam`` bumps them like torch's optimizers)."""
+        if torch.is_grad_enabled() or not frozen_weights_enabled() or torch.cuda.is_current_stream_capturing() or \
+           int(os.environ.get("AG_GROUPED_STREAMS", "1")) != 1:
+            return None
+        tensors = getattr(self, "_frozen_tensors", None)
+        if tensors is None:
+            tensors = self._frozen_tensors = [t for n in self.nets for t in list(n.parameters()) + list(n.buffers())]
+        token = (agc.get_math(), tuple((s.data_ptr(), s._version) for s in styles), sum(t._version for t in tensors),
+                 sum(t.data_ptr() for t in tensors))
+        if getattr(self, "_frozen_token", None) != token:
+            self._frozen_token, self._frozen_cache = token, {}
+        return self._frozen_cache
+
+    def invalidate_frozen(self):
+        """Drop the frozen-weight cache (after writing parameters in a way their version counters do not see, e.g. through ``.data``)."""
+        self._frozen_token, self._frozen_cache = None, {}
+
+    def _styles(self, i, b, stages, lat):
+        """``nets[i]._stage_styles(b, stages, lat[i])``; frozen weights: the SAME tensors frame after frame (the layer calls' cache is keyed on them)."""
+        if _FROZEN is None:
+            return self.nets[i]._stage_styles(b, stages, lat[i])
+        key = ("styles", i, b, tuple(stages))
+        if key not in _FROZEN:
+            _FROZEN[key] = self.nets[i]._stage_styles(b, stages, lat[i])
+        return _FROZEN[key]
+
+    def _forward(self, styles, x, view_features=None):
         nets = self.nets
         view_features = dict(view_features or {})
         # the mapping networks of all networks: one native launch per layer (styleunet.latents_of); fixed noise buffers (randomize_noise False)
-        lat = latents_of(nets, list(styles))
-        lat = [w[:, 0] if w.dim() == 3 else w for w in lat]
+        if _FROZEN is not None and ("lat",) in _FROZEN:
+            lat = _FROZEN[("lat",)]
+        else:
+            lat = latents_of(nets, list(styles))
+            lat = [w[:, 0] if w.dim() == 3 else w for w in lat]
+            if _FROZEN is not None:
+                _FROZEN[("lat",)] = lat
         noises = [n._latent_and_noise([w], True, None, False)[1] for n, w in zip(nets, lat)]
         levels = self._encode(x)
         for i, v in view_features.items():
@@ -851,7 +936,7 @@ class GroupedStyleUNets:
         nets, n0 = self.nets, self.nets[0]
         shared_stages = list(range(0, min(n0.VIEW_STAGE + 1, len(n0.dec))))
         tail_stages = list(range(n0.VIEW_STAGE + 1, len(n0.dec)))
-        st = [nets[i]._stage_styles(b, shared_stages, lat[i]) for i, b in members]
+        st = [self._styles(i, b, shared_stages, lat) for i, b in members]
         out, skips = None, None
         for n in shared_stages:
             out, skips = self._stage(n, members, st, noises, out, skips, levels)
@@ -867,7 +952,7 @@ class GroupedStyleUNets:
         results = {}
         step = max(2, min(_lib.AG_MAX_GROUPS, int(os.environ.get("AG_GROUPED_TAIL_CHUNK", _lib.AG_MAX_GROUPS))))
         # the tail stages' styles depend on (network, branch) only: one modulation GEMM per pair, shared by all views and chunks
-        tail_styles = {ib: nets[ib[0]]._stage_styles(ib[1], tail_stages, lat[ib[0]]) for ib in dict.fromkeys((i, b) for i, b, _, _ in tail)}
+        tail_styles = {ib: self._styles(ib[0], ib[1], tail_stages, lat) for ib in dict.fromkeys((i, b) for i, b, _, _ in tail)}
         for c0 in range(0, len(tail), step):
             chunk = tail[c0:c0 + step]
             tm = [(i, b) for i, b, _, _ in chunk]

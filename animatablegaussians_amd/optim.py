@@ -84,6 +84,9 @@ class FusedAdam(torch.optim.Optimizer):
                     del keep
             for st in states:
                 st["step"] += 1.0
+            # the kernel wrote the parameters behind autograd's back: bump their version counters, as torch.optim.Adam's in-place ops do (anything
+            # keyed on a parameter's version -- the frozen-weight cache of inference, grouped.py -- must see the update)
+            torch.autograd.graph.increment_version(ps)
         return loss
 
     def load_state_dict(self, state_dict):

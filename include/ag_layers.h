@@ -114,6 +114,13 @@ typedef struct AgGroupedLayerArgs {
                                       They MUST be current: a maximum that is too small overflows fp16 (reported through ag_conv_status, AG_ERR_RANGE) */
     float* out_maxima;             /* forward: AG_MAX_GROUPS * 256 floats or NULL: receives the largest magnitudes of `out` (from the kernel that writes
                                       it wherever that kernel can, by a sweep otherwise; untouched outside AG_CONV_MATH_SPLIT_F16) */
+    /* Frozen weights (round 5; forward only): inference runs the same weights and styles frame after frame (main_avatar.py:525-776), and their
+       modulation, maxima and tile-blocked fp16 image are a seventh of a frame's device time.  `packed_weights`: ag_grouped_layer_packed_bytes()
+       bytes the caller keeps between calls; the call leaves the packed convolution weights there.  `weights_cached` = 1: w_mod / demod, the weight
+       slot of operand_maxima and packed_weights ARE those a previous call with the same weights, styles and arithmetic mode left -- the call
+       launches no modulation, no weight sweep and no pack kernel.  (Nothing checks that they are current: the caller's contract.) */
+    void* packed_weights;
+    int32_t weights_cached, reserved_i;
 } AgGroupedLayerArgs;
 
 size_t ag_grouped_layer_args_bytes(void);
@@ -121,6 +128,7 @@ int ag_grouped_layer_output_size(const AgGroupedLayerArgs* a, int32_t* OH, int32
 size_t ag_grouped_layer_scratch_floats(const AgGroupedLayerArgs* a, int32_t backward);
 size_t ag_grouped_layer_workspace_bytes(const AgGroupedLayerArgs* a);
 size_t ag_grouped_layer_maxima_floats(void);
+size_t ag_grouped_layer_packed_bytes(const AgGroupedLayerArgs* a);
 int ag_grouped_layer_forward(const AgGroupedLayerArgs* a, void* stream);
 int ag_grouped_layer_backward(const AgGroupedLayerArgs* a, void* stream);
 
@@ -149,6 +157,7 @@ typedef struct AgGroupedToRgbArgs {
     float* g_weight;               /* [G][Cout][Cin] or NULL */
     float* g_style;                /* [G][Cin] (required with g_weight) */
     float* g_skip;                 /* [G][Cout][H / 2][W / 2] or NULL */
+    int32_t weights_cached, reserved_i;   /* forward: 1 = w_mod already holds these weights' modulation (as AgGroupedLayerArgs.weights_cached) */
 } AgGroupedToRgbArgs;
 
 size_t ag_grouped_to_rgb_args_bytes(void);
@@ -193,12 +202,16 @@ typedef struct AgGroupedCombArgs {
                                       read by the backward of the same call) */
     const float* x_maxima;         /* as AgGroupedLayerArgs.x_maxima, for the members' input `x` */
     float* out_maxima;             /* as AgGroupedLayerArgs.out_maxima */
+    void* packed_x;                /* frozen weights, as AgGroupedLayerArgs.packed_weights: ag_grouped_comb_packed_bytes(a, 0) bytes for W[:, :C1] ... */
+    void* packed_lev;              /* ... and ag_grouped_comb_packed_bytes(a, 1) bytes for W[:, C1:] */
+    int32_t weights_cached, reserved_i;   /* 1: both images and the two weight slots of operand_maxima are a previous call's */
 } AgGroupedCombArgs;
 
 size_t ag_grouped_comb_args_bytes(void);
 size_t ag_grouped_comb_scratch_floats(const AgGroupedCombArgs* a, int32_t backward);
 size_t ag_grouped_comb_workspace_bytes(const AgGroupedCombArgs* a);
 size_t ag_grouped_comb_maxima_floats(void);
+size_t ag_grouped_comb_packed_bytes(const AgGroupedCombArgs* a, int32_t level_half);
 int ag_grouped_comb_forward(const AgGroupedCombArgs* a, void* stream);
 int ag_grouped_comb_backward(const AgGroupedCombArgs* a, void* stream);
 

@@ -13,6 +13,7 @@ from torch.profiler import ProfilerActivity, profile  # noqa: E402
 
 dev = torch.device("cuda:0")
 step = bench_avatar.TrainingStep(dev)
+step.net.eval()
 for i in range(4):
     step.infer(i, 1)
 torch.cuda.synchronize()
