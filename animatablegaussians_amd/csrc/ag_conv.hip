@@ -596,6 +596,27 @@ __global__ void __launch_bounds__(kAmaxThreads) absmax_kernel(AmaxJobs J)
     }
 }
 
+// The same for a launch whose jobs are all short (the bookkeeping launches of a layer call whose operands' maxima are all known: 256 handed-over
+// partial maxima to copy into a slot, slots to zero for a producer's atomic maxima): one workgroup per job instead of 256 x 16 waves that find
+// nothing to do -- a frame of inference with frozen weights issues ~40 of them.  Same result layout: slot 0 = the job's maximum, the others 0.
+__global__ void __launch_bounds__(256) absmax_small_kernel(AmaxJobs J)
+{
+    const int job = blockIdx.x;
+    const float* __restrict__ x = J.ptr[job];
+    const long long len = J.len[job], n = len * J.rows[job];
+    float m = 0.f;
+    for (long long i = threadIdx.x; i < n; i += 256) {
+        const long long r = i / (len > 0 ? len : 1);
+        m = fmaxf(m, fabsf(x[r * J.stride[job] + (i - r * len)]));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    __shared__ float wm[4];
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    J.outp[job][threadIdx.x] = threadIdx.x == 0 ? fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3])) : 0.f;
+}
+
 // Byte offset of the 16-byte chunk (row, kh) inside a plane of 32-byte rows.  The XOR puts rows r and r + 8 (same banks at a 32-byte
 // pitch) on different halves, so the ds_read_b128 of 16 consecutive rows covers all 64 banks once.
 __device__ __forceinline__ int chunk_off(int row, int kh) { return row * kRowB + ((kh ^ ((row >> 3) & 1)) << 4); }
@@ -1595,7 +1616,10 @@ int conv_absmax(const AmaxTensor* t, int n, int G, float* out, hipStream_t s, fl
     AmaxJobs J;
     int jobs = 0;
     auto flush = [&]() {
-        hipLaunchKernelGGL(absmax_kernel, dim3(kAmaxParts, jobs), dim3(kAmaxThreads), 0, s, J);
+        bool small = true;
+        for (int j = 0; j < jobs; j++) small = small && J.len[j] * J.rows[j] <= 4096;
+        if (small) hipLaunchKernelGGL(absmax_small_kernel, dim3(jobs), dim3(256), 0, s, J);
+        else       hipLaunchKernelGGL(absmax_kernel, dim3(kAmaxParts, jobs), dim3(kAmaxThreads), 0, s, J);
         jobs = 0;
     };
     for (int i = 0; i < n; i++) {
