@@ -8,7 +8,7 @@
 namespace ag {
 
 typedef float lf4 __attribute__((ext_vector_type(4)));
-constexpr int kLinRowsPerWave = 16;       // backward: rows of a job whose g_x contributions one workgroup adds up (one partial row per chunk)
+constexpr int kLinRowsPerChunk = 16;       // backward: rows of a job whose g_x contributions one workgroup adds up (one partial row per chunk)
 constexpr float kSqrt2 = 1.41421356237309504880f;
 
 struct LinearLaunch {
@@ -73,13 +73,13 @@ typedef float lf2 __attribute__((ext_vector_type(2)));
 __global__ void __launch_bounds__(256) equal_linear_backward_kernel(LinearLaunch L, int total_chunks)
 {
     const AgEqualLinearArgs& a = L.a;
-    __shared__ float s_g[kLinRowsPerWave];
+    __shared__ float s_g[kLinRowsPerChunk];
     const int tid = threadIdx.x, lane = tid & 63;
     const int chunk = blockIdx.x;
     int j = 0;
     for (int i = 1; i < a.n_jobs; i++) j = (chunk >= L.chunk_begin[i]) ? i : j;
     const int in = a.in_features, out = a.out_features[j];
-    const int o0 = (chunk - L.chunk_begin[j]) * kLinRowsPerWave, nr = min(out, o0 + kLinRowsPerWave) - o0;
+    const int o0 = (chunk - L.chunk_begin[j]) * kLinRowsPerChunk, nr = min(out, o0 + kLinRowsPerChunk) - o0;
     const float alpha = a.alpha[j];
     const float* __restrict__ W = a.weight[j];
     float* __restrict__ gW = a.g_weight[j];
@@ -385,7 +385,7 @@ bool prepare(const AgEqualLinearArgs* a, LinearLaunch& L, int& total_chunks, con
         L.row_begin[j] = (int32_t)rows;
         L.chunk_begin[j] = (int32_t)chunks;
         rows += a->out_features[j];
-        chunks += (a->out_features[j] + kLinRowsPerWave - 1) / kLinRowsPerWave;
+        chunks += (a->out_features[j] + kLinRowsPerChunk - 1) / kLinRowsPerChunk;
     }
     if (rows > 0x3fffffffLL) { set_error("%s: too many rows", who); return false; }
     for (int j = a->n_jobs; j <= AG_LINEAR_MAX_JOBS; j++) { L.row_begin[j] = (int32_t)rows; L.chunk_begin[j] = (int32_t)chunks; }

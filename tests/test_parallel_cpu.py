@@ -253,3 +253,25 @@ def test_pose_per_rank_dealing_of_the_training_step():
             if not mode:
                 assert sorted(dealt) == sorted(set(dealt)) and len(dealt) == world * V          # one pose: no camera rendered twice in a step
             assert all(len(per_rank[r][i]) == V for r in range(world))
+
+
+def test_split_pairs_node_equals_the_row_slices_it_replaces():
+    """grouped._SplitPairs (one autograd node for the (network, view) image pairs of a stacked decoder output): same values and the same gradient
+    as the per-view slices ``img[2 v : 2 v + 2].reshape(1, 2 C, H, W)`` it replaces, including views that receive no gradient (host logic, CPU)."""
+    import torch
+    from animatablegaussians_amd.grouped import _SplitPairs
+    g = torch.Generator().manual_seed(0)
+    img = torch.randn(6, 3, 5, 4, generator=g)
+    a = img.clone().requires_grad_(True)
+    b = img.clone().requires_grad_(True)
+    pairs = _SplitPairs.apply(a)
+    want = [b[2 * v:2 * v + 2].reshape(1, 6, 5, 4) for v in range(3)]
+    assert len(pairs) == 3 and all(torch.equal(p, w) for p, w in zip(pairs, want))
+    ups = [torch.randn(1, 6, 5, 4, generator=g) for _ in range(3)]
+    (pairs[0] * ups[0]).sum().backward(retain_graph=True)               # only view 0: the others' rows must come back zero
+    (want[0] * ups[0]).sum().backward(retain_graph=True)
+    assert torch.equal(a.grad, b.grad) and not a.grad[2:].any()
+    a.grad = b.grad = None
+    sum((p * u).sum() for p, u in zip(pairs, ups)).backward()
+    sum((w * u).sum() for w, u in zip(want, ups)).backward()
+    assert torch.equal(a.grad, b.grad)
