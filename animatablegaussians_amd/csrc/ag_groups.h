@@ -62,7 +62,7 @@ int noise_bias_act_backward_g(float* gx, const float* gy, const float* y, int G,
                               float* gnw, long long gnw_stride, float* partials, int C, int HW, float slope, float scale, hipStream_t s, float* amax = nullptr);
 // out [G][Co][Ci][K2] (or [G][Ci][Co][K2] transposed), dcoef [G][Co] (may be null)
 int modulate_weight_forward_g(float* out, float* dcoef, int G, const PtrTable& W, const PtrTable& style, float scale, int demod, int Co, int Ci,
-                              int K2, int transposed, hipStream_t s);
+                              int K2, int transposed, hipStream_t s, float* rowmax = nullptr);
 size_t modulate_weight_partial_floats(int G, int Co, int Ci);
 // dW [G][Co][Ci][K2], dstyle [G][Ci], g = dL/dout stacked like out; deterministic (partials [G][Co][Ci] + fixed-order finish)
 int modulate_weight_backward_g(float* dW, float* dstyle, float* partials, const float* g, int G, const PtrTable& W, const PtrTable& style,

@@ -61,7 +61,7 @@ bool fused_act()
 
 // float offsets of the regions inside `scratch`
 struct Scratch {
-    size_t pre, aux, g_blur, g_wm, nba_part, mod_part, amax, total;
+    size_t pre, aux, g_blur, g_wm, nba_part, mod_part, amax, rowmax, total;
 };
 
 Scratch scratch_layout(const AgGroupedLayerArgs* a, const Geo& g, bool backward)
@@ -82,6 +82,8 @@ Scratch scratch_layout(const AgGroupedLayerArgs* a, const Geo& g, bool backward)
     if (backward && a->modulated) o += pad64(modulate_weight_partial_floats(a->G, a->Cout, a->Cin));
     s.amax = o;
     if (backward) o += pad64(conv_absmax_floats(3));                                               // fp16 split form: maxima of dy, w, x
+    s.rowmax = o;
+    if (!backward && a->modulated) o += pad64(G * a->Cout);                                        // the modulated weight's row maxima
     s.total = o + 64;
     return s;
 }
@@ -159,9 +161,11 @@ int ag_grouped_layer_forward(const AgGroupedLayerArgs* a, void* stream)
     // fp16 split form of the MFMA convolutions: the maxima of the forward's operands (weights as convolved, input as convolved) go to
     // a->operand_maxima, where the backward finds them -- its convolutions have the same operands
     const long long w_len = (long long)a->Cout * a->Cin * a->k * a->k;
+    const float* w_rowmax = nullptr;      // set by the StyledConv branch: [G][Cout] row maxima of the modulated weights
     auto keep_maxima = [&](const PtrTable& w, const float* x, long long xgs, long long x_len, ConvOpts& o) -> int {
         if (!conv_math_needs_absmax() || a->k < 3 || !a->operand_maxima) return AG_OK;
         AmaxTensor t[2] = { AmaxTensor{ nullptr, &w, 0, w_len, 0, 1 }, AmaxTensor{ x, nullptr, xgs, x_len, 0, 1 } };
+        if (w_rowmax) t[0] = AmaxTensor{ w_rowmax, nullptr, a->Cout, a->Cout, 0, 1 };
         if (a->weights_cached) t[0] = AmaxTensor{};          // frozen weights: their slot of operand_maxima is a previous call's
         const bool x_known = a->x_maxima && x == a->x;        // handed over by the call that produced x
         // ... then the x slot of operand_maxima gets the handed maxima themselves ("maxima of the 256 partial maxima": the same largest magnitude, inside
@@ -214,8 +218,13 @@ int ag_grouped_layer_forward(const AgGroupedLayerArgs* a, void* stream)
     if (!table_complete(style_t, G) || !a->w_mod || !a->demod) { set_error("ag_layer_forward: StyledConv needs style, w_mod and demod"); return AG_ERR_INVALID_ARGUMENT; }
     // the modulated weight is kept [Cout][Cin][k][k] for the transposed convolution too (wt_oihw below): the modulation kernels read and
     // write it coalesced both ways (conv_transpose2d's own [Cin][Cout] order made them 9x slower than their bytes, round 4)
+    // (rowmax: the modulation kernel leaves every output row's largest magnitude, so the fp16 split form's weight maximum is a sweep of
+    // G * Cout numbers instead of the whole modulated weight)
+    float* const rowmax = a->scratch + L.rowmax;
+    const bool row_maxima = conv_math_needs_absmax() && a->k >= 3 && a->operand_maxima && !a->weights_cached;
     if (!a->weights_cached &&
-        (rc = modulate_weight_forward_g(a->w_mod, a->demod, G, w_t, style_t, a->scale, 1, a->Cout, a->Cin, a->k * a->k, 0, s))) return rc;
+        (rc = modulate_weight_forward_g(a->w_mod, a->demod, G, w_t, style_t, a->scale, 1, a->Cout, a->Cin, a->k * a->k, 0, s,
+                                        row_maxima ? rowmax : nullptr))) return rc;
     // the modulated weights of the instances, stacked
     PtrTable wm_t{};
     const size_t wn = (size_t)a->Cout * a->Cin * a->k * a->k;
@@ -223,6 +232,7 @@ int ag_grouped_layer_forward(const AgGroupedLayerArgs* a, void* stream)
     PtrTable noise_t{}, nw_t{};
     for (int i = 0; i < G; i++)
         if (a->noise[i] && a->noise_weight[i]) { noise_t.p[i] = a->noise[i]; nw_t.p[i] = a->noise_weight[i]; }
+    if (row_maxima) w_rowmax = rowmax;
     ConvOpts om = kOihw;          // (wt_oihw is ignored by the plain convolution of the non-resampling case)
     om.packed = reinterpret_cast<float*>(a->packed_weights); om.packed_valid = packed_frozen;
     if ((rc = keep_maxima(wm_t, a->x, x_gs, (long long)a->Cin * a->H * a->W, om))) return rc;

@@ -216,9 +216,11 @@ __global__ void __launch_bounds__(256) nba_finish_kernel(const float* __restrict
 // ------------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) modulate_weight_forward_kernel(float* __restrict__ out, float* __restrict__ dcoef,
                                                                      const PtrTable W_t, const PtrTable style_t,
-                                                                     float scale, int demod, int Co, int Ci, int K2, int transposed)
+                                                                     float scale, int demod, int Co, int Ci, int K2, int transposed,
+                                                                     float* __restrict__ rowmax)
 {
     __shared__ float s_red[4];
+    float vmax = 0.f;
     const int grp = blockIdx.x / Co, co = blockIdx.x - grp * Co, n = Ci * K2;
     const float* __restrict__ style = style_t.p[grp];
     const float* w = W_t.p[grp] + (size_t)co * n;
@@ -237,7 +239,18 @@ __global__ void __launch_bounds__(256) modulate_weight_forward_kernel(float* __r
         const int ci = i / K2, k = i - ci * K2;
         const float v = (scale * w[i]) * style[ci];
         const size_t o = transposed ? ((size_t)ci * Co + co) * K2 + k : (size_t)co * n + i;
-        out[o] = demod ? v * d : v;
+        const float r = demod ? v * d : v;
+        out[o] = r;
+        vmax = fmaxf(vmax, fabsf(r));
+    }
+    if (rowmax) {        // round 5: the row's largest magnitude as it is stored -- the fp16-split convolutions need the tensor's maximum, and
+                         // Cout row maxima replace a sweep of the whole modulated weight (ag_layers.hip keep_maxima)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = vmax;
+        __syncthreads();
+        if (threadIdx.x == 0) rowmax[blockIdx.x] = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
     }
 }
 
@@ -815,13 +828,13 @@ int noise_bias_act_backward_g(float* gx, const float* gy, const float* y, int G,
 }
 
 int modulate_weight_forward_g(float* out, float* dcoef, int G, const PtrTable& W, const PtrTable& style, float scale, int demod, int Co, int Ci,
-                              int K2, int transposed, hipStream_t s)
+                              int K2, int transposed, hipStream_t s, float* rowmax)
 {
     if (bad_groups(G) || Co <= 0 || Ci <= 0 || K2 <= 0 || !out || !table_complete(W, G) || !table_complete(style, G)) {
         set_error("bad modulate_weight arguments");
         return AG_ERR_INVALID_ARGUMENT;
     }
-    hipLaunchKernelGGL(modulate_weight_forward_kernel, dim3(G * Co), dim3(256), 0, s, out, dcoef, W, style, scale, demod, Co, Ci, K2, transposed);
+    hipLaunchKernelGGL(modulate_weight_forward_kernel, dim3(G * Co), dim3(256), 0, s, out, dcoef, W, style, scale, demod, Co, Ci, K2, transposed, rowmax);
     return check_hip(hipGetLastError(), "modulate_weight_forward_kernel");
 }
 
