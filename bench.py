@@ -64,6 +64,9 @@ def main() -> None:
                     "the host-side wait for a view's instance count (the reference's num_rendered read-back) overlaps the kernels "
                     "of the previous views, and the latency-bound stages of one view fill the gaps of another.  Library-owned step, "
                     "same box: 2 streams 4860, 3 streams 5250, 4 streams 4560 views/s")
+    ap.add_argument("--exchange-every", type=int, default=0, help="N > 1: the ranks all-reduce their per-Gaussian gradient sums once per this "
+                    "many steps (views) of a rank; 0 = 16 // N, BASELINE configs[3]'s 16-view iteration sharded over the ranks (2 views per "
+                    "rank and exchange at N = 8).  In between a rank adds its views' gradients on the device")
     ap.add_argument("--engine-threads", action="store_true", help="operator path: keep autograd's multithreaded engine (default: "
                     "backward nodes run on the calling thread)")
     ap.add_argument("--operator-path", action="store_true", help="time GaussianRasterizer + torch.autograd.backward (the reference's "
@@ -118,7 +121,7 @@ def main() -> None:
     up = synth.upstream_grads(W, H, 12345 + rank)
     g_color, g_depth, g_alpha = t(up["dL_dcolor"]), t(up["dL_ddepth"]), t(up["dL_dalpha"])
     comm_stream = torch.cuda.Stream(dev) if world > 1 else None
-    grad_pack = torch.zeros((P, 14), device=dev) if world > 1 else None
+    exch_every = (args.exchange_every if args.exchange_every > 0 else max(1, 16 // world)) if world > 1 else 0
     R_seen = []
 
     # One step = forward + backward of one view.  The default goes through the library-owned step (rasterizer.FusedRasterStep ->
@@ -135,14 +138,38 @@ def main() -> None:
         # operator path: the graph of a step is ONE node; run it on the calling thread instead of autograd's per-device worker
         torch.autograd.set_multithreading_enabled(False)
 
-    def exchange(grads, producer_stream):
-        # exchange step of view sharding: sum the per-Gaussian attribute gradients over the views of this step (N > 1)
+    # Exchange step of view sharding (N > 1): the per-Gaussian attribute gradients (P x 14 fp32 = 15 MB) summed over the views of an
+    # iteration -- exch_every views of this rank on the device, then over the ranks by one all-reduce.  Pipeline (round 5; rounds 1-4 made
+    # every step's kernels wait for the previous step's all-reduce, so compute and exchange never overlapped):
+    #   slot stream k:  raster forward + backward of the view  ->  wait consumed[k]  ->  pack the five gradient arrays into packs[k]
+    #   comm stream:    wait for that pack  ->  acc = / += packs[k]  ->  record consumed[k]  ->  every exch_every-th step: all-reduce(acc)
+    # A slot's raster kernels wait for nothing (the previous reader of its gradient arrays is the pack on its own stream); its pack waits
+    # only for the comm stream's copy of the slot's previous pack, len(slots) steps back -- so the views of the next steps run under an
+    # all-reduce, and the all-reduce of an iteration is ordered before the first addition of the next one by the comm stream itself.
+    n_slots = max(1, args.streams)
+    packs = [torch.zeros((P, 14), device=dev) for _ in range(n_slots)] if world > 1 else None
+    grad_acc = torch.zeros((P, 14), device=dev) if world > 1 else None
+    consumed = [torch.cuda.Event() for _ in range(n_slots)] if world > 1 else None
+    exch = {"count": 0, "every": exch_every, "chk": None}
+
+    def exchange(k, grads, producer_stream):
+        with torch.cuda.stream(producer_stream):
+            producer_stream.wait_event(consumed[k])           # (a no-op until the event has been recorded once)
+            torch.cat(grads, dim=1, out=packs[k])
         comm_stream.wait_stream(producer_stream)
         with torch.cuda.stream(comm_stream):
-            for g in grads:
-                g.record_stream(comm_stream)
-            torch.cat(grads, dim=1, out=grad_pack)
-            dist.all_reduce(grad_pack)
+            j = exch["count"] % exch["every"]
+            if j == 0:
+                grad_acc.copy_(packs[k])
+            else:
+                grad_acc.add_(packs[k])
+            if exch["chk"] is not None:                        # the untimed check after the regions: checksums of what was packed
+                exch["chk"][0] += packs[k].sum(dtype=torch.float64)
+                exch["chk"][1] += packs[k].abs().sum(dtype=torch.float64)
+            consumed[k].record(comm_stream)
+            if j == exch["every"] - 1:
+                dist.all_reduce(grad_acc)
+        exch["count"] += 1
 
     # the cameras of a capture rig are fixed: one prepared handle (argument structures + output images) per (camera, stream slot), all
     # built here, before the warm-up, as a multi-view trainer builds them once at start-up (allocation only: no kernel runs)
@@ -155,14 +182,12 @@ def main() -> None:
     def step_fused(i: int, slot=None):
         v = (i * world + rank) % len(settings)                     # this rank's view of the step
         k = (i % len(fused.slots)) if slot is None else slot
-        if world > 1:
-            fused.slots[k]["stream"].wait_stream(comm_stream)       # the slot's gradient arrays are still being packed for step i - n
         h = handles.get((v, k))
         if h is None:
             h = handles[(v, k)] = fused.prepare(settings[v], g_color, g_depth, g_alpha, k)
         _, _, _, _, g = fused.run(h, det[0], det[1], det[2], det[3], det[4], inputs_outlive_join=True)
         if world > 1:
-            exchange([g["dL_dmeans3D"], g["dL_dscales"], g["dL_drotations"], g["dL_dopacity"], g["dL_dcolors"]], fused.slots[k]["stream"])
+            exchange(k, [g["dL_dmeans3D"], g["dL_dscales"], g["dL_drotations"], g["dL_dopacity"], g["dL_dcolors"]], fused.slots[k]["stream"])
 
     def step_operator_on(i: int):
         r = rasterizers[(i * world + rank) % len(rasterizers)]
@@ -171,7 +196,7 @@ def main() -> None:
                                        colors_precomp=colors, scales=scales, rotations=rotations, cov3D_precomp=None)
         torch.autograd.backward([color, depth, alpha], [g_color, g_depth, g_alpha])
         if world > 1:
-            exchange([means3D.grad, scales.grad, rotations.grad, opacities.grad, colors.grad], torch.cuda.current_stream(dev))
+            exchange(i % n_slots, [means3D.grad, scales.grad, rotations.grad, opacities.grad, colors.grad], torch.cuda.current_stream(dev))
         for leaf in leaves:
             leaf.grad = None
 
@@ -208,6 +233,7 @@ def main() -> None:
     DOM = 5  # AG_K_BLEND_BACKWARD: bracket the dominant kernel with HIP events on its own launch stream
     _lib.prof_enable([DOM])
     sync_all()
+    exch["count"] = 0                   # N > 1: the timed region starts on an iteration boundary of the exchange
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
@@ -234,6 +260,35 @@ def main() -> None:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    # N > 1, untimed: one more iteration with the all-reduce held back, checked by linearity (a checksum of checksums): the rank's
+    # accumulator must hold the sum of what its steps packed, and after the all-reduce every rank must hold the same buffer whose
+    # checksum is the sum of the ranks' checksums
+    exchange_check = None
+    if world > 1:
+        sync_all()
+        exch.update(count=0, every=1 << 30, chk=torch.zeros(2, dtype=torch.float64, device=dev))
+        for i in range(exch_every):
+            step(i)
+        sync_all()
+        chk = exch["chk"]
+        exch.update(count=0, every=exch_every, chk=None)
+        local = torch.stack([grad_acc.sum(dtype=torch.float64), grad_acc.abs().sum(dtype=torch.float64)])
+        acc_ok = bool((local[0] - chk[0]).abs() <= 1e-6 * chk[1] + 1e-30) and bool(chk[1] > 0)
+        dist.all_reduce(grad_acc)
+        glob = grad_acc.sum(dtype=torch.float64).reshape(1)
+        want = torch.stack([local[0], local[1]])
+        dist.all_reduce(want)                                  # sum over the ranks of (checksum, sum of magnitudes)
+        lo, hi = glob.clone(), glob.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        flags = torch.tensor([float(acc_ok), float(bool((glob - want[0]).abs() <= 1e-6 * want[1])), float(bool(lo == hi))], device=dev)
+        dist.all_reduce(flags, op=dist.ReduceOp.MIN)
+        exchange_check = {"ok": bool(flags.min().item() == 1.0), "accumulator_equals_the_packed_views": bool(flags[0].item() == 1.0),
+                          "allreduce_checksum_is_the_sum_of_the_ranks": bool(flags[1].item() == 1.0),
+                          "ranks_hold_the_same_buffer_checksum": bool(flags[2].item() == 1.0), "views_per_rank_checked": exch_every,
+                          "sum_of_magnitudes": float(want[1].item())}
+        exch["count"] = 0
+
     # instance count of the views this rank rendered (data-dependent: read back from one extra untimed pass)
     from animatablegaussians_amd.rasterizer import native_rasterize_gaussians
     empty = torch.Tensor([])
@@ -259,7 +314,7 @@ def main() -> None:
     # N > 1: the exchange north_star names for the full training step -- the bucketed all-reduce of the three networks' gradients
     # (223.6 M fp32 = 895 MB, parallel.BucketedGradSync's 128-MB buckets) -- timed on its own after the headline region, so the
     # scaling runs record what RCCL over xGMI delivers for it even though the headline workload is raster-only
-    exchange = None
+    exchange_leg = None
     if world > 1:
         n_el = 223648936
         buf = torch.zeros(n_el, device=dev)
@@ -283,7 +338,7 @@ def main() -> None:
         dt = torch.tensor([(time.perf_counter() - t2) / reps], device=dev, dtype=torch.float64)
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
         ms = 1e3 * float(dt.item())
-        exchange = {"what": "bucketed all-reduce of the StyleUNet gradients (223.6 M fp32, 128-MB buckets), not part of `value`",
+        exchange_leg = {"what": "bucketed all-reduce of the StyleUNet gradients (223.6 M fp32, 128-MB buckets), not part of `value`",
                     "bytes": 4 * n_el, "ms": round(ms, 3), "bus_GBps": round(2 * (world - 1) / world * 4 * n_el / (ms * 1e-3) / 1e9, 1)}
         del buf
 
@@ -367,7 +422,11 @@ def main() -> None:
                            "output images prepared once, FusedRasterStep.prepare / run)"),
             "gaussians": P, "instances_per_view": int(R_mean), "tiles": T_tiles, "views": len(settings), "streams": args.streams,
             "prewarm": max(0, args.prewarm),      # untimed steps BEFORE the --warmup steps (round 4: the first region of a process is cold)
-            "parallelism": "1 process" if world == 1 else f"view-sharded x{world}, RCCL all-reduce of per-Gaussian grads (14 f32 each)",
+            "parallelism": "1 process" if world == 1 else
+                           f"view-sharded x{world}: every rank renders its own view per step and sums its views' per-Gaussian gradients (14 f32 each, "
+                           f"{P * 14 * 4 / 1e6:.1f} MB) on the device; one RCCL all-reduce of the sums per {exch_every} steps of a rank "
+                           f"(= a {exch_every * world}-view iteration), on a communication stream under the next views' kernels",
+            "exchange_every_steps": exch_every if world > 1 else None,
             "backend": None if world == 1 else (backend if backend == "nccl" else f"{backend}: fewer GPUs than ranks, ranks share devices -- a "
                                                 "functional run of the N > 1 control flow, NOT a measurement"),
         },
@@ -441,8 +500,10 @@ def main() -> None:
             out["roofline"]["frac_one_stream"] = round(alg_dom / (us1 * 1e-6) / 1e9 / HBM_PEAK_GBS, 5)
     if oper is not None:
         out["operator_path"] = oper
-    if exchange is not None:
-        out["exchange_styleunet"] = exchange
+    if exchange_leg is not None:
+        out["exchange_styleunet"] = exchange_leg
+    if exchange_check is not None:
+        out["exchange_check"] = exchange_check
     if world == 1 and not args.no_full_step:
         # BASELINE configs[2] and the MFMA roofline north_star asks for, measured in this process (about 15 s): the whole training
         # iteration at the reference's batch shape (1 view per step) and at 4 views of one pose per step, and the convolution kernels'

@@ -112,6 +112,11 @@ def test_bench_two_ranks_control_flow_on_one_gpu():
         assert d["config"]["backend"].startswith("gloo") and "NOT a measurement" in d["config"]["backend"]
     x = d["exchange_styleunet"]
     assert x["bytes"] == 4 * 223648936 and x["ms"] > 0 and x["bus_GBps"] > 0
+    # the per-Gaussian gradient exchange of the headline loop (round 5: packed on the view's stream, summed over the rank's views on the
+    # communication stream, one all-reduce per 16 // N steps under the next views' kernels): one untimed iteration checked by linearity
+    assert d["config"]["exchange_every_steps"] == 8
+    c = d["exchange_check"]
+    assert c["ok"] is True and c["views_per_rank_checked"] == 8 and c["sum_of_magnitudes"] > 0, c
 
 
 def test_training_replicas_stay_identical_over_two_adam_steps_two_ranks_one_gpu():
