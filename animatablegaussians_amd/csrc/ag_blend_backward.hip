@@ -172,6 +172,14 @@ extern "C" int ag_debug_bwd_stats(unsigned long long* out)
 #ifndef AG_BWD_TIGHT_CULL
 #define AG_BWD_TIGHT_CULL 1
 #endif
+#ifndef AG_BWD_PRIO
+#define AG_BWD_PRIO 0
+#endif
+#ifndef AG_BWD_PRIO_T1
+#define AG_BWD_PRIO_T1 512u
+#define AG_BWD_PRIO_T2 1024u
+#define AG_BWD_PRIO_T3 2048u
+#endif
 #ifndef AG_BWD_WAVE_OCC
 #define AG_BWD_WAVE_OCC 6       // waves per SIMD the register budget is cut for
 #endif
@@ -219,6 +227,14 @@ __global__ void __launch_bounds__(64, AG_BWD_WAVE_OCC) blend_backward_wave_kerne
         const uint32_t wmax = wave_umax(last_contributor);
         if (wmax == 0) continue;
         const uint32_t rend = rbeg + wmax;                   // walk [rbeg, rend) from the back
+#if AG_BWD_PRIO
+        // issue priority by list length: the blocks of the longest tiles are the kernel's critical path (they start first and are still
+        // walking when the short items of the tail share their SIMD)
+        if (wmax >= AG_BWD_PRIO_T3) __builtin_amdgcn_s_setprio(3);
+        else if (wmax >= AG_BWD_PRIO_T2) __builtin_amdgcn_s_setprio(2);
+        else if (wmax >= AG_BWD_PRIO_T1) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
+#endif
         ST(ST_ITEMS, 1); ST(ST_WALKED, wmax);
 
         float P = 1.0f;              // prod (1 - alpha) over the entries done so far (all four lanes of the pixel)

@@ -111,6 +111,14 @@ extern "C" int ag_debug_fwd_stats(unsigned long long* out)
 #define FST(k, v) do { } while (0)
 #endif
 
+#ifndef AG_FWD_PRIO
+#define AG_FWD_PRIO 0
+#endif
+#ifndef AG_FWD_PRIO_T1
+#define AG_FWD_PRIO_T1 1024u
+#define AG_FWD_PRIO_T2 2048u
+#define AG_FWD_PRIO_T3 4096u
+#endif
 #ifndef AG_FWD_LDS_PAD
 #define AG_FWD_LDS_PAD 0
 #endif
@@ -169,6 +177,15 @@ __global__ void __launch_bounds__(kBlendThreads) blend_forward_kernel(BlendFwdPa
 
         const int tile = (int)hdr.x, reg = (int)hdr.w;
         const uint2 range = make_uint2(hdr.y, hdr.z);
+#if AG_FWD_PRIO
+        {   // issue priority by list length (the regions of the longest tiles are the kernel's critical path)
+            const uint32_t len = range.y - range.x;
+            if (len >= AG_FWD_PRIO_T3) __builtin_amdgcn_s_setprio(3);
+            else if (len >= AG_FWD_PRIO_T2) __builtin_amdgcn_s_setprio(2);
+            else if (len >= AG_FWD_PRIO_T1) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
+#endif
         const int tile_x = tile % p.gx, tile_y = tile / p.gx;
         const int rx0 = tile_x * kTileX + (reg & 1) * kRegW, ry0 = tile_y * kTileY + (reg >> 1) * kRegH;
         // the wave's 4 pixels form a 2x2 block (better coherence of the per-wave early-outs than a 4x1 strip)

@@ -39,6 +39,81 @@ def views_of_rank(n_views: int, rank: int, world: int) -> List[int]:
     return list(range(rank, n_views, world))
 
 
+class ViewGradExchange:
+    """The exchange step of view-sharded rendering (``bench.py --gpus N``): every rank renders its own view per step; the
+    per-Gaussian attribute gradients of a rank's views are summed on the device and the ranks all-reduce the sums once per iteration of
+    ``every`` steps (BASELINE configs[3]: a 16-view iteration over N ranks = 16 // N steps of a rank).
+
+    Pipeline (one stream per in-flight view = "slot", one communication stream)::
+
+        slot stream k:  raster forward + backward of the view  ->  wait consumed[k]  ->  pack the gradient arrays into packs[k]
+        comm stream:    wait for that pack  ->  acc = / += packs[k]  ->  record consumed[k]  ->  every `every`-th step: all-reduce(acc)
+
+    A slot's raster kernels wait for nothing (the previous reader of its gradient arrays is the pack on its own stream); its pack waits only
+    for the communication stream's copy of the slot's PREVIOUS pack, ``n_slots`` steps back -- so the views of the next steps run under an
+    all-reduce, and the all-reduce of an iteration is ordered before the first addition of the next one by the communication stream
+    itself.  (Rounds 1-4 made every step's kernels wait for the previous step's all-reduce: compute and exchange never overlapped.)
+
+    ``acc`` holds the reduced sums of the last completed iteration once the communication stream has been joined (``join()``).  On a CPU
+    device (gloo tests) the same control flow runs without streams."""
+
+    def __init__(self, rows: int, cols: int, device, n_slots: int, every: int):
+        self.dev = torch.device(device)
+        self.cuda = self.dev.type == "cuda"
+        self.every = max(1, int(every))
+        self.packs = [torch.zeros((rows, cols), dtype=torch.float32, device=self.dev) for _ in range(max(1, n_slots))]
+        self.acc = torch.zeros((rows, cols), dtype=torch.float32, device=self.dev)
+        self.comm = torch.cuda.Stream(self.dev) if self.cuda else None
+        self.consumed = [torch.cuda.Event() for _ in self.packs] if self.cuda else None
+        self.count = 0                 # steps submitted since the last reset()
+        self.reduced = 0               # all-reduces issued
+        self.hold_back = False         # True: accumulate only, never all-reduce (the check of bench.py reduces by hand)
+        self.checksums = None          # a 2-element float64 tensor: += (sum, sum of magnitudes) of every pack (the untimed check)
+
+    def reset(self):
+        """Start the next step on an iteration boundary."""
+        self.count = 0
+
+    def submit(self, slot: int, grads: Sequence[torch.Tensor], producer_stream=None):
+        """Pack ``grads`` (arrays [rows, c_i], sum of c_i = cols) of the view just rendered on ``producer_stream`` and hand them to the
+        communication stream.  Never blocks the host (RCCL) -- gloo's all-reduce is synchronous."""
+        k = int(slot) % len(self.packs)
+        j = self.count % self.every
+        if self.cuda:
+            with torch.cuda.stream(producer_stream):
+                producer_stream.wait_event(self.consumed[k])          # (a no-op until the event has been recorded once)
+                torch.cat(list(grads), dim=1, out=self.packs[k])
+            self.comm.wait_stream(producer_stream)
+            with torch.cuda.stream(self.comm):
+                self._accumulate(k, j)
+                self.consumed[k].record(self.comm)
+                self._reduce(j)
+        else:
+            torch.cat(list(grads), dim=1, out=self.packs[k])
+            self._accumulate(k, j)
+            self._reduce(j)
+        self.count += 1
+
+    def _accumulate(self, k, j):
+        if j == 0:
+            self.acc.copy_(self.packs[k])
+        else:
+            self.acc.add_(self.packs[k])
+        if self.checksums is not None:
+            self.checksums[0] += self.packs[k].sum(dtype=torch.float64)
+            self.checksums[1] += self.packs[k].abs().sum(dtype=torch.float64)
+
+    def _reduce(self, j):
+        if j == self.every - 1 and not self.hold_back and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.acc)
+            self.reduced += 1
+
+    def join(self, stream=None):
+        """``stream`` (default: the current one) waits for everything submitted so far."""
+        if self.cuda:
+            (stream or torch.cuda.current_stream(self.dev)).wait_stream(self.comm)
+
+
 class GradSync:
     """Packs a fixed list of gradient tensors into one flat buffer and all-reduces it (sum, optionally mean).
 

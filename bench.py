@@ -120,7 +120,7 @@ def main() -> None:
     rasterizers = [GaussianRasterizer(s) for s in settings]
     up = synth.upstream_grads(W, H, 12345 + rank)
     g_color, g_depth, g_alpha = t(up["dL_dcolor"]), t(up["dL_ddepth"]), t(up["dL_dalpha"])
-    comm_stream = torch.cuda.Stream(dev) if world > 1 else None
+    comm_stream = None
     exch_every = (args.exchange_every if args.exchange_every > 0 else max(1, 16 // world)) if world > 1 else 0
     R_seen = []
 
@@ -138,38 +138,18 @@ def main() -> None:
         # operator path: the graph of a step is ONE node; run it on the calling thread instead of autograd's per-device worker
         torch.autograd.set_multithreading_enabled(False)
 
-    # Exchange step of view sharding (N > 1): the per-Gaussian attribute gradients (P x 14 fp32 = 15 MB) summed over the views of an
-    # iteration -- exch_every views of this rank on the device, then over the ranks by one all-reduce.  Pipeline (round 5; rounds 1-4 made
-    # every step's kernels wait for the previous step's all-reduce, so compute and exchange never overlapped):
-    #   slot stream k:  raster forward + backward of the view  ->  wait consumed[k]  ->  pack the five gradient arrays into packs[k]
-    #   comm stream:    wait for that pack  ->  acc = / += packs[k]  ->  record consumed[k]  ->  every exch_every-th step: all-reduce(acc)
-    # A slot's raster kernels wait for nothing (the previous reader of its gradient arrays is the pack on its own stream); its pack waits
-    # only for the comm stream's copy of the slot's previous pack, len(slots) steps back -- so the views of the next steps run under an
-    # all-reduce, and the all-reduce of an iteration is ordered before the first addition of the next one by the comm stream itself.
+    # Exchange step of view sharding (N > 1): parallel.ViewGradExchange -- the per-Gaussian attribute gradients (P x 14 fp32 = 15 MB) packed on
+    # the view's own stream, summed over the rank's views on a communication stream, one all-reduce per exch_every steps under the next
+    # views' kernels (rounds 1-4 made every step's kernels wait for the previous step's all-reduce: compute and exchange never overlapped)
     n_slots = max(1, args.streams)
-    packs = [torch.zeros((P, 14), device=dev) for _ in range(n_slots)] if world > 1 else None
-    grad_acc = torch.zeros((P, 14), device=dev) if world > 1 else None
-    consumed = [torch.cuda.Event() for _ in range(n_slots)] if world > 1 else None
-    exch = {"count": 0, "every": exch_every, "chk": None}
+    xchg = None
+    if world > 1:
+        from animatablegaussians_amd.parallel import ViewGradExchange
+        xchg = ViewGradExchange(P, 14, dev, n_slots, exch_every)
+        comm_stream = xchg.comm
 
     def exchange(k, grads, producer_stream):
-        with torch.cuda.stream(producer_stream):
-            producer_stream.wait_event(consumed[k])           # (a no-op until the event has been recorded once)
-            torch.cat(grads, dim=1, out=packs[k])
-        comm_stream.wait_stream(producer_stream)
-        with torch.cuda.stream(comm_stream):
-            j = exch["count"] % exch["every"]
-            if j == 0:
-                grad_acc.copy_(packs[k])
-            else:
-                grad_acc.add_(packs[k])
-            if exch["chk"] is not None:                        # the untimed check after the regions: checksums of what was packed
-                exch["chk"][0] += packs[k].sum(dtype=torch.float64)
-                exch["chk"][1] += packs[k].abs().sum(dtype=torch.float64)
-            consumed[k].record(comm_stream)
-            if j == exch["every"] - 1:
-                dist.all_reduce(grad_acc)
-        exch["count"] += 1
+        xchg.submit(k, grads, producer_stream)
 
     # the cameras of a capture rig are fixed: one prepared handle (argument structures + output images) per (camera, stream slot), all
     # built here, before the warm-up, as a multi-view trainer builds them once at start-up (allocation only: no kernel runs)
@@ -233,7 +213,8 @@ def main() -> None:
     DOM = 5  # AG_K_BLEND_BACKWARD: bracket the dominant kernel with HIP events on its own launch stream
     _lib.prof_enable([DOM])
     sync_all()
-    exch["count"] = 0                   # N > 1: the timed region starts on an iteration boundary of the exchange
+    if xchg is not None:
+        xchg.reset()                    # N > 1: the timed region starts on an iteration boundary of the exchange
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
@@ -266,12 +247,15 @@ def main() -> None:
     exchange_check = None
     if world > 1:
         sync_all()
-        exch.update(count=0, every=1 << 30, chk=torch.zeros(2, dtype=torch.float64, device=dev))
+        xchg.reset()
+        xchg.hold_back, xchg.checksums = True, torch.zeros(2, dtype=torch.float64, device=dev)
         for i in range(exch_every):
             step(i)
         sync_all()
-        chk = exch["chk"]
-        exch.update(count=0, every=exch_every, chk=None)
+        chk = xchg.checksums
+        xchg.hold_back, xchg.checksums = False, None
+        xchg.reset()
+        grad_acc = xchg.acc
         local = torch.stack([grad_acc.sum(dtype=torch.float64), grad_acc.abs().sum(dtype=torch.float64)])
         acc_ok = bool((local[0] - chk[0]).abs() <= 1e-6 * chk[1] + 1e-30) and bool(chk[1] > 0)
         dist.all_reduce(grad_acc)
@@ -286,8 +270,7 @@ def main() -> None:
         exchange_check = {"ok": bool(flags.min().item() == 1.0), "accumulator_equals_the_packed_views": bool(flags[0].item() == 1.0),
                           "allreduce_checksum_is_the_sum_of_the_ranks": bool(flags[1].item() == 1.0),
                           "ranks_hold_the_same_buffer_checksum": bool(flags[2].item() == 1.0), "views_per_rank_checked": exch_every,
-                          "sum_of_magnitudes": float(want[1].item())}
-        exch["count"] = 0
+                          "sum_of_magnitudes": float(want[1].item()), "allreduces_in_the_run": xchg.reduced}
 
     # instance count of the views this rank rendered (data-dependent: read back from one extra untimed pass)
     from animatablegaussians_amd.rasterizer import native_rasterize_gaussians
@@ -304,12 +287,16 @@ def main() -> None:
     breakdown = None
     if rank == 0 and (args.breakdown or world == 1):      # round 5: always at N = 1 (64 one-stream steps = ~20 ms), so that the driver's record carries
         _lib.prof_enable(range(_lib.AG_K_COUNT))          # every raster kernel's fraction (`roofline_raster_kernels`), not the dominant one's only
+        if xchg is not None:
+            xchg.hold_back = True                         # rank 0 alone runs this pass: no collective in it
         for i in range(64 if not args.breakdown else min(args.steps, 64)):
             step_on(i)            # one stream: per-kernel times without the overlap of the pipelined timed region
         sync_all() if world == 1 else torch.cuda.synchronize(dev)
         bd = _lib.prof_collect()
         _lib.prof_enable([])
         breakdown = {k: round(1e3 * ms / max(n, 1), 2) for k, (n, ms) in bd.items()}
+        if xchg is not None:
+            xchg.hold_back = False
 
     # N > 1: the exchange north_star names for the full training step -- the bucketed all-reduce of the three networks' gradients
     # (223.6 M fp32 = 895 MB, parallel.BucketedGradSync's 128-MB buckets) -- timed on its own after the headline region, so the

@@ -275,3 +275,61 @@ def test_split_pairs_node_equals_the_row_slices_it_replaces():
     sum((p * u).sum() for p, u in zip(pairs, ups)).backward()
     sum((w * u).sum() for w, u in zip(want, ups)).backward()
     assert torch.equal(a.grad, b.grad)
+
+
+def _exchange_worker(rank, world, port, out):
+    """bench.py's N > 1 exchange (parallel.ViewGradExchange) on two gloo ranks: every rank submits the gradient arrays of its own view per
+    step through 3 slots; after every iteration of `every` steps the accumulator must hold the sum over BOTH ranks and the iteration's
+    steps, the held-back mode must leave the rank's own sum, and the checksums must add up."""
+    from animatablegaussians_amd.parallel import ViewGradExchange
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    P, cols, every, n_slots = 257, (3, 3, 4, 1, 3), 4, 3
+
+    def grads_of(step, r):
+        g = torch.Generator().manual_seed(1000 * r + step)
+        return [torch.randn(P, c, generator=g) for c in cols]
+
+    x = ViewGradExchange(P, sum(cols), "cpu", n_slots, every)
+    ok = True
+    for it in range(3):
+        for j in range(every):
+            step = it * every + j
+            x.submit(step % n_slots, grads_of(step, rank))
+        x.join()
+        want = sum(torch.cat(grads_of(it * every + j, r), dim=1) for j in range(every) for r in range(world))
+        ok = ok and torch.allclose(x.acc, want, rtol=1e-5, atol=1e-5)
+    ok = ok and x.reduced == 3 and x.count == 3 * every
+    # held back (bench.py's untimed check): the rank's own sum, checksums of what was packed
+    x.reset()
+    x.hold_back, x.checksums = True, torch.zeros(2, dtype=torch.float64)
+    for j in range(every):
+        x.submit(j % n_slots, grads_of(100 + j, rank))
+    mine = sum(torch.cat(grads_of(100 + j, rank), dim=1) for j in range(every))
+    ok = ok and torch.allclose(x.acc, mine, rtol=1e-5, atol=1e-5) and x.reduced == 3
+    ok = ok and abs(float(x.checksums[0]) - float(mine.double().sum())) <= 1e-6 * float(x.checksums[1])
+    # an iteration that is cut short leaves no collective behind: the next reset() starts a fresh one
+    x.hold_back, x.checksums = False, None
+    x.reset()
+    x.submit(0, grads_of(200, rank))
+    x.reset()
+    for j in range(every):
+        x.submit(j % n_slots, grads_of(300 + j, rank))
+    want = sum(torch.cat(grads_of(300 + j, r), dim=1) for j in range(every) for r in range(world))
+    ok = ok and torch.allclose(x.acc, want, rtol=1e-5, atol=1e-5) and x.reduced == 4
+    out[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def test_view_grad_exchange_accumulates_and_reduces_once_per_iteration_gloo_world2():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    out = ctx.Manager().dict()
+    procs = [ctx.Process(target=_exchange_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert dict(out) == {0: True, 1: True}
