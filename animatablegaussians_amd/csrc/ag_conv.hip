@@ -1137,6 +1137,59 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(WgradReduce r)
     }
 }
 
+// The same sum for MANY terms (round 5, third session).  The 64-row layers at 512 x 512 (the per-view stage of the colour network) have 10 output
+// tiles, so their pixel loop is cut into 28 slices; one thread per element then walks all of them in a single dependent chain of additions
+// behind loads that the compiler issues four at a time, on 1 150 waves in all: ~38 us per launch for 9 MB, four launches per view.  Here an element's
+// terms (term t = (instance - g0) * splits + slice) are dealt to PAR = 256 / EPB threads -- thread (e, j) of a workgroup owns element e of the
+// workgroup's EPB consecutive elements (EPB lanes = one coalesced segment) and adds the terms t = j, j + PAR, ... in ascending order, eight loads in
+// flight -- and thread (e, 0) adds the PAR partial sums in ascending j.  A fixed order: the same bits on every run (not the bits of the
+// one-thread kernel: a different association of the same terms).
+template <int EPB>
+__global__ void __launch_bounds__(256) wgrad_reduce_par_kernel(WgradReduce r)
+{
+    constexpr int PAR = 256 / EPB;
+    __shared__ float s_part[PAR][EPB];
+    const int run = blockIdx.y;
+    const int g0 = r.begin[run], g1 = r.begin[run + 1];
+    float* __restrict__ dst = const_cast<float*>(r.dst.p[run]);
+    const size_t inst = (size_t)r.Mpad * r.Npad, zstride = inst * r.G;
+    const long long total = (long long)r.Mw * r.Nw;
+    const int e = threadIdx.x % EPB, j = threadIdx.x / EPB;
+    const int T = (g1 - g0) * r.splits;
+    for (long long base = (long long)blockIdx.x * EPB; base < total; base += (long long)gridDim.x * EPB) {
+        const long long i = base + e;
+        const bool ok = i < total;
+        const int m = ok ? (int)(i / r.Nw) : 0, nn = ok ? (int)(i - (long long)m * r.Nw) : 0;
+        const float* __restrict__ src = r.partial + (size_t)m * r.Npad + nn;
+        float v = 0.f;
+        int t = j;
+        for (; t + 7 * PAR < T; t += 8 * PAR) {
+            float x[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int tt = t + u * PAR, g = g0 + tt / r.splits, z = tt - (tt / r.splits) * r.splits;
+                x[u] = src[(size_t)z * zstride + (size_t)g * inst];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) v += x[u];
+        }
+        for (; t < T; t += PAR) {
+            const int g = g0 + t / r.splits, z = t - (t / r.splits) * r.splits;
+            v += src[(size_t)z * zstride + (size_t)g * inst];
+        }
+        s_part[j][e] = v;
+        __syncthreads();
+        if (j == 0 && ok) {
+            float acc = s_part[0][e];
+#pragma unroll
+            for (int q = 1; q < PAR; q++) acc += s_part[q][e];
+            const int ch = nn / r.ntaps;
+            dst[(size_t)m * r.c_row_stride + (size_t)ch * r.c_chan_stride + (nn - ch * r.ntaps)] = acc;
+        }
+        __syncthreads();
+    }
+}
+
 // AVEC: the rows of A are 16-byte aligned (pixel count a multiple of 4, always true in the product): one dwordx4 per thread and
 // tile; the scalar form is kept for arbitrary sizes.  Everything in the K loop is branch-free: loads are unconditional from clamped
 // addresses, validity (image border, end of the K slice) travels as a bit mask and is applied at the LDS write.
@@ -2166,6 +2219,17 @@ int conv_backward_weight_g(const AgConvDesc* d, int G, const float* x, long long
     wr.partial = wp.partial; wr.G = G; wr.splits = splits; wr.Mw = wp.Mw; wr.Nw = Nw; wr.Mpad = wp.Mpad; wr.Npad = wp.Npad; wr.ntaps = k2;
     wr.c_row_stride = wp.c_row_stride; wr.c_chan_stride = wp.c_chan_stride;
     const long long total = (long long)wp.Mw * Nw;
+    // many terms per element (the few-tile layers at large images): the terms of an element over 8 or 16 threads; AG_WGRAD_REDUCE_PAR=0: always
+    // the one-thread-per-element kernel (the A/B)
+    static const bool par_on = [] { const char* e = getenv("AG_WGRAD_REDUCE_PAR"); return !(e && e[0] == '0'); }();
+    const int terms_per_elem = splits * longest_run;
+    if (par_on && terms_per_elem >= 8) {
+        if (terms_per_elem >= 48)
+            hipLaunchKernelGGL(wgrad_reduce_par_kernel<16>, dim3((unsigned)std::min<long long>((total + 15) / 16, 8192), nruns), dim3(256), 0, s, wr);
+        else
+            hipLaunchKernelGGL(wgrad_reduce_par_kernel<32>, dim3((unsigned)std::min<long long>((total + 31) / 32, 8192), nruns), dim3(256), 0, s, wr);
+        return check_hip(hipGetLastError(), "wgrad_reduce_par_kernel");
+    }
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 2048), nruns), dim3(256), 0, s, wr);
     return check_hip(hipGetLastError(), "wgrad_reduce_kernel");
 }
