@@ -565,7 +565,7 @@ __global__ void __launch_bounds__(kAmaxThreads) absmax_kernel(AmaxJobs J)
     const long long len = J.len[job];
     float m = 0.f;
     if (J.rows[job] == 1 && (len & 3) == 0 && (((size_t)x) & 15) == 0) {
-        const long long n4 = len >> 2, step = (long long)kAmaxParts * kAmaxThreads;
+        const long long n4 = len >> 2, step = (long long)gridDim.x * kAmaxThreads;
         const f32x4* __restrict__ x4 = reinterpret_cast<const f32x4*>(x);
         long long i = (long long)blockIdx.x * kAmaxThreads + threadIdx.x;
         for (; i + 3 * step < n4; i += 4 * step) {              // four loads in flight per thread: the sweep is latency-bound otherwise
@@ -579,7 +579,7 @@ __global__ void __launch_bounds__(kAmaxThreads) absmax_kernel(AmaxJobs J)
         }
     } else {
         const long long n = len * J.rows[job];
-        for (long long i = (long long)blockIdx.x * kAmaxThreads + threadIdx.x; i < n; i += (long long)kAmaxParts * kAmaxThreads) {
+        for (long long i = (long long)blockIdx.x * kAmaxThreads + threadIdx.x; i < n; i += (long long)gridDim.x * kAmaxThreads) {
             const long long r = i / len;
             m = fmaxf(m, fabsf(x[r * J.stride[job] + (i - r * len)]));
         }
@@ -594,6 +594,10 @@ __global__ void __launch_bounds__(kAmaxThreads) absmax_kernel(AmaxJobs J)
         for (int i = 1; i < kAmaxThreads / 64; i++) m = fmaxf(m, wm[i]);
         J.outp[job][blockIdx.x] = m;
     }
+    // a launch of fewer than kAmaxParts workgroups per job (third session: conv_absmax sizes the grid to the largest job): the slots nobody
+    // owns are zeroed, dealt round-robin to the workgroups that exist
+    if ((int)gridDim.x < kAmaxParts && (int)threadIdx.x < kAmaxParts && threadIdx.x >= gridDim.x && threadIdx.x % gridDim.x == blockIdx.x)
+        J.outp[job][threadIdx.x] = 0.f;
 }
 
 // The same for a launch whose jobs are all short (the bookkeeping launches of a layer call whose operands' maxima are all known: 256 handed-over
@@ -1668,11 +1672,25 @@ int conv_absmax(const AmaxTensor* t, int n, int G, float* out, hipStream_t s, fl
 {
     AmaxJobs J;
     int jobs = 0;
+    static const bool trace = [] { const char* e = getenv("AG_AMAX_TRACE"); return e && e[0] == '1'; }();     // diagnostic: what is swept
     auto flush = [&]() {
         bool small = true;
         for (int j = 0; j < jobs; j++) small = small && J.len[j] * J.rows[j] <= 4096;
+        if (trace) {
+            long long tot = 0, mx = 0;
+            for (int j = 0; j < jobs; j++) { const long long e = J.len[j] * J.rows[j]; tot += e; mx = e > mx ? e : mx; }
+            fprintf(stderr, "AMAX jobs %d total %lld largest %lld rows %d %s\n", jobs, tot, mx, J.rows[0], small ? "small" : "full");
+        }
         if (small) hipLaunchKernelGGL(absmax_small_kernel, dim3(jobs), dim3(256), 0, s, J);
-        else       hipLaunchKernelGGL(absmax_kernel, dim3(kAmaxParts, jobs), dim3(kAmaxThreads), 0, s, J);
+        else {
+            // workgroups per job: one pass of the four-loads-in-flight loop (16 K floats per workgroup) over the LARGEST job, at most
+            // kAmaxParts -- 256 x jobs workgroups of 1024 threads for a stack of 36 K-float weight tensors were mostly dispatch
+            long long largest = 0;
+            for (int j = 0; j < jobs; j++) largest = std::max(largest, J.len[j] * J.rows[j]);
+            static const bool sized = [] { const char* e = getenv("AG_AMAX_SIZED_GRID"); return !(e && e[0] == '0'); }();
+            const int parts = sized ? (int)std::min<long long>(kAmaxParts, std::max<long long>(1, (largest + 16383) / 16384)) : kAmaxParts;
+            hipLaunchKernelGGL(absmax_kernel, dim3(parts, jobs), dim3(kAmaxThreads), 0, s, J);
+        }
         jobs = 0;
     };
     for (int i = 0; i < n; i++) {
