@@ -80,6 +80,8 @@ class ViewGradExchange:
         k = int(slot) % len(self.packs)
         j = self.count % self.every
         if self.cuda:
+            if producer_stream is None:
+                producer_stream = torch.cuda.current_stream(self.dev)
             with torch.cuda.stream(producer_stream):
                 producer_stream.wait_event(self.consumed[k])          # (a no-op until the event has been recorded once)
                 torch.cat(list(grads), dim=1, out=self.packs[k])
