@@ -157,6 +157,23 @@ class CanoGaussianModel:
     get_rotation = property(lambda self: self._activated()[2])
 
 
+_BG_CACHE = {}
+
+
+def _bg_tensor(bg_color, dev):
+    """The background colour on the device, uploaded once per (colour, device): a pageable host-to-device copy at the head of every render call
+    is a host wait for everything queued before it (the previous step's backward and optimizer)."""
+    if isinstance(bg_color, torch.Tensor):
+        return bg_color.to(device=dev, dtype=torch.float32)
+    key = (tuple(float(c) for c in np.asarray(bg_color, dtype=np.float64).reshape(-1)), str(dev))
+    t = _BG_CACHE.get(key)
+    if t is None:
+        if len(_BG_CACHE) > 64:
+            _BG_CACHE.clear()
+        t = _BG_CACHE[key] = torch.as_tensor(np.asarray(bg_color), dtype=torch.float32).to(dev)
+    return t
+
+
 class AvatarNet(nn.Module):
     """Re-host of the reference's ``network.avatar.AvatarNet`` (``network/avatar.py:16-239``) on this package's kernels:
     three ``DualStyleUNet`` (position / other / colour), the view-direction encoder, the fused per-Gaussian assembly,
@@ -507,7 +524,7 @@ class AvatarNet(nn.Module):
 
     def render(self, items, bg_color=(0., 0., 0.), use_pca=False, use_vae=False):
         dev = self.core.xyz.device
-        bg = torch.as_tensor(np.asarray(bg_color), dtype=torch.float32).to(dev)
+        bg = _bg_tensor(bg_color, dev)
         assert not (use_pca and use_vae), "Cannot use both PCA and VAE!"
         key = 'smpl_pos_map_pca' if use_pca else 'smpl_pos_map_vae' if use_vae else 'smpl_pos_map'
         pose_map = items[key][:3]
@@ -542,7 +559,7 @@ class AvatarNet(nn.Module):
         ``{**items, **view}`` (in training mode up to the view-direction jitter's random draw); under autograd the
         shared part is back-propagated once with the gradients of all views summed."""
         dev = self.core.xyz.device
-        bg = torch.as_tensor(np.asarray(bg_color), dtype=torch.float32).to(dev)
+        bg = _bg_tensor(bg_color, dev)
         pose_map = items['smpl_pos_map'][:3]
         x = pose_map[None].contiguous()
         feats = [self.get_viewdir_feat({**items, **v}) if self.with_viewdirs else (None, None) for v in views]

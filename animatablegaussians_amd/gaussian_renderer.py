@@ -8,6 +8,8 @@ Differences in mechanism, not in results:
 """
 from __future__ import annotations
 
+import os
+import weakref
 from typing import Dict
 
 import numpy as np
@@ -23,9 +25,31 @@ _SH_C3 = (-0.5900435899266435, 2.890611442640554, -0.4570457994644658, 0.3731763
           1.445305721320277, -0.5900435899266435)
 
 _camera_cache: Dict[bytes, dict] = {}
+# The same camera TENSORS again (the cameras of a capture rig kept on the device, a multi-view trainer's fixed views): no device->host copy at
+# all.  The copy below is a host wait for everything queued before it -- in a training step that is the whole StyleUNet forward, after which
+# the host has lost its lead over the GPU and the small kernels that follow (loss, the first backward nodes) are issued into an idle device
+# (profiles/r05c_step_gaps.txt).  Keyed on the two tensors' identity (weak references: a freed tensor's address can be handed out again) and
+# version counters (an in-place change of the values misses).  AG_CAMERA_IDENT_CACHE=0: always the copy (the A/B).
+_camera_ident: Dict[tuple, tuple] = {}
+_IDENT_ON = os.environ.get("AG_CAMERA_IDENT_CACHE", "1") != "0"
 
 
 def _camera_tensors(extr: torch.Tensor, intr: torch.Tensor, img_w: int, img_h: int, device) -> dict:
+    ident = None
+    if _IDENT_ON and isinstance(extr, torch.Tensor) and isinstance(intr, torch.Tensor):
+        ident = (id(extr), extr.data_ptr(), extr._version, id(intr), intr.data_ptr(), intr._version, img_w, img_h, str(device))
+        got = _camera_ident.get(ident)
+        if got is not None and got[0]() is extr and got[1]() is intr:
+            return got[2]
+    hit = _camera_tensors_by_value(extr, intr, img_w, img_h, device)
+    if ident is not None:
+        if len(_camera_ident) > 256:
+            _camera_ident.clear()
+        _camera_ident[ident] = (weakref.ref(extr), weakref.ref(intr), hit)
+    return hit
+
+
+def _camera_tensors_by_value(extr: torch.Tensor, intr: torch.Tensor, img_w: int, img_h: int, device) -> dict:
     host = torch.cat([extr.reshape(-1).float(), intr.reshape(-1).float()]).cpu().numpy()   # the one host sync
     key = host.tobytes() + np.array([img_w, img_h], np.int32).tobytes() + str(device).encode()
     hit = _camera_cache.get(key)
