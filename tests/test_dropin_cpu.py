@@ -63,3 +63,45 @@ def test_flipped_fir_kernel_cache_never_serves_a_recycled_address():
     assert _flipped(k) is _flipped(k)                                # still a cache for a kernel that stays alive
     k.mul_(2.0)                                                      # in-place change bumps the version: recomputed
     assert torch.equal(_flipped(k), torch.flip(k, [0, 1]))
+
+
+def test_camera_identity_cache_follows_the_tensors_values():
+    """gaussian_renderer._camera_tensors: the same extr / intr TENSORS again -> no device->host copy (the cached matrices, same objects); an in-place
+    change of the values, or other tensors, -> the matrices of the new values; a dead tensor whose address is handed out again cannot alias."""
+    import gc
+
+    import numpy as np
+    import torch
+
+    from animatablegaussians_amd import gaussian_renderer as gr
+
+    extr = torch.eye(4)
+    extr[:3, 3] = torch.tensor([0.1, -0.2, 2.5])
+    intr = torch.tensor([[1100., 0., 512.], [0., 1100., 512.], [0., 0., 1.]])
+    a = gr._camera_tensors(extr, intr, 1024, 1024, "cpu")
+    calls = []
+    real = gr._camera_tensors_by_value
+    gr._camera_tensors_by_value = lambda *args: (calls.append(1), real(*args))[1]
+    try:
+        assert gr._camera_tensors(extr, intr, 1024, 1024, "cpu") is a and not calls            # identity hit: the by-value path (the copy) is not taken
+        assert gr._camera_tensors(extr, intr, 512, 512, "cpu") is not a and len(calls) == 1     # another image size: another camera
+        extr[2, 3] = 3.0                                                                        # in place: the version counter moves
+        b = gr._camera_tensors(extr, intr, 1024, 1024, "cpu")
+        assert len(calls) == 2 and not torch.equal(b["viewmatrix"], a["viewmatrix"])
+        c = gr._camera_tensors(extr.clone(), intr.clone(), 1024, 1024, "cpu")                   # other tensors, same values: the by-value cache
+        assert len(calls) == 3 and c is b
+        # a stale identity entry (its tensors are gone) never hits, whatever address and version a new tensor has
+        e2, i2 = extr.clone(), intr.clone()
+        gr._camera_tensors(e2, i2, 1024, 1024, "cpu")
+        key = [k for k, v in gr._camera_ident.items() if v[0]() is e2][0]
+        stale = gr._camera_ident[key]
+        del e2, i2
+        gc.collect()
+        assert stale[0]() is None and stale[1]() is None
+        e3 = torch.eye(4)
+        gr._camera_ident[(id(e3), e3.data_ptr(), e3._version, id(intr), intr.data_ptr(), intr._version, 1024, 1024, "cpu")] = stale
+        n = len(calls)
+        d = gr._camera_tensors(e3, intr, 1024, 1024, "cpu")
+        assert len(calls) == n + 1 and np.allclose(d["viewmatrix"].numpy()[3, :3], 0.0)         # identity extrinsics: no translation row
+    finally:
+        gr._camera_tensors_by_value = real
