@@ -442,6 +442,345 @@ __global__ void __launch_bounds__(64, AG_BWD_WAVE_OCC) blend_backward_wave_kerne
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// Round 6 EXPERIMENT, not in the product build (bash profiles/ub/build_variant.sh pixel ag_blend_backward -DAG_BWD_PIXEL_KERNEL, then
+// AG_LIB_PATH=.../libag_pixel.so): the pixel-lane kernel.  MEASURED (profiles/r06_bwd_pixel.md): correct (all raster GPU tests pass), 45 % of its
+// consume lanes active against the wave kernel's 31 %, 16.2 M VALU instructions against 21.3 M -- and 356 us against 77.8 us, for two reasons
+// that are properties of the hardware, not of this code:
+//   * ds_add_f32 is a SERIAL unit on gfx950: 194 cycles per wave instruction whatever the address pattern (3 cycles per lane;
+//     profiles/ub/lds_atomic_rate.hip, profiles/r06_lds_atomic_rate.txt: ds_add_u32 5.9 cycles) -- 39 M lane-adds per view = 457 k LDS cycles per CU.
+//     Any design whose lanes hold DIFFERENT splats needs such adds (or ten global atomics per pair); that includes the tile-level LDS merge
+//     of the wave kernel's block sums (3 ds_add_f32 x 16 lanes per step = 144 LDS cycles per step, 57 us per view of LDS time alone);
+//   * with plain stores in place of the adds (wrong sums, timing only) it still takes 169 us: 2221 regions are 2.2 waves per SIMD, each a
+//     dependent chain LDS read -> exp -> rcp -> ... per trip, so the SIMDs idle (VALU 30 % busy) -- the bench view has 142 k covered pixels,
+//     one lane per pixel is 2.2 k waves; the wave kernel spends 4 lanes per pixel on the scan and gets 8.3 k.
+// Kept as the record of why the sums over the pixels stay register reductions over entry-aligned lanes.
+#ifdef AG_BWD_PIXEL_KERNEL
+// The pixel-lane kernel.  The wave kernel above keeps the 4 entries of a step aligned across its 16 pixels so that the sums over
+// the pixels are register exchanges -- and pays for it with 31 % active (pixel, entry) lanes: a splat of the bench scene covers ~5 of a
+// block's 16 pixels (profiles/r05b_bwd_step_stats_tight.txt).  Here a wave owns an 8 x 8-pixel REGION (a tile quadrant), lane = pixel, and every
+// lane walks ITS OWN list of covering splats at its own pace, so a lane slot is wasted only while its pixel has less to do than the busiest
+// pixel of the region (55 % active on the bench view, CPU simulation of the schedule: profiles/r06_bwd_pixel_sim.txt), and a pair costs the plain
+// serial recurrences of the reference (no scans, no cross-lane sums: ~50 VALU per 64 lanes against 83).  The price: different lanes hold
+// different splats, so the sums over the pixels are LDS float atomics (ds_add_f32, 10 per pair) into a per-slot accumulator that leaves
+// as line-coalesced global atomics once per (region, splat) -- 4 blocks' worth of the wave kernel's line requests in one.
+//
+//   production (all 64 lanes = list entries): the region's exact quadratic-form cull, 64 entries per pass, records one pass ahead in
+//     registers; survivors are committed in walking order to a ring of kPxSlots records as space frees up (a culled pass waits in registers);
+//   sealing (per batch of 32 ring slots; lanes = 32 splats x 2 region halves): the splat's pixel coverage, row by row, from the roots of
+//     q(x) = qcut on that row (a superset of alpha >= 1/255: qcut carries the preprocess's slack), then a 32 x 32 bit-matrix transpose inside
+//     each half-wave (5 butterfly steps) turns "pixels of a splat" into "splats of a pixel": one 32-bit word per lane and batch;
+//   consumption (lane = pixel): take the lowest set bit of the word, read that record, do the reference's serial step (backward.cu:494-600,
+//     T by the running product as in the wave kernel), add the ten terms to the slot's accumulators;
+//   retirement: a batch all lanes are through is flushed (16 lanes = one 64-byte accumulator line) and its 32 slots return to the ring.
+// Nothing waits: single-wave workgroups, LDS traffic of one wave is in order.
+constexpr int kReg = 8;                                   // 8 x 8 pixels per wave
+constexpr int kRegsPerTile = (kTileX / kReg) * (kTileY / kReg);
+constexpr int kPxBatch = 32;
+#ifndef AG_BWD_PX_NB
+#define AG_BWD_PX_NB 4
+#endif
+constexpr int kPxNB = AG_BWD_PX_NB;                       // batches in the ring
+constexpr int kPxSlots = kPxBatch * kPxNB;
+#ifndef AG_BWD_PX_GRID
+#define AG_BWD_PX_GRID 16384
+#endif
+constexpr int kPxGrid = AG_BWD_PX_GRID;
+constexpr int kPxAccStride = 11;                          // odd: a slot's ten sums start on any of the 32 banks
+static_assert((kPxSlots & (kPxSlots - 1)) == 0, "ring size must be a power of two");
+#ifndef AG_BWD_PX_OCC
+#define AG_BWD_PX_OCC 4
+#endif
+
+struct RegionItemIter {
+    uint32_t i, stride, x, n_active;
+    __device__ __forceinline__ RegionItemIter(uint32_t block, uint32_t grid, uint32_t n_active_)
+        : i(block / kQueues), stride((grid + kQueues - 1 - (block % kQueues)) / kQueues), x(block % kQueues), n_active(n_active_) {}
+    __device__ __forceinline__ bool next(uint32_t& tile_rank, uint32_t& rg)
+    {
+        tile_rank = (i / kRegsPerTile) * kQueues + x;        // the 4 regions of a tile on one XCD (they gather the same list)
+        rg = i % kRegsPerTile;
+        i += stride;
+        return tile_rank < n_active;
+    }
+};
+
+#ifdef AG_BWD_STATS
+enum { PX_ITEMS = 0, PX_WALKED, PX_SURVIVORS, PX_ITERS, PX_ACTIVE_PAIRS, PX_MASK_BITS, PX_TRIPS, PX_BATCHES, PX_N = 8 };
+__device__ unsigned long long g_bwd_px_stats[PX_N];
+#define PST(k, v) do { if (lane == 0) atomicAdd(&g_bwd_px_stats[k], (unsigned long long)(v)); } while (0)
+extern "C" int ag_debug_bwd_px_stats(unsigned long long* out)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return AG_ERR_HIP;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bwd_px_stats), sizeof(g_bwd_px_stats)) != hipSuccess) return AG_ERR_HIP;
+    unsigned long long zero[PX_N] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_bwd_px_stats), zero, sizeof(zero)) != hipSuccess) return AG_ERR_HIP;
+    return AG_OK;
+}
+#else
+#define PST(k, v) do { } while (0)
+#endif
+
+__global__ void __launch_bounds__(64, AG_BWD_PX_OCC) blend_backward_pixel_kernel(BlendBwdParams p)
+{
+    __shared__ float4 s_rec[kPxSlots * 3];        // [x, y, ca, cb] [cc, op, r, g] [b, depth, position, gaussian id]
+    __shared__ float s_qc[kPxSlots];              // the splat's threshold on q (GaussRec::qcut)
+    __shared__ float s_acc[kPxSlots * kPxAccStride];
+    __shared__ uint32_t s_mask[kPxNB * 64];       // [batch of the ring][pixel]: which of the batch's 32 splats may reach the pixel
+
+    const int lane = threadIdx.x;
+    const int rx = lane & 7, ry = lane >> 3;
+    const int mj = lane & 31, mh = lane >> 5;     // sealing: splat of the batch, half of the region (rows 4 mh .. 4 mh + 3)
+    const int f_ent = lane >> 4, f_comp = lane & 15;
+    const uint32_t n_active = p.counts[1];
+    const size_t HW = (size_t)p.W * p.H;
+    const float bg0 = p.bg[0], bg1 = p.bg[1], bg2 = p.bg[2];
+    for (int i = lane; i < kPxSlots * kPxAccStride; i += 64) s_acc[i] = 0.f;
+
+    RegionItemIter it(blockIdx.x, gridDim.x, n_active);
+    uint32_t tr, rg;
+    while (it.next(tr, rg)) {
+        const uint4 hdr = p.tile_order[tr];
+        const int tile = (int)hdr.x;
+        const uint32_t rbeg = hdr.y;
+        const int tile_x = tile % p.gx, tile_y = tile / p.gx;
+        const int bx0 = tile_x * kTileX + (int)(rg & 1) * kReg, by0 = tile_y * kTileY + (int)(rg >> 1) * kReg;
+        const int px = bx0 + rx, py = by0 + ry;
+        const bool inside = px < p.W && py < p.H;
+        const float pxf = (float)px, pyf = (float)py;
+        const float qx0f = (float)bx0, qy0f = (float)by0, qx1f = (float)(bx0 + kReg - 1), qy1f = (float)(by0 + kReg - 1);
+        const int pix = p.W * py + px;
+        uint32_t last_contributor = 0;
+        float T_final = 0.f, gr = 0.f, gg = 0.f, gb = 0.f, gd = 0.f, ga = 0.f;
+        if (inside) {
+            last_contributor = p.n_contrib[pix];
+            T_final = 1.0f - p.alphas[pix];
+            gr = p.dL_dpix[pix];
+            gg = p.dL_dpix[HW + pix];
+            gb = p.dL_dpix[2 * HW + pix];
+            gd = p.dL_ddepth[pix];
+            ga = p.dL_dalpha[pix];
+        }
+        const float ntf_bg = -T_final * (bg0 * gr + bg1 * gg + bg2 * gb);
+        const uint32_t wmax = wave_umax(last_contributor);
+        if (wmax == 0) continue;
+        const uint32_t rend = rbeg + wmax;                   // walk [rbeg, rend) from the back
+        PST(PX_ITEMS, 1); PST(PX_WALKED, wmax);
+
+        // ---- production state.  n*: records of the next pass (loads in flight), r*: the culled pass waiting to be committed ----
+        uint32_t id_n = p.point_list[(uint32_t)lane < wmax ? rend - 1u - (uint32_t)lane : rbeg];
+        uint32_t id_nn = p.point_list[(uint32_t)lane + 64u < wmax ? rend - 1u - ((uint32_t)lane + 64u) : rbeg];
+        // (named scalars, not float4 variables: carried around the loop as vectors the compiler parks single components in scratch memory)
+#define AG_PX_LOAD_NEXT(ID)                                                                 \
+        {                                                                                   \
+            const float4* src = reinterpret_cast<const float4*>(p.rec + (ID));              \
+            const float4 t0 = src[0], t1 = src[1], t2 = src[2];                             \
+            n_x = t0.x; n_y = t0.y; n_ca = t0.z; n_cb = t0.w;                               \
+            n_cc = t1.x; n_op = t1.y; n_r = t1.z; n_g = t1.w;                               \
+            n_b = t2.x; n_d = t2.y; n_qc = t2.w;                                            \
+        }
+        float n_x, n_y, n_ca, n_cb, n_cc, n_op, n_r, n_g, n_b, n_d, n_qc;
+        AG_PX_LOAD_NEXT(id_n)
+        float r_x = 0.f, r_y = 0.f, r_ca = 0.f, r_cb = 0.f, r_cc = 0.f, r_op = 0.f, r_r = 0.f, r_g = 0.f, r_b = 0.f, r_d = 0.f, r_qc = 0.f;
+        uint32_t id_r = 0, pos_r = 0;
+        bool keep = false;
+        uint32_t rank = 0;
+        uint32_t started = 0;        // list entries whose pass has been culled (multiple of 64)
+        uint32_t ptotal = 0, pc = 0; // survivors of the pending pass, committed so far
+        uint32_t cnt = 0;            // ring positions committed
+        uint32_t sealed = 0;         // batches with their pixel words built
+        uint32_t tail = 0;           // batches retired
+        // ---- consumption state (per pixel) ----
+        float P = 1.0f;              // prod (1 - alpha) over the pixel's entries done so far
+        float S = 0.f;               // g . (blended state behind the entries done so far)
+        int cur = -1;                // batch of `word`
+        uint32_t word = 0;           // splats of batch `cur` still to do for this pixel
+
+        for (;;) {
+            // ================= production =================
+            if (pc == ptotal && started < wmax) {
+                // cull the next pass against the region (the exact rectangle minimum of the wave kernel, on 8 x 8 pixels)
+                r_x = n_x; r_y = n_y; r_ca = n_ca; r_cb = n_cb; r_cc = n_cc; r_op = n_op; r_r = n_r; r_g = n_g; r_b = n_b; r_d = n_d; r_qc = n_qc;
+                id_r = id_n;
+                const uint32_t o = started + (uint32_t)lane;     // offset from the back
+                pos_r = wmax - o;
+                const float U0 = qx0f - r_x, U1 = qx1f - r_x, V0 = qy0f - r_y, V1 = qy1f - r_y;
+                const float ue = __builtin_amdgcn_fmed3f(0.f, U0, U1), ve = __builtin_amdgcn_fmed3f(0.f, V0, V1);
+                const float ca = r_ca, cb = r_cb, cc = r_cc, qc = r_qc;
+                const float det = fmaf(ca, cc, -cb * cb);
+                const float bue = cb * ue, bve = cb * ve;
+                const float w1 = __builtin_amdgcn_fmed3f(0.f, fmaf(cc, V0, bue), fmaf(cc, V1, bue));
+                const float w2 = __builtin_amdgcn_fmed3f(0.f, fmaf(ca, U0, bve), fmaf(ca, U1, bve));
+                const float l1 = fmaf(w1, w1, det * ue * ue), l2 = fmaf(w2, w2, det * ve * ve);
+                keep = (o < wmax) && ((l1 <= cc * qc) | (l2 <= ca * qc));
+                const unsigned long long km = __ballot(keep);
+                rank = (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0u));
+                ptotal = (uint32_t)__popcll(km);
+                pc = 0;
+                started += 64u;
+                // the pass after: records now, the indices of the one after that
+                id_n = id_nn;
+                AG_PX_LOAD_NEXT(id_nn)
+                const uint32_t onn = started + 64u + (uint32_t)lane;
+                id_nn = p.point_list[onn < wmax ? rend - 1u - onn : rbeg];
+            }
+            if (pc < ptotal) {
+                const uint32_t room = (uint32_t)kPxSlots - (cnt - tail * (uint32_t)kPxBatch);
+                const uint32_t n = min(room, ptotal - pc);
+                if (n) {
+                    const uint32_t rel = rank - pc;          // wraps for survivors committed earlier
+                    if (keep && rel < n) {
+                        const uint32_t slot = (cnt + rel) & (uint32_t)(kPxSlots - 1);
+                        s_rec[slot * 3 + 0] = make_float4(r_x, r_y, r_ca, r_cb);
+                        s_rec[slot * 3 + 1] = make_float4(r_cc, r_op, r_r, r_g);
+                        s_rec[slot * 3 + 2] = make_float4(r_b, r_d, __uint_as_float(pos_r), __uint_as_float(id_r));
+                        s_qc[slot] = r_qc;
+                    }
+                    cnt += n; pc += n;
+                    PST(PX_SURVIVORS, n);
+                }
+            }
+            const bool fed = (started >= wmax) && (pc == ptotal);        // nothing more will enter the ring
+            while ((sealed + 1u) * (uint32_t)kPxBatch <= cnt || (fed && sealed * (uint32_t)kPxBatch < cnt)) {
+                // ---- seal batch `sealed`: coverage of splat mj on rows 4 mh .. 4 mh + 3 of the region, transposed to splats per pixel ----
+                const uint32_t nb = min((uint32_t)kPxBatch, cnt - sealed * (uint32_t)kPxBatch);
+                const uint32_t slot = (sealed * (uint32_t)kPxBatch + (uint32_t)mj) & (uint32_t)(kPxSlots - 1);
+                const float4 a = s_rec[slot * 3 + 0];
+                const float2 co = *reinterpret_cast<const float2*>(&s_rec[slot * 3 + 1]);
+                const float qc = s_qc[slot];
+                const float ca = a.z, cb = a.w, cc = co.x;
+                const float det = fmaf(ca, cc, -cb * cb);
+                const float inva = __builtin_amdgcn_rcpf(ca);
+                const float aq = ca * qc;
+                const float cxr = a.x - qx0f;                // splat centre relative to the region's first column
+                const bool pd = (ca > 0.f) & (det > 0.f) & (qc < 1.0e37f);
+                uint32_t w = 0;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const float dy = a.y - (qy0f + (float)(mh * 4 + r));
+                    const float t = det * dy;
+                    const float disc = fmaf(-t, dy, aq);     // a qcut - det dy^2: a times the discriminant quarter of q(dx) = qcut on this row
+                    const float sq = __builtin_amdgcn_sqrtf(fmaxf(disc, 0.f));
+                    const float bdy = cb * dy;
+                    const float lo = fmaf(bdy - sq, inva, cxr) - 2e-3f, hi = fmaf(bdy + sq, inva, cxr) + 2e-3f;
+                    // columns k with lo < k <= hi (a superset of the exact set by the 2e-3 px margins)
+                    int xl = (int)floorf(lo) + 1, xh = (int)floorf(hi);
+                    xl = max(xl, 0); xh = min(xh, kReg - 1);
+                    uint32_t bits = (disc >= 0.f && xl <= xh) ? ((2u << xh) - (1u << xl)) : 0u;
+                    if (!(lo <= hi) || !pd) bits = 0xffu;     // NaN / not positive definite / never-culled splat: whole row
+                    w |= bits << (8 * r);
+                }
+                if ((uint32_t)mj >= nb) w = 0;
+                // 32 x 32 bit-matrix transpose inside each half-wave: lane (splat j) bit (pixel i)  ->  lane (pixel i) bit (splat j)
+#define AG_TR_STEP(SH, MASK)                                                                               \
+                {                                                                                          \
+                    const uint32_t o_ = (uint32_t)__shfl_xor((int)w, SH, 64);                              \
+                    w = (mj & SH) ? ((w & MASK) | ((o_ & MASK) >> SH)) : ((w & ~MASK) | ((o_ & ~MASK) << SH)); \
+                }
+                AG_TR_STEP(16, 0xffff0000u) AG_TR_STEP(8, 0xff00ff00u) AG_TR_STEP(4, 0xf0f0f0f0u) AG_TR_STEP(2, 0xccccccccu) AG_TR_STEP(1, 0xaaaaaaaau)
+#undef AG_TR_STEP
+                // the batch's frontmost splat is its last: a pixel whose list ends in front of it... (position > n_contrib) has nothing here
+                const uint32_t fslot = (sealed * (uint32_t)kPxBatch + nb - 1u) & (uint32_t)(kPxSlots - 1);
+                const uint32_t fpos = __float_as_uint(s_rec[fslot * 3 + 2].z);
+                if (fpos > last_contributor) w = 0;
+                s_mask[(sealed % (uint32_t)kPxNB) * 64u + (uint32_t)lane] = w;
+                PST(PX_BATCHES, 1);
+#ifdef AG_BWD_STATS
+                { unsigned long long tot = 0; for (int l = 0; l < 64; l++) tot += __popc(__shfl((int)w, l, 64)); PST(PX_MASK_BITS, tot); }
+#endif
+                sealed++;
+            }
+
+            // ================= consumption: one entry per pixel =================
+            while (word == 0u && cur + 1 < (int)sealed) {
+                cur++;
+                word = s_mask[((uint32_t)cur % (uint32_t)kPxNB) * 64u + (uint32_t)lane];
+            }
+            const bool has = word != 0u;
+            const unsigned long long hm = __ballot(has);
+            PST(PX_TRIPS, 1);
+            if (hm != 0ull) {
+                const uint32_t j = has ? (uint32_t)__builtin_ctz(word) : 0u;
+                word &= word - 1u;
+                const uint32_t slot = has ? (((uint32_t)cur * (uint32_t)kPxBatch + j) & (uint32_t)(kPxSlots - 1)) : 0u;
+                const float4 a = s_rec[slot * 3 + 0];   // x, y, conic a, conic b
+                const float4 b = s_rec[slot * 3 + 1];   // conic c, opacity, r, g
+                const float4 c = s_rec[slot * 3 + 2];   // b, depth, position, id
+                const float dx = a.x - pxf, dy = a.y - pyf;
+                const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
+                const float G = __builtin_amdgcn_exp2f(power * 1.4426950408889634f);
+                const bool pre = (int)has & (int)(__float_as_uint(c.z) <= last_contributor) & (int)(power <= 0.0f);
+                const float al0 = pre ? fminf(0.99f, b.y * G) : 0.f;
+                const bool act = al0 >= 1.0f / 255.0f;
+                const float al = act ? al0 : 0.f;
+                const float fac = 1.0f - al;
+                const float w = fmaf(b.z, gr, fmaf(b.w, gg, fmaf(c.x, gb, fmaf(c.y, gd, ga))));
+                P *= fac;                                                   // prod (1 - alpha) up to and including this entry
+                const float Tin = T_final * __builtin_amdgcn_rcpf(P);       // transmittance in front of the entry
+                float dL_dopa = w - S;
+                dL_dopa = fmaf(dL_dopa, Tin, __builtin_amdgcn_rcpf(fac) * ntf_bg);
+                S = fmaf(fac, S, al * w);
+                const float q = G * dL_dopa;
+                const float wgt = al * Tin;
+                const float qdx = q * dx, qdy = q * dy;
+                { const unsigned long long am_ = __ballot(act); PST(PX_ITERS, 1); PST(PX_ACTIVE_PAIRS, __popcll(am_)); }
+#ifndef AG_PX_ATOMIC
+#define AG_PX_ATOMIC 1
+#endif
+                if (act) {
+                    float* dst = s_acc + slot * kPxAccStride;
+#if AG_PX_ATOMIC == 1
+#define AG_PX_ADD(K, V) atomicAdd(dst + (K), (V))
+#elif AG_PX_ATOMIC == 2      /* timing probe only: integer atomics (wrong sums) */
+#define AG_PX_ADD(K, V) atomicAdd(reinterpret_cast<uint32_t*>(dst + (K)), __float_as_uint(V))
+#else                        /* timing probe only: plain stores (wrong sums) */
+#define AG_PX_ADD(K, V) dst[K] = (V)
+#endif
+                    AG_PX_ADD(A_QDX, qdx);
+                    AG_PX_ADD(A_QDY, qdy);
+                    AG_PX_ADD(A_QXX, qdx * dx);
+                    AG_PX_ADD(A_QXY, qdx * dy);
+                    AG_PX_ADD(A_QYY, qdy * dy);
+                    AG_PX_ADD(A_Q, q);
+                    AG_PX_ADD(A_COLR, wgt * gr);
+                    AG_PX_ADD(A_COLG, wgt * gg);
+                    AG_PX_ADD(A_COLB, wgt * gb);
+                    AG_PX_ADD(A_DEPTH, wgt * gd);
+#undef AG_PX_ADD
+                }
+            }
+
+            // ================= retirement =================
+            if (tail < sealed) {
+                const bool busy = (cur < (int)tail) | ((cur == (int)tail) & (word != 0u));
+                if (__ballot(busy) == 0ull) {
+                    const uint32_t nb = min((uint32_t)kPxBatch, cnt - tail * (uint32_t)kPxBatch);
+                    const uint32_t base = (tail * (uint32_t)kPxBatch) & (uint32_t)(kPxSlots - 1);
+                    float val[kPxBatch / 4];
+                    uint32_t gid[kPxBatch / 4];
+#pragma unroll
+                    for (int pass = 0; pass < kPxBatch / 4; pass++) {
+                        const uint32_t slot = base + (uint32_t)(pass * 4 + f_ent);
+                        val[pass] = s_acc[slot * kPxAccStride + (f_comp < 10 ? f_comp : 10)];
+                        gid[pass] = __float_as_uint(s_rec[slot * 3 + 2].w);
+                    }
+#pragma unroll
+                    for (int pass = 0; pass < kPxBatch / 4; pass++) {
+                        const uint32_t ent = (uint32_t)(pass * 4 + f_ent);
+                        if (ent < nb && f_comp < 10 && val[pass] != 0.f) atomicAdd(p.accum + (size_t)gid[pass] * kAccumFloats + f_comp, val[pass]);
+                    }
+                    for (int i = lane; i < kPxBatch * kPxAccStride; i += 64) s_acc[base * kPxAccStride + i] = 0.f;
+                    tail++;
+                }
+            } else if (fed && hm == 0ull) {
+                break;        // everything walked, committed, sealed, consumed and retired
+            }
+        }
+    }
+}
+
+#endif  // AG_BWD_PIXEL_KERNEL
+
 // Calibration (profiles/atomic_rate.py): how many line-coalesced float atomics per second the memory side sustains -- the
 // ceiling of every design that flushes the backward's sums with less pre-reduction.  Each wave instruction adds to the first
 // `comps` slots of 4 pseudo-random 64-byte accumulator lines (16 adjacent lanes per line), exactly the flush's access shape.
@@ -488,6 +827,15 @@ int launch_blend_backward(const AgRasterBackwardArgs& a, hipStream_t s)
     if (a.num_rendered <= 0) return AG_OK;
     const long long items = (long long)p.T * kBlocksPerTile;
     const int grid = (int)(items < kWaveGrid ? items : kWaveGrid);
+#ifdef AG_BWD_PIXEL_KERNEL
+    static const bool use_wave = [] { const char* e = getenv("AG_BWD_KERNEL"); return e && e[0] == 'w'; }();
+    if (!use_wave) {
+        const long long ritems = (long long)p.T * kRegsPerTile;
+        const int rgrid = (int)(ritems < kPxGrid ? ritems : kPxGrid);
+        { ProfScope ps(AG_K_BLEND_BACKWARD, s); hipLaunchKernelGGL(blend_backward_pixel_kernel, dim3(rgrid), dim3(64), 0, s, p); }
+        return check_hip(hipGetLastError(), "blend_backward_pixel_kernel");
+    }
+#endif
     { ProfScope ps(AG_K_BLEND_BACKWARD, s); hipLaunchKernelGGL(blend_backward_wave_kernel, dim3(grid), dim3(64), 0, s, p); }
     return check_hip(hipGetLastError(), "blend_backward_wave_kernel");
 }
