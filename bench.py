@@ -275,14 +275,26 @@ def main() -> None:
     # instance count of the views this rank rendered (data-dependent: read back from one extra untimed pass)
     from animatablegaussians_amd.rasterizer import native_rasterize_gaussians
     empty = torch.Tensor([])
+    # ... and its (pixel, entry) PAIR EVALUATIONS: the iterations of the reference's per-pixel loops (renderCUDA forward.cu:310-369 runs a pixel
+    # until it is done, the backward backward.cu:494-600 from its last contributor back) = the sum over the pixels of n_contrib, read from the
+    # forward's own per-pixel counters (the blend kernels are reported against HBM AND as pair evaluations per second)
+    import ctypes
+    pairs_seen = []
+    lay = _lib.AgRasterScratchLayout()
     with torch.no_grad():
         for v in range(len(settings)):
             s = settings[v]
-            R_seen.append(native_rasterize_gaussians(s.bg, means3D, colors, opacities, scales, rotations, 1.0, empty,
-                                                     s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy, H, W, empty, 0,
-                                                     s.campos, False, False)[0])
+            res = native_rasterize_gaussians(s.bg, means3D, colors, opacities, scales, rotations, 1.0, empty,
+                                             s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy, H, W, empty, 0,
+                                             s.campos, False, False)
+            R_seen.append(res[0])
+            _lib.check(_lib.lib().ag_raster_describe_scratch(P, W, H, int(res[0]), ctypes.byref(lay)), "describe")
+            img = res[7]
+            start = ((img.data_ptr() + 255) & ~255) - img.data_ptr() + lay.img_n_contrib_off
+            pairs_seen.append(int(img[start:start + W * H * 4].view(torch.int32).sum(dtype=torch.int64).item()))
     views_of_rank = [(i * world + rank) % len(settings) for i in range(args.warmup, args.warmup + args.steps)]
     R_mean = float(np.mean([R_seen[v] for v in views_of_rank]))
+    pairs_mean = float(np.mean([pairs_seen[v] for v in views_of_rank]))
 
     breakdown = None
     if rank == 0 and (args.breakdown or world == 1):      # round 5: always at N = 1 (64 one-stream steps = ~20 ms), so that the driver's record carries
@@ -423,7 +435,8 @@ def main() -> None:
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": int(alg_dom), "avg_launch_us": round(dom_us, 2), "launches_timed": n_dom,
             "whole_step_algorithmic_GBps": round(alg_step / (ms_per_step * 1e-3) / 1e9, 2),
-            "note": "VALU/LDS/atomic-bound kernel reported against HBM as SURVEY.md 8(d) prescribes",
+            "note": "VALU/LDS/atomic-bound kernel reported against HBM as SURVEY.md 8(d) prescribes; `valu` = the yardstick that fits it",
+            "valu": valu_roofline(pairs_mean, dom_us, "backward"),
         },
     }
     if breakdown is not None:
@@ -485,6 +498,10 @@ def main() -> None:
         if us1 > 0:
             out["roofline"]["avg_launch_us_one_stream"] = us1
             out["roofline"]["frac_one_stream"] = round(alg_dom / (us1 * 1e-6) / 1e9 / HBM_PEAK_GBS, 5)
+            out["roofline"]["valu_one_stream"] = valu_roofline(float(np.mean(pairs_seen)), us1, "backward")
+    if breakdown is not None and breakdown.get("blend_forward_kernel", 0) > 0:
+        out["roofline_raster_kernels"]["blend_forward_kernel"]["valu"] = valu_roofline(float(np.mean(pairs_seen)), breakdown["blend_forward_kernel"], "forward")
+        out["roofline_raster_kernels"]["blend_backward_kernel"]["valu"] = valu_roofline(float(np.mean(pairs_seen)), breakdown["blend_backward_kernel"], "backward")
     if oper is not None:
         out["operator_path"] = oper
     if exchange_leg is not None:
@@ -514,10 +531,82 @@ def main() -> None:
         out["cpu_baseline"] = cpu_baseline(av, cams_np, up, W, H)
         out["cpu_baseline_lbs"] = cpu_baseline_lbs()
         out["cpu_baseline_styleunet"] = cpu_baseline_styleunet()
+    out["headline"] = headline_of(out)
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+VALU_PEAK_LANE_OPS = 78.6e12   # MI355X_MICROARCH.md: 157.3 TFLOP/s fp32 vector = 256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz fused multiply-adds
+# lane operations of the REFERENCE's loop bodies, counted from its source: every evaluated pair pays the contributor test, d, power, exp, alpha and
+# the two cut-offs (forward.cu:325-343 / backward.cu:513-531: 18); a pair that passes them pays the blend (forward.cu:345-362: 14) or the gradient
+# chain (backward.cu:533-598, the two divisions at ~8 each: 85).  Share of pairs that pass: measured by the diagnostic build on bench views 0 / 2 / 5
+# (profiles/bwd_step_stats.py, profiles/r05b_bwd_step_stats_tight.txt against the views' n_contrib sums): 0.089 / 0.056 / 0.094 -> 0.09
+REF_OPS_TEST, REF_OPS_FWD_ACTIVE, REF_OPS_BWD_ACTIVE, ACTIVE_SHARE = 18.0, 14.0, 85.0, 0.09
+
+
+def valu_roofline(pairs: float, us: float, which: str):
+    """the two blend kernels as (pixel, entry) pair evaluations per second, and against the VALU floor of the reference's own
+    algorithm: lane operations of its loop body x the pairs it evaluates / the fp32 vector peak.  `frac` 1.0 would mean: as fast as the
+    reference's loop could run if every lane of every SIMD did nothing but its arithmetic."""
+    if us <= 0 or pairs <= 0:
+        return None
+    ops = pairs * (REF_OPS_TEST + ACTIVE_SHARE * (REF_OPS_BWD_ACTIVE if which == "backward" else REF_OPS_FWD_ACTIVE))
+    return {"pair_evals_per_launch": int(pairs), "pair_evals_per_s": round(pairs / (us * 1e-6), 0), "G_pair_evals_per_s": round(pairs / (us * 1e-6) / 1e9, 1),
+            "reference_lane_ops_per_launch": int(ops), "peak_lane_ops_per_s": VALU_PEAK_LANE_OPS,
+            "frac": round(ops / (us * 1e-6) / VALU_PEAK_LANE_OPS, 4), "avg_launch_us": round(us, 2)}
+
+
+def headline_of(out):
+    """The numbers a reader of the LAST 2000 characters of the line needs (the driver keeps that much): short keys, no notes."""
+    h = {"value_views_per_s": out["value"], "n_gpus": out["n_gpus"]}
+    r = out.get("roofline", {})
+    h["bwd_us_overlapped"] = r.get("avg_launch_us")
+    h["bwd_frac_hbm"] = r.get("frac")
+    h["bwd_us_one_stream"] = r.get("avg_launch_us_one_stream")
+    h["bwd_frac_hbm_one_stream"] = r.get("frac_one_stream")
+    v = r.get("valu_one_stream") or r.get("valu")
+    if v:
+        h["bwd_G_pair_evals_per_s"] = v["G_pair_evals_per_s"]
+        h["bwd_frac_valu"] = v["frac"]
+    rk = out.get("roofline_raster_kernels")
+    if rk:
+        h["raster_one_stream_sum_us"] = rk.get("one_stream_sum_us")
+        h["raster_kernel_us"] = {k.replace("_kernel", ""): d["avg_launch_us"] for k, d in rk.items() if isinstance(d, dict) and "avg_launch_us" in d}
+        h["raster_kernel_frac_hbm"] = {k.replace("_kernel", ""): d["frac"] for k, d in rk.items() if isinstance(d, dict) and "frac" in d}
+        fv = rk.get("blend_forward_kernel", {}).get("valu")
+        if fv:
+            h["fwd_G_pair_evals_per_s"] = fv["G_pair_evals_per_s"]
+            h["fwd_frac_valu"] = fv["frac"]
+    if "sequential" in out:
+        h["sequential_views_per_s"] = out["sequential"]["views_per_s"]
+    if "operator_path" in out:
+        h["operator_path_views_per_s"] = out["operator_path"]["views_per_s"]
+    fs = out.get("full_step")
+    if fs:
+        h["full_step_math"] = fs.get("conv_math")
+        v16 = fs.get("views16_one_pose_configs3_n1", {})
+        h["full_step_views_per_s_1_4_16"] = [fs.get("views_per_s_1view_per_step"), fs.get("views_per_s_4views_per_step"), v16.get("views_per_s")]
+        h["full_step_ms_1_4_16"] = [fs.get("ms_per_step_1view"), fs.get("ms_per_step_4views"), v16.get("ms_per_step")]
+        if "inference_1view" in fs:
+            h["inference_views_per_s"] = fs["inference_1view"].get("views_per_s")
+    rm = out.get("roofline_mfma")
+    if rm:
+        h["mfma_achieved_TF_fp32_equiv"] = rm.get("achieved")
+        h["mfma_frac_of_2.5PF_executed"] = rm.get("frac")
+    st = out.get("stress_1m_2048")
+    if st:
+        h["stress_1m_2048_views_per_s"] = st.get("views_per_s")
+    cb = out.get("cpu_baseline")
+    if cb:
+        h["cpu_baseline_views_per_s"] = cb.get("value")
+        h["cpu_cores"] = cb.get("cores")
+    x = out.get("exchange_styleunet")
+    if x:
+        h["exchange_styleunet_ms"] = x.get("ms")
+        h["exchange_styleunet_bus_GBps"] = x.get("bus_GBps")
+    return h
 
 
 def stress_1m_2048(dev, steps: int = 60, warmup: int = 12):
