@@ -157,6 +157,7 @@ struct GatherProblem {
     int xcd_order;         // 1: workgroups take their (N tile, instance * M tile) in the XCD-aware order of tile_of_workgroup() (host: gridDim.x * gridDim.y % 8 == 0)
     float* out_amax;       // act != 0: zeroed [G][kAmaxParts] slots for the largest magnitude of the activated output (ConvAct::out_amax), or null
     int* status;           // host-visible sticky flag raised on a non-finite accumulator (ag_conv_status), or null
+    int status_tag;        // what the offending launch stores there: kind << 28 | rows << 14 | channels (status_tag_of)
     // fp16 split form: partial maxima (absmax_kernel) of the packed weights' source tensors [G][kAmaxParts] and of the gathered tensor
     // ([G][kAmaxParts], or one row when the instances share their input); amax_a_mult = |weight_scale| (the packed values are w * scale)
     const float* amax_a;
@@ -223,7 +224,7 @@ __device__ __forceinline__ void emit_amax(float* slots, float mx, int salt)
 // Range guard (ag_conv_status): a lane that holds a non-finite accumulator raises the host-visible flag.  Runs once per tile; the store is
 // executed by offending lanes only, so a healthy launch never touches the word.
 template <int WMB, int WNB>
-__device__ __forceinline__ void flag_non_finite(int* status, const f32x16 (&acc)[WMB][WNB])
+__device__ __forceinline__ void flag_non_finite(int* status, int tag, const f32x16 (&acc)[WMB][WNB])
 {
     if (!status) return;
     bool bad = false;
@@ -233,7 +234,7 @@ __device__ __forceinline__ void flag_non_finite(int* status, const f32x16 (&acc)
         for (int j = 0; j < WNB; j++)
 #pragma unroll
             for (int r = 0; r < 16; r++) bad |= !(fabsf(acc[i][j][r]) <= 3.4028234664e38f);      // inf or NaN
-    if (bad) __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (bad) __hip_atomic_store(status, tag ? tag : 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // Epilogue shared by the gather kernels.  C/D layout of the 32 x 32 MFMAs: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
@@ -243,7 +244,7 @@ __device__ __forceinline__ void gather_epilogue(const GatherProblem& p, const Gr
 {
     const int gw = cl.gw;
     const int col = lane & 31, rbase = 4 * (lane >> 5);
-    flag_non_finite<WMB, WNB>(p.status, acc);
+    flag_non_finite<WMB, WNB>(p.status, p.status_tag, acc);
     if (gridDim.z > 1) {
         float* part = gv.partial + (size_t)blockIdx.z * p.Mpad * p.Ncols + cl.col_begin;
 #pragma unroll
@@ -1065,6 +1066,7 @@ struct WgradProblem {
                            // slices (and the instances that share a destination) in a fixed order; null: one slice, stored straight to the destination
     int Mpad, Npad;
     int* status;           // host-visible sticky flag raised on a non-finite accumulator (ag_conv_status), or null
+    int status_tag;        // what the offending launch stores there: kind << 28 | rows << 14 | channels (status_tag_of)
     const float* amax_a;   // fp16 split form: partial maxima of `a` and of `xin` ([G][kAmaxParts], one row where the instances share the tensor)
     const float* amax_b;
     int c_row_stride, c_chan_stride;  // element (m, nn = (channel, tap)) of the output sits at m * c_row_stride + channel * c_chan_stride + tap:
@@ -1083,7 +1085,7 @@ __device__ __forceinline__ void wgrad_store(const WgradProblem& p, const f32x16 
 {
     const int col = lane & 31, rbase = 4 * (lane >> 5);
     const float f = unscale * p.wscale;
-    flag_non_finite<WMB, WNB>(p.status, acc);
+    flag_non_finite<WMB, WNB>(p.status, p.status_tag, acc);
     if (p.partial) {
         float* __restrict__ part = p.partial + ((size_t)blockIdx.z * p.G + grp) * p.Mpad * p.Npad;
 #pragma unroll
@@ -1729,6 +1731,10 @@ static int* status_word()
     }();
     return w;
 }
+// The guard is armed in the SCALED fp16 forms only (round 6): there a non-finite accumulator means the scale was wrong and the outputs are
+// garbage; in the fp32 / bf16 forms an inf or NaN operand simply propagates, as it does through the reference's cuDNN convolutions.
+static int* armed_status_word() { return is_f16_form(split_terms()) ? status_word() : nullptr; }
+static int status_tag_of(int kind, int rows, int chans) { return (kind << 28) | ((rows & 0x3fff) << 14) | (chans & 0x3fff); }
 static int take_status(bool clear)
 {
     int* w = status_word();
@@ -1736,7 +1742,10 @@ static int take_status(bool clear)
     const int v = __atomic_load_n(w, __ATOMIC_RELAXED);
     if (v && clear) __atomic_store_n(w, 0, __ATOMIC_RELAXED);
     if (!v) return AG_OK;
-    set_error("a convolution produced a non-finite accumulator: an operand exceeded the maximum its fp16 scale was taken from (a stale handed-over maximum?) or was not finite");
+    static const char* kinds[] = {"?", "forward / input-gradient gather", "weight gradient", "?"};
+    set_error("a convolution launched EARLIER (%s kernel, %d output rows x %d gathered channels; the last one to raise the flag) produced a non-finite "
+              "accumulator: an operand exceeded the maximum its fp16 scale was taken from (a stale handed-over maximum?) or was not finite",
+              kinds[(v >> 28) & 3], (v >> 14) & 0x3fff, v & 0x3fff);
     return AG_ERR_RANGE;
 }
 
@@ -1987,7 +1996,7 @@ static int run_gather_family(const AgConvDesc* d, bool backward_input, int G, co
     float* amax = reinterpret_cast<float*>(aligned_base(workspace) + (size_t)G * packed_bytes(d) + kMaxPartialBytes);
 
     GatherProblem gp;
-    gp.status = status_word();
+    gp.status = armed_status_word();
     gp.out_scale = out_scale; gp.bias_t = bias; gp.yout = yout; gp.xin = xin;
     gp.G = G; gp.x_gs = x_gs; gp.y_gs = y_gs;
     gp.act = opt.act ? opt.act->kind : 0;
@@ -2014,6 +2023,7 @@ static int run_gather_family(const AgConvDesc* d, bool backward_input, int G, co
     AmaxTensor w_shape{ nullptr, nullptr, 0, (long long)d->Cout * d->Cin * k2, 0, 1 };
     const float* const pre_in = backward_input ? opt.amax_dy : opt.amax_x;
     if (opt.w_cin_total && opt.w_cin_total != d->Cin) { w_shape.len = (long long)d->Cin * k2; w_shape.stride = cin_rows * k2; w_shape.rows = d->Cout; }
+    gp.status_tag = status_tag_of(1, M, Cg);
     gp.Cg = Cg; gp.Hg = Hg; gp.Wg = Wg; gp.M = M; const int bm = pick_bm(M); gp.Mpad = round_up(M, bm); gp.OHf = OHf; gp.OWf = OWf;
     gp.Cpad = round_up(Cg, BK);
     TapSet taps[kMaxClasses];
@@ -2126,7 +2136,7 @@ int conv_backward_weight_g(const AgConvDesc* d, int G, const float* x, long long
         wp.sy = wp.sx = 2;
         for (int t = 0; t < k2; t++) { wp.dy[t] = t / k; wp.dx[t] = t % k; }
     }
-    wp.status = status_word();
+    wp.status = armed_status_word(); wp.status_tag = status_tag_of(2, wp.Mw, wp.Cg);
     wp.c = dw; wp.c_gs = dw_gs; wp.G = G; wp.ntaps = k2; wp.wscale = wscale_of(d);
     wp.c_row_stride = wp.Cg * k2; wp.c_chan_stride = k2;                         // [Mw][Cg][taps]
     if (o.wt_oihw && d->kind == AG_CONV_TRANSPOSE) { wp.c_row_stride = k2; wp.c_chan_stride = wp.Mw * k2; }   // rows = Cin: [Cout][Cin][taps]

@@ -36,7 +36,9 @@ _IDENT_ON = os.environ.get("AG_CAMERA_IDENT_CACHE", "1") != "0"
 
 def _camera_tensors(extr: torch.Tensor, intr: torch.Tensor, img_w: int, img_h: int, device) -> dict:
     ident = None
-    if _IDENT_ON and isinstance(extr, torch.Tensor) and isinstance(intr, torch.Tensor):
+    # Only version-tracked in-place writes are seen by the identity key (a write through .data, a numpy alias or an external kernel is not: such
+    # callers set AG_CAMERA_IDENT_CACHE=0 or pass fresh tensors); tensors without a version counter (torch.inference_mode) take the by-value path.
+    if _IDENT_ON and isinstance(extr, torch.Tensor) and isinstance(intr, torch.Tensor) and not (extr.is_inference() or intr.is_inference()):
         ident = (id(extr), extr.data_ptr(), extr._version, id(intr), intr.data_ptr(), intr._version, img_w, img_h, str(device))
         got = _camera_ident.get(ident)
         if got is not None and got[0]() is extr and got[1]() is intr:

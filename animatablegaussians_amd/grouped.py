@@ -120,10 +120,17 @@ def _frozen_entry(site):
     if _FROZEN is None:
         return None, False
     e = _FROZEN.get(site)
-    if e is not None:
+    if e is not None and e.get("_filled"):
         return e, True
+    # (an entry counts as a hit only once the native call that fills it has succeeded: _frozen_commit.  An exception in between must not leave an
+    # empty 'hit' behind for the next frame)
     e = _FROZEN[site] = {}
     return e, False
+
+
+def _frozen_commit(e):
+    if e is not None:
+        e["_filled"] = True
 
 
 def _handed_maxima(x):
@@ -252,6 +259,7 @@ class _GroupedLayer(torch.autograd.Function):
             fz.update(keep=keep if modulated else None, mx=mx, packed=packed)
         with _lib.on_device(dev):
             _lib.check(_lib.lib().ag_grouped_layer_forward(ctypes.byref(a), _stream(dev)), "ag_grouped_layer_forward")
+        _frozen_commit(fz)
         ctx.save_for_backward(x, out, keep, _flipped(k_blur) if resample else None, mx, xm, *ws, *styles, *noises, *nws, *biases)
         ctx.math = agc.get_math()
         ctx.cfg = (G, bool(shared), bool(resample), bool(modulated), float(scale))
@@ -400,6 +408,7 @@ class _GroupedToRGB(torch.autograd.Function):
             a.workspace_bytes = wsb
             with _lib.on_device(dev):
                 _lib.check(_lib.lib().ag_grouped_to_rgb_forward(ctypes.byref(a), _stream(dev)), "ag_grouped_to_rgb_forward")
+            _frozen_commit(fz)
             outs.append(out)
             wms.append(wm)
         ctx.save_for_backward(x, *wms, *ws, *styles)
@@ -522,6 +531,7 @@ class _GroupedComb(torch.autograd.Function):
             a.packed_x, a.packed_lev, a.weights_cached = fz["px"].data_ptr(), fz["pl"].data_ptr(), int(fz_hit)
         with _lib.on_device(dev):
             _lib.check(_lib.lib().ag_grouped_comb_forward(ctypes.byref(a), _stream(dev)), "ag_grouped_comb_forward")
+        _frozen_commit(fz)
         ctx.save_for_backward(x, lev, out, mx, xm, *ws, *bs)
         ctx.cfg = (tuple(begin), float(scale))
         ctx.math = agc.get_math()
@@ -848,11 +858,12 @@ class GroupedStyleUNets:
         if torch.is_grad_enabled() or not frozen_weights_enabled() or torch.cuda.is_current_stream_capturing() or \
            int(os.environ.get("AG_GROUPED_STREAMS", "1")) != 1:
             return None
-        tensors = getattr(self, "_frozen_tensors", None)
-        if tensors is None:
-            tensors = self._frozen_tensors = [t for n in self.nets for t in list(n.parameters()) + list(n.buffers())]
-        token = (agc.get_math(), tuple((s.data_ptr(), s._version) for s in styles), sum(t._version for t in tensors),
-                 sum(t.data_ptr() for t in tensors))
+        # the tensor list is rebuilt on every call (a REPLACED Parameter object must be seen) and the token is a tuple, not a sum (sums of addresses
+        # and versions can collide); a non-contiguous parameter or style would be cached under the address of a per-call temporary: no cache then
+        tensors = [t for n in self.nets for t in list(n.parameters()) + list(n.buffers())]
+        if not all(t.is_contiguous() for t in tensors) or not all(s.is_contiguous() for s in styles):
+            return None
+        token = (agc.get_math(), tuple((s.data_ptr(), s._version) for s in styles), tuple((t.data_ptr(), t._version) for t in tensors))
         if getattr(self, "_frozen_token", None) != token:
             self._frozen_token, self._frozen_cache = token, {}
         return self._frozen_cache

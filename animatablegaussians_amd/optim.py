@@ -19,7 +19,7 @@ class FusedAdam(torch.optim.Optimizer):
         if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1) or weight_decay < 0:
             raise ValueError("FusedAdam: invalid hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, maximize=maximize))
-        self._calls = {}        # per parameter group: the filled argument structures (everything but the gradient pointers is fixed between steps)
+        self._calls = {}        # per parameter group: the ALLOCATED argument structures (every field is refilled on every step)
 
     def _state(self, p):
         st = self.state[p]
@@ -54,29 +54,30 @@ class FusedAdam(torch.optim.Optimizer):
                 t = float(st["step"]) + 1.0
                 if t not in bcs:
                     bcs[t] = (1.0 - b1 ** t, math.sqrt(1.0 - b2 ** t))
-            key = (gi, tuple(id(p) for p in ps))
-            calls = self._calls.get(key)
-            if calls is None:
-                calls = []
-                for c0 in range(0, len(ps), _lib.AG_ADAM_MAX_TENSORS):
-                    a = _lib.AgAdamArgs()
-                    chunk = list(zip(ps[c0:c0 + _lib.AG_ADAM_MAX_TENSORS], states[c0:c0 + _lib.AG_ADAM_MAX_TENSORS]))
-                    a.n = len(chunk)
-                    for i, (p, st) in enumerate(chunk):
-                        if not (st["exp_avg"].is_contiguous() and st["exp_avg_sq"].is_contiguous() and st["exp_avg"].device == dev):
-                            raise RuntimeError("FusedAdam: optimizer state must be contiguous and on the parameters' device")
-                        a.param[i], a.exp_avg[i], a.exp_avg_sq[i], a.numel[i] = p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel()
-                    calls.append((a, [p for p, _ in chunk], [st for _, st in chunk]))
-                self._calls = {key: calls}          # one cached layout per optimizer (a changed parameter set rebuilds it)
+            # The argument structures are allocated once per (group, tensor count); every pointer in them is REFILLED from the live tensors on
+            # every step.  (Round 5 cached the filled structures keyed on id(p): a parameter whose storage was replaced -- p.data = ...,
+            # module.to() -- or an optimizer state replaced without load_state_dict would have been updated through stale addresses.)
+            n_calls = (len(ps) + _lib.AG_ADAM_MAX_TENSORS - 1) // _lib.AG_ADAM_MAX_TENSORS
+            cached = self._calls.get(gi)
+            if cached is None or len(cached) != n_calls:
+                cached = self._calls[gi] = [_lib.AgAdamArgs() for _ in range(n_calls)]
             stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
             with _lib.on_device(dev):
-                for a, chunk, sts in calls:
+                for ci, a in enumerate(cached):
+                    c0 = ci * _lib.AG_ADAM_MAX_TENSORS
+                    chunk, sts = ps[c0:c0 + _lib.AG_ADAM_MAX_TENSORS], states[c0:c0 + _lib.AG_ADAM_MAX_TENSORS]
+                    a.n = len(chunk)
                     a.maximize = int(bool(group["maximize"]))
                     a.lr, a.beta1, a.beta2, a.eps, a.weight_decay = float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"])
                     a.one_minus_beta1, a.one_minus_beta2 = 1.0 - float(b1), 1.0 - float(b2)          # in double, rounded once
                     keep = []                       # contiguous copies must outlive the launch (the allocator would hand their block to the next copy)
-                    for i, p in enumerate(chunk):
-                        a.bias_correction1[i], a.bias_correction2_sqrt[i] = bcs[float(sts[i]["step"]) + 1.0]
+                    for i, (p, st) in enumerate(zip(chunk, sts)):
+                        m, v = st["exp_avg"], st["exp_avg_sq"]
+                        if not (m.is_contiguous() and v.is_contiguous() and m.device == dev and v.device == dev
+                                and m.dtype == torch.float32 and v.dtype == torch.float32 and m.numel() == p.numel() and v.numel() == p.numel()):
+                            raise RuntimeError("FusedAdam: optimizer state must be contiguous fp32 of the parameter's size on the parameters' device")
+                        a.param[i], a.exp_avg[i], a.exp_avg_sq[i], a.numel[i] = p.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel()
+                        a.bias_correction1[i], a.bias_correction2_sqrt[i] = bcs[float(st["step"]) + 1.0]
                         g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                         keep.append(g)
                         a.grad[i] = g.data_ptr()

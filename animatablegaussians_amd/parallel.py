@@ -65,6 +65,10 @@ class ViewGradExchange:
         self.acc = torch.zeros((rows, cols), dtype=torch.float32, device=self.dev)
         self.comm = torch.cuda.Stream(self.dev) if self.cuda else None
         self.consumed = [torch.cuda.Event() for _ in self.packs] if self.cuda else None
+        self.released = torch.cuda.Event() if self.cuda else None      # recorded by release(): the reader of `acc` is done with the previous iteration
+        self._released_pending = False
+        if self.cuda:
+            self.comm.wait_stream(torch.cuda.current_stream(self.dev))   # the zero fills above ran on the constructing stream
         self.count = 0                 # steps submitted since the last reset()
         self.reduced = 0               # all-reduces issued
         self.hold_back = False         # True: accumulate only, never all-reduce (the check of bench.py reduces by hand)
@@ -87,6 +91,10 @@ class ViewGradExchange:
                 torch.cat(list(grads), dim=1, out=self.packs[k])
             self.comm.wait_stream(producer_stream)
             with torch.cuda.stream(self.comm):
+                if j == 0 and self._released_pending:
+                    # the first view of an iteration OVERWRITES acc: not before the stream that read the previous iteration's sum (join) is through
+                    self.comm.wait_event(self.released)
+                    self._released_pending = False
                 self._accumulate(k, j)
                 self.consumed[k].record(self.comm)
                 self._reduce(j)
@@ -111,9 +119,16 @@ class ViewGradExchange:
             self.reduced += 1
 
     def join(self, stream=None):
-        """``stream`` (default: the current one) waits for everything submitted so far."""
+        """``stream`` (default: the current one) waits for everything submitted so far; work queued on it AFTER this call (the reader of
+        ``acc``) is what the next iteration's first overwrite of ``acc`` waits for -- call ``release(stream)`` once the reads are queued."""
         if self.cuda:
             (stream or torch.cuda.current_stream(self.dev)).wait_stream(self.comm)
+
+    def release(self, stream=None):
+        """The reads of ``acc`` queued on ``stream`` so far must finish before the next iteration's first view overwrites it."""
+        if self.cuda:
+            self.released.record(stream or torch.cuda.current_stream(self.dev))
+            self._released_pending = True
 
 
 class GradSync:

@@ -98,7 +98,9 @@ int ag_conv_get_math(void);
  * (the same happens for operands that were not finite to begin with).  The flag is read WITHOUT synchronising:
  *   - the NEXT convolution call on any stream returns AG_ERR_RANGE (and clears the flag) instead of launching,
  *   - ag_conv_status(clear) returns AG_ERR_RANGE / AG_OK on demand (after a stream synchronisation it covers everything enqueued before).
- * A kernel that raised the flag still wrote its (non-finite) outputs; nothing is repaired. */
+ * A kernel that raised the flag still wrote its (non-finite) outputs; nothing is repaired.  Round 6: the guard is armed in SPLIT_F16 / F16 only
+ * (in the fp32 / bf16 forms a non-finite operand propagates into the outputs as it does through the reference's cuDNN calls, and nothing is
+ * refused), and the flag carries which launch raised it (kernel kind, output rows, gathered channels: named in ag_last_error). */
 int ag_conv_status(int clear);
 
 int ag_debug_mfma_rate(int blocks, int iters, float* out, void* stream);

@@ -103,5 +103,11 @@ def test_camera_identity_cache_follows_the_tensors_values():
         n = len(calls)
         d = gr._camera_tensors(e3, intr, 1024, 1024, "cpu")
         assert len(calls) == n + 1 and np.allclose(d["viewmatrix"].numpy()[3, :3], 0.0)         # identity extrinsics: no translation row
+        # tensors created under torch.inference_mode() have no version counter (reading ._version raises): they take the by-value path
+        with torch.inference_mode():
+            ei, ii = extr.clone(), intr.clone()
+            n = len(calls)
+            f = gr._camera_tensors(ei, ii, 1024, 1024, "cpu")
+            assert len(calls) == n + 1 and f is b
     finally:
         gr._camera_tensors_by_value = real

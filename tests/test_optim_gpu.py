@@ -86,3 +86,49 @@ def test_fused_adam_counts_steps_per_parameter_like_torch():
     for i, (a, b) in enumerate(zip(ours, ref)):
         assert float(oa.state[a]["step"]) == float(ob.state[b]["step"]) == (2.0 if i % 2 else 4.0)
         assert torch.allclose(a, b, rtol=2e-6, atol=1e-7), (i, float((a - b).abs().max()))
+
+
+def test_fused_adam_follows_replaced_storage_and_replaced_state():
+    """Round-5 advice: the filled argument structures were cached on id(p), so a parameter whose STORAGE was replaced (p.data = ..., module.to())
+    or an optimizer state replaced without load_state_dict was updated through stale addresses.  Every pointer is now refilled per step: after
+    either replacement the step equals torch.optim.Adam's on the same history."""
+    import torch
+    from animatablegaussians_amd.optim import FusedAdam
+    g = torch.Generator().manual_seed(9)
+    base = [torch.randn(1031, generator=g) for _ in range(3)]
+    ours = [torch.nn.Parameter(t.clone().cuda()) for t in base]
+    ref = [torch.nn.Parameter(t.clone().cuda()) for t in base]
+    oa, ob = FusedAdam(ours, lr=1e-2), torch.optim.Adam(ref, lr=1e-2)
+
+    def one_step():
+        for a, b in zip(ours, ref):
+            gr = torch.randn(a.shape, generator=g).cuda()
+            a.grad, b.grad = gr.clone(), gr.clone()
+        oa.step()
+        ob.step()
+
+    one_step()
+    old_storage = ours[1].data
+    ours[1].data = ours[1].data.clone()                   # same Parameter object, new storage
+    keep_old = old_storage.clone()
+    one_step()
+    assert torch.equal(old_storage, keep_old)             # the old storage is no longer written
+    for a, b in zip(ours, ref):
+        assert torch.allclose(a, b, rtol=2e-6, atol=1e-7)
+    # the moment buffers replaced behind the optimizer's back (same values, new tensors)
+    st = oa.state[ours[0]]
+    old_m = st["exp_avg"]
+    st["exp_avg"], st["exp_avg_sq"] = st["exp_avg"].clone(), st["exp_avg_sq"].clone()
+    keep_m = old_m.clone()
+    one_step()
+    assert torch.equal(old_m, keep_m)
+    for a, b in zip(ours, ref):
+        assert torch.allclose(a, b, rtol=2e-6, atol=1e-7)
+    # two parameter groups keep their own structures (the second used to evict the first)
+    p1, p2 = torch.nn.Parameter(torch.ones(5).cuda()), torch.nn.Parameter(torch.ones(7).cuda())
+    o2 = FusedAdam([{"params": [p1]}, {"params": [p2], "lr": 1e-1}], lr=1e-2)
+    for _ in range(2):
+        p1.grad, p2.grad = torch.ones_like(p1), torch.ones_like(p2)
+        o2.step()
+    assert len(o2._calls) == 2
+    assert abs(float(p1[0]) - (1 - 2e-2)) < 1e-6 and abs(float(p2[0]) - (1 - 2e-1)) < 1e-6
