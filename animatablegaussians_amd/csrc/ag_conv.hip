@@ -892,6 +892,176 @@ __global__ void __launch_bounds__(64 * WVM * WVN, AG_CONV_WAVES_PER_SIMD) gather
     gather_epilogue<WMB, WNB>(p, gv, cl, acc, m0, n0, N, wm, wn, lane);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Round 6: the same GEMM with an LDS-DMA loader over PRE-SPLIT activation planes
+// ------------------------------------------------------------------------------------------------------------------
+// gather_conv_split_kernel converts every gathered activation fp32 -> (hi, lo) fp16 in the loader thread, once per TAP and per OUTPUT-CHANNEL
+// TILE that reads it (18 times on a 256 -> 256 layer), through VGPRs: 8 scalar global loads, ~40 VALU and the LDS stores per thread and
+// 16-deep K tile -- as much issue time as the tile's MFMAs, serial with them inside a wave (PMC, profiles/r05_pmc_conv_modes: matrix pipe
+// 48 % busy).  Here the split happens ONCE per launch, in a streaming pass of its own (presplit_kernel: fp32 [C][H][W] -> fp16 planes
+// [plane][C / 8][H W][8], 4 bytes per element like the fp32 tensor), and a K tile's operands reach LDS by global_load_lds_dwordx4: a lane's
+// 16-byte chunk = 8 consecutive channels of ONE pixel of one plane, so the lane-linear LDS image of a DMA (lane i -> base + 16 i) is the
+// swizzled [row][chunk] layout read_split_operands wants once the lane picks the matching (row, chunk) as its SOURCE; a tap that falls
+// outside the image, or a row past the class, reads a 64-byte zero page instead (the source address is per lane, so padding costs two
+// selects).  No staging registers, no conversion, no LDS stores; per K tile a wave issues its DMAs (one per 1-KB piece: a 32-row slice of
+// an activation plane, or 1 KB of the packed weight tile, which already is its LDS image) and twelve MFMAs on a 64 x 64 wave tile.  Three
+// LDS buffers, DMAs two tiles ahead, one barrier per tile: wait vmcnt(own DMAs of ONE tile) -> barrier -> issue tile kt + 2 -> read -> MFMA.
+__device__ __attribute__((aligned(64))) uint32_t g_zero_page[16];
+
+struct PresplitProblem {
+    const float* x;            // [G'][C][HW]
+    char* xs;                  // [G'][planes][Cpad / 8][HW][8] fp16
+    const float* amax;         // [G' or 1][kAmaxParts]
+    long long x_gs;            // floats between instances (0: one shared instance)
+    long long xs_gs;           // bytes between instances of xs
+    int C, Cpad, HW, planes;
+};
+__global__ void __launch_bounds__(256) presplit_kernel(PresplitProblem p)
+{
+    const int grp = blockIdx.z, cb = blockIdx.y;
+    const TensorScale sc = tensor_scale(p.amax + (p.x_gs ? (size_t)grp * kAmaxParts : 0), 1.f, threadIdx.x & 63);
+    const float* __restrict__ x = p.x + (size_t)grp * p.x_gs;
+    char* __restrict__ xs = p.xs + (size_t)grp * p.xs_gs;
+    const size_t plane_b = (size_t)(p.Cpad / 8) * p.HW * 16;
+    for (int q = blockIdx.x * 256 + threadIdx.x; q < p.HW; q += gridDim.x * 256) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int c = cb * 8 + j;
+            v[j] = c < p.C ? x[(size_t)c * p.HW + q] * sc.s : 0.f;
+        }
+        u32x4 h, l;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            uint32_t a, b;
+            split_pair_h(v[2 * e], v[2 * e + 1], a, b);
+            h[e] = a; l[e] = b;
+        }
+        const size_t off = ((size_t)cb * p.HW + q) * 16;
+        *reinterpret_cast<u32x4*>(xs + off) = h;
+        if (p.planes == 2) *reinterpret_cast<u32x4*>(xs + plane_b + off) = l;
+    }
+}
+
+template <int WMB, int WNB, int WVM, int WVN, int NTERMS>
+__global__ void __launch_bounds__(64 * WVM * WVN, 3) gather_conv_dma_kernel(GatherProblem p, const char* __restrict__ xs, long long xs_gs)
+{
+    constexpr int NPL = planes_of(NTERMS);
+    static_assert(is_f16_form(NTERMS), "the DMA loader serves the fp16 forms");
+    using T = SplitTile<WMB, WNB, WVM, WVN, NPL>;
+    constexpr int BM = T::BM, BN = T::BN, NT = T::NT, NW = NT / 64;
+    constexpr int PA = T::a_bytes / 1024, PB = T::b_bytes / 1024;      // 1-KB pieces of a K tile's two operand images
+    static_assert((PA + PB) % NW == 0, "every wave issues the same number of DMAs per tile (the vmcnt count is an immediate)");
+    static_assert(PA % NW == 0, "piece k of every wave is on the same side (A or B): no branch per piece");
+    constexpr int PER = (PA + PB) / NW;
+    constexpr int NBUF = 3;
+    constexpr int stage_bytes = T::a_bytes + T::b_bytes;
+    __shared__ __attribute__((aligned(1024))) char smem[NBUF * stage_bytes];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WVN, wn = wave % WVN;
+
+    const TileId tw = tile_of_workgroup(p);
+    int ci = 0;
+#pragma unroll
+    for (int c = 1; c < kMaxClasses; c++)
+        if (c < p.nclasses && tw.bx >= p.cls[c].tile_begin) ci = c;
+    const GatherClass& cl = p.cls[ci];
+    const int gw = cl.gw, ntaps = cl.ntaps;
+    const int N = cl.gh * gw;
+    const GroupView gv = group_view(p, tw.by);
+    const int m0 = gv.my * BM, n0 = (tw.bx - cl.tile_begin) * BN;
+    const int HW = p.Hg * p.Wg;
+
+    f32x16 acc[WMB][WNB];
+#pragma unroll
+    for (int i = 0; i < WMB; i++)
+#pragma unroll
+        for (int j = 0; j < WNB; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    const int nkt_all = cl.nkt;
+    const int kt_beg = min(nkt_all, (int)blockIdx.z * p.kt_per_split), kt_end = min(nkt_all, kt_beg + p.kt_per_split);
+    const int nkt = kt_end - kt_beg;
+    TensorScale sa = tensor_scale(p.amax_a + (size_t)gv.grp * kAmaxParts, p.amax_a_mult, lane);
+    TensorScale sb = tensor_scale(p.amax_b + (p.x_gs ? (size_t)gv.grp * kAmaxParts : 0), 1.f, lane);
+
+    // ---- this wave's pieces.  Piece q < PA: bytes [1024 q, 1024 q + 1024) of the packed weight tile; piece PA + j: plane j / (BN / 32), rows
+    //      32 (j % (BN / 32)) ... + 31 of the activation tile; lane i of a B piece owns LDS chunk i = (row i / 2, slot i & 1), slot = kh ^ bit 3 of row
+    const char* const a_tile0 = reinterpret_cast<const char*>(p.At) + ((size_t)gv.grp * p.at_gs + (size_t)cl.at_off) * (2 * NPL) + ((size_t)gv.my * nkt_all + kt_beg) * T::a_bytes;
+    const char* const xs_g = xs + (size_t)(p.x_gs ? gv.grp : 0) * xs_gs;
+    const size_t plane_b = (size_t)(p.Cpad / 8) * HW * 16;
+    const char* src[PER];          // per-lane source of piece k at tile 0 / tap offset 0 / channel block 0
+    uint32_t vmask[PER];           // B pieces: taps of this lane's pixel that lie inside the image; A pieces: all ones
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        const int q = wave + k * NW;                       // wave-uniform
+        if (k * NW < PA) {
+            src[k] = a_tile0 + q * 1024 + lane * 16;
+            vmask[k] = 0xffffffffu;
+        } else {
+            const int j = q - PA, pl = j / (BN / 32), rp = j % (BN / 32);
+            const int row = rp * 32 + (lane >> 1), kh = (lane & 1) ^ ((row >> 3) & 1);
+            const int n = n0 + row;
+            const bool n_ok = n < N;
+            const int gy = n_ok ? n / gw : 0, gx = n_ok ? n - (n / gw) * gw : 0;
+            const int iy0 = gy * p.sy, ix0 = gx * p.sx;
+            uint32_t vm = 0;
+            for (int t = 0; t < ntaps; t++) {
+                const int iy = iy0 + cl.dy[t], ix = ix0 + cl.dx[t];
+                if (n_ok && iy >= 0 && iy < p.Hg && ix >= 0 && ix < p.Wg) vm |= 1u << t;
+            }
+            vmask[k] = vm;
+            src[k] = xs_g + (size_t)pl * plane_b + ((long long)kh * HW + (long long)iy0 * p.Wg + ix0) * 16;
+        }
+    }
+    const int tl = lane & (kMaxTaps - 1);
+    const int toff_vec = cl.dy[tl] * p.Wg + cl.dx[tl];
+    const char* const zero = reinterpret_cast<const char*>(g_zero_page) + (lane & 3) * 16;
+
+    int t_cur = kt_beg % ntaps;
+    long long cb_off = (long long)(kt_beg / ntaps) * 2 * HW * 16;      // byte offset of the tile's channel-block pair inside a plane
+    long long a_off = 0;
+    auto issue = [&](int buf) {
+        char* const stage = smem + buf * stage_bytes;
+        const long long uoff = cb_off + (long long)__builtin_amdgcn_readlane(toff_vec, t_cur) * 16;
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            const int q = wave + k * NW;
+            const char* g;
+            if (k * NW < PA) g = src[k] + a_off;
+            else          g = ((vmask[k] >> t_cur) & 1u) ? src[k] + uoff : zero;
+            char* dst = stage + q * 1024;                  // A pieces first, then the B planes: the stage IS [a image][b image]
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+        a_off += T::a_bytes;
+        t_cur++;
+        const bool wrap = t_cur == ntaps;
+        t_cur = wrap ? 0 : t_cur;
+        cb_off += wrap ? (long long)2 * HW * 16 : 0;
+    };
+    SplitOperands<WMB, WNB> O;
+
+    if (nkt > 0) {
+        issue(0);
+        if (nkt > 1) issue(1);
+        int buf = 0;
+        for (int kt = 0; kt < nkt; kt++) {
+            if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PER) : "memory");
+            else              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            lds_barrier();
+            if (kt + 2 < nkt) issue(buf >= 1 ? buf - 1 : NBUF - 1);          // (kt + 2) % 3
+            const char* stage = smem + buf * stage_bytes;
+            read_split_operands<WMB, WNB, BM, BN, NTERMS>(stage, stage + T::a_bytes, wm, wn, lane, O);
+            mma_split_h<WMB, WNB, NTERMS>(O, acc);
+            buf = buf + 1 == NBUF ? 0 : buf + 1;
+        }
+    }
+    unscale_f16<WMB, WNB>(acc, sa.inv, sb.inv);
+    gather_epilogue<WMB, WNB>(p, gv, cl, acc, m0, n0, N, wm, wn, lane);
+}
+
 // split-K finish: y = (sum_z partial[z][m][col]) * out_scale[m] + bias[m], in a fixed order (deterministic)
 __global__ void __launch_bounds__(256) reduce_splits_kernel(GatherProblem p, int splits)
 {
@@ -1824,7 +1994,7 @@ static int choose_splits(long long tiles, int Mpad, int Ncols, int nkt, int G = 
 // weights of all classes with one launch and runs them with one launch (+ one split-K finish).
 static int pack_and_launch(GatherProblem& gp, const TapSet* taps, int bm, const PtrTable& w, long long stride_c, long long stride_m,
                            float wscale, int k, float* At, float* partial, float* amax, const AmaxTensor& w_shape, const float* pre_w,
-                           const float* pre_in, hipStream_t s, bool skip_pack = false)
+                           const float* pre_in, hipStream_t s, bool skip_pack = false, char* xs_buf = nullptr)
 {
     const bool split = split_math();
     const int terms = split_terms();
@@ -1904,6 +2074,35 @@ static int pack_and_launch(GatherProblem& gp, const TapSet* taps, int bm, const 
     char tag[64];
     snprintf(tag, sizeof(tag), "g bm%d G%d M%d C%d N%d cls%d nkt%d sp%d wg%lld", bm, G, gp.M, gp.Cg, cols, gp.nclasses, nkt_max, splits,
              (long long)grid.x * grid.y * grid.z);
+    // Round 6: the LDS-DMA loader over pre-split planes (gather_conv_dma_kernel) for the fp16 forms on whole 16-channel blocks; AG_CONV_DMA=0: the
+    // register-staged loader (same-box A/B)
+    static const bool dma_on = [] { const char* e = getenv("AG_CONV_DMA"); return !(e && e[0] == '0'); }();
+    const bool dma = dma_on && f16 && xs_buf && gp.Cg % BK == 0 && !(terms == kF16S && bm == 64);
+    if (dma) {
+        PresplitProblem ps_;
+        const int inst = gp.x_gs ? G : 1;
+        ps_.x = gp.xin; ps_.xs = xs_buf; ps_.amax = gp.amax_b; ps_.x_gs = gp.x_gs;
+        ps_.C = gp.Cg; ps_.Cpad = gp.Cpad; ps_.HW = gp.Hg * gp.Wg; ps_.planes = planes_of(terms);
+        ps_.xs_gs = (long long)ps_.planes * (gp.Cpad / 8) * ps_.HW * 16;
+        const int bx = std::max(1, std::min((ps_.HW + 255) / 256, 2048 / std::max(1, (gp.Cpad / 8) * inst / 8)));
+        hipLaunchKernelGGL(presplit_kernel, dim3(bx, gp.Cpad / 8, inst), dim3(256), 0, s, ps_);
+        rc = check_hip(hipGetLastError(), "presplit_kernel");
+        if (rc) return rc;
+        ProfScope ps(AG_K_GATHER_CONV, s, flops, tag);
+#define AG_LAUNCH_DMA(WMB, WNB, WVM, WVN, NTM) hipLaunchKernelGGL((gather_conv_dma_kernel<WMB, WNB, WVM, WVN, NTM>), grid, dim3(64 * WVM * WVN), 0, s, gp, (const char*)xs_buf, ps_.xs_gs)
+        if (bm == 64) AG_LAUNCH_DMA(2, 2, 1, 4, kF16);
+        else if (terms == kF16S) AG_LAUNCH_DMA(2, 2, 2, 2, kF16S);
+        else AG_LAUNCH_DMA(2, 2, 2, 2, kF16);
+#undef AG_LAUNCH_DMA
+        rc = check_hip(hipGetLastError(), "gather_conv_dma_kernel");
+        if (rc || splits == 1) return rc;
+        const long long total = (long long)gp.M * cols;
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 4096) blocks = 4096;
+        if (gp.act && gp.out_amax && blocks * G > 2048) blocks = std::max(1, 2048 / G);
+        hipLaunchKernelGGL(reduce_splits_kernel, dim3(blocks, G), dim3(256), 0, s, gp, splits);
+        return check_hip(hipGetLastError(), "reduce_splits_kernel");
+    }
     ProfScope ps(AG_K_GATHER_CONV, s, flops, tag);      // covers the split-K finish too
     if (split) {
         const bool cexact = gp.Cg % BK == 0 && (size_t)gp.Cg * gp.Hg * gp.Wg * sizeof(float) < (size_t(1) << 32);
@@ -1959,16 +2158,24 @@ size_t ag_conv_workspace_bytes(const AgConvDesc* d)
 {
     if (validate(d)) return 0;
     // packed weights of all tap subsets together + split-K partial sums (choose_splits keeps them under the cap)
-    return packed_bytes(d) + kMaxPartialBytes + kAmaxBytes + 512;
+    return conv_workspace_bytes_g(d, 1);
 }
 
 }  // extern "C"
 
 namespace ag {
+// the pre-split activation planes of the DMA loader (round 6): 4 bytes per element of the larger of the two tensors a gather launch may read
+static size_t presplit_bytes(const AgConvDesc* d, int G)
+{
+    int OH, OW;
+    out_size(d, OH, OW);
+    const size_t a = (size_t)round_up(d->Cin, BK) * d->H * d->W, b = (size_t)round_up(d->Cout, BK) * OH * OW;
+    return align_up((size_t)G * std::max(a, b) * 4, 256) + 256;
+}
 size_t conv_workspace_bytes_g(const AgConvDesc* d, int G)
 {
     if (validate(d) || G < 1 || G > kMaxGroups) return 0;
-    return (size_t)G * packed_bytes(d) + kMaxPartialBytes + kAmaxBytes + 512;
+    return (size_t)G * packed_bytes(d) + kMaxPartialBytes + kAmaxBytes + 512 + presplit_bytes(d, G);
 }
 size_t conv_packed_bytes_g(const AgConvDesc* d, int G)
 {
@@ -1994,6 +2201,7 @@ static int run_gather_family(const AgConvDesc* d, bool backward_input, int G, co
     float* At = opt.packed ? reinterpret_cast<float*>(aligned_base(opt.packed)) : reinterpret_cast<float*>(aligned_base(workspace));
     float* partial = reinterpret_cast<float*>(aligned_base(workspace) + (size_t)G * packed_bytes(d));
     float* amax = reinterpret_cast<float*>(aligned_base(workspace) + (size_t)G * packed_bytes(d) + kMaxPartialBytes);
+    char* xs_buf = aligned_base(workspace) + align_up((size_t)G * packed_bytes(d) + kMaxPartialBytes + kAmaxBytes, 256);
 
     GatherProblem gp;
     gp.status = armed_status_word();
@@ -2049,7 +2257,7 @@ static int run_gather_family(const AgConvDesc* d, bool backward_input, int G, co
             for (int t = 0; t < k2; t++) { cl.dy[t] = ts.ky[t]; cl.dx[t] = ts.kx[t]; }
         }
         for (int t = k2; t < kMaxTaps; t++) cl.dy[t] = cl.dx[t] = 0;
-        return pack_and_launch(gp, taps, bm, w, stride_c, stride_m, wscale_of(d), k, At, partial, amax, w_shape, opt.amax_w, pre_in, s, opt.packed && opt.packed_valid);
+        return pack_and_launch(gp, taps, bm, w, stride_c, stride_m, wscale_of(d), k, At, partial, amax, w_shape, opt.amax_w, pre_in, s, opt.packed && opt.packed_valid, xs_buf);
     }
     // scatter with stride 2: output coordinate o = 2*i + ky - poff  (poff = padding for the conv gradient, 0 for convT).
     // Class (qy, qx) = parity of the output coordinate; it receives only taps with ky = (o + poff) mod 2, from
@@ -2087,7 +2295,7 @@ static int run_gather_family(const AgConvDesc* d, bool backward_input, int G, co
             gp.cls[pos] = cl; taps[pos] = ts;
             gp.nclasses++;
         }
-    return pack_and_launch(gp, taps, bm, w, stride_c, stride_m, wscale_of(d), k, At, partial, amax, w_shape, opt.amax_w, pre_in, s, opt.packed && opt.packed_valid);
+    return pack_and_launch(gp, taps, bm, w, stride_c, stride_m, wscale_of(d), k, At, partial, amax, w_shape, opt.amax_w, pre_in, s, opt.packed && opt.packed_valid, xs_buf);
 }
 
 }  // extern "C"
