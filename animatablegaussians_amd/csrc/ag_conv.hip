@@ -943,8 +943,11 @@ __global__ void __launch_bounds__(256) presplit_kernel(PresplitProblem p)
     }
 }
 
+// waves per SIMD the register budget is cut for: one 8-wave workgroup per CU for the 128 x 64 wave tiles (128 accumulator registers), two for the
+// 64 x 64 ones, three 4-wave workgroups
+constexpr int dma_wps(int wmb, int wnb, int nt) { return wmb * wnb > 4 ? 2 : (nt == 512 ? 4 : 3); }
 template <int WMB, int WNB, int WVM, int WVN, int NTERMS>
-__global__ void __launch_bounds__(64 * WVM * WVN, 3) gather_conv_dma_kernel(GatherProblem p, const char* __restrict__ xs, long long xs_gs)
+__global__ void __launch_bounds__(64 * WVM * WVN, dma_wps(WMB, WNB, 64 * WVM * WVN)) gather_conv_dma_kernel(GatherProblem p, const char* __restrict__ xs, long long xs_gs)
 {
     constexpr int NPL = planes_of(NTERMS);
     static_assert(is_f16_form(NTERMS), "the DMA loader serves the fp16 forms");
@@ -1990,16 +1993,39 @@ static int choose_splits(long long tiles, int Mpad, int Ncols, int nkt, int G = 
     return best;
 }
 
+// Round 6 EXPERIMENT (opt-in, AG_CONV_DMA=1: big tiles only, =2: every eligible launch): the LDS-DMA loader over pre-split planes
+// (gather_conv_dma_kernel) for the fp16 forms on whole 16-channel blocks.  Correct (tests/test_conv_gpu.py green in this mode) and NOT faster on the
+// training step: profiles/r06_conv_dma.md.
+static bool conv_dma_possible(int Cg)
+{
+    static const bool dma_on = [] { const char* e = getenv("AG_CONV_DMA"); return e && (e[0] == '1' || e[0] == '2'); }();      // OPT-IN: measured no net gain (below)
+    return dma_on && is_f16_form(split_terms()) && Cg % BK == 0;
+}
+// Workgroup tile.  A 128 x 128 tile moves 16 KB of operands per 16-deep K tile from L2 for 1.57 M products: 96 products per byte, i.e. ~26 TB/s of
+// L2 -> LDS traffic at the matrix pipe's peak -- the 128-wide kernels are L2-bandwidth-bound at about half of it (profiles/r06_conv_dma.md).  With the
+// DMA loader's registers free for accumulators: 256 x 256 (192 products per byte) where the output has whole 256-row tiles and enough of them to
+// fill the chip, 128 x 256 (131) for the 128-channel layers; AG_CONV_BIG_TILES=0 keeps the 128-wide tiles.
+static void pick_tile(int M, long long N, int G, bool dma, int& bm, int& bn)
+{
+    bm = pick_bm(M); bn = bn_of(bm);
+    static const bool big = [] { const char* e = getenv("AG_CONV_BIG_TILES"); return !(e && e[0] == '0'); }();
+    if (!dma || !big) return;
+    const int terms = split_terms();
+    const long long nt256 = (N + 255) / 256;
+    if (M % 256 == 0 && nt256 * (M / 256) * G >= 192) { bm = 256; bn = 256; }
+    else if (M % 128 == 0 && terms == kF16 && nt256 * (M / 128) * G >= 384) { bm = 128; bn = 256; }
+}
+
 // Fills tile_begin / col_begin / at_off / nkt of the classes (dy, dx, gh, gw, y0, x0, ntaps set by the caller), packs the
 // weights of all classes with one launch and runs them with one launch (+ one split-K finish).
 static int pack_and_launch(GatherProblem& gp, const TapSet* taps, int bm, const PtrTable& w, long long stride_c, long long stride_m,
                            float wscale, int k, float* At, float* partial, float* amax, const AmaxTensor& w_shape, const float* pre_w,
-                           const float* pre_in, hipStream_t s, bool skip_pack = false, char* xs_buf = nullptr)
+                           const float* pre_in, hipStream_t s, bool skip_pack = false, char* xs_buf = nullptr, int bn = 0)
 {
     const bool split = split_math();
     const int terms = split_terms();
     const bool f16 = is_f16_form(terms);
-    const int BN = bn_of(bm);
+    const int BN = bn ? bn : bn_of(bm);
     const int G = gp.G;
     PackProblem pp;
     pp.w_t = w; pp.At = At; pp.C = gp.Cg; pp.Cpad = gp.Cpad; pp.M = gp.M; pp.Mpad = gp.Mpad; pp.BM = bm; pp.nclasses = gp.nclasses;
@@ -2076,8 +2102,10 @@ static int pack_and_launch(GatherProblem& gp, const TapSet* taps, int bm, const 
              (long long)grid.x * grid.y * grid.z);
     // Round 6: the LDS-DMA loader over pre-split planes (gather_conv_dma_kernel) for the fp16 forms on whole 16-channel blocks; AG_CONV_DMA=0: the
     // register-staged loader (same-box A/B)
-    static const bool dma_on = [] { const char* e = getenv("AG_CONV_DMA"); return !(e && e[0] == '0'); }();
-    const bool dma = dma_on && f16 && xs_buf && gp.Cg % BK == 0 && !(terms == kF16S && bm == 64);
+    // the DMA loader pays for its pre-split pass (8 bytes per input element at ~5 TB/s) only where it buys the big tiles: on 128-wide tiles it is
+    // 2-4 % faster than the register-staged loader before that pass, 5-10 % slower after it (profiles/r06_conv_dma.md); AG_CONV_DMA=2 forces it everywhere
+    static const bool dma_all = [] { const char* e = getenv("AG_CONV_DMA"); return e && e[0] == '2'; }();
+    const bool dma = conv_dma_possible(gp.Cg) && xs_buf && !(terms == kF16S && bm == 64) && (dma_all || BN * bm >= 128 * 256);
     if (dma) {
         PresplitProblem ps_;
         const int inst = gp.x_gs ? G : 1;
@@ -2090,7 +2118,9 @@ static int pack_and_launch(GatherProblem& gp, const TapSet* taps, int bm, const 
         if (rc) return rc;
         ProfScope ps(AG_K_GATHER_CONV, s, flops, tag);
 #define AG_LAUNCH_DMA(WMB, WNB, WVM, WVN, NTM) hipLaunchKernelGGL((gather_conv_dma_kernel<WMB, WNB, WVM, WVN, NTM>), grid, dim3(64 * WVM * WVN), 0, s, gp, (const char*)xs_buf, ps_.xs_gs)
-        if (bm == 64) AG_LAUNCH_DMA(2, 2, 1, 4, kF16);
+        if (bm == 256 && BN == 256) { if (terms == kF16S) AG_LAUNCH_DMA(4, 2, 2, 4, kF16S); else AG_LAUNCH_DMA(4, 2, 2, 4, kF16); }
+        else if (bm == 128 && BN == 256) AG_LAUNCH_DMA(2, 2, 2, 4, kF16);
+        else if (bm == 64) AG_LAUNCH_DMA(2, 2, 1, 4, kF16);
         else if (terms == kF16S) AG_LAUNCH_DMA(2, 2, 2, 2, kF16S);
         else AG_LAUNCH_DMA(2, 2, 2, 2, kF16);
 #undef AG_LAUNCH_DMA
@@ -2175,7 +2205,8 @@ static size_t presplit_bytes(const AgConvDesc* d, int G)
 size_t conv_workspace_bytes_g(const AgConvDesc* d, int G)
 {
     if (validate(d) || G < 1 || G > kMaxGroups) return 0;
-    return (size_t)G * packed_bytes(d) + kMaxPartialBytes + kAmaxBytes + 512 + presplit_bytes(d, G);
+    static const bool dma_on = [] { const char* e = getenv("AG_CONV_DMA"); return e && (e[0] == '1' || e[0] == '2'); }();
+    return (size_t)G * packed_bytes(d) + kMaxPartialBytes + kAmaxBytes + 512 + (dma_on ? presplit_bytes(d, G) : 0);
 }
 size_t conv_packed_bytes_g(const AgConvDesc* d, int G)
 {
@@ -2232,7 +2263,10 @@ static int run_gather_family(const AgConvDesc* d, bool backward_input, int G, co
     const float* const pre_in = backward_input ? opt.amax_dy : opt.amax_x;
     if (opt.w_cin_total && opt.w_cin_total != d->Cin) { w_shape.len = (long long)d->Cin * k2; w_shape.stride = cin_rows * k2; w_shape.rows = d->Cout; }
     gp.status_tag = status_tag_of(1, M, Cg);
-    gp.Cg = Cg; gp.Hg = Hg; gp.Wg = Wg; gp.M = M; const int bm = pick_bm(M); gp.Mpad = round_up(M, bm); gp.OHf = OHf; gp.OWf = OWf;
+    const bool scatter_ = (d->kind == AG_CONV && backward_input && d->stride == 2) || (d->kind != AG_CONV && !backward_input);
+    int bm, bn;
+    pick_tile(M, (long long)OHf * OWf / (scatter_ ? 4 : 1), G, conv_dma_possible(Cg), bm, bn);
+    gp.Cg = Cg; gp.Hg = Hg; gp.Wg = Wg; gp.M = M; gp.Mpad = round_up(M, bm); gp.OHf = OHf; gp.OWf = OWf;
     gp.Cpad = round_up(Cg, BK);
     TapSet taps[kMaxClasses];
 
@@ -2257,7 +2291,7 @@ static int run_gather_family(const AgConvDesc* d, bool backward_input, int G, co
             for (int t = 0; t < k2; t++) { cl.dy[t] = ts.ky[t]; cl.dx[t] = ts.kx[t]; }
         }
         for (int t = k2; t < kMaxTaps; t++) cl.dy[t] = cl.dx[t] = 0;
-        return pack_and_launch(gp, taps, bm, w, stride_c, stride_m, wscale_of(d), k, At, partial, amax, w_shape, opt.amax_w, pre_in, s, opt.packed && opt.packed_valid, xs_buf);
+        return pack_and_launch(gp, taps, bm, w, stride_c, stride_m, wscale_of(d), k, At, partial, amax, w_shape, opt.amax_w, pre_in, s, opt.packed && opt.packed_valid, xs_buf, bn);
     }
     // scatter with stride 2: output coordinate o = 2*i + ky - poff  (poff = padding for the conv gradient, 0 for convT).
     // Class (qy, qx) = parity of the output coordinate; it receives only taps with ky = (o + poff) mod 2, from
@@ -2295,7 +2329,7 @@ static int run_gather_family(const AgConvDesc* d, bool backward_input, int G, co
             gp.cls[pos] = cl; taps[pos] = ts;
             gp.nclasses++;
         }
-    return pack_and_launch(gp, taps, bm, w, stride_c, stride_m, wscale_of(d), k, At, partial, amax, w_shape, opt.amax_w, pre_in, s, opt.packed && opt.packed_valid, xs_buf);
+    return pack_and_launch(gp, taps, bm, w, stride_c, stride_m, wscale_of(d), k, At, partial, amax, w_shape, opt.amax_w, pre_in, s, opt.packed && opt.packed_valid, xs_buf, bn);
 }
 
 }  // extern "C"
