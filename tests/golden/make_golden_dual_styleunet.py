@@ -37,6 +37,21 @@ def sub(t, n=256):
     return f[::step][:n].double().numpy().copy()
 
 
+NBLK = 16
+
+
+def full_stats(t):
+    """Round 6: statistics over EVERY element of a gradient tensor (the 256-sample probe above covers 0.08 % of the 74 M gradient elements; a fault
+    confined to one output-channel block of one layer can sit between its samples): sum, sum of magnitudes, sum of squares, and the sums / sums of
+    magnitudes of NBLK contiguous blocks of the flattened tensor (dimension 0 -- output channels -- is the slowest), all accumulated in float64."""
+    f = t.detach().double().flatten()
+    n = f.numel()
+    edges = [(n * b) // NBLK for b in range(NBLK + 1)]
+    blk = np.array([f[edges[b]:edges[b + 1]].sum().item() for b in range(NBLK)])
+    blkabs = np.array([f[edges[b]:edges[b + 1]].abs().sum().item() for b in range(NBLK)])
+    return {"sum": f.sum().item(), "abs": f.abs().sum().item(), "sq": (f * f).sum().item(), "blk": blk, "blkabs": blkabs}
+
+
 def run(dtype):
     torch.manual_seed(0)
     net = DualStyleUNet(inp_size=512, inp_ch=3, out_ch=OUT_CH, out_size=1024, style_dim=512, n_mlp=2)
@@ -58,17 +73,28 @@ def run(dtype):
     }
     scal = {"images_absmean": img.abs().double().mean().item(), "images_max": img.abs().max().item(),
             "pose_grad_max": pose.grad.abs().max().item()}
+    stats = {}
     for name, p in net.named_parameters():
         res["grad:" + name] = sub(p.grad)
         scal["gmax:" + name] = p.grad.abs().max().item()
+        stats[name] = full_stats(p.grad)
+    stats["@pose"] = full_stats(pose.grad)
     shapes = {"shape:" + n: np.asarray(p.shape, dtype=np.int64) for n, p in net.named_parameters()}
     shapes.update({"shape:" + n: np.asarray(b.shape, dtype=np.int64) for n, b in net.named_buffers() if n.startswith("noises.")})
-    return res, scal, shapes
+    return res, scal, shapes, stats
 
 
-r64, s64, shapes = run(torch.float64)
-r32, s32, _ = run(torch.float32)
+r64, s64, shapes, st64 = run(torch.float64)
+r32, s32, _, st32 = run(torch.float32)
 out = dict(shapes)
+# full-tensor statistics of the float64 run, and how far the reference's own float32 run is from them (the yardstick, as err32 above)
+for name, a in st64.items():
+    b = st32[name]
+    out["fsum:" + name] = np.float64(a["sum"]); out["fabs:" + name] = np.float64(a["abs"]); out["fsq:" + name] = np.float64(a["sq"])
+    out["fblk:" + name] = a["blk"]; out["fblkabs:" + name] = a["blkabs"]
+    out["e32sum:" + name] = np.float64(abs(b["sum"] - a["sum"]) / max(a["abs"], 1e-300))
+    out["e32sq:" + name] = np.float64(abs(b["sq"] - a["sq"]) / max(a["sq"], 1e-300))
+    out["e32blk:" + name] = np.float64(np.max(np.abs(b["blk"] - a["blk"]) / np.maximum(a["blkabs"], 1e-300)))
 for k, v in r64.items():
     out[k] = v.astype(np.float32)
     if k.startswith("images"):

@@ -154,14 +154,15 @@ _SLOT_OF = {"dL_dmeans2D": (0, 1, None), "dL_dconic": (2, 3, None, 4), "dL_dopac
             "dL_ddepths": (9,)}
 
 
-def assert_accum_parity(got, ref, rtol=1e-4, k_eps=64.0, ref_perturbed=None, k_sens=0.0):
+def assert_accum_parity(got, ref, rtol=1e-4, k_eps=64.0, ref_perturbed=None, k_sens=0.0, max_ratio=1.0):
     """Blend-backward accumulators vs the fp64-accumulated oracle.
 
     |got - ref| <= rtol*|ref| + k_eps*eps_fp32*sum|term| + 1e-7: the first term is the stated 1e-4 fp32 bar, the
     second is the spread between admissible float summation orders of the reference's atomicAdds (any order is
     "the reference"), with abs_sum measured by the oracle.  ``ref_perturbed`` (end-to-end comparisons only): the oracle's result
     with every exp() scaled by 1 + 2^-20 -- k_sens * |ref_perturbed - ref| is the reference algorithm's own movement under a
-    rounding-sized change of its transcendental, added per element.  Returns the worst ratio to the limit."""
+    rounding-sized change of its transcendental, added per element.  ``max_ratio``: the cap on the worst ratio to the limit (1.0 = the limit
+    itself; a measured-and-capped comparison passes its cap here).  Returns the worst ratio to the limit."""
     eps = float(np.finfo(np.float32).eps)
     worst_all = 0.0
     for name, slots in _SLOT_OF.items():
@@ -178,7 +179,7 @@ def assert_accum_parity(got, ref, rtol=1e-4, k_eps=64.0, ref_perturbed=None, k_s
                 lim = lim + k_sens * np.abs(np.asarray(ref_perturbed[name], np.float64)[:, col] - r[:, col])
             worst = float((d / lim).max()) if d.size else 0.0
             worst_all = max(worst_all, worst)
-            assert worst <= 1.0, (f"{name}[:, {col}]: {int((d > lim).sum())} of {d.size} over tolerance, worst ratio "
+            assert worst <= max_ratio, (f"{name}[:, {col}]: {int((d > lim * max_ratio).sum())} of {d.size} over tolerance x {max_ratio:g}, worst ratio "
                                   f"{worst:.2f}, max |diff| {d.max():.3e}, ref max {np.abs(r[:, col]).max():.3e}")
     return worst_all
 

@@ -78,3 +78,22 @@ def test_matrix_to_quaternion_on_non_orthonormal_matrices_matches_the_independen
     np.testing.assert_allclose(got32[clear], q[clear], rtol=0, atol=2e-6 * max(1.0, float(np.abs(q).max())))
     # and the composition LBS uses: q' = m2q(M @ q2m(q)) keeps the blended matrix's scale (the output quaternions are not unit)
     assert float(np.abs(np.linalg.norm(q[:1200], axis=1) - 1.0).max()) > 1e-2
+
+
+def test_which_source_pins_the_quaternion_helpers():
+    """Row a5's pin, stated by the run itself.  `tests/golden/m2q_pytorch3d.npz` exists only where `make_golden_m2q_pytorch3d.py` ran with
+    pytorch3d importable (not in the build image): then the oracle's `matrix_to_quaternion` / `quaternion_to_matrix` are asserted against
+    pytorch3d's OWN outputs (float64: same operations -> 1e-12).  Otherwise the pin is the independent derivation of the published 0.7.4
+    algorithm (test above) and the test says so -- "parity unpinned" in DESIGN.md means exactly this branch."""
+    import os
+    path = os.path.join(os.path.dirname(__file__), "golden", "m2q_pytorch3d.npz")
+    if not os.path.exists(path):
+        print("\n[parity] LBS quaternion helpers pinned by: the independent float64 derivation (tests/golden/make_golden_m2q.py) + scipy on rotations; "
+              "pytorch3d itself: NOT available in this image (tests/golden/make_golden_m2q_pytorch3d.py writes the pin where it is)")
+        return
+    g = np.load(path)
+    got = ao.matrix_to_quaternion(torch.from_numpy(g["M"])).numpy()
+    np.testing.assert_allclose(got, g["q_m2q"], rtol=1e-12, atol=1e-14)
+    R = ao.quaternion_to_matrix(torch.from_numpy(g["Q"])).numpy()
+    np.testing.assert_allclose(R, g["R_q2m"], rtol=1e-12, atol=1e-14)
+    print(f"\n[parity] LBS quaternion helpers pinned by: pytorch3d {g['version']} itself (tests/golden/m2q_pytorch3d.npz)")

@@ -69,10 +69,10 @@ def test_exr_reads_a_hand_built_file(tmp_path):
     with pytest.raises(ValueError):
         (tmp_path / "bad.exr").write_bytes(b'\0' * 64)
         exr.imread(str(tmp_path / "bad.exr"))
-    piz = head.replace(attr('compression', 'compression', b'\3'), attr('compression', 'compression', b'\4'))
-    (tmp_path / "piz.exr").write_bytes(piz + struct.pack('<Q', 0))
+    pxr = head.replace(attr('compression', 'compression', b'\3'), attr('compression', 'compression', b'\5'))       # PXR24: not supported
+    (tmp_path / "pxr.exr").write_bytes(pxr + struct.pack('<Q', 0))
     with pytest.raises(NotImplementedError):
-        exr.imread(str(tmp_path / "piz.exr"))
+        exr.imread(str(tmp_path / "pxr.exr"))
 
 
 def test_position_map_and_lbs_files_feed_the_avatar_constructor_layout(tmp_path):
@@ -318,3 +318,218 @@ def test_pre_round2_checkpoints_load_by_name_and_their_optimizer_file_is_refused
     for k, v in checkpoint.avatar_state_dict(net).items():
         assert torch.equal(v, want[k]), k
     assert len(optm2.state_dict()['state']) == 0                      # the optimizer file was not applied
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# PIZ (round 6).  No OpenEXR / OpenCV in the image, so the files are built HERE by an encoder written from the published algorithm
+# (ImfPizCompressor.cpp / ImfWav.cpp / ImfHuf.cpp), sharing nothing with exr.py: scalar Python loops for the forward wavelet, a heap-built
+# Huffman code whose LENGTHS go into the file (the decoder must derive the canonical codes from them), zero runs in the length table in both
+# packed forms, run-length symbols in the stream.  Parity with a file OpenEXR itself wrote stays unpinned.
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _piz_wenc14(a, b):
+    a, b = (a ^ 0x8000) - 0x8000 if a & 0x8000 else a, (b ^ 0x8000) - 0x8000 if b & 0x8000 else b      # as signed shorts
+    return ((a + b) >> 1) & 0xFFFF, (a - b) & 0xFFFF
+
+
+def _piz_wenc16(a, b):
+    ao = (a + 0x8000) & 0xFFFF
+    m, d = (ao + b) >> 1, ao - b
+    if d < 0:
+        m = (m + 0x8000) & 0xFFFF
+    return m & 0xFFFF, d & 0xFFFF
+
+
+def _piz_wav2_encode(a, nx, ny, mx):
+    enc = _piz_wenc14 if mx < (1 << 14) else _piz_wenc16
+    n = min(nx, ny)
+    p, p2 = 1, 2
+    while p2 <= n:
+        for y in range(0, ny - p2 + 1, p2):
+            x = 0
+            for x in range(0, nx - p2 + 1, p2):
+                i00, i01 = enc(a[y][x], a[y][x + p])
+                i10, i11 = enc(a[y + p][x], a[y + p][x + p])
+                a[y][x], a[y + p][x] = enc(i00, i10)
+                a[y][x + p], a[y + p][x + p] = enc(i01, i11)
+            if nx & p:
+                xo = (nx - p2) // p2 * p2 + p2 if nx >= p2 else 0
+                i00, a[y + p][xo] = enc(a[y][xo], a[y + p][xo])
+                a[y][xo] = i00
+        if ny & p:
+            yo = (ny - p2) // p2 * p2 + p2 if ny >= p2 else 0
+            for x in range(0, nx - p2 + 1, p2):
+                i00, a[yo][x + p] = enc(a[yo][x], a[yo][x + p])
+                a[yo][x] = i00
+        p, p2 = p2, p2 << 1
+
+
+def _piz_huffman(symbols, force_long=False):
+    """(packed table + stream bytes as ImfHuf.cpp hufCompress lays them out).  Lengths from a heap-built Huffman tree over the symbols plus the
+    run-length symbol iM; runs of >= 3 equal symbols are coded as symbol, iM, count."""
+    import heapq
+    from collections import Counter
+    # run-length pre-pass: (sym) or (sym, RL, count)
+    items, i = [], 0
+    while i < len(symbols):
+        j = i
+        while j + 1 < len(symbols) and symbols[j + 1] == symbols[i] and j - i < 255:
+            j += 1
+        run = j - i                                # repeats after the first
+        items.append((symbols[i], run if run >= 2 else 0))
+        i += (run + 1) if run >= 2 else 1
+    freq = Counter(s for s, _ in items)
+    im, iM = min(freq), max(freq) + 1              # iM = the run-length symbol
+    freq[iM] = max(1, sum(1 for _, r in items if r))
+    heap = [(f, k, (k,)) for k, f in freq.items()]
+    heapq.heapify(heap)
+    lens = {k: 0 for k in freq}
+    if len(heap) == 1:
+        lens[heap[0][1]] = 1
+    while len(heap) > 1:
+        f1, k1, s1 = heapq.heappop(heap)
+        f2, k2, s2 = heapq.heappop(heap)
+        for k in s1 + s2:
+            lens[k] += 1
+        heapq.heappush(heap, (f1 + f2, min(k1, k2), s1 + s2))
+    assert max(lens.values()) <= 58
+    # canonical codes (the decoder's rule: longest codes get the smallest values, symbols in increasing order within a length)
+    n = [0] * 59
+    for l in lens.values():
+        n[l] += 1
+    c = 0
+    for l in range(58, 0, -1):
+        nc = (c + n[l]) >> 1
+        n[l] = c
+        c = nc
+    code = {}
+    for k in sorted(lens):
+        code[k] = (lens[k], n[lens[k]])
+        n[lens[k]] += 1
+    bits = []
+
+    def put(v, nb):
+        bits.extend((v >> (nb - 1 - t)) & 1 for t in range(nb))
+
+    k = im
+    while k <= iM:                                 # the length table: 6 bits per symbol, zero runs as 59 + (run - 2) or 63 + 8-bit (run - 6)
+        if lens.get(k, 0):
+            put(lens[k], 6)
+            k += 1
+            continue
+        z = k
+        while z <= iM and not lens.get(z, 0):
+            z += 1
+        run = z - k
+        while run:
+            if run >= 6 or (force_long and run >= 6):
+                r = min(run, 255 + 6)
+                put(63, 6); put(r - 6, 8)
+            elif run >= 2:
+                r = min(run, 5)
+                put(59 + r - 2, 6)
+            else:
+                r = 1
+                put(0, 6)
+            run -= r
+            k += r
+    while len(bits) % 8:
+        bits.append(0)
+    table = bytes(int(''.join(map(str, bits[t:t + 8])), 2) for t in range(0, len(bits), 8))
+    bits = []
+    for s_, r in items:
+        put(code[s_][1], code[s_][0])
+        if r:
+            put(code[iM][1], code[iM][0]); put(r, 8)
+    nbits = len(bits)
+    while len(bits) % 8:
+        bits.append(0)
+    stream = bytes(int(''.join(map(str, bits[t:t + 8])), 2) for t in range(0, len(bits), 8))
+    return struct.pack('<5I', im, iM, len(table), nbits, 0) + table + stream
+
+
+def _piz_chunk(rows_by_channel, dtypes, W):
+    """rows_by_channel[c]: [rows, W] array of dtypes[c]; returns the chunk's data bytes."""
+    rows = rows_by_channel[0].shape[0]
+    words = [np.ascontiguousarray(a.astype(dt)).view('<u2').reshape(rows, W, dt.itemsize // 2) for a, dt in zip(rows_by_channel, dtypes)]
+    allw = np.concatenate([w.reshape(-1) for w in words])
+    present = np.zeros(65536, bool)
+    present[allw] = True
+    present[0] = False                                         # zero is never stored
+    nz = np.nonzero(present)[0]
+    bitmap = np.packbits(present, bitorder='little')
+    mn, mx = (int(nz[0]) >> 3, int(nz[-1]) >> 3) if nz.size else (8191, 0)
+    fwd = np.zeros(65536, np.int64)
+    vals = np.concatenate([[0], nz])
+    fwd[vals] = np.arange(vals.size)
+    max_value = vals.size - 1
+    syms = []
+    for w in words:
+        q = fwd[w]
+        for j in range(w.shape[2]):
+            a = [[int(v) for v in row] for row in q[:, :, j]]
+            _piz_wav2_encode(a, W, rows, max_value)
+            q[:, :, j] = np.array(a)
+        syms.extend(int(v) for v in q.reshape(-1))
+    huf = _piz_huffman(syms)
+    out = struct.pack('<HH', mn, mx) + (bitmap[mn:mx + 1].tobytes() if mn <= mx else b'') + struct.pack('<i', len(huf)) + huf
+    return out, max_value
+
+
+@pytest.mark.parametrize("case", ["float_bgr_37x45", "half_y_16bit_range", "constant_runs", "two_chunks_70_lines"])
+def test_exr_piz_files_built_by_an_independent_encoder_decode_exactly(tmp_path, case):
+    from animatablegaussians_amd import exr
+    rng = np.random.default_rng(7)
+    if case == "float_bgr_37x45":                  # odd sizes: the wavelet's odd-column / odd-line branches at several levels; 14-bit path
+        H, W, names, dts = 37, 45, ['B', 'G', 'R'], [np.dtype('<f4')] * 3
+        yy, xx = np.mgrid[0:H, 0:W]
+        planes = [np.round(np.sin(0.2 * xx + c) + 0.1 * yy, 1).astype(np.float32) for c in range(3)]       # few distinct values: 14-bit wavelet
+    elif case == "half_y_16bit_range":             # > 16383 distinct 16-bit values in a chunk: the 16-bit wavelet
+        H, W, names, dts = 32, 700, ['Y'], [np.dtype('<f2')]
+        planes = [rng.integers(0, 65536, (H, W)).astype(np.uint16).view(np.float16)]           # random bit patterns: ~19 k distinct values
+    elif case == "constant_runs":                  # long runs -> run-length symbols in the Huffman stream, a one-symbol code
+        H, W, names, dts = 20, 33, ['A', 'B', 'G', 'R'], [np.dtype('<f4')] * 4
+        planes = [np.full((H, W), v, np.float32) for v in (1.0, 0.0, 0.5, -2.0)]
+        planes[2][5:9, 7:20] = 3.25
+    else:                                          # more than one chunk (32 lines each), UINT + HALF + FLOAT channels mixed
+        H, W, names, dts = 70, 19, ['B', 'G', 'R'], [np.dtype('<u4'), np.dtype('<f2'), np.dtype('<f4')]
+        planes = [rng.integers(0, 1000, (H, W)).astype(np.uint32), rng.standard_normal((H, W)).astype(np.float16), rng.standard_normal((H, W)).astype(np.float32)]
+
+    def attr(name, typ, payload):
+        return name.encode() + b'\0' + typ.encode() + b'\0' + struct.pack('<i', len(payload)) + payload
+
+    ptype = {np.dtype('<u4'): 0, np.dtype('<f2'): 1, np.dtype('<f4'): 2}
+    ch = b''.join(n.encode() + b'\0' + struct.pack('<iB3xii', ptype[dt], 0, 1, 1) for n, dt in zip(names, dts)) + b'\0'
+    head = struct.pack('<ii', 20000630, 2) + attr('channels', 'chlist', ch) + attr('compression', 'compression', b'\4')
+    head += attr('dataWindow', 'box2i', struct.pack('<4i', 0, 0, W - 1, H - 1)) + attr('lineOrder', 'lineOrder', b'\0') + b'\0'
+    chunks, paths_used = [], set()
+    for y in range(0, H, 32):
+        rows = min(32, H - y)
+        data, max_value = _piz_chunk([p[y:y + rows] for p in planes], dts, W)
+        paths_used.add(max_value < (1 << 14))
+        chunks.append(struct.pack('<ii', y, len(data)) + data)
+    table, off = [], len(head) + 8 * len(chunks)
+    for c in chunks:
+        table.append(off)
+        off += len(c)
+    path = tmp_path / f"{case}.exr"
+    path.write_bytes(head + struct.pack(f'<{len(table)}Q', *table) + b''.join(chunks))
+    img = exr.imread(str(path))
+    if case == "half_y_16bit_range":
+        assert paths_used == {False}                # the 16-bit wavelet was exercised
+        assert img.shape == (H, W) and np.array_equal(img.view(np.uint16), planes[0].view(np.uint16))
+    else:
+        if case != "two_chunks_70_lines":
+            assert paths_used == {True}
+        order = {'B': 0, 'G': 1, 'R': 2, 'A': 3}
+        assert img.shape == (H, W, len(names))
+        for n, p_ in zip(names, planes):
+            got = img[..., order[n]]
+            assert np.array_equal(got.astype(np.float64), p_.astype(np.float64)), (case, n)
+    # a corrupted stream is refused, not mis-decoded silently into the wrong shape
+    bad = bytearray(path.read_bytes())
+    bad[table[0] + 8 + 4 + 30] ^= 0xFF
+    (tmp_path / "bad.exr").write_bytes(bytes(bad))
+    try:
+        exr.imread(str(tmp_path / "bad.exr"))
+    except (ValueError, IndexError):
+        pass

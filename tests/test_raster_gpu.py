@@ -6,6 +6,8 @@ keys, conics, cov3D, sorted point_list, tile ranges); rendered colour/depth/alph
 """
 import ctypes
 
+import os
+
 import numpy as np
 import pytest
 
@@ -166,7 +168,7 @@ def _masked_grads(scene, ref):
     return {k: np.ascontiguousarray(scene[k] * keep) for k in ("dL_dcolor", "dL_ddepth", "dL_dalpha")}
 
 
-def _check_backward(scene, cam, ill_expected):
+def _check_backward(scene, cam, ill_expected, exempt_cap=1.0):
     """Three-level backward parity:
     (1) blend-backward accumulators on the SAME saved forward state (the oracle's alpha map is passed as the
         `alphas` input, exactly as the reference's backward takes it) vs the fp64-accumulated oracle;
@@ -276,6 +278,18 @@ def _check_backward(scene, cam, ill_expected):
         lim = 1e-3 * np.abs(gref[k]) + 1e-4 * np.abs(gref[k]).max(axis=1, keepdims=True) + 1e-6
         loose = max(loose, float((d > lim).mean()))
         assert (d > lim).mean() < 1e-3, f"end-to-end {k}: {(d > lim).mean():.2e} of elements beyond the coarse bound"
+    # (5) round 6: the EXEMPTED pixels at the strict bar where both sides share the alpha map.  Upstream gradients restricted to the ill-conditioned
+    # (not fragile, not flipping) pixels; the GPU blend backward on its own saved state against the oracle's blend backward evaluated on the alpha
+    # map the GPU forward saved -- the forward-rounding amplification d_alpha / T_final is then the same on both sides, what is left is the backward's
+    # own arithmetic near saturation (the reference divides T by (1 - alpha) entry after entry, we carry the product and take one reciprocal).
+    # EVERY accumulator element, no outlier budget: 1e-4 |ref| + 64 eps sum|term| (the summation-order slack of level 1), worst ratio printed and
+    # capped at `exempt_cap` (1.0 = the level-1 bar itself).
+    exempt_cap = float(os.environ.get("AG_TEST_EXEMPT_CAP", exempt_cap))       # (measuring runs)
+    exempt = (ill & ~(frag | flips)).astype(np.float32)[None]
+    ge = {k: np.ascontiguousarray(scene[k] * exempt) for k in ("dL_dcolor", "dL_ddepth", "dL_dalpha")}
+    acc_e = ro.backward_blend(dict(ref, alpha=fw["alpha"]), scene["colors"], scene["bg"], ge["dL_dcolor"], ge["dL_ddepth"], ge["dL_dalpha"])
+    worst_ex = h.assert_accum_parity(h.gpu_native_backward(fw, ge), acc_e, max_ratio=exempt_cap)
+    print(f"\n[parity] exempted pixels ({exempt.mean():.3f} of the image) on the shared alpha map: worst ratio to 1e-4 |ref| + 64 eps sum|term| = {worst_ex:.2f} (cap {exempt_cap:g})")
     print(f"\n[parity] P={ref['radii'].shape[0]} {cam['img_w']}x{cam['img_h']}: fragile pixels {frag.mean():.2e} (+ {(flips & ~frag).mean():.2e} "
           f"that flip under the exp probe), ill-conditioned {ill.mean():.2e} (T_final < 1e-2: {sat.mean():.2e}, forward difference "
           f"amplified past 2e-5: {(amp & ~sat).mean():.2e}); well-conditioned set: every accumulator element within the 1e-4 bound "
