@@ -168,7 +168,7 @@ def _masked_grads(scene, ref):
     return {k: np.ascontiguousarray(scene[k] * keep) for k in ("dL_dcolor", "dL_ddepth", "dL_dalpha")}
 
 
-def _check_backward(scene, cam, ill_expected, exempt_cap=1.0):
+def _check_backward(scene, cam, ill_expected, exempt_cap=1.25):
     """Three-level backward parity:
     (1) blend-backward accumulators on the SAME saved forward state (the oracle's alpha map is passed as the
         `alphas` input, exactly as the reference's backward takes it) vs the fp64-accumulated oracle;
@@ -283,7 +283,8 @@ def _check_backward(scene, cam, ill_expected, exempt_cap=1.0):
     # map the GPU forward saved -- the forward-rounding amplification d_alpha / T_final is then the same on both sides, what is left is the backward's
     # own arithmetic near saturation (the reference divides T by (1 - alpha) entry after entry, we carry the product and take one reciprocal).
     # EVERY accumulator element, no outlier budget: 1e-4 |ref| + 64 eps sum|term| (the summation-order slack of level 1), worst ratio printed and
-    # capped at `exempt_cap` (1.0 = the level-1 bar itself).
+    # capped at `exempt_cap` x that limit.  Measured (profiles/r06_parity_measure_raster.txt): 0.94 on the avatar (10.9 % of the image exempted), 0.91 on
+    # the 10 k random scene, 0.22 / 0.03 on the small ones -- inside the level-1 limit itself; the cap of 1.25 leaves room for the order of the atomics.
     exempt_cap = float(os.environ.get("AG_TEST_EXEMPT_CAP", exempt_cap))       # (measuring runs)
     exempt = (ill & ~(frag | flips)).astype(np.float32)[None]
     ge = {k: np.ascontiguousarray(scene[k] * exempt) for k in ("dL_dcolor", "dL_ddepth", "dL_dalpha")}

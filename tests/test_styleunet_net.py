@@ -28,10 +28,14 @@ GOLD = os.path.join(os.path.dirname(__file__), "golden", "dual_styleunet_512_102
 # full-tensor statistics (round 6): our percentiles within FULL_MULT x the reference-fp32's own; per-tensor caps on the block sums (of a block's sum of
 # magnitudes), the tensor sum (of its sum of magnitudes) and the sum of squares (relative).  A wrong output-channel block of one layer moves its
 # block sum by O(1) of the block's magnitude; values measured on the three paths are in profiles/r06_styleunet_fullstats/.
-FULL_MULT = float(os.environ.get("AG_TEST_FULL_MULT", "4"))
-FULL_CAP_SUM = float(os.environ.get("AG_TEST_FULL_CAP_SUM", "2e-2"))
-FULL_CAP_BLK = float(os.environ.get("AG_TEST_FULL_CAP_BLK", "5e-2"))
+# Measured (profiles/r06_styleunet_fullstats/, four paths): ours / reference-fp32 = 2.0-3.0 at the median and 1.2-1.9 at the 90th percentile of the three
+# statistics; largest block-sum deviation of a TENSOR 5.0e-3 of the block's magnitude (an activate.bias), of a one-number noise strength 3.3e-2 of its
+# value (convs2.5, where the reference's own fp32 run is 6.1e-2 off).
+FULL_MULT = float(os.environ.get("AG_TEST_FULL_MULT", "5"))
+FULL_CAP_SUM = float(os.environ.get("AG_TEST_FULL_CAP_SUM", "1e-2"))
+FULL_CAP_BLK = float(os.environ.get("AG_TEST_FULL_CAP_BLK", "2e-2"))
 FULL_CAP_SQ = float(os.environ.get("AG_TEST_FULL_CAP_SQ", "2e-2"))
+FULL_CAP_SCALAR = float(os.environ.get("AG_TEST_FULL_CAP_SCALAR", "8e-2"))      # one-element tensors (the twelve noise strengths): relative error of the number
 
 
 def _sub(t, n=256):
@@ -167,7 +171,7 @@ def _golden_body(math, grouped=False):
         d_sum = abs(float(g.sum()) - float(gold["fsum:" + ref_name])) / max(float(gold["fabs:" + ref_name]), 1e-300)
         d_blk = float(np.max(np.abs(blk - gold["fblk:" + ref_name]) / np.maximum(gold["fblkabs:" + ref_name], 1e-300)))
         d_sq = abs(float((g * g).sum()) - float(gold["fsq:" + ref_name])) / max(float(gold["fsq:" + ref_name]), 1e-300)
-        full.append((ref_name, d_sum, float(gold["e32sum:" + ref_name]), d_blk, float(gold["e32blk:" + ref_name]), d_sq, float(gold["e32sq:" + ref_name])))
+        full.append((ref_name, d_sum, float(gold["e32sum:" + ref_name]), d_blk, float(gold["e32blk:" + ref_name]), d_sq, float(gold["e32sq:" + ref_name]), n))
     fo = {k: np.array([r[i] for r in full]) for k, i in (("sum", 1), ("rsum", 2), ("blk", 3), ("rblk", 4), ("sq", 5), ("rsq", 6))}
     print(f"\n[parity] full-tensor gradient statistics over {len(full)} tensors ({math}{', grouped' if grouped else ''}), ours / reference fp32 at p50 p90 p99 max: "
           + "; ".join(f"{k}: " + " ".join(f"{np.percentile(fo[k], q):.1e}/{np.percentile(fo['r' + k], q):.1e}" for q in (50, 90, 99, 100)) for k in ("sum", "blk", "sq")))
@@ -179,8 +183,10 @@ def _golden_body(math, grouped=False):
     for k, caps in (("sum", FULL_CAP_SUM), ("blk", FULL_CAP_BLK), ("sq", FULL_CAP_SQ)):
         for q in (50, 90):
             assert np.percentile(fo[k], q) <= FULL_MULT * max(np.percentile(fo["r" + k], q), 1e-7), (k, q, np.percentile(fo[k], q), np.percentile(fo["r" + k], q))
-        worst = max(full, key=lambda r: r[{"sum": 1, "blk": 3, "sq": 5}[k]])
-        assert fo[k].max() <= caps, (k, worst)
+        col = {"sum": 1, "blk": 3, "sq": 5}[k]
+        for r in full:
+            cap = (2 * FULL_CAP_SCALAR if k == "sq" else FULL_CAP_SCALAR) if r[7] == 1 else caps
+            assert r[col] <= cap, (k, r)
     if out_dir:
         with open(os.path.join(out_dir, f"styleunet_grad_report_{math}{'_grouped' if grouped else ''}.txt"), "w") as f:
             for o, r, n in fwd_rows:
