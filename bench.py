@@ -337,9 +337,34 @@ def main() -> None:
         dt = torch.tensor([(time.perf_counter() - t2) / reps], device=dev, dtype=torch.float64)
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
         ms = 1e3 * float(dt.item())
+        # per-rank times (round 6: the first 8-GPU run must yield the whole curve in one command): every rank's own wall time of the same collective
+        mine = torch.tensor([(time.perf_counter() - t2) / reps * 1e3], device=dev, dtype=torch.float64)
+        per_rank = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(per_rank, mine)
         exchange_leg = {"what": "bucketed all-reduce of the StyleUNet gradients (223.6 M fp32, 128-MB buckets), not part of `value`",
-                    "bytes": 4 * n_el, "ms": round(ms, 3), "bus_GBps": round(2 * (world - 1) / world * 4 * n_el / (ms * 1e-3) / 1e9, 1)}
+                    "bytes": 4 * n_el, "ms": round(ms, 3), "bus_GBps": round(2 * (world - 1) / world * 4 * n_el / (ms * 1e-3) / 1e9, 1),
+                    "ms_per_rank": [round(float(t.item()), 3) for t in per_rank]}
         del buf
+        # ... and the headline's own exchange on its own: the all-reduce of the per-Gaussian gradient sums (P x 14 fp32), back to back
+        vb = torch.zeros(P * 14, device=dev)
+        for _ in range(3):
+            dist.all_reduce(vb)
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        t3 = time.perf_counter()
+        vreps = 20
+        for _ in range(vreps):
+            dist.all_reduce(vb)
+        torch.cuda.synchronize(dev)
+        vmine = torch.tensor([(time.perf_counter() - t3) / vreps * 1e3], device=dev, dtype=torch.float64)
+        vper = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(vper, vmine)
+        vms = max(float(t.item()) for t in vper)
+        exchange_leg["view_gradients"] = {"what": "all-reduce of the per-Gaussian attribute gradient sums (the headline's exchange), back to back, not part of `value`",
+                                          "bytes": 4 * P * 14, "ms": round(vms, 4), "ms_per_rank": [round(float(t.item()), 4) for t in vper],
+                                          "bus_GBps": round(2 * (world - 1) / world * 4 * P * 14 / (vms * 1e-3) / 1e9, 1),
+                                          "views_per_exchange_per_rank": exch_every}
+        del vb
 
     if rank != 0:
         if world > 1:

@@ -163,7 +163,9 @@ def _order_worker(rank, world, port, out):
     assert len(sync.buckets) == 6
     ok = True
     orders = {0: [list(range(11, -1, -1)), [5, 4, 11, 10, 1, 0, 7, 6, 3, 2, 9, 8]],
-              1: [list(range(12)), [0, 7, 3, 10, 1, 6, 11, 4, 9, 2, 5, 8]]}
+              1: [list(range(12)), [0, 7, 3, 10, 1, 6, 11, 4, 9, 2, 5, 8]],
+              2: [[6, 7, 8, 9, 10, 11, 0, 1, 2, 3, 4, 5], [11, 0, 10, 1, 9, 2, 8, 3, 7, 4, 6, 5]],          # (world size 4, round 6)
+              3: [[1, 0, 3, 2, 5, 4, 7, 6, 9, 8, 11, 10], [2, 9, 4, 7, 0, 11, 6, 1, 8, 3, 10, 5]]}
     launch_orders = []
     for step in range(2):
         sync.zero()
@@ -333,3 +335,86 @@ def test_view_grad_exchange_accumulates_and_reduces_once_per_iteration_gloo_worl
         p.join(120)
         assert p.exitcode == 0
     assert dict(out) == {0: True, 1: True}
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Round 6: world size 4 with UNEVEN view counts (10 views over 4 ranks: 3, 3, 2, 2) -- the ranks then take different numbers of steps per
+# iteration but must issue the same collectives in the same order
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _uneven_worker(rank, world, port, out):
+    from animatablegaussians_amd.parallel import GradSync, ViewGradExchange, views_of_rank
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n_views, P, cols, n_slots = 10, 131, (3, 3, 4, 1, 3), 3
+    mine = views_of_rank(n_views, rank, world)
+    ok = len(mine) == (3 if rank < 2 else 2)
+
+    # (1) GradSync: per-parameter gradients summed over a rank's own views, one all-reduce
+    params = [torch.zeros(P, c, requires_grad=True) for c in cols]
+
+    def grad_of_view(v, p):
+        return torch.full_like(p, float(v + 1)) * torch.arange(p.numel()).reshape(p.shape) / p.numel()
+
+    for p in params:
+        p.grad = sum(grad_of_view(v, p) for v in mine)
+    sync = GradSync(params)
+    sync.start()
+    sync.finish()
+    ok = ok and all(torch.allclose(p.grad, sum(grad_of_view(v, p) for v in range(n_views)), rtol=1e-6) for p in params)
+
+    # (2) ViewGradExchange: `every` = the rank's OWN number of views per iteration; one all-reduce per iteration on every rank
+    def grads_of(it, v):
+        g = torch.Generator().manual_seed(100 * it + v)
+        return [torch.randn(P, c, generator=g) for c in cols]
+
+    x = ViewGradExchange(P, sum(cols), "cpu", n_slots, every=len(mine))
+    for it in range(3):
+        for j, v in enumerate(mine):
+            x.submit(j % n_slots, grads_of(it, v))
+        x.join()
+        want = sum(torch.cat(grads_of(it, v), dim=1) for v in range(n_views))
+        ok = ok and torch.allclose(x.acc, want, rtol=1e-5, atol=1e-5)
+        x.release()
+    ok = ok and x.reduced == 3
+
+    out[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def test_world4_uneven_views_gradsync_and_exchange_gloo():
+    world, port = 4, _free_port()
+    ctx = mp.get_context("spawn")
+    out = ctx.Manager().dict()
+    procs = [ctx.Process(target=_uneven_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert dict(out) == {0: True, 1: True, 2: True, 3: True}
+
+
+def _run_world(worker, world, timeout=240):
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    out = ctx.Manager().dict()
+    procs = [ctx.Process(target=worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout)
+        assert p.exitcode == 0
+    res = dict(out)
+    assert set(res) == set(range(world)) and all((v[0] if isinstance(v, tuple) else v) is True for v in res.values()), res
+    return res
+
+
+def test_world4_bucketed_grad_sync_order_and_exchange_gloo():
+    """The three world-2 workers above at world size 4 (they are written for any world size): bucketed all-reduce = the mean over FOUR ranks'
+    gradients with buckets firing during backward, four different gradient-arrival orders issuing one collective order, and bench.py's
+    ViewGradExchange over four ranks (sums per iteration, held-back mode, cut-short iterations)."""
+    _run_world(_bucket_worker, 4)
+    res = _run_world(_order_worker, 4)
+    assert all(res[r][1] == res[0][1] for r in range(4))                     # the same collective order on every rank, both steps
+    _run_world(_exchange_worker, 4)
