@@ -214,11 +214,22 @@ __global__ void __launch_bounds__(kBlendThreads) blend_forward_kernel(BlendFwdPa
         }
         // cull of chunk 0
         bool keep;
+#ifndef AG_FWD_TIGHT_CULL
+#define AG_FWD_TIGHT_CULL 0      /* round 6, measured and NOT kept: the exact quadratic-form cull of the backward (rect_reaches) instead of the cut-off
+                                    disc keeps 172 instead of 196 entries per region and 58 instead of 72 per wave (2.9 instead of 3.4 steps), all raster
+                                    tests pass -- and the kernel takes 62.3 us instead of 47.2 (74.7 with the short-circuit form): this kernel is bound by
+                                    its per-item critical path, and the test's ~15 dependent instructions per cull pass sit on it while the steps it
+                                    saves do not pay them back (profiles/r06_fwd_exact_cull.txt).  -DAG_FWD_TIGHT_CULL=1 builds it. */
+#endif
+#if AG_FWD_TIGHT_CULL
+        keep = (int)(range.x + tid < range.y) & (int)rect_reaches(qx0f - r0.x, qx1f - r0.x, qy0f - r0.y, qy1f - r0.y, r0.z, r0.w, r1.x, r2.w);     // no short circuit: a branch here waits for the prefetched records on the spot
+#else
         {
             const float ddx = fmaxf(fmaxf(qx0f - r0.x, r0.x - qx1f), 0.f);
             const float ddy = fmaxf(fmaxf(qy0f - r0.y, r0.y - qy1f), 0.f);
             keep = (range.x + tid < range.y) && ((ddx * ddx + ddy * ddy) <= r2.z);
         }
+#endif
         unsigned long long mask = __ballot(keep);
         if (lane == 0) { s_wave_cnt[0][wave] = __popcll(mask); s_wave_done[wave] = 0; }
         lds_barrier();
@@ -248,7 +259,7 @@ __global__ void __launch_bounds__(kBlendThreads) blend_forward_kernel(BlendFwdPa
                 const int slot = off + rank;
                 s_rec[slot * 3 + 0] = r0;
                 s_rec[slot * 3 + 1] = r1;
-                s_rec[slot * 3 + 2] = make_float4(r2.x, r2.y, __uint_as_float(k - range.x + 1u), r2.z);  // b, depth, 1-based position, r2cut
+                s_rec[slot * 3 + 2] = make_float4(r2.x, r2.y, __uint_as_float(k - range.x + 1u), AG_FWD_TIGHT_CULL ? r2.w : r2.z);  // b, depth, 1-based position, qcut (r2cut)
             }
             // issue the gathers of chunk c+1 and the index loads of chunk c+2; both are consumed after the blend
             const uint32_t kn = k + kChunk, knn = kn + kChunk;
@@ -271,9 +282,14 @@ __global__ void __launch_bounds__(kBlendThreads) blend_forward_kernel(BlendFwdPa
                     if (i < K) {
                         const float4 a0 = s_rec[i * 3 + 0];
                         const float r2c = s_rec[i * 3 + 2].w;
+#if AG_FWD_TIGHT_CULL
+                        const float cc0 = s_rec[i * 3 + 1].x;
+                        mine = rect_reaches(bx0 - a0.x, bx0 + 1.0f - a0.x, by0 - a0.y, by0 + 1.0f - a0.y, a0.z, a0.w, cc0, r2c);
+#else
                         const float ddx = fmaxf(fmaxf(bx0 - a0.x, a0.x - (bx0 + 1.0f)), 0.f);
                         const float ddy = fmaxf(fmaxf(by0 - a0.y, a0.y - (by0 + 1.0f)), 0.f);
                         mine = (ddx * ddx + ddy * ddy) <= r2c;
+#endif
                     }
                     const unsigned long long m = __ballot(mine);
                     if (mine) s_widx[wave][cntw + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint16_t)i;
@@ -336,11 +352,15 @@ __global__ void __launch_bounds__(kBlendThreads) blend_forward_kernel(BlendFwdPa
             }
 
             // ---- cull of the next chunk (its records have landed by now) + completion vote ----
+#if AG_FWD_TIGHT_CULL
+            keep = (int)(kn < range.y) & (int)rect_reaches(qx0f - r0.x, qx1f - r0.x, qy0f - r0.y, qy1f - r0.y, r0.z, r0.w, r1.x, r2.w);
+#else
             {
                 const float ddx = fmaxf(fmaxf(qx0f - r0.x, r0.x - qx1f), 0.f);
                 const float ddy = fmaxf(fmaxf(qy0f - r0.y, r0.y - qy1f), 0.f);
                 keep = (kn < range.y) && ((ddx * ddx + ddy * ddy) <= r2.z);
             }
+#endif
             mask = __ballot(keep);
             const int wdone = __all(done);
             if (lane == 0) { s_wave_cnt[cpar ^ 1][wave] = __popcll(mask); s_wave_done[wave] = wdone; }

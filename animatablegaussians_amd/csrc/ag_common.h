@@ -34,6 +34,23 @@ static_assert(sizeof(GaussRec) == 48, "GaussRec must be 48 bytes");
 constexpr int kAccumFloats = 16;
 enum AccumSlot { A_QDX = 0, A_QDY, A_QXX, A_QXY, A_QYY, A_Q, A_COLR, A_COLG, A_COLB, A_DEPTH };
 
+// Exact cull of a splat against a rectangle of pixel centres (round 5 in the blend backward, round 6 in the forward too): the smallest value of
+// q(u, v) = a u^2 + 2 b u v + c v^2 (= -2 power) over [U0, U1] x [V0, V1] (the rectangle relative to the splat) against the splat's own threshold
+// qcut = 2 ln(255 op) (+ slack, ag_preprocess.hip).  q is convex with its minimum 0 at the splat, so over the rectangle it is smallest on an edge
+// that faces the splat: the lines u = ue and v = ve through the rectangle's point nearest to the splat (ue = med3(0, U0, U1)); on u = ue,
+// c q = (c v + b ue)^2 + det ue^2 with w = c v + b ue in [c V0 + b ue, c V1 + b ue], so min c q = med3(0, W0, W1)^2 + det ue^2 -- no division.
+// A conic that is not positive definite carries qcut = 3e38 (never culled).
+__device__ __forceinline__ bool rect_reaches(float U0, float U1, float V0, float V1, float ca, float cb, float cc, float qc)
+{
+    const float ue = __builtin_amdgcn_fmed3f(0.f, U0, U1), ve = __builtin_amdgcn_fmed3f(0.f, V0, V1);
+    const float det = fmaf(ca, cc, -cb * cb);
+    const float bue = cb * ue, bve = cb * ve;
+    const float w1 = __builtin_amdgcn_fmed3f(0.f, fmaf(cc, V0, bue), fmaf(cc, V1, bue));
+    const float w2 = __builtin_amdgcn_fmed3f(0.f, fmaf(ca, U0, bve), fmaf(ca, U1, bve));
+    const float l1 = fmaf(w1, w1, det * ue * ue), l2 = fmaf(w2, w2, det * ve * ve);
+    return (l1 <= cc * qc) | (l2 <= ca * qc);
+}
+
 // Blend kernels: a workgroup of 8 waves owns an 8x4 pixel region (8 regions per 16x16 tile); each wave blends
 // 4 pixels (one per 16-lane DPP row) x 16 list entries per step.
 constexpr int kRegW = 8, kRegH = 4, kRegionsPerTile = (kTileX / kRegW) * (kTileY / kRegH);
