@@ -338,3 +338,52 @@ def test_weight_gradient_is_deterministic_and_needs_no_zeroed_target(kind, Cin, 
         out.backward(gy)
         grads.append(wg.grad.clone())
     assert torch.equal(grads[0], grads[1]) and torch.equal(grads[0], grads[2])
+
+
+@pytest.mark.parametrize("dma", ["1", "2"])
+def test_the_opt_in_dma_loader_gives_the_register_staged_loaders_results(dma):
+    """Round 6: the LDS-DMA loader over pre-split fp16 planes (`AG_CONV_DMA`, csrc/ag_conv.hip gather_conv_dma_kernel; opt-in, profiles/r06_conv_dma.md) is
+    a process-wide switch read once, so it runs in a child process: the convolutions of the fp16 forms -- forward and input gradient, plain 3 x 3, stride
+    2, the transposed convolution's parity classes, grouped instances, 128- and 256-row tiles -- must equal the default loader's results computed HERE
+    to the last bit of the split (same products, same K order inside a tile; the tile shape changes the order of the fp32 accumulation: 2e-6 of scale)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    import torch
+    from animatablegaussians_amd import conv as agc
+    code = r'''
+import sys, json, torch
+sys.path.insert(0, %r)
+from animatablegaussians_amd import conv as agc
+agc.set_math(sys.argv[1])
+out = {}
+for name, (cin, cout, h, w, k, s, p, tr) in json.loads(sys.argv[2]).items():
+    g = torch.Generator().manual_seed(sum(map(ord, name)))          # (hash() of a str differs between processes)
+    x = torch.randn(1, cin, h, w, generator=g).cuda().requires_grad_(True)
+    wt = (torch.randn(cin, cout, k, k, generator=g) if tr else torch.randn(cout, cin, k, k, generator=g)).cuda()
+    y = agc.conv_transpose2d(x, wt, stride=s, padding=p) if tr else agc.conv2d(x, wt, stride=s, padding=p)
+    gy = torch.randn(y.shape, generator=g).cuda()
+    gx, = torch.autograd.grad(y, x, gy)
+    out[name] = [float(y.double().sum()), float(y.double().abs().sum()), float(gx.double().sum()), float(gx.double().abs().sum()),
+                 y.flatten()[::max(1, y.numel() // 64)][:64].tolist(), gx.flatten()[::max(1, gx.numel() // 64)][:64].tolist()]
+agc.check_status()
+print("RESULT" + json.dumps(out))
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cases = {"c256_64": (256, 256, 64, 64, 3, 1, 1, False), "c128_96": (128, 128, 96, 96, 3, 1, 1, False), "c64_s2": (64, 128, 64, 64, 3, 2, 1, False),
+             "c512_32": (512, 256, 32, 32, 3, 1, 1, False), "t64_up": (64, 32, 24, 24, 3, 2, 0, True), "c48": (48, 80, 40, 36, 3, 1, 1, False),
+             # large enough for pick_tile to choose the 256 x 256 and the 128 x 256 tile (AG_CONV_DMA=1 uses the DMA loader only there)
+             "c256_256big": (256, 256, 256, 256, 3, 1, 1, False), "c128_384big": (128, 128, 384, 384, 3, 1, 1, False)}
+    res = {}
+    for label, env in (("base", {"AG_CONV_DMA": "0"}), ("dma", {"AG_CONV_DMA": dma})):
+        p = subprocess.run([sys.executable, "-c", code, "split_f16", json.dumps(cases)], capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, **env))
+        assert p.returncode == 0, p.stderr[-2000:]
+        res[label] = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("RESULT")][-1][6:])
+    for name in cases:
+        a, b = res["base"][name], res["dma"][name]
+        for i in (0, 2):
+            assert abs(a[i] - b[i]) <= 2e-6 * max(a[i + 1], 1e-30), (name, i, a[i], b[i])
+        for i in (4, 5):
+            sc = max(abs(v) for v in a[i]) + 1e-30
+            assert max(abs(u - v) for u, v in zip(a[i], b[i])) <= 2e-6 * sc, (name, i)
