@@ -111,3 +111,78 @@ def test_camera_identity_cache_follows_the_tensors_values():
             assert len(calls) == n + 1 and f is b
     finally:
         gr._camera_tensors_by_value = real
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree only exists in the build container")
+def test_the_references_render3_through_the_dropin_issues_the_native_call_of_our_rehost():
+    """Boundary B1 / row a6, one level deeper than the import check (round 6).  The REFERENCE'S OWN `gaussians/gaussian_renderer.render3`
+    (its file, unmodified, imported from /root/reference) is run with `diff_gaussian_rasterization_depth_alpha` resolving to our drop-in package,
+    for a colour call and a spherical-harmonics call; so is our re-host `animatablegaussians_amd.gaussian_renderer.render3` on the same inputs.
+    The native entry point both end in (`rasterizer.native_rasterize_gaussians`, the `_C.rasterize_gaussians` equivalent) is replaced by a recorder:
+    both paths must hand it the same 19-argument tuple -- same order, same tensors to 1e-6 (view / projection matrices, camera centre, tan fov,
+    colours incl. the SH -> RGB the reference does in Python), same flags -- and route the outputs back under the reference's keys.  No GPU here: the
+    reference's two `.cuda()` calls and its `device="cuda"` are mapped to the CPU for the duration of the test.  (Running the reference's Python ON the
+    GPU box is ruled out by the task: it cannot travel there.)"""
+    import numpy as np
+    import torch
+    from animatablegaussians_amd import gaussian_renderer as ours
+    from animatablegaussians_amd import rasterizer as rz
+    sys.path.insert(0, DROPIN)
+    sys.path.insert(0, REF)
+    calls = []
+
+    def recorder(*args, **kw):
+        calls.append((args, kw))
+        H, W, P = int(args[12]), int(args[13]), args[1].shape[0]
+        z = lambda *s: torch.zeros(*s)  # noqa: E731
+        return (0, 0), z(3, H, W), z(1, H, W), z(1, H, W), torch.zeros(P, dtype=torch.int32), z(1), z(1), z(1), z(1)[:0]
+
+    real_native, real_cuda, real_zl = rz.native_rasterize_gaussians, torch.Tensor.cuda, torch.zeros_like
+
+    def zeros_like_cpu(t, **kw):
+        kw.pop("device", None)
+        return real_zl(t, **kw)
+
+    try:
+        rz.native_rasterize_gaussians = lambda *a, **k: recorder(*a, **k)[:8]
+        torch.Tensor.cuda = lambda self, *a, **k: self
+        torch.zeros_like = zeros_like_cpu
+        ref_mod = __import__("gaussians.gaussian_renderer", fromlist=["render3"])
+        g = torch.Generator().manual_seed(5)
+        P = 37
+        base = {"positions": torch.randn(P, 3, generator=g) + torch.tensor([0., 0., 3.]), "opacity": torch.rand(P, 1, generator=g),
+                "scales": torch.rand(P, 3, generator=g) * 0.05, "rotations": torch.nn.functional.normalize(torch.randn(P, 4, generator=g)),
+                "max_sh_degree": 0}
+        extr = torch.eye(4)
+        extr[:3, :3] = torch.tensor([[0.8, 0., 0.6], [0., 1., 0.], [-0.6, 0., 0.8]])
+        extr[:3, 3] = torch.tensor([0.1, -0.2, 2.5])
+        intr = torch.tensor([[1100., 0., 250.], [0., 1090., 260.], [0., 0., 1.]])
+        bg = torch.tensor([0.1, 0.2, 0.3])
+        for variant in ("colors", "shs"):
+            vals = dict(base)
+            if variant == "colors":
+                vals["colors"] = torch.rand(P, 3, generator=g)
+            else:
+                vals["shs"] = torch.randn(P, 3, 4, generator=g) * 0.3
+                vals["max_sh_degree"] = 1
+            del calls[:]
+            out_ref = ref_mod.render3(vals, bg, extr, intr, 512, 480, 1.0)
+            out_our = ours.render3(vals, bg, extr, intr, 512, 480, 1.0)
+            assert len(calls) == 2
+            (a_ref, k_ref), (a_our, k_our) = calls
+            assert len(a_ref) == len(a_our) == 19 and k_ref == k_our
+            for i, (x, y) in enumerate(zip(a_ref, a_our)):
+                if torch.is_tensor(x):
+                    assert torch.is_tensor(y) and x.shape == y.shape and x.dtype == y.dtype, (variant, i)
+                    if x.numel():
+                        assert float((x.double() - y.double()).abs().max()) <= 1e-6 * max(1.0, float(x.double().abs().max())), (variant, i)
+                else:
+                    assert (abs(x - y) <= 1e-7 * max(1.0, abs(x))) if isinstance(x, float) else x == y, (variant, i, x, y)
+            assert set(out_ref) == set(out_our) == {"render", "depth", "mask", "viewspace_points", "visibility_filter", "radii"}
+            assert out_ref["render"].shape == (3, 480, 512) and out_ref["visibility_filter"].dtype == torch.bool
+    finally:
+        rz.native_rasterize_gaussians, torch.Tensor.cuda, torch.zeros_like = real_native, real_cuda, real_zl
+        sys.path.remove(DROPIN)
+        sys.path.remove(REF)
+        for m in [m for m in sys.modules if m in ("gaussians", "utils") or m.startswith(("gaussians.", "utils."))]:
+            del sys.modules[m]
