@@ -267,7 +267,11 @@ __global__ void __launch_bounds__(64, AG_BWD_WAVE_OCC) blend_backward_wave_kerne
 #pragma unroll
             for (int pass = 0; pass < kWin / 4; pass++) {
                 const int ent = pass * 4 + (lane >> 4), comp = lane & 15;
+#ifdef AG_BWD_NO_ATOMICS      /* timing probe only (wrong sums): plain stores in place of the atomics -- what do the line-coalesced atomics cost? */
+                if (ent < win && comp < 10 && val[pass] != 0.f) p.accum[(size_t)gid[pass] * kAccumFloats + comp] = val[pass];
+#else
                 if (ent < win && comp < 10 && val[pass] != 0.f) atomicAdd(p.accum + (size_t)gid[pass] * kAccumFloats + comp, val[pass]);
+#endif
             }
             win = 0;
         };
