@@ -329,6 +329,9 @@ __global__ void __launch_bounds__(64, AG_BWD_WAVE_OCC) blend_backward_wave_kerne
             if (win) flush();
 
             // ---- blend 4 ring entries per step ----
+#if defined(AG_BWD_KO) && AG_BWD_KO == 1      /* timing probe (wrong results): the walk alone -- loads, cull, ring writes; no blend steps */
+            head = cnt;
+#endif
             while (cnt - head >= 4 || (last_pass && cnt > head)) {
                 const int idx = head + e;
                 const bool ev = idx < cnt;
@@ -408,6 +411,10 @@ __global__ void __launch_bounds__(64, AG_BWD_WAVE_OCC) blend_backward_wave_kerne
                 asm volatile("s_nop 1\n\t"
                              "v_mul_f32_dpp %0, %1, %2 row_ror:4 row_mask:0xf bank_mask:0xf" : "=&v"(S) : "v"(B), "v"(bank0));
 
+#if defined(AG_BWD_KO) && AG_BWD_KO == 2      /* timing probe (wrong results): the step without the sums over the pixels and without the window / flush */
+                if (v[0] + v[1] + v[2] + v[3] + v[4] + v[5] + v[6] + v[7] + v[8] + v[9] == 12345.678f) s_out[lane] = P + S;
+                continue;
+#endif
                 // sum over the block's 16 pixels per entry: rows (y) by register exchange 10 -> 5 -> 3, then x inside the quads
                 float s[6];
 #pragma unroll
