@@ -274,7 +274,15 @@ __global__ void __launch_bounds__(kBlendThreads) blend_forward_kernel(BlendFwdPa
             // Each wave keeps the indices of the entries whose cut-off disc touches ITS block (same conservative test, so the
             // dropped entries contribute exactly nothing) and blends only those: half the steps of walking the region's list.
             int cntw = 0;
+#if defined(AG_FWD_KO) && AG_FWD_KO == 1      /* timing probe (same results, more steps): no second cull -- every wave walks all K region survivors */
+            if (!__all(done)) {
+                for (int i0 = 0; i0 < K; i0 += 64) if (i0 + lane < K) s_widx[wave][i0 + lane] = (uint16_t)(i0 + lane);
+                cntw = K;
+            }
+            if (false) {
+#else
             if (!__all(done)) {     // a wave whose four pixels are finished has nothing to pick from this chunk
+#endif
                 const float bx0 = (float)(rx0 + (wave & 3) * 2), by0 = (float)(ry0 + (wave >> 2) * 2);
                 for (int i0 = 0; i0 < K; i0 += 64) {
                     const int i = i0 + lane;
@@ -300,6 +308,9 @@ __global__ void __launch_bounds__(kBlendThreads) blend_forward_kernel(BlendFwdPa
             if (wave == 0) FST(FS_REGION_SURV, K);
             FST(FS_SUBCULL_PASSES, (K + 63) / 64); FST(FS_WAVE_SURV, cntw);
             // ---- blend: 16 entries per step per pixel row ----
+#if defined(AG_FWD_KO) && AG_FWD_KO == 2      /* timing probe (wrong results): the culls alone, no blend steps */
+            cntw = 0;
+#endif
             for (int s0 = 0; s0 < cntw; s0 += 16) {
                 if (__all(done)) { FST(FS_BREAKS, 1); break; }
                 FST(FS_STEPS, 1);
